@@ -1,0 +1,251 @@
+"""Generate golden vectors by running the reference's own modules (CPU, fp32) in this container.
+
+    PYTHONDONTWRITEBYTECODE=1 python tests/golden/make_golden.py
+
+Writes tests/golden/*.npz (+ state_dict key/shape listings as .json.gz).  The fixtures hold data
+only: inputs that cannot be regenerated and the outputs the reference produced.  Weights are
+regenerated on both sides by tests/golden/weights.py.  Cameras come from cd360.synth
+(deterministic).  The reference is imported through tests/golden/refshim.py; its third-party
+dependencies (pytorch3d / xformers / omegaconf) are stand-ins, so these vectors pin the
+reference's *own* code, not those libraries ("parity unpinned" at that boundary).
+"""
+from __future__ import annotations
+
+import ast
+import gzip
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+import refshim  # noqa: E402
+import weights as W  # noqa: E402
+
+ns = refshim.import_reference()
+from cd360 import synth  # noqa: E402
+from cd360.cameras import pack_cameras  # noqa: E402
+
+torch.set_grad_enabled(False)
+torch.set_num_threads(8)
+
+
+class Recorder:
+    """Records grid_sample calls and the random draws made inside a reference forward."""
+
+    def __init__(self):
+        self.grid_calls, self.rand = [], []
+
+    def __enter__(self):
+        F = torch.nn.functional
+        self._gs, self._rand, self._rand_like = F.grid_sample, torch.rand, torch.rand_like
+
+        def gs(inp, grid, **kw):
+            out = self._gs(inp, grid, **kw)
+            self.grid_calls.append((inp.clone(), grid.clone(), out.clone()))
+            return out
+
+        def rand(*a, **k):
+            t = self._rand(*a, **k)
+            self.rand.append(t.clone())
+            return t
+
+        def rand_like(x, **k):
+            t = self._rand_like(x, **k)
+            self.rand.append(t.clone())
+            return t
+
+        F.grid_sample, torch.rand, torch.rand_like = gs, rand, rand_like
+        return self
+
+    def __exit__(self, *a):
+        F = torch.nn.functional
+        F.grid_sample, torch.rand, torch.rand_like = self._gs, self._rand, self._rand_like
+
+
+def npz(name, **arrays):
+    out = {}
+    for k, v in arrays.items():
+        if v is None:
+            continue
+        out[k] = v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **out)
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB")
+
+
+def keyfile(name, module):
+    sd = module.state_dict()
+    listing = {k: list(v.shape) for k, v in sd.items()}
+    with gzip.open(os.path.join(HERE, name + ".keys.json.gz"), "wt") as f:
+        json.dump(listing, f)
+    return listing
+
+
+def jitter_kw(rec):
+    """rand draws in call order: xs jitter [r+1], ys jitter [r+1], depth jitter [hw,S+1] (train mode)."""
+    if not rec.rand:
+        return {}
+    return dict(jit_x=rec.rand[0], jit_y=rec.rand[1], jit_d=rec.rand[2])
+
+
+# ---------------------------------------------------------------- 1. NerfSDModule
+def case_nerf(train: bool):
+    C, r, n, S, b = 64, 8, 2, 4, 2
+    m = ns.nerf.NerfSDModule(mode="feature-nerf", out_channels=C, far_plane=2.0, num_samples=S, rgb_predict=True, stratified=True)
+    W.load_into(m, seed=1)
+    m.train(train)
+    pose = synth.pose_batch(b, n, seed=3)
+    xref = W.tensor("xref", (b, n, r * r, C), seed=1)
+    torch.manual_seed(11)
+    ray_out = {}
+    h = m.raymarcher.register_forward_hook(lambda mod, i, o: ray_out.update(rays=o[0], points=o[1], dists=o[2]))
+    with Recorder() as rec:
+        feats, sigma, dists, attn, rgb, _, _ = m(pose, xref)
+    h.remove()
+    _, grid, plane = rec.grid_calls[0]
+    npz("nerf_train" if train else "nerf_eval", cams=pack_cameras(pose), xref=xref, rays=ray_out["rays"], points=ray_out["points"],
+        dists=dists, grid=grid, plane=plane, feats=feats, sigma=sigma, view_weights=attn, rgb=rgb, **jitter_kw(rec))
+    return m
+
+
+# ---------------------------------------------------------------- 2. BasicTransformerBlock with pose
+def make_block(C, heads, ctx_dim, S):
+    return ns.attention.BasicTransformerBlock(C, heads, 64, context_dim=ctx_dim, checkpoint=False, attn_mode="softmax-xformers",
+                                              image_cross=True, far=2, num_samples=S, rgb_predict=True, mode="feature-nerf", stratified=True)
+
+
+def case_block(train: bool):
+    C, heads, r, n, S, b, T, cd = 64, 1, 8, 2, 4, 2, 77, 32
+    blk = make_block(C, heads, cd, S)
+    W.load_into(blk, seed=2)
+    blk.train(train)
+    pose = synth.pose_batch(b, n, seed=4)
+    x = W.tensor("x", (b, r * r, C), seed=2)
+    ctx = W.tensor("ctx", (b, T, cd), seed=2)
+    cref = W.tensor("cref", (b * n, r * r, C), seed=2)
+    torch.manual_seed(12)
+    with Recorder() as rec:
+        out, fg, wts, alphas, rgb = blk(x, context=ctx, context_ref=cref, pose=pose)
+    assert wts is None
+    plain = blk(x, context=ctx)[0]
+    npz("block_train" if train else "block_eval", cams=pack_cameras(pose), x=x, ctx=ctx, cref=cref, out=out, fg=fg, alphas=alphas, rgb=rgb,
+        plain=plain, **jitter_kw(rec))
+    if not train:
+        keyfile("block", blk)
+
+
+# ---------------------------------------------------------------- 3. SpatialTransformer dual stream
+def make_st(C, heads, depth, cd, S):
+    return ns.attention.SpatialTransformer(C, heads, 64, depth=depth, context_dim=cd, use_linear=True, attn_type="softmax-xformers",
+                                           use_checkpoint=False, image_cross=True, rgb_predict=True, far=2, num_samples=S,
+                                           mode="feature-nerf", stratified=True)
+
+
+def case_st_dual():
+    C, heads, depth, r, n, S, b, T, cd = 128, 2, 5, 8, 2, 4, 1, 77, 32
+    st = make_st(C, heads, depth, cd, S)
+    W.load_into(st, seed=3)
+    st.eval()
+    pose = synth.pose_batch(b, n, seed=5)
+    x = W.tensor("x", (b, C, r, r), seed=3)
+    xr = W.tensor("xr", (b * n, C, r, r), seed=3)
+    ctx = W.tensor("ctx", (b, T, cd), seed=3)
+    ctxr = W.tensor("ctxr", (b * n, T, cd), seed=3)
+    out, xro, fgs, pw, alphas, rgbs = st(x, xr, context=ctx, contextr=ctxr, pose=pose)
+    assert pw is None and len(fgs) == 2
+    plain = st(x, None, context=ctx)[0]
+    npz("st_dual", cams=pack_cameras(pose), x=x, xr=xr, ctx=ctx, ctxr=ctxr, out=out, xr_out=xro, fg0=fgs[0], fg1=fgs[1],
+        alphas0=alphas[0], alphas1=alphas[1], rgb0=rgbs[0], rgb1=rgbs[1], plain=plain)
+    keyfile("st", st)
+
+
+# ---------------------------------------------------------------- 4. sample.py's patched forwards (cached render, CFG x3)
+def _sample_py_functions():
+    src = open(os.path.join(refshim.REF_ROOT, "sample.py")).read()
+    tree = ast.parse(src)
+    wanted = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("customforward", "_customforward")]
+    mod = ast.Module(body=wanted, type_ignores=[])
+    from einops import rearrange
+    env = {"torch": torch, "rearrange": rearrange, "choices": []}
+    exec(compile(mod, "sample.py", "exec"), env)
+    return env
+
+
+def case_customforward():
+    C, heads, depth, r, S, T, cd, n_train = 128, 2, 5, 8, 4, 77, 32, 4
+    st = make_st(C, heads, depth, cd, S)
+    W.load_into(st, seed=4)
+    st.eval()
+    env = _sample_py_functions()
+    env["choices"][:] = [0, 2]  # global `choices` (sample.py:274-277)
+    st.forward = env["customforward"].__get__(st, st.__class__)
+    refs = {}
+    for d, blk in enumerate(st.transformer_blocks):
+        blk.forward = env["_customforward"].__get__(blk, blk.__class__)
+        if hasattr(blk, "pose_emb_layers"):
+            refs[d] = W.tensor(f"references.{d}", (n_train + 1, r * r, C), seed=4)
+            blk.register_buffer("references", refs[d])
+    pose1 = synth.pose_batch(1, 2, seed=6, n_train=n_train)
+    pose = pose1 * 3  # 3-way CFG (sample.py:166-171)
+    x0 = W.tensor("x0", (3, C, r, r), seed=4)
+    x1 = W.tensor("x1", (3, C, r, r), seed=4)
+    ctx = W.tensor("ctx", (3, T, cd), seed=4)
+    out0, _, fgs, _, alphas, rgbs = st(x0, None, context=ctx, pose=pose)
+    rend = {d: blk.rendered_feat.clone() for d, blk in enumerate(st.transformer_blocks) if getattr(blk, "rendered_feat", None) is not None}
+    out1 = st(x1, None, context=ctx, pose=pose)[0]
+    npz("customforward_cfg3", cams=pack_cameras(pose), x0=x0, x1=x1, ctx=ctx, out0=out0, out1=out1, fg0=fgs[0], fg1=fgs[1],
+        rgb0=rgbs[0], rgb1=rgbs[1], rend0=rend[0], rend4=rend[4], choices=np.array([0, 2]))
+
+
+# ---------------------------------------------------------------- 5. UNet (reduced depth/width), dual-stream eval
+UNET_TINY = dict(in_channels=4, model_channels=64, out_channels=4, num_res_blocks=1, attention_resolutions=[2], channel_mult=[1, 2],
+                 num_head_channels=64, use_linear_in_transformer=True, transformer_depth=[1, 1], context_dim=32, adm_in_channels=16,
+                 num_classes="sequential", use_checkpoint=False, spatial_transformer_attn_type="softmax-xformers",
+                 image_cross_blocks=[0, 1, 2], rgb=True, far=2, num_samples=4, not_add_context_in_triplane=False, rgb_predict=True,
+                 add_lora=False, average=False, use_prev_weights_imp_sample=True, stratified=True, imp_sampling_percent=0.9)
+
+
+def case_unet():
+    net = ns.openaimodel.UNetModel(**UNET_TINY)
+    W.load_into(net, seed=5)
+    net.eval()
+    b, n, L, T = 1, 2, 16, 77
+    pose = synth.pose_batch(b, n, seed=7)
+    x = W.tensor("x", (b, 4, L, L), seed=5)
+    xin = W.tensor("input_ref", (b, n, 4, L, L), seed=5)
+    ctx = W.tensor("ctx", (b + b * n, T, 32), seed=5)
+    y = W.tensor("y", (b + b * n, 16), seed=5)
+    t = torch.tensor([500.0])
+    sref = torch.tensor([120.0])
+    out, fgs, alphas, rgbs = net(x, timesteps=t, context=ctx, y=y, pose=pose, input_ref=xin, sigmas_ref=sref, mask_ref=None)
+    assert len(fgs) == 3
+    npz("unet_tiny", cams=pack_cameras(pose), x=x, input_ref=xin, ctx=ctx, y=y, t=t, sigmas_ref=sref, out=out,
+        **{f"fg{i}": v for i, v in enumerate(fgs)}, **{f"alphas{i}": v for i, v in enumerate(alphas)}, **{f"rgb{i}": v for i, v in enumerate(rgbs)})
+    keyfile("unet_tiny", net)
+
+
+def case_sdxl_keys():
+    """state_dict names/shapes of the full SDXL-config UNet (configs/train_co3d_concept.yaml:27-54), built on the meta device."""
+    import yaml
+    cfg = yaml.safe_load(open(os.path.join(refshim.REF_ROOT, "configs", "train_co3d_concept.yaml")))
+    params = cfg["model"]["params"]["network_config"]["params"]
+    with torch.device("meta"):
+        net = ns.openaimodel.UNetModel(**params)
+    listing = keyfile("unet_sdxl", net)
+    print("sdxl keys:", len(listing), "params(M):", sum(int(np.prod(s)) for s in listing.values()) / 1e6)
+
+
+if __name__ == "__main__":
+    case_nerf(False)
+    case_nerf(True)
+    case_block(False)
+    case_block(True)
+    case_st_dual()
+    case_customforward()
+    case_unet()
+    case_sdxl_keys()
+    assert not os.path.exists(os.path.join(refshim.REF_ROOT, "sgm", "__pycache__")), "bytecode leaked into the reference tree"
