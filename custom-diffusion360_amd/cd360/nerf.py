@@ -1,0 +1,162 @@
+"""Host side of the fused FeatureNeRF render (the caller of cd360_nerf_mlp_aggregate).
+
+Restructures FeatureNeRFEncoding.forward (reference sgm/modules/nerfsd_pytorch3d.py:53-161) so that the
+`[b, n, hw, S, C+198]` concat is never formed.  With W1 = plane_coefs.0.weight split by input group
+  W1 = [ Wf (C) | Wx (96+3: enc16(q_i), q_i) | Wp (96+3: enc8(plucker_i), dir_i) ]
+and w_v = nviews.weight split as [ vf (C) | enc16(q_0), q_0 (99) | o_i^tgt (3) | enc16(o_i^tgt) (96) ]:
+
+  z_i(sample)  = bilinear(Y_i)(sample) + zP_i(ray) + Wx . [enc16(q_i), q_i]        Y_i = xref_i Wf^T
+  logit_i      = bilinear(lv_i)(sample) + c_i  (+ terms common to all views)        lv_i = xref_i vf,  zP_i = Wp.feat + b1
+  h(sample)    = W2 . sum_i softmax_i(logit) SiLU(z_i) + b2                          (softmax weights sum to 1)
+
+The three tables (Y, zP, lv) are plain library GEMMs over n*hw rows (S = 24 times fewer rows than the
+reference's per-sample Linear) and the rest happens inside one HIP kernel (csrc/nerf_fused.hip).
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional
+
+import numpy as np
+import torch
+
+from . import ops
+
+NUM_FREQS = 16
+
+
+def xyz_k_columns(C: int) -> list:
+    """Column of plane_coefs.0.weight feeding each of the kernel's 112 per-sample inputs (-1 = zero pad).
+    Kernel order: k = ks*16 + h*8 + j, pair = j>>1, w = ks*4 + pair; w < 24: (comp = w%3, freq = 2*(w//3) + h),
+    j even = sin, odd = cos; w == 24: raw q (h=0: q0, q1; h=1: q2).  Reference order (utils_cameraray.py:222-242):
+    enc = [sin f0 (xyz) ... sin f15 (xyz) | cos f0 (xyz) ... cos f15 (xyz)], then q (3)."""
+    cols = []
+    for ks in range(7):
+        for h in range(2):
+            for j in range(8):
+                w, is_cos = ks * 4 + (j >> 1), j & 1
+                if w < 24:
+                    comp, kf = w % 3, 2 * (w // 3) + h
+                    cols.append(C + (48 if is_cos else 0) + kf * 3 + comp)
+                elif w == 24:
+                    raw = {(0, 0): 0, (0, 1): 1, (1, 0): 2}.get((h, j), None)
+                    cols.append(-1 if raw is None else C + 96 + raw)
+                else:
+                    cols.append(-1)
+    return cols
+
+
+def positional_encoding(x: torch.Tensor, n_freqs: int) -> torch.Tensor:
+    """utils_cameraray.py:222-242 (only used here for the per-view constants: O(b*n) values)."""
+    start = -1 * (n_freqs / 2)
+    freqs = 2.0 ** torch.arange(start, start + n_freqs, device=x.device) * np.pi
+    return torch.cat([torch.sin(x * f) for f in freqs] + [torch.cos(x * f) for f in freqs], dim=-1)
+
+
+class FusedNerfWeights:
+    """Derived, cached forms of one FeatureNeRFEncoding's parameters."""
+
+    def __init__(self, W1, b1, W2, b2, wv, bv, Wd, dtype=torch.bfloat16):
+        C = W2.shape[0]
+        self.C = C
+        dev = W1.device
+        W1f = W1.detach().float()
+        self.Wf_t = W1f[:, :C].t().contiguous().to(dtype)  # [C, C]: Y = xref @ Wf_t
+        cols = xyz_k_columns(C)
+        Wk = torch.zeros(C, len(cols), dtype=torch.float32, device=dev)
+        idx = torch.tensor([c for c in cols if c >= 0], device=dev)
+        pos = torch.tensor([i for i, c in enumerate(cols) if c >= 0], device=dev)
+        Wk[:, pos] = W1f[:, idx]
+        self.Wk_f32 = Wk  # [C, 112] fp32 (kept for tests / re-quantisation)
+        self.Wk = Wk.to(torch.bfloat16).contiguous()
+        Wp = torch.zeros(104, C, dtype=torch.float32, device=dev)
+        Wp[:99] = W1f[:, C + 99:C + 198].t()
+        self.Wp_t = Wp.contiguous()  # [104, C] fp32
+        self.b1 = b1.detach().float().contiguous()
+        self.W2_t = W2.detach().t().contiguous().to(dtype)
+        self.b2 = b2.detach().to(dtype).contiguous()
+        wvf = wv.detach().float().reshape(-1)
+        self.vf = wvf[:C].contiguous()
+        self.v_otgt = wvf[C + 99:C + 102].contiguous()
+        self.v_otgt_enc = wvf[C + 102:C + 198].contiguous()
+        self.bv = bv.detach().float().reshape(())
+        self.Wd = Wd.detach().float().contiguous()  # [4, C]
+
+
+_grid_cache = {}
+
+
+def patch_positions(r: int, device, jitter: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """utils_cameraray.py:106-147 on the host (r floats), then uploaded; cached in eval mode."""
+    key = (r, str(device))
+    if jitter is None and key in _grid_cache:
+        return _grid_cache[key]
+    edges = torch.linspace(1, -1, r + 1)
+    if jitter is None:
+        pos = (edges[:-1] + edges[1:]) / 2
+    else:
+        center = (edges[1:] + edges[:-1]) / 2.0
+        upper = torch.cat([center, edges[-1:]], -1)
+        lower = torch.cat([edges[:1], center], -1)
+        pos = (lower + (upper - lower) * jitter.cpu())[:-1]
+    out = pos.to(device)
+    if jitter is None:
+        _grid_cache[key] = out
+    return out
+
+
+def depth_samples(num_samples: int, far: float, near: float, device, num_rays: int, jitter: Optional[torch.Tensor] = None):
+    """Raymarcher buffers + stratified_sampling (nerfsd_pytorch3d.py:248-259,308-330).
+    Returns (t, dists): [S] each in eval mode, [hw, S] with jitter."""
+    l = torch.linspace(near, near + (near + far), num_samples + 1)
+    if jitter is None:
+        return ((l[1:] + l[:-1]) / 2.0).to(device), (l[1:] - l[:-1]).to(device)
+    center = (l[1:] + l[:-1]) / 2.0
+    upper = torch.cat([center, l[-1:]], -1).to(device)
+    lower = torch.cat([l[:1], center], -1).to(device)
+    j = lower[None] + (upper[None] - lower[None]) * jitter.to(device)
+    return ((j[..., :-1] + j[..., 1:]) / 2.0).contiguous(), (j[..., 1:] - j[..., :-1]).contiguous()
+
+
+def view_constants(fw: FusedNerfWeights, cams: torch.Tensor) -> torch.Tensor:
+    """c_i = w_v[o_tgt].o_i^tgt + w_v[enc].enc16(o_i^tgt) + b_v, with o_i^tgt the reference camera centre in the
+    target view frame (nerfsd_pytorch3d.py:116-123,146-147).  cams [b, n+1, 16] -> [b, n] fp32."""
+    R = cams[..., :9].reshape(*cams.shape[:-1], 3, 3)
+    T = cams[..., 9:12]
+    center = -(T[..., None, :] * R).sum(-1)  # -T @ R^T
+    o = (center[:, 1:, :, None] * R[:, :1]).sum(-2) + T[:, :1]  # centre_i @ R_0 + T_0
+    return ((o * fw.v_otgt).sum(-1) + (positional_encoding(o, NUM_FREQS) * fw.v_otgt_enc).sum(-1) + fw.bv).contiguous()
+
+
+def fused_feature_nerf(fw: FusedNerfWeights, cams: torch.Tensor, xref: torch.Tensor, num_samples: int, far: float, near: float = 0.0,
+                       xy_jitter=None, depth_jitter=None, want_view_weights: bool = False, tables=None):
+    """cams [b, n+1, 16] fp32 (device), xref [b, n, hw, C] -> (h [b,hw,S,C] bf16, dec [b,hw,S,4] fp32, dists, view_weights|None)."""
+    b, n, hw, C = xref.shape
+    r = int(math.isqrt(hw))
+    dev = xref.device
+    xs = patch_positions(r, dev, None if xy_jitter is None else xy_jitter[0])
+    ys = patch_positions(r, dev, None if xy_jitter is None else xy_jitter[1])
+    t, dists = depth_samples(num_samples, far, near, dev, hw, depth_jitter)
+    if tables is None:
+        tables = reference_tables(fw, xref)
+    Y, lv = tables
+    pf = ops.plucker_features(cams, xs, ys).reshape(b * n * hw, 104)
+    zP = torch.addmm(fw.b1, pf, fw.Wp_t).to(torch.bfloat16).reshape(b * n, hw, C)
+    cview = view_constants(fw, cams)
+    g, logits, lse = ops.nerf_mlp_aggregate(cams, xs, ys, t, Y, zP, lv, cview, fw.Wk, want_logits=want_view_weights)
+    h = torch.addmm(fw.b2, g.reshape(-1, C), fw.W2_t).reshape(b, hw, num_samples, C)
+    dec = ops.rowdot4(h, fw.Wd)
+    vw = None
+    if want_view_weights:
+        vw = torch.softmax(logits, dim=1).reshape(b, n, hw, num_samples, 1)
+    return h, dec, dists, vw
+
+
+def reference_tables(fw: FusedNerfWeights, xref: torch.Tensor):
+    """Per-pixel tables that depend only on the reference features (cacheable across target poses and steps):
+    Y = xref @ Wf^T (bf16) and lv = xref @ vf (fp32)."""
+    b, n, hw, C = xref.shape
+    x2 = xref.reshape(b * n * hw, C)
+    Y = torch.mm(x2.to(fw.Wf_t.dtype), fw.Wf_t).reshape(b * n, hw, C)
+    lv = torch.mv(x2.float(), fw.vf).reshape(b * n, hw)
+    return Y.contiguous(), lv.contiguous()

@@ -1,0 +1,201 @@
+"""Torch-tensor front end of the C ABI.  torch owns memory and the stream; every call goes to libcd360_hip.so.
+
+No operator here has a PyTorch/CPU implementation: a CPU tensor (or a missing library) raises."""
+from __future__ import annotations
+
+import ctypes
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import Cd360Error, check
+
+_I64x3 = ctypes.c_int64 * 3
+
+
+def _stream() -> ctypes.c_void_p:
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
+    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise Cd360Error("cd360 operators run only on the GPU (HIP extension); got a CPU tensor")
+        if t.requires_grad and torch.is_grad_enabled():
+            raise NotImplementedError("the cd360 HIP operators are forward-only in this round; call them under torch.no_grad()")
+
+
+# ----------------------------------------------------------------------------------------------- attention
+def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, nk: Optional[int] = None,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """softmax(q k^T / 8) v per head, projection layouts consumed in place.
+    q [b, Nq, H*64], k [b, Nk, H*64] (last dim contiguous), vt [b, H*64, >=round_up(Nk,8)] (V transposed) -> [b, Nq, H*64]."""
+    _need_gpu(q, k, vt)
+    b, nq, inner = q.shape
+    assert inner == heads * 64 and q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16 and vt.dtype == torch.bfloat16
+    assert q.stride(2) == 1 and k.stride(2) == 1 and vt.stride(2) == 1
+    nk = k.shape[1] if nk is None else nk
+    if out is None:
+        out = torch.empty(b, nq, inner, dtype=torch.bfloat16, device=q.device)
+    lib = _lib.load()
+    check(
+        lib.cd360_attn_fwd_bf16(
+            _ptr(q), _ptr(k), _ptr(vt), _ptr(out), b, heads, nq, nk,
+            _I64x3(q.stride(0), 64, q.stride(1)), _I64x3(k.stride(0), 64, k.stride(1)),
+            _I64x3(vt.stride(0), 64 * vt.stride(1), vt.stride(1)), _I64x3(out.stride(0), 64, out.stride(1)),
+            64 ** -0.5, _stream()),
+        "cd360_attn_fwd_bf16")
+    return out
+
+
+def memory_efficient_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, attn_bias=None, op=None) -> torch.Tensor:
+    """Same contract as xformers.ops.memory_efficient_attention for the layout the reference uses:
+    q, k, v contiguous [B*H, N, 64] (sgm/modules/attention.py:393-408)."""
+    if attn_bias is not None:
+        raise NotImplementedError("attn_bias is not used on this path (attention.py:403)")
+    _need_gpu(q, k, v)
+    bh, nq, d = q.shape
+    nk = k.shape[1]
+    if d != 64:
+        raise Cd360Error(f"head dim {d} unsupported (SDXL uses 64)")
+    dt = q.dtype
+    q, k, v = (t.to(torch.bfloat16).contiguous() for t in (q, k, v))
+    lib = _lib.load()
+    ws = torch.empty(lib.cd360_attn_vt_workspace_bytes(bh, nk), dtype=torch.uint8, device=q.device)
+    out = torch.empty_like(q)
+    check(lib.cd360_attn_fwd_xformers_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(ws), bh, nq, nk, 64 ** -0.5, _stream()),
+          "cd360_attn_fwd_xformers_bf16")
+    return out.to(dt)
+
+
+# ----------------------------------------------------------------------------------------------- rays / projection
+def patch_rays(cams: torch.Tensor, xs: torch.Tensor, ys: torch.Tensor) -> torch.Tensor:
+    _need_gpu(cams, xs, ys)
+    b, n1, _ = cams.shape
+    r = xs.numel()
+    rays = torch.empty(b, n1, r * r, 6, dtype=torch.float32, device=cams.device)
+    check(_lib.load().cd360_patch_rays(_ptr(cams), _ptr(xs), _ptr(ys), _ptr(rays), b, n1 - 1, r, _stream()), "cd360_patch_rays")
+    return rays
+
+
+def ray_project_index(cams, xs, ys, t, want_points=True, want_grid=True, want_index=True):
+    """t: [S] or [hw, S] fp32.  Returns dict(points, grid, x0, y0, mask)."""
+    _need_gpu(cams, xs, ys, t)
+    b, n1, _ = cams.shape
+    n, r = n1 - 1, xs.numel()
+    hw, S = r * r, t.shape[-1]
+    stride = 0 if t.dim() == 1 else S
+    dev = cams.device
+    pts = torch.empty(b, hw, S, 3, dtype=torch.float32, device=dev) if want_points else None
+    grid = torch.empty(b, n, hw, S, 2, dtype=torch.float32, device=dev) if want_grid else None
+    x0 = torch.empty(b, n, hw, S, dtype=torch.int32, device=dev) if want_index else None
+    y0 = torch.empty_like(x0) if want_index else None
+    mask = torch.empty_like(x0) if want_index else None
+    check(_lib.load().cd360_ray_project_index(_ptr(cams), _ptr(xs), _ptr(ys), _ptr(t.contiguous()), stride, b, n, r, S, _ptr(pts), _ptr(grid),
+                                             _ptr(x0), _ptr(y0), _ptr(mask), _stream()), "cd360_ray_project_index")
+    return dict(points=pts, grid=grid, x0=x0, y0=y0, mask=mask)
+
+
+def feature_gather(xref: torch.Tensor, grid: torch.Tensor) -> torch.Tensor:
+    """xref [n_img, r*r, C] (fp32|bf16), grid [n_img, P, 2] fp32 -> [n_img, P, C]."""
+    _need_gpu(xref, grid)
+    n_img, hw, C = xref.shape
+    r = int(round(hw ** 0.5))
+    assert r * r == hw and grid.dtype == torch.float32
+    xref, grid = xref.contiguous(), grid.contiguous()
+    P = grid.shape[1]
+    out = torch.empty(n_img, P, C, dtype=xref.dtype, device=xref.device)
+    dt = {torch.float32: 0, torch.bfloat16: 1}[xref.dtype]
+    check(_lib.load().cd360_feature_gather(_ptr(xref), _ptr(grid), _ptr(out), n_img, P, r, C, dt, _stream()), "cd360_feature_gather")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- FeatureNeRF
+def plucker_features(cams, xs, ys) -> torch.Tensor:
+    _need_gpu(cams, xs, ys)
+    b, n1, _ = cams.shape
+    r = xs.numel()
+    out = torch.empty(b, n1 - 1, r * r, 104, dtype=torch.float32, device=cams.device)
+    check(_lib.load().cd360_plucker_features(_ptr(cams), _ptr(xs), _ptr(ys), _ptr(out), b, n1 - 1, r, _stream()), "cd360_plucker_features")
+    return out
+
+
+def nerf_k_padded() -> int:
+    return _lib.load().cd360_nerf_k_padded()
+
+
+def nerf_mlp_aggregate(cams, xs, ys, t, Y, zP, lv, cview, Wk, want_logits=False):
+    _need_gpu(cams, xs, ys, t, Y, zP, lv, cview, Wk)
+    b, n1, _ = cams.shape
+    n, r = n1 - 1, xs.numel()
+    hw, S = r * r, t.shape[-1]
+    C = Y.shape[-1]
+    assert Y.shape == (b * n, hw, C) and zP.shape == (b * n, hw, C) and Y.dtype == torch.bfloat16 and zP.dtype == torch.bfloat16
+    assert lv.shape == (b * n, hw) and lv.dtype == torch.float32 and cview.shape == (b, n) and cview.dtype == torch.float32
+    assert Wk.shape == (C, nerf_k_padded()) and Wk.dtype == torch.bfloat16
+    for x in (Y, zP, lv, cview, Wk):
+        assert x.is_contiguous()
+    stride = 0 if t.dim() == 1 else S
+    g = torch.empty(b, hw * S, C, dtype=torch.bfloat16, device=Y.device)
+    logits = torch.empty(b, n, hw * S, dtype=torch.float32, device=Y.device) if want_logits else None
+    lse = torch.empty(b, hw * S, 2, dtype=torch.float32, device=Y.device) if want_logits else None
+    check(_lib.load().cd360_nerf_mlp_aggregate(_ptr(cams), _ptr(xs), _ptr(ys), _ptr(t.contiguous()), stride, _ptr(Y), _ptr(zP), _ptr(lv),
+                                              _ptr(cview), _ptr(Wk), _ptr(g), _ptr(logits), _ptr(lse), b, n, r, S, C, _stream()),
+          "cd360_nerf_mlp_aggregate")
+    return g, logits, lse
+
+
+# ----------------------------------------------------------------------------------------------- volume rendering
+def volrender(feats, sigma_raw, dists, rgb_raw=None, want_weights=False, sigma_is_raw=True, rgb_is_raw=True):
+    """feats [b,hw,S,C] (fp32|bf16), sigma_raw [b,hw,S] fp32, dists [S] or [hw,S] fp32, rgb_raw [b,hw,S,3] fp32|None."""
+    _need_gpu(feats, sigma_raw, dists, rgb_raw)
+    b, hw, S, C = feats.shape
+    feats, sigma_raw, dists = feats.contiguous(), sigma_raw.contiguous().float(), dists.contiguous().float()
+    if rgb_raw is not None:
+        rgb_raw = rgb_raw.contiguous().float()
+    dev = feats.device
+    rendered = torch.empty(b, hw, C, dtype=feats.dtype, device=dev)
+    fg = torch.empty(b, hw, 1, dtype=torch.float32, device=dev)
+    alphas = torch.empty(b, hw, S, 1, dtype=torch.float32, device=dev)
+    weights = torch.empty(b, hw, S, 1, dtype=torch.float32, device=dev) if want_weights else None
+    rgb = torch.empty(b, hw, 3, dtype=torch.float32, device=dev) if rgb_raw is not None else None
+    dt = {torch.float32: 0, torch.bfloat16: 1}[feats.dtype]
+    stride = 0 if dists.dim() == 1 else S
+    check(_lib.load().cd360_volrender(_ptr(feats), _ptr(sigma_raw), _ptr(rgb_raw), _ptr(dists), stride, _ptr(rendered), _ptr(fg),
+                                     _ptr(alphas), _ptr(weights), _ptr(rgb), b, hw, S, C, dt, (0 if sigma_is_raw else 1) | (0 if rgb_is_raw else 2),
+                                     _stream()), "cd360_volrender")
+    return rendered, fg, alphas, weights, rgb
+
+
+def rowdot4(h: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """h [..., C] bf16, w [4, C] fp32 -> [..., 4] fp32 (FeatureNeRF decoder)."""
+    _need_gpu(h, w)
+    C = h.shape[-1]
+    assert h.dtype == torch.bfloat16 and h.is_contiguous() and w.shape == (4, C) and w.dtype == torch.float32 and w.is_contiguous()
+    rows = h.numel() // C
+    out = torch.empty(*h.shape[:-1], 4, dtype=torch.float32, device=h.device)
+    check(_lib.load().cd360_rowdot4_bf16(_ptr(h), _ptr(w), _ptr(out), rows, C, _stream()), "cd360_rowdot4_bf16")
+    return out
+
+
+# ----------------------------------------------------------------------------------------------- GroupNorm (+SiLU)
+def gn_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, silu: bool,
+            out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x: channels-last bf16 viewed as [N, P, C] (contiguous).  gamma/beta fp32 [C]."""
+    _need_gpu(x, gamma, beta)
+    N, P, C = x.shape
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    lib = _lib.load()
+    ws = torch.empty(lib.cd360_gn_workspace_bytes(N, P, C), dtype=torch.uint8, device=x.device)
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib.cd360_gn_silu_bf16(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(ws), N, P, C, groups, float(eps), int(silu), _stream()),
+          "cd360_gn_silu_bf16")
+    return out

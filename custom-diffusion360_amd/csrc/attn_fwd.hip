@@ -1,0 +1,248 @@
+// Flash attention forward, bf16 in / fp32 accumulate / bf16 out, head dim 64, no mask.
+//
+// Replaces the reference's only working attention operator,
+//   xformers.ops.memory_efficient_attention(q, k, v, attn_bias=None)      (sgm/modules/attention.py:393-408)
+// for all three call shapes of the pose path:
+//   self-attn  Nq = Nk = hw,  text cross-attn Nk = 77,  pose-token cross-attn Nq = hw*S (up to 98 304), Nk = 77.
+//
+// CDNA4 design (one wave = 32 query rows, 4 waves per workgroup, 64-key tiles):
+//   * "swapped" scores  S^T = K Q^T  with v_mfma_f32_32x32x16_bf16, so every lane owns ONE query column:
+//     the row max / row sum of the online softmax are in-register reductions plus one exchange with lane^32.
+//   * O^T = V^T P^T: the P^T B-operand is taken straight from the lane's own S^T accumulator registers
+//     (the contraction order over keys is permuted identically on the V^T side), so P never goes through LDS.
+//   * K tile in LDS is XOR-swizzled at 16-B granularity (conflict-free ds_read_b128); V arrives already
+//     transposed ([.., d, key], produced for free by the projection GEMM) and sits in LDS with a 136-B row
+//     pitch (conflict-free ds_read_b64).
+//   * all tensors are addressed through explicit strides, so the kernel reads the projection outputs
+//     [b, N, H*64] in place and writes [b, N, H*64] directly: no head split/merge copies.
+#include "cd360_common.h"
+
+namespace {
+
+struct AttnParams {
+  const uint16_t* q;
+  const uint16_t* k;
+  const uint16_t* vt;
+  uint16_t* o;
+  int B, H, Nq, Nk;
+  long q_sb, q_sh, q_sn;  // element strides, d contiguous
+  long k_sb, k_sh, k_sn;
+  long v_sb, v_sh, v_sd;  // vt[b][h][d][key], key contiguous
+  long o_sb, o_sh, o_sn;
+  float scale_log2e;
+  int n_qtiles;
+};
+
+constexpr int BM = 128;       // queries per workgroup
+constexpr int BN = 64;        // keys per tile
+constexpr int K_PITCH = 128;  // bytes per K row in LDS (64 d * 2 B), XOR-swizzled
+constexpr int V_PITCH = 136;  // bytes per V^T row in LDS (64 keys * 2 B + 8 B pad)
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[BN * K_PITCH + 64 * V_PITCH];
+  unsigned char* Ks = lds;
+  unsigned char* Vs = lds + BN * K_PITCH;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = tile / p.n_qtiles, qt = tile - bh * p.n_qtiles;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const uint16_t* qp = p.q + b * p.q_sb + h * p.q_sh;
+  const uint16_t* kp = p.k + b * p.k_sb + h * p.k_sh;
+  const uint16_t* vp = p.vt + b * p.v_sb + h * p.v_sh;
+  uint16_t* op = p.o + b * p.o_sb + h * p.o_sh;
+
+  const int qrow = qt * BM + wave * 32 + l31;
+  const bool qok = qrow < p.Nq;
+
+  bf16x8 qf[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (qok) v = *reinterpret_cast<const u32x4*>(qp + (long)qrow * p.q_sn + 16 * ks + 8 * hh);
+    qf[ks] = __builtin_bit_cast(bf16x8, v);
+  }
+
+  f32x16 oT[2];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { oT[0][i] = 0.f; oT[1][i] = 0.f; }
+  float m_run = -INFINITY, l_run = 0.f;
+
+  for (int kt0 = 0; kt0 < p.Nk; kt0 += BN) {
+    __syncthreads();  // previous tile fully consumed
+    const bool ragged = kt0 + BN > p.Nk;
+    // ---- stage K tile [64 keys][64 d] and V^T tile [64 d][64 keys] ----
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int row = (tid >> 3) + 32 * pass, chunk = tid & 7;
+      u32x4 kv = {0u, 0u, 0u, 0u};
+      const int key = kt0 + row;
+      if (key < p.Nk) kv = *reinterpret_cast<const u32x4*>(kp + (long)key * p.k_sn + chunk * 8);
+      *reinterpret_cast<u32x4*>(Ks + row * K_PITCH + ((chunk ^ ((row >> 1) & 7)) << 4)) = kv;
+
+      const int key0 = kt0 + chunk * 8;
+      u32x4 vv = {0u, 0u, 0u, 0u};
+      if (key0 < p.Nk) {
+        vv = *reinterpret_cast<const u32x4*>(vp + (long)row * p.v_sd + key0);
+        if (ragged) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            uint32_t w = vv[e];
+            if (key0 + 2 * e >= p.Nk) w &= 0xffff0000u;
+            if (key0 + 2 * e + 1 >= p.Nk) w &= 0x0000ffffu;
+            vv[e] = w;
+          }
+        }
+      }
+      u32x2 lo = {vv[0], vv[1]}, hi = {vv[2], vv[3]};
+      *reinterpret_cast<u32x2*>(Vs + row * V_PITCH + chunk * 16) = lo;
+      *reinterpret_cast<u32x2*>(Vs + row * V_PITCH + chunk * 16 + 8) = hi;
+    }
+    __syncthreads();
+
+    const int nkb = (p.Nk - kt0 > 32) ? 2 : 1;  // 32-key blocks with at least one valid key
+    // ---- S^T = K Q^T ----
+    f32x16 sT[2];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int i = 0; i < 16; ++i) sT[kb][i] = 0.f;
+      if (kb < nkb) {
+        const int krow = kb * 32 + l31;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ks + krow * K_PITCH + (((2 * ks + hh) ^ ((krow >> 1) & 7)) << 4));
+          sT[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], sT[kb], 0, 0, 0);
+        }
+      }
+    }
+    // ---- online softmax (this lane: one query column; keys spread over registers and lane^32) ----
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        float s = sT[kb][r] * p.scale_log2e;
+        if (ragged) {
+          const int key = kt0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+          if (key >= p.Nk) s = -INFINITY;
+        }
+        if (kb >= nkb) s = -INFINITY;
+        sT[kb][r] = s;
+        mx = fmaxf(mx, s);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    float rs = 0.f;
+    uint32_t pk[16];
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(sT[kb][r] - m_new);
+        const float p1 = __builtin_amdgcn_exp2f(sT[kb][r + 1] - m_new);
+        rs += p0 + p1;
+        pk[kb * 8 + (r >> 1)] = pack_bf16x2(p0, p1);
+      }
+    }
+    rs += __shfl_xor(rs, 32);
+    l_run = l_run * alpha + rs;
+    m_run = m_new;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { oT[0][i] *= alpha; oT[1][i] *= alpha; }
+
+    // ---- O^T += V^T P^T ----
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      if (kk < 2 * nkb) {
+        u32x4 pw = {pk[kk * 4 + 0], pk[kk * 4 + 1], pk[kk * 4 + 2], pk[kk * 4 + 3]};
+        const bf16x8 pb = __builtin_bit_cast(bf16x8, pw);
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const unsigned char* vrow = Vs + (db * 32 + l31) * V_PITCH + (16 * kk + 4 * hh) * 2;
+          const u32x2 v0 = *reinterpret_cast<const u32x2*>(vrow);
+          const u32x2 v1 = *reinterpret_cast<const u32x2*>(vrow + 16);
+          u32x4 vw = {v0[0], v0[1], v1[0], v1[1]};
+          oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vw), pb, oT[db], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  if (qok) {
+    const float inv = 1.f / l_run;
+    uint16_t* orow = op + (long)qrow * p.o_sn;
+#pragma unroll
+    for (int db = 0; db < 2; ++db) {
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = db * 32 + 8 * g + 4 * hh;
+        u32x2 w = {pack_bf16x2(oT[db][4 * g + 0] * inv, oT[db][4 * g + 1] * inv),
+                   pack_bf16x2(oT[db][4 * g + 2] * inv, oT[db][4 * g + 3] * inv)};
+        *reinterpret_cast<u32x2*>(orow + d) = w;
+      }
+    }
+  }
+}
+
+// [BH, N, 64] -> [BH, 64, ldk] transpose used by the xformers-layout entry point (V arrives row-major there).
+__global__ void transpose_v_kernel(const uint16_t* v, uint16_t* vt, int N, int ldk) {
+  __shared__ uint16_t t[64][66];
+  const int bh = blockIdx.y, n0 = blockIdx.x * 64;
+  const uint16_t* src = v + ((long)bh * N) * 64;
+  uint16_t* dst = vt + (long)bh * 64 * ldk;
+  for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
+    const int n = i >> 6, d = i & 63;
+    t[n][d] = (n0 + n < N) ? src[(long)(n0 + n) * 64 + d] : (uint16_t)0;
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
+    const int d = i >> 6, n = i & 63;
+    if (n0 + n < ldk) dst[(long)d * ldk + n0 + n] = t[n][d];
+  }
+}
+
+}  // namespace
+
+extern "C" int cd360_attn_fwd_bf16(const void* q, const void* k, const void* vt, void* o, int B, int H, int Nq, int Nk,
+                                   const int64_t* q_strides, const int64_t* k_strides, const int64_t* vt_strides,
+                                   const int64_t* o_strides, float scale, void* stream) {
+  if (!q || !k || !vt || !o || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return CD360_ERR_ARG;
+  AttnParams p;
+  p.q = (const uint16_t*)q; p.k = (const uint16_t*)k; p.vt = (const uint16_t*)vt; p.o = (uint16_t*)o;
+  p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk;
+  p.q_sb = q_strides[0]; p.q_sh = q_strides[1]; p.q_sn = q_strides[2];
+  p.k_sb = k_strides[0]; p.k_sh = k_strides[1]; p.k_sn = k_strides[2];
+  p.v_sb = vt_strides[0]; p.v_sh = vt_strides[1]; p.v_sd = vt_strides[2];
+  p.o_sb = o_strides[0]; p.o_sh = o_strides[1]; p.o_sn = o_strides[2];
+  // 16-byte vector access requirements
+  const int64_t all[] = {p.q_sb, p.q_sh, p.q_sn, p.k_sb, p.k_sh, p.k_sn, p.v_sb, p.v_sh, p.v_sd};
+  for (int64_t s : all) if (s % 8) return CD360_ERR_SHAPE;
+  if (p.o_sb % 4 || p.o_sh % 4 || p.o_sn % 4) return CD360_ERR_SHAPE;
+  if (p.v_sd < ((Nk + 7) / 8) * 8) return CD360_ERR_SHAPE;
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) % 16 || (uintptr_t)o % 8) return CD360_ERR_ARG;
+  p.scale_log2e = scale * 1.4426950408889634f;
+  p.n_qtiles = (Nq + BM - 1) / BM;
+  const long nwg = (long)p.n_qtiles * B * H;
+  if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+  CD360_LAUNCH_CHECK();
+  return CD360_OK;
+}
+
+// xformers-layout convenience entry: q,k,v,o all contiguous [BH, N, 64]; `vt_ws` is caller-provided workspace
+// of cd360_attn_vt_workspace_bytes(BH, Nk) bytes.
+extern "C" int64_t cd360_attn_vt_workspace_bytes(int BH, int Nk) { return (int64_t)BH * 64 * (((int64_t)Nk + 7) / 8 * 8) * 2; }
+
+extern "C" int cd360_attn_fwd_xformers_bf16(const void* q, const void* k, const void* v, void* o, void* vt_ws, int BH, int Nq,
+                                            int Nk, float scale, void* stream) {
+  if (!v || !vt_ws || BH <= 0) return CD360_ERR_ARG;
+  const int ldk = (Nk + 7) / 8 * 8;
+  hipLaunchKernelGGL(transpose_v_kernel, dim3((ldk + 63) / 64, BH), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)v,
+                     (uint16_t*)vt_ws, Nk, ldk);
+  CD360_LAUNCH_CHECK();
+  const int64_t qs[3] = {0, (int64_t)Nq * 64, 64}, ks[3] = {0, (int64_t)Nk * 64, 64}, vs[3] = {0, (int64_t)64 * ldk, ldk};
+  return cd360_attn_fwd_bf16(q, k, vt_ws, o, 1, BH, Nq, Nk, qs, ks, vs, qs, scale, stream);
+}

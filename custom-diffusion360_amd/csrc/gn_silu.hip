@@ -1,0 +1,130 @@
+// K7: GroupNorm (fp32 statistics, as the reference's GroupNorm32: sgm/modules/diffusionmodules/util.py:309-311)
+// with an optional fused SiLU, on channels-last bf16 activations [N, P=H*W, C].
+// Brackets the injected transformer blocks: ResBlock in/out layers (openaimodel.py:280-328, GN -> SiLU -> conv)
+// and SpatialTransformer.norm (attention.py:118-121,748, GN only, eps 1e-6).  HBM-bound: 2 reads + 1 write of the
+// activation instead of the 5-6 passes of the eager float()/group_norm/type()/silu chain, and the channels-last
+// result is already the "b (h w) c" token layout the transformer wants (no rearrange copy).
+//   pass 1: per-(n, slab) per-channel partial sums (coalesced 16-byte reads), deterministic (no atomics)
+//   pass 2: each workgroup rebuilds scale/shift per channel in LDS from the partials, then streams its slab.
+#include "cd360_common.h"
+
+namespace {
+
+constexpr int MAX_C = 4096;
+
+__global__ __launch_bounds__(256) void gn_partial_kernel(const uint16_t* __restrict__ x, float* __restrict__ partial, int P, int C,
+                                                         int nslab) {
+  // grid: (nslab, N); partial [N, nslab, C, 2].  Thread (row, cv) sums 8 channels over pixels row, row+rstep, ...
+  // then the rows are added in a fixed order: bit-reproducible.
+  __shared__ float red[2 * MAX_C];  // [rstep][C][2], rstep*C <= 2048 whenever rstep > 1
+  const int n = blockIdx.y, slab = blockIdx.x, CV = C >> 3, tid = threadIdx.x;
+  const int p0 = (int)((long)P * slab / nslab), p1 = (int)((long)P * (slab + 1) / nslab);
+  const bool wide = CV > 256;
+  const int rstep = wide ? 1 : 256 / CV;
+  const int row = wide ? 0 : tid / CV;
+  if (row < rstep) {
+    for (int cv = wide ? tid : tid % CV; cv < CV; cv += wide ? 256 : CV) {
+      float s[8], ss[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { s[e] = 0.f; ss[e] = 0.f; }
+      for (int pix = p0 + row; pix < p1; pix += rstep) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>(x + ((long)n * P + pix) * C + cv * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a = bf16lo_to_f32(v[e]), c = bf16hi_to_f32(v[e]);
+          s[2 * e] += a; ss[2 * e] = fmaf(a, a, ss[2 * e]);
+          s[2 * e + 1] += c; ss[2 * e + 1] = fmaf(c, c, ss[2 * e + 1]);
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        red[2 * ((long)row * C + cv * 8 + e)] = s[e];
+        red[2 * ((long)row * C + cv * 8 + e) + 1] = ss[e];
+      }
+    }
+  }
+  __syncthreads();
+  float* dst = partial + ((long)n * nslab + slab) * 2 * C;
+  for (int i = tid; i < 2 * C; i += 256) {
+    float acc = 0.f;
+    for (int rr = 0; rr < rstep; ++rr) acc += red[(long)rr * 2 * C + i];
+    dst[i] = acc;
+  }
+}
+
+template <bool SILU>
+__global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ x, const float* __restrict__ partial,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       uint16_t* __restrict__ y, int P, int C, int G, float eps, int nslab,
+                                                       int nslab_apply) {
+  __shared__ float ab[2 * MAX_C];  // per channel: scale, shift
+  __shared__ float gstat[2 * 64];
+  const int n = blockIdx.y, slab = blockIdx.x, cpg = C / G, CV = C >> 3;
+  // group statistics from the per-channel partial sums (fixed summation order: deterministic)
+  for (int g = threadIdx.x; g < G; g += blockDim.x) {
+    float s = 0.f, ss = 0.f;
+    for (int sl = 0; sl < nslab; ++sl) {
+      const float* src = partial + ((long)n * nslab + sl) * 2 * C + 2 * g * cpg;
+      for (int c = 0; c < cpg; ++c) { s += src[2 * c]; ss += src[2 * c + 1]; }
+    }
+    const float cnt = (float)cpg * (float)P;
+    const float mean = s / cnt;
+    const float var = fmaxf(ss / cnt - mean * mean, 0.f);
+    gstat[2 * g] = mean;
+    gstat[2 * g + 1] = 1.f / sqrtf(var + eps);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const int g = c / cpg;
+    const float a = gstat[2 * g + 1] * gamma[c];
+    ab[2 * c] = a;
+    ab[2 * c + 1] = beta[c] - gstat[2 * g] * a;
+  }
+  __syncthreads();
+  const long i0 = (long)P * slab / nslab_apply * CV, i1 = (long)P * (slab + 1) / nslab_apply * CV;
+  for (long it = i0 + threadIdx.x; it < i1; it += blockDim.x) {
+    const long pix = it / CV;
+    const int cv = (int)(it - pix * CV);
+    const long off = ((long)n * P + pix) * C + cv * 8;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(x + off);
+    float o[8];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      o[2 * e] = fmaf(bf16lo_to_f32(v[e]), ab[2 * (cv * 8 + 2 * e)], ab[2 * (cv * 8 + 2 * e) + 1]);
+      o[2 * e + 1] = fmaf(bf16hi_to_f32(v[e]), ab[2 * (cv * 8 + 2 * e + 1)], ab[2 * (cv * 8 + 2 * e + 1) + 1]);
+    }
+    if (SILU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = o[e] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * o[e]));
+    }
+    u32x4 w = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3]), pack_bf16x2(o[4], o[5]), pack_bf16x2(o[6], o[7])};
+    *reinterpret_cast<u32x4*>(y + off) = w;
+  }
+}
+
+}  // namespace
+
+extern "C" int64_t cd360_gn_workspace_bytes(int N, int P, int C) {
+  const int nslab = P >= 4096 ? 32 : (P >= 1024 ? 16 : (P >= 256 ? 4 : 1));
+  return (int64_t)N * nslab * 2 * C * 4;
+}
+
+// x, y: [N, P, C] bf16 channels-last (y may alias x); gamma, beta: [C] fp32; ws: cd360_gn_workspace_bytes(N, P, C) bytes
+extern "C" int cd360_gn_silu_bf16(const void* x, const void* gamma, const void* beta, void* y, void* ws, int N, int P, int C, int G,
+                                  float eps, int silu, void* stream) {
+  if (!x || !gamma || !beta || !y || !ws || N <= 0 || P <= 0 || C <= 0 || G <= 0) return CD360_ERR_ARG;
+  if (C % 8 || C % G || C > MAX_C || G > 64) return CD360_ERR_SHAPE;
+  const int nslab = P >= 4096 ? 32 : (P >= 1024 ? 16 : (P >= 256 ? 4 : 1));
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nslab, N), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (float*)ws, P, C, nslab);
+  CD360_LAUNCH_CHECK();
+  const int nslab_apply = (int)(((long)P * (C / 8) + 256 * 8 - 1) / (256 * 8));
+  const int na = nslab_apply < 1 ? 1 : (nslab_apply > 1024 ? 1024 : nslab_apply);
+  if (silu)
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(na, N), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (const float*)ws,
+                       (const float*)gamma, (const float*)beta, (uint16_t*)y, P, C, G, eps, nslab, na);
+  else
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(na, N), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (const float*)ws,
+                       (const float*)gamma, (const float*)beta, (uint16_t*)y, P, C, G, eps, nslab, na);
+  CD360_LAUNCH_CHECK();
+  return CD360_OK;
+}

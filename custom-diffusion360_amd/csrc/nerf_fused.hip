@@ -1,0 +1,283 @@
+// A5-A8 fused: FeatureNeRFEncoding.forward (sgm/modules/nerfsd_pytorch3d.py:53-158) without ever
+// materialising the [b, n, hw, S, C+198] tensor the reference builds with torch.cat.
+//
+// Algebra (exact in real arithmetic):
+//   plane_coefs.0 is linear, so its action on the bilinearly gathered features equals the bilinear
+//   gather of  Y = xref @ W1[:, :C]^T  (one GEMM over n*hw pixels instead of n*hw*S samples);
+//   its action on [enc8(plucker), dir] depends on (view, ray) only -> table zP (+ bias b1);
+//   only [enc16(q_i), q_i] (99 inputs) is truly per (view, ray, sample): that part runs here on MFMA.
+//   The view softmax weights sum to 1, so plane_coefs.2 commutes with the weighted sum over views
+//   and is applied once per sample afterwards (host GEMM on the output of this kernel).
+//   The view logit keeps only its view-dependent terms: the bilinear gather of lv = xref @ w_v[:C]
+//   plus a per-view constant; the [enc16(q_0), q_0] terms are common to all views and cancel.
+//
+// Kernel: one wave = 32 samples x 64 channels.  z^T[channel, sample] = Wk[channel, 112] . F^T[112, sample]
+// on v_mfma_f32_32x32x16_bf16 with the 112 = 96 sin/cos + 3 xyz (+ pad) inputs generated in registers in
+// MFMA B-operand layout (v_sin/v_cos on exact power-of-two phase scalings; no tables, no LDS);
+// the gathered Y / zP rows are added with fp32 bilinear weights; SiLU; flash-style online softmax over views.
+// Each (lane, lane^32) pair owns one sample and reads one full 128-B line per texel corner.
+#include "cd360_geom.h"
+
+namespace {
+
+constexpr int CN = 64;          // channels per workgroup
+constexpr int KP = 112;         // padded K of the per-sample GEMM (7 k-steps of 16)
+constexpr int W_PITCH = 240;    // bytes per Wk row in LDS (224 + 16 pad: conflict-free ds_read_b128)
+constexpr int TILES_PER_WAVE = 4;
+constexpr int PTS_PER_WG = 4 * 32 * TILES_PER_WAVE;
+
+struct NerfParams {
+  const float* cams;      // [b, n+1, 16]
+  const float* xs;        // [r]
+  const float* ys;        // [r]
+  const float* t;         // [hw, S] or [S]
+  const uint16_t* Y;      // [b*n, hw, C] bf16
+  const uint16_t* zP;     // [b*n, hw, C] bf16 (bias folded in)
+  const float* lv;        // [b*n, hw]
+  const float* cview;     // [b, n]
+  const uint16_t* Wk;     // [C, KP] bf16, k-permuted (see nerf.py: xyz_k_columns)
+  uint16_t* g;            // [b, hw*S, C] bf16 out: sum_i softmax_i * silu(z_i)
+  float* logits;          // optional [b, n, hw*S]
+  float* lse;             // optional [b, hw*S, 2] = (max, sum)
+  int b, n, r, S, C, t_ray_stride, ncc, ngroups;
+};
+
+// A-operand row i of a 32-channel block holds the weights of channel offset pos(i), so that MFMA output
+// register r of lane half h is channel 16*h + r (16 consecutive channels per lane).
+__device__ __forceinline__ int chan_pos(int i) { return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3); }
+
+__global__ __launch_bounds__(256, 2) void nerf_fused_kernel(NerfParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char Ws[CN * W_PITCH];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int hw = p.r * p.r;
+  const long npts = (long)hw * p.S;
+
+  // logical work item: [cc][b][group]  (chunk-major so that one XCD's L2 holds few channel slices)
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int cc = wg / (p.b * p.ngroups);
+  const int rem = wg - cc * (p.b * p.ngroups);
+  const int bi = rem / p.ngroups, grp = rem - bi * p.ngroups;
+  const int ch0 = cc * CN;
+
+  // ---- stage this chunk's Wk rows into LDS ----
+  for (int idx = tid; idx < CN * (KP / 8); idx += 256) {
+    const int row = idx / (KP / 8), c8 = idx - row * (KP / 8);
+    *reinterpret_cast<u32x4*>(Ws + row * W_PITCH + c8 * 16) =
+        *reinterpret_cast<const u32x4*>(p.Wk + (long)(ch0 + row) * KP + c8 * 8);
+  }
+  __syncthreads();
+
+  const Cam c0 = load_cam(p.cams + (long)bi * (p.n + 1) * 16);
+  const float hs = hh ? 2.f : 1.f;
+  const int arow0 = chan_pos(l31);  // my A-operand row within a 32-channel block
+
+  for (int tw = 0; tw < TILES_PER_WAVE; ++tw) {
+    const long pt0 = (long)grp * PTS_PER_WG + (wave * TILES_PER_WAVE + tw) * 32;
+    if (pt0 >= npts) break;  // wave-uniform
+    const long pt = pt0 + l31;
+    const bool valid = pt < npts;
+    const long ptc = valid ? pt : npts - 1;
+    const int k = (int)(ptc / p.S), s = (int)(ptc - (long)k * p.S);
+    float o[3], d[3], P[3];
+    patch_ray(c0, p.xs[k % p.r], p.ys[k / p.r], o, d);
+    const float ts = p.t[(long)k * p.t_ray_stride + s];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) P[j] = o[j] + ts * d[j];
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 g[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { g[0][i] = 0.f; g[1][i] = 0.f; }
+
+    for (int iv = 0; iv < p.n; ++iv) {
+      const Cam ci = load_cam(p.cams + ((long)bi * (p.n + 1) + 1 + iv) * 16);
+      float q[3];
+      world_to_view(ci, P, q);
+      const Corner cr = bilinear_corner(grid_coord(ci.f[0], ci.c[0], q[0], q[2]), grid_coord(ci.f[1], ci.c[1], q[1], q[2]), p.r);
+      const int x0 = min(max(cr.x0, 0), p.r - 1), x1 = min(max(cr.x0 + 1, 0), p.r - 1);
+      const int y0 = min(max(cr.y0, 0), p.r - 1), y1 = min(max(cr.y0 + 1, 0), p.r - 1);
+      const long img = (long)bi * p.n + iv;
+      const long pix[4] = {img * hw + (long)y0 * p.r + x0, img * hw + (long)y0 * p.r + x1, img * hw + (long)y1 * p.r + x0,
+                           img * hw + (long)y1 * p.r + x1};
+      float w[4] = {(1.f - cr.tx) * (1.f - cr.ty), cr.tx * (1.f - cr.ty), (1.f - cr.tx) * cr.ty, cr.tx * cr.ty};
+#pragma unroll
+      for (int c = 0; c < 4; ++c) if (!((cr.mask >> c) & 1)) w[c] = 0.f;
+
+      // ---- issue the gathers early: 4 corners of Y (this lane's 2 x 16 channels) + zP row + lv ----
+      u32x4 yv[4][2][2];
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          const uint16_t* src = p.Y + pix[c] * p.C + ch0 + mb * 32 + 16 * hh;
+          yv[c][mb][0] = *reinterpret_cast<const u32x4*>(src);
+          yv[c][mb][1] = *reinterpret_cast<const u32x4*>(src + 8);
+        }
+      u32x4 zp[2][2];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        const uint16_t* src = p.zP + (img * hw + k) * p.C + ch0 + mb * 32 + 16 * hh;
+        zp[mb][0] = *reinterpret_cast<const u32x4*>(src);
+        zp[mb][1] = *reinterpret_cast<const u32x4*>(src + 8);
+      }
+      float logit = p.cview[bi * p.n + iv];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) logit = fmaf(w[c], p.lv[pix[c]], logit);
+
+      // ---- per-sample inputs in B-operand layout: lane half h handles frequencies 2*kfp + h ----
+      const float qh[3] = {q[0] * hs, q[1] * hs, q[2] * hs};
+      f32x16 z[2];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { z[0][i] = 0.f; z[1][i] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 7; ++ks) {
+        uint32_t fw[4];
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+          const int wi = ks * 4 + pr;
+          if (wi < 24) {
+            const int comp = wi % 3, kfp = wi / 3;
+            const float rev = __builtin_amdgcn_fractf(qh[comp] * __builtin_bit_cast(float, (uint32_t)((127 + 2 * kfp - 9) << 23)));
+            fw[pr] = pack_bf16x2(__builtin_amdgcn_sinf(rev), __builtin_amdgcn_cosf(rev));
+          } else if (wi == 24) {
+            fw[pr] = pack_bf16x2(hh ? q[2] : q[0], hh ? 0.f : q[1]);
+          } else {
+            fw[pr] = 0u;
+          }
+        }
+        u32x4 fv = {fw[0], fw[1], fw[2], fw[3]};
+        const bf16x8 fb = __builtin_bit_cast(bf16x8, fv);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ws + (mb * 32 + arow0) * W_PITCH + ks * 32 + hh * 16);
+          z[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, fb, z[mb], 0, 0, 0);
+        }
+      }
+
+      // ---- online softmax over views ----
+      const float lg = logit * 1.4426950408889634f;
+      const float m_new = fmaxf(m_run, lg);
+      const float sc = __builtin_amdgcn_exp2f(m_run - m_new);
+      const float a = __builtin_amdgcn_exp2f(lg - m_new);
+      l_run = fmaf(l_run, sc, a);
+      m_run = m_new;
+      if (p.logits) {
+        if (valid && hh == 0 && cc == 0) p.logits[((long)bi * p.n + iv) * npts + pt] = logit;
+      }
+
+      // ---- z += zP + bilinear(Y);  g = g*sc + a*silu(z) ----
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int r0 = half * 8 + 2 * e;
+            float z0 = z[mb][r0] + bf16lo_to_f32(zp[mb][half][e]);
+            float z1 = z[mb][r0 + 1] + bf16hi_to_f32(zp[mb][half][e]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              z0 = fmaf(w[c], bf16lo_to_f32(yv[c][mb][half][e]), z0);
+              z1 = fmaf(w[c], bf16hi_to_f32(yv[c][mb][half][e]), z1);
+            }
+            const float s0 = z0 * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z0));
+            const float s1 = z1 * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z1));
+            g[mb][r0] = fmaf(a, s0, g[mb][r0] * sc);
+            g[mb][r0 + 1] = fmaf(a, s1, g[mb][r0 + 1] * sc);
+          }
+        }
+      }
+    }
+
+    if (valid) {
+      const float inv = 1.f / l_run;
+      uint16_t* dst = p.g + ((long)bi * npts + pt) * p.C + ch0 + 16 * hh;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        u32x4 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o0[e] = pack_bf16x2(g[mb][2 * e] * inv, g[mb][2 * e + 1] * inv);
+          o1[e] = pack_bf16x2(g[mb][8 + 2 * e] * inv, g[mb][8 + 2 * e + 1] * inv);
+        }
+        *reinterpret_cast<u32x4*>(dst + mb * 32) = o0;
+        *reinterpret_cast<u32x4*>(dst + mb * 32 + 8) = o1;
+      }
+      if (p.lse && hh == 0 && cc == 0) {
+        p.lse[((long)bi * npts + pt) * 2] = m_run * 0.6931471805599453f;
+        p.lse[((long)bi * npts + pt) * 2 + 1] = l_run;
+      }
+    }
+  }
+}
+
+// (view, ray)-only inputs of plane_coefs.0: [enc8(plucker(target ray in ref-i frame)) 96 | dir 3]
+// (nerfsd_pytorch3d.py:104-112,130-131; utils_cameraray.py:201-242,270-292).  out [b, n, hw, 104] fp32 (99 + 5 zero pad)
+__global__ void plucker_features_kernel(const float* __restrict__ cams, const float* __restrict__ xs, const float* __restrict__ ys,
+                                        float* __restrict__ out, int b, int n, int r) {
+  const int hw = r * r;
+  const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (long)b * n * hw) return;
+  const int k = (int)(gid % hw), iv = (int)((gid / hw) % n), bi = (int)(gid / ((long)hw * n));
+  const Cam c0 = load_cam(cams + (long)bi * (n + 1) * 16);
+  const Cam ci = load_cam(cams + ((long)bi * (n + 1) + 1 + iv) * 16);
+  float o[3], d[3], co[3], cd[3];
+  patch_ray(c0, xs[k % r], ys[k / r], o, d);
+  world_to_view(ci, o, co);
+  rotate_to_view(ci, d, cd);
+  const float nrm = sqrtf(fmaf(cd[2], cd[2], fmaf(cd[1], cd[1], cd[0] * cd[0])));
+  float v[6] = {cd[0] / nrm, cd[1] / nrm, cd[2] / nrm, 0.f, 0.f, 0.f};
+  v[3] = co[1] * v[2] - co[2] * v[1];
+  v[4] = co[2] * v[0] - co[0] * v[2];
+  v[5] = co[0] * v[1] - co[1] * v[0];
+  float* dst = out + gid * 104;
+#pragma unroll
+  for (int kf = 0; kf < 8; ++kf) {
+    const float freq = __builtin_bit_cast(float, (uint32_t)((127 + kf - 4) << 23)) * 3.14159274101257324f;
+#pragma unroll
+    for (int c = 0; c < 6; ++c) {
+      const float arg = v[c] * freq;
+      dst[kf * 6 + c] = sinf(arg);
+      dst[48 + kf * 6 + c] = cosf(arg);
+    }
+  }
+  dst[96] = cd[0]; dst[97] = cd[1]; dst[98] = cd[2];
+#pragma unroll
+  for (int j = 99; j < 104; ++j) dst[j] = 0.f;
+}
+
+}  // namespace
+
+extern "C" int cd360_plucker_features(const void* cams, const void* xs, const void* ys, void* out, int b, int n, int r, void* stream) {
+  if (!cams || !xs || !ys || !out || b <= 0 || n <= 0 || r <= 0) return CD360_ERR_ARG;
+  const long total = (long)b * n * r * r;
+  hipLaunchKernelGGL(plucker_features_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)cams, (const float*)xs, (const float*)ys, (float*)out, b, n, r);
+  CD360_LAUNCH_CHECK();
+  return CD360_OK;
+}
+
+extern "C" int cd360_nerf_k_padded(void) { return KP; }
+
+// See NerfParams for layouts.  C must be a multiple of 64.  logits / lse may be NULL.
+extern "C" int cd360_nerf_mlp_aggregate(const void* cams, const void* xs, const void* ys, const void* t, int t_ray_stride, const void* Y,
+                                        const void* zP, const void* lv, const void* cview, const void* Wk, void* g, void* logits,
+                                        void* lse, int b, int n, int r, int S, int C, void* stream) {
+  if (!cams || !xs || !ys || !t || !Y || !zP || !lv || !cview || !Wk || !g) return CD360_ERR_ARG;
+  if (b <= 0 || n <= 0 || r <= 0 || S <= 0 || C <= 0 || C % CN) return CD360_ERR_SHAPE;
+  if (t_ray_stride != 0 && t_ray_stride != S) return CD360_ERR_SHAPE;
+  if (((uintptr_t)Y | (uintptr_t)zP | (uintptr_t)Wk | (uintptr_t)g) % 16) return CD360_ERR_ARG;
+  NerfParams p;
+  p.cams = (const float*)cams; p.xs = (const float*)xs; p.ys = (const float*)ys; p.t = (const float*)t;
+  p.Y = (const uint16_t*)Y; p.zP = (const uint16_t*)zP; p.lv = (const float*)lv; p.cview = (const float*)cview;
+  p.Wk = (const uint16_t*)Wk; p.g = (uint16_t*)g; p.logits = (float*)logits; p.lse = (float*)lse;
+  p.b = b; p.n = n; p.r = r; p.S = S; p.C = C; p.t_ray_stride = t_ray_stride;
+  p.ncc = C / CN;
+  const long npts = (long)r * r * S;
+  p.ngroups = (int)((npts + PTS_PER_WG - 1) / PTS_PER_WG);
+  const long nwg = (long)p.ncc * b * p.ngroups;
+  if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
+  hipLaunchKernelGGL(nerf_fused_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+  CD360_LAUNCH_CHECK();
+  return CD360_OK;
+}

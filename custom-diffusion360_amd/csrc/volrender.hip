@@ -1,0 +1,150 @@
+// A10: _TruncExp forward + VolRender (sgm/modules/attention.py:192-199,590-594; sgm/modules/nerfsd_pytorch3d.py:170-231).
+//   sigma = exp(sigma_raw); dd = dists*sigma; alpha = 1-exp(-dd); Tr = exp(-excl_cumsum(dd)); w = nan_to_num(alpha*Tr)
+//   rendered = sum_s w*feat ; fg = sum_s w ; rgb = sum_s w*sigmoid(rgb_raw)
+// HBM-bound scan over S samples per ray: one work item = (ray, 8 channels); the S weights are recomputed per item
+// (S=24 scalar exps, negligible next to S x 16-byte feature reads) so the features are streamed exactly once.
+#include "cd360_common.h"
+
+namespace {
+
+constexpr int MAX_S = 64;
+
+template <bool BF16>
+__global__ void volrender_kernel(const void* __restrict__ feats_, const float* __restrict__ sigma_raw, const float* __restrict__ rgb_raw,
+                                 const float* __restrict__ dists, int d_ray_stride, void* __restrict__ rendered_, float* __restrict__ fg,
+                                 float* __restrict__ alphas, float* __restrict__ weights, float* __restrict__ rgb, int b, int hw, int S,
+                                 int C, int flags) {
+  constexpr int VEC = BF16 ? 8 : 4;
+  const int cpv = C / VEC;
+  const long nrays = (long)b * hw;
+  const long total = nrays * cpv;
+  for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+    const long ray = gid / cpv;
+    const int cv = (int)(gid - ray * cpv);
+    const int k = (int)(ray % hw);
+    const float* sr = sigma_raw + ray * S;
+    const float* dr = dists + (long)k * d_ray_stride;
+    float acc[VEC];
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) acc[e] = 0.f;
+    float cum = 0.f, fgsum = 0.f, c0 = 0.f, c1 = 0.f, c2 = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const float dd = dr[s] * ((flags & 1) ? sr[s] : expf(sr[s]));
+      const float alpha = 1.f - expf(-dd);
+      float w = alpha * expf(-cum);
+      cum = cum + dd;
+      if (w != w) w = 0.f;
+      w = fminf(fmaxf(w, -3.402823466e38f), 3.402823466e38f);
+      const long foff = (ray * S + s) * (long)C + (long)cv * VEC;
+      if (BF16) {
+        const u32x4 v = *reinterpret_cast<const u32x4*>((const uint16_t*)feats_ + foff);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc[2 * e] = acc[2 * e] + w * bf16lo_to_f32(v[e]);
+          acc[2 * e + 1] = acc[2 * e + 1] + w * bf16hi_to_f32(v[e]);
+        }
+      } else {
+        const f32x4 v = *reinterpret_cast<const f32x4*>((const float*)feats_ + foff);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = acc[e] + w * v[e];
+      }
+      if (cv == 0) {
+        fgsum = fgsum + w;
+        if (alphas) alphas[ray * S + s] = alpha;
+        if (weights) weights[ray * S + s] = w;
+        if (rgb_raw) {
+          const float* rr = rgb_raw + (ray * S + s) * 3;
+          if (flags & 2) {
+            c0 = c0 + w * rr[0]; c1 = c1 + w * rr[1]; c2 = c2 + w * rr[2];
+          } else {
+            c0 = c0 + w * (1.f / (1.f + expf(-rr[0])));
+            c1 = c1 + w * (1.f / (1.f + expf(-rr[1])));
+            c2 = c2 + w * (1.f / (1.f + expf(-rr[2])));
+          }
+        }
+      }
+    }
+    const long ooff = ray * (long)C + (long)cv * VEC;
+    if (BF16) {
+      u32x4 o = {pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]), pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7])};
+      *reinterpret_cast<u32x4*>((uint16_t*)rendered_ + ooff) = o;
+    } else {
+      f32x4 o = {acc[0], acc[1], acc[2], acc[3]};
+      *reinterpret_cast<f32x4*>((float*)rendered_ + ooff) = o;
+    }
+    if (cv == 0) {
+      if (fg) fg[ray] = fgsum;
+      if (rgb && rgb_raw) { rgb[ray * 3] = c0; rgb[ray * 3 + 1] = c1; rgb[ray * 3 + 2] = c2; }
+    }
+  }
+}
+
+}  // namespace
+
+// feats [b, hw, S, C] (dtype 0 fp32 / 1 bf16), sigma_raw [b, hw, S] fp32 (pre-exp), rgb_raw [b, hw, S, 3] fp32 (pre-sigmoid) or NULL,
+// dists [hw, S] (d_ray_stride = S) or [S] (d_ray_stride = 0).  flags: bit0 = sigma_raw is already exp'ed, bit1 = rgb_raw is already sigmoid'ed.
+// out: rendered [b, hw, C] (same dtype as feats), fg [b, hw], alphas [b, hw, S], weights [b, hw, S], rgb [b, hw, 3] (fp32; any may be NULL)
+extern "C" int cd360_volrender(const void* feats, const void* sigma_raw, const void* rgb_raw, const void* dists, int d_ray_stride,
+                               void* rendered, void* fg, void* alphas, void* weights, void* rgb, int b, int hw, int S, int C, int dtype,
+                               int flags, void* stream) {
+  if (!feats || !sigma_raw || !dists || !rendered || b <= 0 || hw <= 0 || S <= 0 || C <= 0) return CD360_ERR_ARG;
+  if (S > MAX_S || (dtype != 0 && dtype != 1) || C % (dtype ? 8 : 4)) return CD360_ERR_SHAPE;
+  if (d_ray_stride != 0 && d_ray_stride != S) return CD360_ERR_SHAPE;
+  const long total = (long)b * hw * (C / (dtype ? 8 : 4));
+  const unsigned blocks = (unsigned)((total + 255) / 256 > 256 * 32 ? 256 * 32 : (total + 255) / 256);
+  if (dtype)
+    hipLaunchKernelGGL(volrender_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, feats, (const float*)sigma_raw,
+                       (const float*)rgb_raw, (const float*)dists, d_ray_stride, rendered, (float*)fg, (float*)alphas, (float*)weights,
+                       (float*)rgb, b, hw, S, C, flags);
+  else
+    hipLaunchKernelGGL(volrender_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, feats, (const float*)sigma_raw,
+                       (const float*)rgb_raw, (const float*)dists, d_ray_stride, rendered, (float*)fg, (float*)alphas, (float*)weights,
+                       (float*)rgb, b, hw, S, C, flags);
+  CD360_LAUNCH_CHECK();
+  return CD360_OK;
+}
+
+// ---- A9: decoder (zero-init Linear(C -> 4, no bias), sgm/modules/nerfsd_pytorch3d.py:49-51,160) on bf16 tokens with
+// fp32 weights, fp32 accumulation and fp32 output (sigma_raw feeds exp(): it must not be rounded to bf16).
+// One wave per row; HBM-bound (reads h once).
+namespace {
+__global__ __launch_bounds__(256) void rowdot4_kernel(const uint16_t* __restrict__ h, const float* __restrict__ w, float* __restrict__ out,
+                                                      long rows, int C) {
+  const int lane = threadIdx.x & 63;
+  const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  for (long row = wave0; row < rows; row += nwaves) {
+    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    for (int c = lane * 8; c < C; c += 64 * 8) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(h + row * C + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float lo = bf16lo_to_f32(v[e]), hi = bf16hi_to_f32(v[e]);
+        const int ci = c + 2 * e;
+        a0 = fmaf(lo, w[ci], a0); a0 = fmaf(hi, w[ci + 1], a0);
+        a1 = fmaf(lo, w[C + ci], a1); a1 = fmaf(hi, w[C + ci + 1], a1);
+        a2 = fmaf(lo, w[2 * C + ci], a2); a2 = fmaf(hi, w[2 * C + ci + 1], a2);
+        a3 = fmaf(lo, w[3 * C + ci], a3); a3 = fmaf(hi, w[3 * C + ci + 1], a3);
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      a0 += __shfl_xor(a0, off); a1 += __shfl_xor(a1, off); a2 += __shfl_xor(a2, off); a3 += __shfl_xor(a3, off);
+    }
+    if (lane == 0) {
+      f32x4 o = {a0, a1, a2, a3};
+      *reinterpret_cast<f32x4*>(out + row * 4) = o;
+    }
+  }
+}
+}  // namespace
+
+// h [rows, C] bf16, w [4, C] fp32 -> out [rows, 4] fp32
+extern "C" int cd360_rowdot4_bf16(const void* h, const void* w, void* out, int64_t rows, int C, void* stream) {
+  if (!h || !w || !out || rows <= 0 || C <= 0) return CD360_ERR_ARG;
+  if (C % 8) return CD360_ERR_SHAPE;
+  const long nblk = (rows + 3) / 4 > 256 * 32 ? 256 * 32 : (rows + 3) / 4;
+  hipLaunchKernelGGL(rowdot4_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)h, (const float*)w,
+                     (float*)out, (long)rows, C);
+  CD360_LAUNCH_CHECK();
+  return CD360_OK;
+}

@@ -1,0 +1,352 @@
+"""Transformer blocks of the SDXL UNet with FeatureNeRF pose conditioning (reference sgm/modules/attention.py), on HIP.
+
+Same class names, constructor arguments, forward signatures, return tuples, attribute names and state_dict keys as the
+reference so that `load_state_dict`, the delta checkpoint (`references` buffers, `pose*` parameter
+names) and sample.py's monkey patch (which rebinds `forward` by class name and calls `self.attn1/attn2/norm1-3/ff/
+reference_attn/pose_emb_layers`) keep working.  What differs is underneath:
+
+  * attention  : cd360_attn_fwd_bf16 (flash, MFMA) reads the projection outputs in place; q|k (self) and k (cross)
+                 projections are merged GEMMs, V is produced already transposed by its GEMM (no head split copies);
+  * pose path  : NerfSDModule.render_inputs -> one fused kernel + table GEMMs (cd360/nerf.py), pose-token
+                 cross-attention on the same attention kernel, cd360_volrender, concat-free pose_emb_layers;
+  * GroupNorm  : fused channels-last kernel; the whole SpatialTransformer works on [b, hw, C] tokens that alias the
+                 channels-last image (both rearranges of the reference are views here).
+
+The reference's `CrossAttention` ("softmax" mode) cannot be constructed by BasicTransformerBlock (it is passed an
+`add_lora` kwarg it does not accept, attention.py:214-222,495-503); here "softmax" maps to the same HIP attention.
+LoRA branches, `additional_tokens`, `n_times_crossframe_attn_in_self`, `disable_self_attn`, conv proj_in/out and
+`average=True` are not exercised by the shipped config and raise NotImplementedError.
+"""
+from __future__ import annotations
+
+import logging
+import math
+from typing import Optional
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from cd360 import ops
+from ..modules.diffusionmodules.util import checkpoint, group_norm_tokens, tokens_to_image, zero_module  # noqa: F401
+from ..modules.nerfsd_pytorch3d import NerfSDModule, VolRender
+from ..util import default, exists
+
+logpy = logging.getLogger(__name__)
+XFORMERS_IS_AVAILABLE = True  # the operator boundary is served by libcd360_hip.so
+SDP_IS_AVAILABLE = True
+
+
+class _TruncExp(torch.autograd.Function):
+    """exp with a clamped backward (attention.py:192-205)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = x.float()
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * torch.exp(ctx.saved_tensors[0].clamp(-15, 15))
+
+
+trunc_exp = _TruncExp.apply
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+    def forward(self, x):
+        x, gate = self.proj(x).chunk(2, dim=-1)
+        return x * F.gelu(gate)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, dim_out=None, mult=4, glu=False, dropout=0.0):
+        super().__init__()
+        inner_dim = int(dim * mult)
+        dim_out = default(dim_out, dim)
+        project_in = nn.Sequential(nn.Linear(dim, inner_dim), nn.GELU()) if not glu else GEGLU(dim, inner_dim)
+        self.net = nn.Sequential(project_in, nn.Dropout(dropout), nn.Linear(inner_dim, dim_out))
+
+    def forward(self, x):
+        return self.net(x)
+
+
+def Normalize(in_channels):
+    return torch.nn.GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
+
+
+def _pad_tokens(ctx: torch.Tensor, mult: int = 8) -> torch.Tensor:
+    pad = (-ctx.shape[1]) % mult
+    return ctx if pad == 0 else F.pad(ctx, (0, 0, 0, pad))
+
+
+class MemoryEfficientCrossAttention(nn.Module):
+    """to_q / to_k / to_v / to_out.0 exactly as the reference (attention.py:305-425); forward on the HIP kernel."""
+
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64, dropout=0.0, add_lora=False, **kwargs):
+        super().__init__()
+        if add_lora:
+            raise NotImplementedError("add_lora=True is not exercised by the shipped config (yaml:50)")
+        if dim_head != 64:
+            raise NotImplementedError("the HIP attention kernel is specialised for head dim 64 (SDXL)")
+        inner_dim = dim_head * heads
+        context_dim = default(context_dim, query_dim)
+        self.heads, self.dim_head, self.add_lora = heads, dim_head, add_lora
+        self.to_q = nn.Linear(query_dim, inner_dim, bias=False)
+        self.to_k = nn.Linear(context_dim, inner_dim, bias=False)
+        self.to_v = nn.Linear(context_dim, inner_dim, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner_dim, query_dim), nn.Dropout(dropout))
+        self.attention_op = None
+        self._merged = None
+
+    def _qk_weight(self):
+        """[to_q.weight; to_k.weight] for the self-attention GEMM, rebuilt when either changes."""
+        key = (self.to_q.weight.data_ptr(), self.to_q.weight._version, self.to_k.weight.data_ptr(), self.to_k.weight._version,
+               self.to_q.weight.dtype, self.to_q.weight.device)
+        if self._merged is None or self._merged[0] != key:
+            self._merged = (key, torch.cat([self.to_q.weight.detach(), self.to_k.weight.detach()], 0).contiguous())
+        return self._merged[1]
+
+    def project_context(self, context: torch.Tensor):
+        """K [b, Nk_pad, inner] and V^T [b, inner, Nk_pad] for a cross-attention context (reusable across query sets)."""
+        ctx = _pad_tokens(context)
+        k = F.linear(ctx, self.to_k.weight)
+        vt = torch.matmul(self.to_v.weight, ctx.transpose(1, 2))
+        return k, vt, context.shape[1]
+
+    def attend(self, x: torch.Tensor, kv) -> torch.Tensor:
+        """softmax(q k^T / sqrt(d)) v and the output projection for precomputed (k, vt, nk)."""
+        k, vt, nk = kv
+        q = F.linear(x, self.to_q.weight)
+        return self._finish(x, q, k, vt, nk)
+
+    def _finish(self, x, q, k, vt, nk):
+        dt = x.dtype
+        if dt != torch.bfloat16:
+            q, k, vt = q.to(torch.bfloat16), k.to(torch.bfloat16), vt.to(torch.bfloat16)
+        out = ops.attention(q, k, vt, self.heads, nk)
+        if dt != torch.bfloat16:
+            out = out.to(dt)
+        return self.to_out(out)
+
+    def forward(self, x, context=None, mask=None, additional_tokens=None, n_times_crossframe_attn_in_self=0):
+        if additional_tokens is not None or n_times_crossframe_attn_in_self:
+            raise NotImplementedError("additional_tokens / cross-frame attention are not used by the shipped config")
+        if exists(mask):
+            raise NotImplementedError  # as the reference (attention.py:411-412)
+        if context is None:
+            inner = self.heads * self.dim_head
+            if x.shape[1] % 8 == 0:
+                qk = F.linear(x, self._qk_weight())
+                q, k = qk[..., :inner], qk[..., inner:]
+                vt = torch.matmul(self.to_v.weight, x.transpose(1, 2))
+                return self._finish(x, q, k, vt, x.shape[1])
+            context = x
+        return self.attend(x, self.project_context(context))
+
+
+CrossAttention = MemoryEfficientCrossAttention  # "softmax" mode: see module docstring
+
+
+class BasicTransformerBlock(nn.Module):
+    ATTENTION_MODES = {"softmax": CrossAttention, "softmax-xformers": MemoryEfficientCrossAttention}
+
+    def __init__(self, dim, n_heads, d_head, dropout=0.0, context_dim=None, gated_ff=True, checkpoint=True, disable_self_attn=False,
+                 attn_mode="softmax", sdp_backend=None, image_cross=False, far=2, num_samples=32, add_lora=False, rgb_predict=False,
+                 mode="pixel-nerf", average=False, num_freqs=16, use_prev_weights_imp_sample=False, imp_sample_next_step=False,
+                 stratified=False, imp_sampling_percent=0.9, near_plane=0.0):
+        super().__init__()
+        assert attn_mode in self.ATTENTION_MODES
+        if disable_self_attn:
+            raise NotImplementedError("disable_self_attn is not used by the shipped config")
+        self.add_lora, self.image_cross, self.rgb_predict = add_lora, image_cross, rgb_predict
+        self.use_prev_weights_imp_sample, self.imp_sample_next_step = use_prev_weights_imp_sample, imp_sample_next_step
+        self.rendered_feat = None
+        self.reference_choices = None  # set by cd360.sampling.enable_reference_sampling (native sample.py mode)
+        attn_cls = self.ATTENTION_MODES[attn_mode]
+        self.disable_self_attn = disable_self_attn
+        self.attn1 = attn_cls(query_dim=dim, heads=n_heads, dim_head=d_head, dropout=dropout, add_lora=add_lora, context_dim=None,
+                              backend=sdp_backend)
+        self.ff = FeedForward(dim, dropout=dropout, glu=gated_ff)
+        self.attn2 = attn_cls(query_dim=dim, context_dim=context_dim, heads=n_heads, dim_head=d_head, dropout=dropout, add_lora=add_lora,
+                              backend=sdp_backend)
+        if image_cross:
+            self.pose_emb_layers = nn.Linear(2 * dim, dim, bias=False)
+            nn.init.eye_(self.pose_emb_layers.weight)
+            self.pose_featurenerf = NerfSDModule(mode=mode, out_channels=dim, far_plane=far, num_samples=num_samples,
+                                                 rgb_predict=rgb_predict, average=average, num_freqs=num_freqs, stratified=stratified,
+                                                 imp_sampling_percent=imp_sampling_percent, near_plane=near_plane)
+            self.renderer = VolRender()
+        self.norm1 = nn.LayerNorm(dim)
+        self.norm2 = nn.LayerNorm(dim)
+        self.norm3 = nn.LayerNorm(dim)
+        self.checkpoint = checkpoint
+        self._pose_split = None
+        self._ref_tables = None
+
+    # ------------------------------------------------------------------------------------------------ pose path
+    def _pose_weights(self):
+        w = self.pose_emb_layers.weight
+        key = (w.data_ptr(), w._version, w.dtype, w.device)
+        if self._pose_split is None or self._pose_split[0] != key:
+            c = w.shape[0]
+            self._pose_split = (key, w.detach()[:, :c].t().contiguous(), w.detach()[:, c:].t().contiguous())
+        return self._pose_split[1], self._pose_split[2]
+
+    def pose_embed(self, x: torch.Tensor, xref: torch.Tensor) -> torch.Tensor:
+        """pose_emb_layers(cat[x, xref]) without the concat (attention.py:634): x Wa^T + xref Wb^T."""
+        wa, wb = self._pose_weights()
+        b, n, c = x.shape
+        out = torch.mm(x.reshape(-1, c), wa)
+        out.addmm_(xref.reshape(-1, c).to(out.dtype), wb)
+        return out.reshape(b, n, c)
+
+    def reference_attn(self, x, context_ref, context, pose, prev_weights, mask_ref, tables=None):
+        """FeatureNeRF render of the reference features at the target pose (attention.py:571-598).
+        context_ref [b, n, hw, C].  -> (xref [b,hw,C], fg [b,hw,1], prev_weights(None), alphas [b,hw,S,1], rgb [b,hw,3])"""
+        if prev_weights is not None and self.use_prev_weights_imp_sample:
+            raise NotImplementedError("importance sampling is dead code in the reference (SURVEY.md F3)")
+        h, dec, dists, _ = self.pose_featurenerf.render_inputs(pose, context_ref, mask_ref, tables=tables)
+        b, hw, S, C = h.shape
+        tok = h.reshape(b, hw * S, C)
+        if tok.dtype != x.dtype:
+            tok = tok.to(x.dtype)
+        tok = self.attn2(self.norm2(tok), context=context) + tok  # pose-token cross-attention (:581-586)
+        rendered, fg, alphas, _, rgb = ops.volrender(tok.reshape(b, hw, S, C), dec[..., 3], dists,
+                                                    dec[..., :3] if self.rgb_predict else None)
+        return rendered, fg, (None if not self.use_prev_weights_imp_sample else None), alphas, rgb
+
+    def _references_as_context(self, batch_size: int):
+        """sample.py:85-96: reference features for a CFG batch from the `references` buffer; the unconditional third uses the
+        null-image row `references[-1]` for every view."""
+        refs, choices = self.references, self.reference_choices
+        sel = refs[:-1][torch.as_tensor(choices, device=refs.device)]  # [n, hw, C]
+        n = sel.shape[0]
+        if batch_size % 3 == 0:
+            bs = batch_size // 3
+            cond = sel[None].expand(bs, -1, -1, -1)
+            return torch.cat([refs[-1:][None].expand(bs, n, -1, -1), cond, cond], 0)
+        bs = batch_size // 2
+        cond = sel[None].expand(bs, -1, -1, -1)
+        return torch.cat([refs[-1:][None].expand(bs, n, -1, -1), cond], 0)
+
+    # ------------------------------------------------------------------------------------------------ forward
+    def forward(self, x, context=None, context_ref=None, pose=None, mask_ref=None, prev_weights=None, additional_tokens=None,
+                n_times_crossframe_attn_in_self=0):
+        if additional_tokens is not None or n_times_crossframe_attn_in_self:
+            raise NotImplementedError("additional_tokens / cross-frame attention are not used by the shipped config")
+        return self._forward(x, context, context_ref, pose, mask_ref, prev_weights)
+
+    def _forward(self, x, context=None, context_ref=None, pose=None, mask_ref=None, prev_weights=None, additional_tokens=None,
+                 n_times_crossframe_attn_in_self=0):
+        fg_mask = weights = alphas = predicted_rgb = None
+        x = self.attn1(self.norm1(x), context=None) + x
+        x = self.attn2(self.norm2(x), context=context) + x
+        if context_ref is not None:
+            if self.reference_choices is not None:  # native equivalent of sample.py's _customforward (sample.py:82-136)
+                if self.rendered_feat is None:
+                    cref = self._references_as_context(x.size(0))
+                    xref, fg_mask, weights, alphas, predicted_rgb = self.reference_attn(x, cref, context, pose, prev_weights, mask_ref)
+                    self.rendered_feat = xref
+                x = self.pose_embed(x, self.rendered_feat)
+            else:
+                b = x.size(0)
+                cref = context_ref if context_ref.dim() == 4 else context_ref.reshape(b, context_ref.size(0) // b, *context_ref.shape[1:])
+                xref, fg_mask, weights, alphas, predicted_rgb = self.reference_attn(x, cref, context, pose, prev_weights, mask_ref)
+                x = self.pose_embed(x, xref)
+        x = self.ff(self.norm3(x)) + x
+        return x, fg_mask, weights, alphas, predicted_rgb
+
+
+class SpatialTransformer(nn.Module):
+    """GroupNorm -> proj_in -> depth x BasicTransformerBlock -> proj_out -> + input, on one or two streams (attention.py:684-886)."""
+
+    def __init__(self, in_channels, n_heads, d_head, depth=1, dropout=0.0, context_dim=None, disable_self_attn=False, use_linear=False,
+                 attn_type="softmax", use_checkpoint=True, sdp_backend=None, image_cross=True, rgb_predict=False, far=2, num_samples=32,
+                 add_lora=False, mode="feature-nerf", average=False, num_freqs=16, use_prev_weights_imp_sample=False, stratified=False,
+                 poscontrol_interval=4, imp_sampling_percent=0.9, near_plane=0.0):
+        super().__init__()
+        if not use_linear:
+            raise NotImplementedError("conv proj_in/proj_out (use_linear=False) is not used by the SDXL config")
+        if use_checkpoint:
+            raise NotImplementedError("use_checkpoint=True is not supported (config sets it False; it breaks pose blocks upstream)")
+        if exists(context_dim) and not isinstance(context_dim, (list, tuple)) and type(context_dim).__name__ != "ListConfig":
+            context_dim = [context_dim]
+        if exists(context_dim):
+            context_dim = list(context_dim)
+            if depth != len(context_dim):
+                assert all(c == context_dim[0] for c in context_dim), "need homogenous context_dim to match depth automatically"
+                context_dim = depth * [context_dim[0]]
+        else:
+            context_dim = [None] * depth
+        self.in_channels = in_channels
+        inner_dim = n_heads * d_head
+        self.norm = Normalize(in_channels)
+        self.image_cross, self.poscontrol_interval = image_cross, poscontrol_interval
+        self.proj_in = nn.Linear(in_channels, inner_dim)
+        self.transformer_blocks = nn.ModuleList([
+            BasicTransformerBlock(
+                inner_dim, n_heads, d_head, dropout=dropout, context_dim=context_dim[d], disable_self_attn=disable_self_attn,
+                attn_mode=attn_type, checkpoint=use_checkpoint, sdp_backend=sdp_backend,
+                image_cross=self.image_cross and (d % poscontrol_interval == 0), far=far, num_samples=num_samples,
+                add_lora=add_lora and self.image_cross and (d % poscontrol_interval == 0), rgb_predict=rgb_predict, mode=mode,
+                average=average, num_freqs=num_freqs, use_prev_weights_imp_sample=use_prev_weights_imp_sample,
+                imp_sample_next_step=(use_prev_weights_imp_sample and self.image_cross and (d % poscontrol_interval == 0)
+                                      and depth >= poscontrol_interval and d < (depth // poscontrol_interval) * poscontrol_interval),
+                stratified=stratified, imp_sampling_percent=imp_sampling_percent, near_plane=near_plane)
+            for d in range(depth)])
+        self.proj_out = zero_module(nn.Linear(inner_dim, in_channels))
+        self.use_linear = use_linear
+
+    def _tokens(self, x):
+        return self.proj_in(group_norm_tokens(self.norm, x, silu=False))
+
+    def _image(self, t, x_in):
+        return tokens_to_image(self.proj_out(t), x_in.shape[2], x_in.shape[3]) + x_in
+
+    def forward(self, x, xr, context=None, contextr=None, pose=None, mask_ref=None, prev_weights=None):
+        if not isinstance(context, list):
+            context, contextr = [context], [contextr]
+        x_in, xr_in = x, xr
+        sampling = xr is None and pose is not None and any(getattr(b, "reference_choices", None) is not None for b in self.transformer_blocks)
+        if xr is None and not sampling:  # plain path (attention.py:800-820)
+            t = self._tokens(x)
+            for i, block in enumerate(self.transformer_blocks):
+                t = block(t, context=context[i if len(context) > 1 else 0])[0]
+            return self._image(t, x_in), None, None, None, None, None
+
+        fg_masks, alphas, rgbs = [], [], []
+        t = self._tokens(x)
+        tr = None
+        if xr is not None:
+            with torch.no_grad():
+                tr = self._tokens(xr)
+        for i, block in enumerate(self.transformer_blocks):
+            ci = i if len(context) > 1 else 0
+            pose_block = self.image_cross and (i % self.poscontrol_interval == 0)
+            if tr is not None:
+                with torch.no_grad():
+                    tr = block(tr, context=contextr[ci])[0]
+            if pose_block:
+                cref = tr.detach() if tr is not None else t  # sample.py passes context_ref=x as a non-None marker (sample.py:57)
+                t, fg, _, al, rgb = block(t, context=context[ci], context_ref=cref, pose=pose, mask_ref=mask_ref, prev_weights=None)
+                fg_masks.append(fg)
+                if al is not None:
+                    alphas.append(al)
+                if rgb is not None:
+                    rgbs.append(rgb)
+            else:
+                t = block(t, context=context[ci])[0]
+        out = self._image(t, x_in)
+        outr = None
+        if tr is not None:
+            with torch.no_grad():
+                outr = self._image(tr, xr_in).detach()
+        if len(fg_masks) > 0:
+            return out, outr, fg_masks, None, (alphas if alphas else None), (rgbs if rgbs else None)
+        return out, outr, None, None, None, None

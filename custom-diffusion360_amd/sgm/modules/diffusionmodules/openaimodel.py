@@ -1,0 +1,287 @@
+"""SDXL UNet with a reference stream and pose-conditioned transformer blocks (reference
+sgm/modules/diffusionmodules/openaimodel.py:73-376,525-1093), HIP-backed.
+
+Constructor arguments, forward signature, the 4-tuple it returns and every state_dict key match the reference, so SDXL
+safetensors and the delta checkpoint load unchanged.  Differences underneath: activations are kept channels-last in the
+parameter dtype (bf16), GroupNorm+SiLU is one fused kernel in front of each conv, the transformers run on the HIP
+attention / FeatureNeRF kernels, and there is no autocast (the reference's fp16 autocast region, :992, becomes "compute in
+the parameters' dtype").  Convolutions and plain Linear layers stay on MIOpen / hipBLASLt through torch.
+Unused reference options (dims != 2, resblock_updown, scale-shift norm, AttentionBlock, fairscale checkpointing,
+integer / "continuous" / "timestep" class embeddings) raise NotImplementedError.
+"""
+from __future__ import annotations
+
+from abc import abstractmethod
+from typing import List, Optional, Tuple, Union
+
+import torch
+import torch as th
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ...modules.attention import SpatialTransformer
+from ...modules.diffusionmodules.util import (
+    conv_nd,
+    group_norm_tokens,
+    linear,
+    normalization,
+    timestep_embedding,
+    tokens_to_image,
+    zero_module,
+)
+from ...util import default, exists
+
+
+class TimestepBlock(nn.Module):
+    @abstractmethod
+    def forward(self, x, emb):
+        """Apply the module to `x` given `emb` timestep embeddings."""
+
+
+class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
+    """Threads (x, emb) and the no-grad reference stream (xr, embr) through its children (openaimodel.py:73-111)."""
+
+    def forward(self, x, emb, context=None, xr=None, embr=None, contextr=None, pose=None, mask_ref=None, prev_weights=None):
+        weights = fg_mask = alphas = predicted_rgb = None
+        for layer in self:
+            if isinstance(layer, TimestepBlock):
+                x = layer(x, emb)
+                if xr is not None:
+                    with torch.no_grad():
+                        xr = layer(xr, embr).detach()
+            elif isinstance(layer, SpatialTransformer):
+                x, xr, fg_mask, weights, alphas, predicted_rgb = layer(x, xr, context, contextr, pose, mask_ref, prev_weights=prev_weights)
+            else:
+                x = layer(x)
+                if xr is not None:
+                    with torch.no_grad():
+                        xr = layer(xr).detach()
+        return x, xr, fg_mask, weights, alphas, predicted_rgb
+
+
+class Upsample(nn.Module):
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1, third_up=False, kernel_size=3, scale_factor=2):
+        super().__init__()
+        if dims != 2:
+            raise NotImplementedError("2-D only")
+        self.channels, self.out_channels, self.use_conv, self.dims, self.scale_factor = channels, out_channels or channels, use_conv, dims, scale_factor
+        if use_conv:
+            self.conv = conv_nd(dims, self.channels, self.out_channels, kernel_size, padding=padding)
+
+    def forward(self, x):
+        assert x.shape[1] == self.channels
+        x = F.interpolate(x, scale_factor=self.scale_factor, mode="nearest")
+        return self.conv(x) if self.use_conv else x
+
+
+class Downsample(nn.Module):
+    def __init__(self, channels, use_conv, dims=2, out_channels=None, padding=1, third_down=False):
+        super().__init__()
+        if dims != 2:
+            raise NotImplementedError("2-D only")
+        self.channels, self.out_channels, self.use_conv, self.dims = channels, out_channels or channels, use_conv, dims
+        if use_conv:
+            self.op = conv_nd(dims, self.channels, self.out_channels, 3, stride=2, padding=padding)
+        else:
+            assert self.channels == self.out_channels
+            self.op = nn.AvgPool2d(kernel_size=2, stride=2)
+
+    def forward(self, x):
+        assert x.shape[1] == self.channels
+        return self.op(x)
+
+
+class ResBlock(TimestepBlock):
+    """GN -> SiLU -> conv3x3 (+ emb) -> GN -> SiLU -> conv3x3 + skip (openaimodel.py:233-376); GN+SiLU is one HIP kernel."""
+
+    def __init__(self, channels, emb_channels, dropout, out_channels=None, use_conv=False, use_scale_shift_norm=False, dims=2,
+                 use_checkpoint=False, up=False, down=False, kernel_size=3, exchange_temb_dims=False, skip_t_emb=False):
+        super().__init__()
+        if use_scale_shift_norm or up or down or exchange_temb_dims or skip_t_emb or dims != 2 or use_checkpoint:
+            raise NotImplementedError("ResBlock option not used by the SDXL config")
+        self.channels, self.emb_channels, self.dropout = channels, emb_channels, dropout
+        self.out_channels = out_channels or channels
+        self.use_conv, self.use_checkpoint, self.use_scale_shift_norm = use_conv, use_checkpoint, use_scale_shift_norm
+        padding = kernel_size // 2
+        self.in_layers = nn.Sequential(normalization(channels), nn.SiLU(), conv_nd(dims, channels, self.out_channels, kernel_size, padding=padding))
+        self.updown = False
+        self.h_upd = self.x_upd = nn.Identity()
+        self.emb_layers = nn.Sequential(nn.SiLU(), linear(emb_channels, self.out_channels))
+        self.out_layers = nn.Sequential(
+            normalization(self.out_channels), nn.SiLU(), nn.Dropout(p=dropout),
+            zero_module(conv_nd(dims, self.out_channels, self.out_channels, kernel_size, padding=padding)))
+        if self.out_channels == channels:
+            self.skip_connection = nn.Identity()
+        elif use_conv:
+            self.skip_connection = conv_nd(dims, channels, self.out_channels, kernel_size, padding=padding)
+        else:
+            self.skip_connection = conv_nd(dims, channels, self.out_channels, 1)
+
+    @staticmethod
+    def _gn_silu(norm, x):
+        return tokens_to_image(group_norm_tokens(norm, x, silu=True), x.shape[2], x.shape[3])
+
+    def forward(self, x, emb):
+        return self._forward(x, emb)
+
+    def _forward(self, x, emb):
+        h = self.in_layers[2](self._gn_silu(self.in_layers[0], x))
+        emb_out = self.emb_layers(emb).type(h.dtype)
+        h = h + emb_out[:, :, None, None]
+        h = self.out_layers[3](self._gn_silu(self.out_layers[0], h))
+        return self.skip_connection(x) + h
+
+
+class UNetModel(nn.Module):
+    def __init__(self, in_channels: int, model_channels: int, out_channels: int, num_res_blocks: int, attention_resolutions,
+                 dropout: float = 0.0, channel_mult: Union[List, Tuple] = (1, 2, 4, 8), conv_resample: bool = True, dims: int = 2,
+                 num_classes: Optional[Union[int, str]] = None, use_checkpoint: bool = False, num_heads: int = -1,
+                 num_head_channels: int = -1, num_heads_upsample: int = -1, use_scale_shift_norm: bool = False,
+                 resblock_updown: bool = False, transformer_depth=1, context_dim: Optional[int] = None,
+                 disable_self_attentions: Optional[List[bool]] = None, num_attention_blocks: Optional[List[int]] = None,
+                 disable_middle_self_attn: bool = False, use_linear_in_transformer: bool = False,
+                 spatial_transformer_attn_type: str = "softmax", adm_in_channels: Optional[int] = None, use_fairscale_checkpoint=False,
+                 offload_to_cpu=False, transformer_depth_middle: Optional[int] = None,
+                 # pose-conditioning arguments (openaimodel.py:584-599)
+                 image_cross_blocks=None, rgb: bool = False, far: float = 2.0, num_samples: float = 32,
+                 not_add_context_in_triplane: bool = False, rgb_predict: bool = False, add_lora: bool = False, mode: str = "feature-nerf",
+                 average: bool = False, num_freqs: int = 16, use_prev_weights_imp_sample: bool = False, stratified: bool = False,
+                 poscontrol_interval: int = 4, imp_sampling_percent: float = 0.9, near_plane: float = 0.0):
+        super().__init__()
+        if resblock_updown or use_scale_shift_norm or dims != 2 or use_fairscale_checkpoint or use_checkpoint:
+            raise NotImplementedError("UNet option not used by the SDXL config")
+        if num_classes != "sequential":
+            raise NotImplementedError("only num_classes='sequential' (SDXL vector conditioning) is built")
+        if num_head_channels == -1:
+            raise NotImplementedError("set num_head_channels (SDXL uses 64)")
+        if disable_self_attentions is not None or num_attention_blocks is not None or disable_middle_self_attn:
+            raise NotImplementedError("attention-ablation options are not used by the SDXL config")
+        self.in_channels, self.model_channels, self.out_channels = in_channels, model_channels, out_channels
+        self.rgb, self.rgb_predict = rgb, rgb_predict
+        image_cross_blocks = list(image_cross_blocks) if image_cross_blocks is not None else []
+        channel_mult = list(channel_mult)
+        attention_resolutions = list(attention_resolutions)
+        transformer_depth = len(channel_mult) * [transformer_depth] if isinstance(transformer_depth, int) else list(transformer_depth)
+        transformer_depth_middle = default(transformer_depth_middle, transformer_depth[-1])
+        self.num_res_blocks = len(channel_mult) * [num_res_blocks] if isinstance(num_res_blocks, int) else list(num_res_blocks)
+        self.attention_resolutions, self.dropout, self.channel_mult, self.conv_resample = attention_resolutions, dropout, channel_mult, conv_resample
+        self.num_classes, self.use_checkpoint = num_classes, use_checkpoint
+        self.num_heads, self.num_head_channels, self.num_heads_upsample = num_heads, num_head_channels, num_heads_upsample
+
+        time_embed_dim = model_channels * 4
+        self.time_embed = nn.Sequential(linear(model_channels, time_embed_dim), nn.SiLU(), linear(time_embed_dim, time_embed_dim))
+        assert adm_in_channels is not None
+        self.label_emb = nn.Sequential(nn.Sequential(linear(adm_in_channels, time_embed_dim), nn.SiLU(), linear(time_embed_dim, time_embed_dim)))
+
+        st_kw = dict(context_dim=context_dim, use_linear=use_linear_in_transformer, attn_type=spatial_transformer_attn_type,
+                     use_checkpoint=use_checkpoint, rgb_predict=rgb_predict, far=far, num_samples=num_samples, add_lora=add_lora, mode=mode,
+                     average=average, num_freqs=num_freqs, use_prev_weights_imp_sample=use_prev_weights_imp_sample, stratified=stratified,
+                     poscontrol_interval=poscontrol_interval, imp_sampling_percent=imp_sampling_percent, near_plane=near_plane)
+        id_attention = 0
+
+        def transformer(ch, depth):
+            nonlocal id_attention
+            st = SpatialTransformer(ch, ch // num_head_channels, num_head_channels, depth=depth, disable_self_attn=False,
+                                    image_cross=(id_attention in image_cross_blocks), **st_kw)
+            id_attention += 1
+            return st
+
+        self.input_blocks = nn.ModuleList([TimestepEmbedSequential(conv_nd(dims, in_channels, model_channels, 3, padding=1))])
+        input_block_chans = [model_channels]
+        ch, ds = model_channels, 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(self.num_res_blocks[level]):
+                layers = [ResBlock(ch, time_embed_dim, dropout, out_channels=mult * model_channels, dims=dims)]
+                ch = mult * model_channels
+                if ds in attention_resolutions:
+                    layers.append(transformer(ch, transformer_depth[level]))
+                self.input_blocks.append(TimestepEmbedSequential(*layers))
+                input_block_chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(TimestepEmbedSequential(Downsample(ch, conv_resample, dims=dims, out_channels=ch)))
+                input_block_chans.append(ch)
+                ds *= 2
+
+        self.middle_block = TimestepEmbedSequential(
+            ResBlock(ch, time_embed_dim, dropout, dims=dims), transformer(ch, transformer_depth_middle), ResBlock(ch, time_embed_dim, dropout, dims=dims))
+
+        self.output_blocks = nn.ModuleList([])
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(self.num_res_blocks[level] + 1):
+                ich = input_block_chans.pop()
+                layers = [ResBlock(ch + ich, time_embed_dim, dropout, out_channels=model_channels * mult, dims=dims)]
+                ch = model_channels * mult
+                if ds in attention_resolutions:
+                    layers.append(transformer(ch, transformer_depth[level]))
+                if level and i == self.num_res_blocks[level]:
+                    layers.append(Upsample(ch, conv_resample, dims=dims, out_channels=ch))
+                    ds //= 2
+                self.output_blocks.append(TimestepEmbedSequential(*layers))
+
+        self.out = nn.Sequential(normalization(ch), nn.SiLU(), zero_module(conv_nd(dims, model_channels, out_channels, 3, padding=1)))
+
+    @property
+    def dtype(self):
+        return self.out[2].weight.dtype
+
+    def forward(self, x, timesteps=None, context=None, y=None, timesteps2=None, **kwargs):
+        """x [b,4,L,L]; context [b (+ b*n), 77, ctx]; y [b (+ b*n), adm]; kwargs: pose, mask_ref, input_ref [b,n,4,L,L], sigmas_ref.
+        -> (eps [b,4,L,L], fg_mask_list, alphas_list, predicted_rgb_list)   (openaimodel.py:975-1093)"""
+        dt = self.dtype
+        b = x.size(0)
+        pose, mask_ref = kwargs.get("pose"), kwargs.get("mask_ref")
+        reference_image = "input_ref" in kwargs and kwargs["input_ref"] is not None
+        contextr = embr = hr = None
+        fg_mask_list, alphas_list, predicted_rgb_list = [], [], []
+        if "input_ref" in kwargs:
+            contextr = context[b:]
+            yr = y[b:] if y is not None else None
+            xr = kwargs["input_ref"]
+            if xr is not None:
+                b, n = xr.shape[:2]
+        context = context[:b].to(dt)
+        assert y is not None, "must specify y: the model is class-conditional (num_classes='sequential')"
+        y = y[:b]
+        emb = self.time_embed(timestep_embedding(timesteps, self.model_channels).to(dt))
+        assert y.shape[0] == x.shape[0]
+        emb = emb + self.label_emb(y.to(dt))
+
+        h = x.to(dt).contiguous(memory_format=torch.channels_last)
+        if reference_image:
+            with torch.no_grad():
+                if "sigmas_ref" in kwargs and kwargs["sigmas_ref"] is not None:
+                    t_embr = timestep_embedding(kwargs["sigmas_ref"], self.model_channels)
+                elif timesteps2 is not None:
+                    t_embr = timestep_embedding(timesteps2, self.model_channels)
+                else:
+                    t_embr = timestep_embedding(torch.zeros_like(timesteps), self.model_channels)
+                embr = self.time_embed(t_embr.to(dt))[:, None].expand(-1, n, -1).reshape(b * n, -1)
+                embr = embr + self.label_emb(yr.reshape(b * n, -1).to(dt))
+                contextr = contextr.to(dt)
+                hr = xr.reshape(b * n, *xr.shape[2:]).to(dt).contiguous(memory_format=torch.channels_last)
+
+        def collect(fg, al, rgb):
+            if fg is not None:
+                fg_mask_list.extend(fg)
+            if al is not None:
+                alphas_list.extend(al)
+            if rgb is not None:
+                predicted_rgb_list.extend(rgb)
+
+        hs, hrs = [], []
+        for module in self.input_blocks:
+            h, hr, fg, _, al, rgb = module(h, emb, context, hr, embr, contextr, pose, mask_ref=mask_ref, prev_weights=None)
+            collect(fg, al, rgb)
+            hs.append(h)
+            hrs.append(hr)
+        h, hr, fg, _, al, rgb = self.middle_block(h, emb, context, hr, embr, contextr, pose, mask_ref=mask_ref, prev_weights=None)
+        collect(fg, al, rgb)
+        for module in self.output_blocks:
+            h = th.cat([h, hs.pop()], dim=1)
+            hrp = hrs.pop()
+            if reference_image:
+                hr = th.cat([hr, hrp], dim=1)
+            h, hr, fg, _, al, rgb = module(h, emb, context, hr, embr, contextr, pose, mask_ref=mask_ref, prev_weights=None)
+            collect(fg, al, rgb)
+        out = self.out[2](tokens_to_image(group_norm_tokens(self.out[0], h, silu=True), h.shape[2], h.shape[3]))
+        return out.type(x.dtype), fg_mask_list, alphas_list, predicted_rgb_list

@@ -1,0 +1,119 @@
+"""nn utilities of the UNet (reference sgm/modules/diffusionmodules/util.py:153-344), HIP-backed where it matters.
+
+GroupNorm32 runs the fused channels-last GroupNorm(+SiLU) kernel (cd360_gn_silu_bf16); the thin factories
+(conv_nd, linear, zero_module, timestep_embedding) keep the reference's names because openaimodel/attention
+import them by name."""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from cd360 import ops
+
+
+def checkpoint(func, inputs, params, flag):
+    """Activation checkpointing is disabled on this path: the shipped config sets use_checkpoint False and the pose
+    blocks cannot be checkpointed at all (non-tensor `pose` argument).  Kept for signature parity
+    (util.py:153-168)."""
+    if flag:
+        raise NotImplementedError("use_checkpoint=True is not supported on the HIP path (and breaks pose blocks in the reference)")
+    return func(*inputs)
+
+
+def timestep_embedding(timesteps, dim, max_period=10000, repeat_only=False):
+    """Sinusoidal embedding [N, dim] = [cos | sin] (util.py:206-231)."""
+    if repeat_only:
+        return timesteps[:, None].expand(-1, dim)
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(start=0, end=half, dtype=torch.float32, device=timesteps.device) / half)
+    args = timesteps[:, None].float() * freqs[None]
+    emb = torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+    if dim % 2:
+        emb = torch.cat([emb, torch.zeros_like(emb[:, :1])], dim=-1)
+    return emb
+
+
+def zero_module(module):
+    for p in module.parameters():
+        p.detach().zero_()
+    return module
+
+
+def scale_module(module, scale):
+    for p in module.parameters():
+        p.detach().mul_(scale)
+    return module
+
+
+def mean_flat(tensor):
+    return tensor.mean(dim=list(range(1, len(tensor.shape))))
+
+
+def _fp32_affine(norm: nn.GroupNorm):
+    """fp32 copies of gamma/beta for the kernel, refreshed when the parameters change."""
+    key = (norm.weight.data_ptr(), norm.weight._version, norm.bias._version, norm.weight.device)
+    cache = getattr(norm, "_cd360_affine", None)
+    if cache is None or cache[0] != key:
+        cache = (key, norm.weight.detach().float().contiguous(), norm.bias.detach().float().contiguous())
+        norm._cd360_affine = cache
+    return cache[1], cache[2]
+
+
+def group_norm_tokens(norm: nn.GroupNorm, x: torch.Tensor, silu: bool) -> torch.Tensor:
+    """GroupNorm(+SiLU) of an image tensor [N, C, H, W]; returns channels-last tokens [N, H*W, C] in x's dtype.
+    The token tensor aliases a channels-last image: `.reshape(N, H, W, C).permute(0, 3, 1, 2)` is free."""
+    N, C, H, W = x.shape
+    xt = x.permute(0, 2, 3, 1)
+    if not xt.is_contiguous():
+        xt = xt.contiguous()  # NCHW-contiguous input: one layout change, then everything stays channels-last
+    xt = xt.reshape(N, H * W, C)
+    dt = xt.dtype
+    if dt != torch.bfloat16:
+        xt = xt.to(torch.bfloat16)
+    g, b = _fp32_affine(norm)
+    y = ops.gn_silu(xt, g, b, norm.num_groups, norm.eps, silu)
+    return y if dt == torch.bfloat16 else y.to(dt)
+
+
+def tokens_to_image(t: torch.Tensor, H: int, W: int) -> torch.Tensor:
+    """[N, H*W, C] -> [N, C, H, W] view in channels_last memory format (no copy)."""
+    N, _, C = t.shape
+    return t.reshape(N, H, W, C).permute(0, 3, 1, 2)
+
+
+class GroupNorm32(nn.GroupNorm):
+    """fp32-statistics GroupNorm (util.py:309-311) on the HIP kernel."""
+
+    def forward(self, x):
+        N, C, H, W = x.shape
+        return tokens_to_image(group_norm_tokens(self, x, silu=False), H, W)
+
+
+def normalization(channels):
+    return GroupNorm32(32, channels)
+
+
+def conv_nd(dims, *args, **kwargs):
+    if dims == 2:
+        return nn.Conv2d(*args, **kwargs)
+    if dims == 1:
+        return nn.Conv1d(*args, **kwargs)
+    if dims == 3:
+        return nn.Conv3d(*args, **kwargs)
+    raise ValueError(f"unsupported dimensions: {dims}")
+
+
+def linear(*args, **kwargs):
+    return nn.Linear(*args, **kwargs)
+
+
+def avg_pool_nd(dims, *args, **kwargs):
+    if dims == 2:
+        return nn.AvgPool2d(*args, **kwargs)
+    if dims == 1:
+        return nn.AvgPool1d(*args, **kwargs)
+    if dims == 3:
+        return nn.AvgPool3d(*args, **kwargs)
+    raise ValueError(f"unsupported dimensions: {dims}")

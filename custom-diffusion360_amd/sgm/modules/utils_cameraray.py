@@ -1,0 +1,57 @@
+"""Ray utilities of the pose path (reference sgm/modules/utils_cameraray.py:61-314) on the HIP kernels.
+
+`pose` stays what the reference passes around -- a list (length b) of camera batches of size n+1, real pytorch3d
+`PerspectiveCameras` or `cd360.cameras.PerspectiveCameras` -- and is packed once into a `[b, n+1, 16]` fp32 device
+tensor; nothing ever goes back to the host (the reference bounces GPU->CPU->GPU per call, :79-99,191-193)."""
+from __future__ import annotations
+
+import torch
+
+from cd360 import nerf as _nerf
+from cd360 import ops
+from cd360.cameras import pack_cameras
+
+
+def packed_pose(pose, device) -> torch.Tensor:
+    """Pack (and memoise on the list object's elements) the cameras of one forward call."""
+    if isinstance(pose, torch.Tensor):
+        return pack_cameras(pose, device)
+    key = tuple(id(c) for c in pose)
+    cache = _PACK_CACHE.get(key)
+    if cache is not None and cache[0] == str(device):
+        return cache[1]
+    packed = pack_cameras(pose, device)
+    if len(_PACK_CACHE) > 64:
+        _PACK_CACHE.clear()
+    _PACK_CACHE[key] = (str(device), packed, pose)  # keep `pose` alive so ids stay unique
+    return packed
+
+
+_PACK_CACHE = {}
+
+
+def get_patch_rays(cameras_list, num_patches_x, num_patches_y, device, return_xys=False, stratified=False):
+    """(b, n+1, hw, 6) patch rays = (origin, unit direction), ray k = row*num_patches_x + col (:161-196)."""
+    assert num_patches_x == num_patches_y, "square feature maps only (as the reference's reshape assumes)"
+    r = num_patches_x
+    cams = packed_pose(cameras_list, device)
+    jx = torch.rand(r + 1) if stratified else None  # CPU RNG, x then y, as get_patch_raybundle draws them (:121-140)
+    jy = torch.rand(r + 1) if stratified else None
+    xs, ys = _nerf.patch_positions(r, device, jx), _nerf.patch_positions(r, device, jy)
+    rays = ops.patch_rays(cams, xs, ys)
+    if return_xys:
+        hx, hy = torch.meshgrid(xs, ys, indexing="xy")
+        return rays, torch.stack([hx.reshape(-1), hy.reshape(-1)], -1)[None]
+    return rays
+
+
+def get_plucker_parameterization(ray):
+    """(d_hat, o x d_hat) (:201-219); tiny elementwise helper kept for API parity."""
+    o, d = ray[..., :3], ray[..., 3:]
+    d = d / d.norm(dim=-1).unsqueeze(-1)
+    return torch.cat([d, torch.cross(o, d, dim=-1)], dim=-1)
+
+
+def positional_encoding(ray, n_freqs=10, start_freq=0):
+    """[sin(f_k x)]_k || [cos(f_k x)]_k with f_k = 2^(k - n/2) pi (:222-242)."""
+    return _nerf.positional_encoding(ray, n_freqs)

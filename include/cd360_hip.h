@@ -1,0 +1,108 @@
+/* cd360_hip.h -- C ABI of libcd360_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the pose-conditioned denoising hot path of custom-diffusion360
+ * (SURVEY.md §8b).  The reference is pure Python; the native arithmetic it reaches on this path
+ * lives in third-party operators.  Each entry point below names the reference call site(s) it
+ * replaces (paths relative to the reference tree).
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch allocates; nothing is allocated here);
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, no hidden synchronisation,
+ *     no global mutable state: re-entrant across streams;
+ *   - workspace sizes come from the *_workspace_bytes() queries, the caller provides the buffer;
+ *   - return 0 on success, <0 on error (CD360_ERR_*): the Python side raises;
+ *   - bf16 tensors are raw uint16 storage; "fp32"/"int32" as named;
+ *   - cameras are packed rows of 16 fp32: R (row-major 9) | T (3) | focal (2) | principal point (2), PyTorch3D
+ *     NDC convention (X_view = X_world R + T, +X left, +Y up), index 0 = target view, 1..n = reference views.
+ */
+#ifndef CD360_HIP_H
+#define CD360_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CD360_OK 0
+#define CD360_ERR_ARG (-1)    /* null / misaligned pointer, non-positive size */
+#define CD360_ERR_SHAPE (-2)  /* unsupported shape or stride */
+#define CD360_ERR_LAUNCH (-3) /* HIP launch failure */
+
+/* ---- attention ---------------------------------------------------------------------------------------------
+ * replaces xformers.ops.memory_efficient_attention(q, k, v, attn_bias=None, op=None)
+ *          sgm/modules/attention.py:393-408 (MemoryEfficientCrossAttention.forward), head dim 64, no mask.
+ * Strided form: q[b][h][n][d] at q + b*qs[0] + h*qs[1] + n*qs[2] + d (element strides, multiples of 8);
+ * k likewise; vt is V TRANSPOSED, vt[b][h][d][key] at vt + b*vs[0] + h*vs[1] + d*vs[2] + key with
+ * vs[2] >= round_up(Nk, 8); o like q (strides multiples of 4).  With these strides the kernel consumes the
+ * to_q/to_k/to_v projection outputs [b, N, H*64] in place and writes [b, N, H*64] (attention.py:394-418 copies gone). */
+int cd360_attn_fwd_bf16(const void* q, const void* k, const void* vt, void* o, int B, int H, int Nq, int Nk,
+                        const int64_t* q_strides, const int64_t* k_strides, const int64_t* vt_strides, const int64_t* o_strides,
+                        float scale, void* stream);
+/* xformers layout: q, k, v, o contiguous [B*H, N, 64]; vt_ws = workspace of cd360_attn_vt_workspace_bytes(BH, Nk). */
+int64_t cd360_attn_vt_workspace_bytes(int BH, int Nk);
+int cd360_attn_fwd_xformers_bf16(const void* q, const void* k, const void* v, void* o, void* vt_ws, int BH, int Nq, int Nk, float scale,
+                                 void* stream);
+
+/* ---- rays, projection, integer bilinear indices ----------------------------------------------------------------
+ * replaces get_patch_rays / get_patch_raybundle / get_directional_raybundle  (sgm/modules/utils_cameraray.py:61-196)
+ *          and the pytorch3d calls inside them (unproject_points, get_camera_center).
+ * cams [b, n+1, 16]; xs, ys [r] NDC patch positions (host computes them exactly as utils_cameraray.py:106-147);
+ * rays out [b, n+1, r*r, 6] fp32 = (origin, unit direction), ray k = row*r + col. */
+int cd360_patch_rays(const void* cams, const void* xs, const void* ys, void* rays, int b, int n, int r, void* stream);
+/* replaces ray_bundle_to_ray_points (nerfsd_pytorch3d.py:381-387), cam.transform_points_ndc (:73-77), the
+ * negate / nan_to_num / clip (:89-95) and the index arithmetic inside F.grid_sample(align_corners=True) (:79-98).
+ * t: sample depths [hw, S] (t_ray_stride = S) or [S] (t_ray_stride = 0).
+ * outputs, any may be NULL: points [b, hw, S, 3] fp32; grid [b, n, hw, S, 2] fp32 (x first);
+ * x0, y0 [b, n, hw, S] int32 north-west texel; mask [b, n, hw, S] int32 (bit0 nw, bit1 ne, bit2 sw, bit3 se in-bounds).
+ * Bit-exact against oracle/pose_path.py (sample_grid, bilinear_corners). */
+int cd360_ray_project_index(const void* cams, const void* xs, const void* ys, const void* t, int t_ray_stride, int b, int n, int r, int S,
+                            void* points, void* grid, void* x0, void* y0, void* mask, void* stream);
+
+/* ---- feature gather --------------------------------------------------------------------------------------------
+ * replaces F.grid_sample(input[b*n, C, r, r], grid[b*n, hw, S, 2], bilinear, align_corners=True, zeros)
+ *          nerfsd_pytorch3d.py:79-98, on channels-last data: xref [n_img, r*r, C], grid [n_img, P, 2] fp32,
+ * out [n_img, P, C].  dtype: 0 = fp32, 1 = bf16 (xref and out). */
+int cd360_feature_gather(const void* xref, const void* grid, void* out, int n_img, int pts_per_img, int r, int C, int dtype, void* stream);
+
+/* ---- FeatureNeRF per-sample MLP + view aggregation ----------------------------------------------------------------
+ * replaces FeatureNeRFEncoding.forward lines nerfsd_pytorch3d.py:102-158 (frame changes, positional encodings,
+ * torch.cat, plane_coefs, nviews softmax, weighted sum over views) together with cd360_plucker_features and three
+ * host GEMMs (see custom-diffusion360_amd/cd360/nerf.py and DESIGN.md §3 for the algebra).
+ *   Y     [b*n, hw, C] bf16 = xref @ W1[:, :C]^T            zP [b*n, hw, C] bf16 = plucker_feats @ W1[:, C+99:]^T + b1
+ *   lv    [b*n, hw] fp32    = xref @ w_v[:C]                cview [b, n] fp32 per-view logit constant
+ *   Wk    [C, cd360_nerf_k_padded()] bf16 = W1[:, C:C+99] with columns permuted to the kernel's input order
+ *   g out [b, hw*S, C] bf16 = sum_i softmax_i(logit_i) * SiLU(z_i)   (plane_coefs.2 is applied to g by the caller)
+ *   logits [b, n, hw*S] fp32 and lse [b, hw*S, 2] = (max, sum) are optional (NULL to skip).  C % 64 == 0. */
+int cd360_plucker_features(const void* cams, const void* xs, const void* ys, void* out /* [b, n, hw, 104] fp32 */, int b, int n, int r,
+                           void* stream);
+int cd360_nerf_k_padded(void);
+int cd360_nerf_mlp_aggregate(const void* cams, const void* xs, const void* ys, const void* t, int t_ray_stride, const void* Y,
+                             const void* zP, const void* lv, const void* cview, const void* Wk, void* g, void* logits, void* lse, int b,
+                             int n, int r, int S, int C, void* stream);
+
+/* ---- volume rendering --------------------------------------------------------------------------------------------
+ * replaces _TruncExp.forward (sgm/modules/attention.py:192-199) + VolRender.forward/get_weights
+ *          (nerfsd_pytorch3d.py:170-231) + the sigmoid on rgb (attention.py:594).
+ * feats [b, hw, S, C] (dtype 0 fp32 / 1 bf16), sigma_raw [b, hw, S] fp32, rgb_raw [b, hw, S, 3] fp32 or NULL,
+ * dists [hw, S] (d_ray_stride = S) or [S] (0).  Outputs: rendered [b, hw, C] (dtype of feats); fg [b, hw];
+ * alphas, weights [b, hw, S]; rgb [b, hw, 3] (fp32; any of fg/alphas/weights/rgb may be NULL).  S <= 64.
+ * flags: bit0 = sigma_raw already exponentiated, bit1 = rgb_raw already sigmoid'ed (the VolRender module API, :196-231). */
+int cd360_volrender(const void* feats, const void* sigma_raw, const void* rgb_raw, const void* dists, int d_ray_stride, void* rendered,
+                    void* fg, void* alphas, void* weights, void* rgb, int b, int hw, int S, int C, int dtype, int flags, void* stream);
+
+/* replaces FeatureNeRFEncoding.decoder, Linear(C -> 1+3, bias=False) (nerfsd_pytorch3d.py:49-51,160) and the channel split in
+ * NerfSDModule.forward (:443-449): h [rows, C] bf16, w [4, C] fp32 -> out [rows, 4] fp32 = (rgb_raw 0..2, sigma_raw 3). */
+int cd360_rowdot4_bf16(const void* h, const void* w, void* out, int64_t rows, int C, void* stream);
+
+/* ---- GroupNorm (+SiLU) ---------------------------------------------------------------------------------------------
+ * replaces GroupNorm32 -> SiLU (sgm/modules/diffusionmodules/util.py:309-311, openaimodel.py:280-283,315-318) and
+ *          SpatialTransformer.norm (attention.py:118-121,833) on channels-last bf16 [N, P, C]; gamma/beta fp32 [C];
+ * ws = cd360_gn_workspace_bytes(N, P, C) bytes; y may alias x.  C % 8 == 0, C <= 4096, G <= 64. */
+int64_t cd360_gn_workspace_bytes(int N, int P, int C);
+int cd360_gn_silu_bf16(const void* x, const void* gamma, const void* beta, void* y, void* ws, int N, int P, int C, int G, float eps,
+                       int silu, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CD360_HIP_H */

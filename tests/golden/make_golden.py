@@ -202,11 +202,7 @@ def case_customforward():
 
 
 # ---------------------------------------------------------------- 5. UNet (reduced depth/width), dual-stream eval
-UNET_TINY = dict(in_channels=4, model_channels=64, out_channels=4, num_res_blocks=1, attention_resolutions=[2], channel_mult=[1, 2],
-                 num_head_channels=64, use_linear_in_transformer=True, transformer_depth=[1, 1], context_dim=32, adm_in_channels=16,
-                 num_classes="sequential", use_checkpoint=False, spatial_transformer_attn_type="softmax-xformers",
-                 image_cross_blocks=[0, 1, 2], rgb=True, far=2, num_samples=4, not_add_context_in_triplane=False, rgb_predict=True,
-                 add_lora=False, average=False, use_prev_weights_imp_sample=True, stratified=True, imp_sampling_percent=0.9)
+from make_golden_params import UNET_TINY  # noqa: E402
 
 
 def case_unet():

@@ -1,0 +1,202 @@
+"""Host-side logic of the product package, on CPU: drop-in surface (class / argument / state_dict parity with the reference),
+the weight re-layouts feeding the fused kernel (validated through a test-only torch emulation of the kernel's arithmetic
+against the oracle), the C-ABI export list, and loud failure without a GPU."""
+import ctypes
+import gzip
+import json
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import weights as W
+from oracle import pose_path as O
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+
+
+def keys(name):
+    with gzip.open(os.path.join(GOLD, name + ".keys.json.gz"), "rt") as f:
+        return json.load(f)
+
+
+def shapes(mod):
+    return {k: list(v.shape) for k, v in mod.state_dict().items()}
+
+
+# ------------------------------------------------------------------------------------------------ drop-in surface
+def test_block_and_st_state_dict_match_reference():
+    from sgm.modules.attention import BasicTransformerBlock, SpatialTransformer
+    blk = BasicTransformerBlock(64, 1, 64, context_dim=32, checkpoint=False, attn_mode="softmax-xformers", image_cross=True, far=2,
+                                num_samples=4, rgb_predict=True, mode="feature-nerf", stratified=True)
+    assert shapes(blk) == keys("block")
+    st = SpatialTransformer(128, 2, 64, depth=5, context_dim=32, use_linear=True, attn_type="softmax-xformers", use_checkpoint=False,
+                            image_cross=True, rgb_predict=True, far=2, num_samples=4, mode="feature-nerf", stratified=True)
+    assert shapes(st) == keys("st")
+    pose_blocks = [d for d, b in enumerate(st.transformer_blocks) if hasattr(b, "pose_emb_layers")]
+    assert pose_blocks == [0, 4]  # d % poscontrol_interval == 0 (attention.py:772)
+    w = st.transformer_blocks[0].pose_emb_layers.weight
+    assert torch.equal(w, torch.cat([torch.eye(128), torch.zeros(128, 128)], 1))  # [I, 0] init (attention.py:515-516)
+    assert torch.all(st.transformer_blocks[0].pose_featurenerf.model.decoder.weight == 0) and torch.all(st.proj_out.weight == 0)
+
+
+def test_unet_tiny_state_dict_matches_reference():
+    from make_golden_params import UNET_TINY
+    from sgm.modules.diffusionmodules.openaimodel import UNetModel
+    net = UNetModel(**UNET_TINY)
+    assert shapes(net) == keys("unet_tiny")
+
+
+def test_sdxl_config_instantiates_with_reference_keys():
+    """configs/train_co3d_concept.yaml:27-54 (network_config) -> UNetModel via instantiate_from_config, on the meta device:
+    1836 tensors / 2634.1 M parameters, names and shapes identical to the reference's."""
+    from make_golden_params import SDXL_NETWORK_CONFIG
+    from sgm.util import instantiate_from_config
+    with torch.device("meta"):
+        net = instantiate_from_config(SDXL_NETWORK_CONFIG)
+    ref = keys("unet_sdxl")
+    mine = shapes(net)
+    assert mine == ref
+    assert abs(sum(int(np.prod(s)) for s in mine.values()) / 1e6 - 2634.12) < 0.5
+    from cd360.sampling import pose_blocks
+    names = [n for n, _ in pose_blocks(net)]
+    assert len(names) == 12 and names[0] == "input_blocks.4.1.transformer_blocks.0" and "middle_block.1.transformer_blocks.8" in names
+    trainable = [k for k, _ in net.named_parameters() if "pose" in k]
+    assert abs(sum(int(np.prod(mine[k])) for k in trainable) / 1e6 - 66.7) < 0.2  # the params main.py fine-tunes (diffusion.py:139-144)
+
+
+def test_attention_modes_and_signatures():
+    import inspect
+    from sgm.modules import attention as A
+    assert set(A.BasicTransformerBlock.ATTENTION_MODES) == {"softmax", "softmax-xformers"}
+    sig = inspect.signature(A.BasicTransformerBlock.forward)
+    assert list(sig.parameters)[1:] == ["x", "context", "context_ref", "pose", "mask_ref", "prev_weights", "additional_tokens",
+                                        "n_times_crossframe_attn_in_self"]
+    assert list(inspect.signature(A.SpatialTransformer.forward).parameters)[1:] == ["x", "xr", "context", "contextr", "pose", "mask_ref", "prev_weights"]
+    assert list(inspect.signature(A.MemoryEfficientCrossAttention.forward).parameters)[1:] == ["x", "context", "mask", "additional_tokens",
+                                                                                                "n_times_crossframe_attn_in_self"]
+    from sgm.modules.nerfsd_pytorch3d import NerfSDModule, VolRender
+    assert list(inspect.signature(NerfSDModule.forward).parameters)[1:] == ["pose", "xref", "mask_ref", "prev_weights", "imp_sample_next_step"]
+    assert list(inspect.signature(VolRender.forward).parameters)[1:] == ["features", "densities", "dists", "return_weight", "densities_uniform",
+                                                                         "dists_uniform", "return_weights_uniform", "rgb"]
+
+
+def test_cpu_forward_fails_loudly():
+    """There is no CPU / PyTorch fallback behind the operators."""
+    from cd360 import ops
+    from cd360._lib import Cd360Error
+    from sgm.modules.attention import MemoryEfficientCrossAttention
+    att = MemoryEfficientCrossAttention(64, heads=1, dim_head=64)
+    with pytest.raises(Cd360Error):
+        att(torch.randn(1, 8, 64))
+    with pytest.raises(Cd360Error):
+        ops.memory_efficient_attention(torch.randn(2, 8, 64), torch.randn(2, 8, 64), torch.randn(2, 8, 64))
+
+
+# ------------------------------------------------------------------------------------------------ C ABI
+def test_library_exports_every_declared_symbol():
+    from cd360 import _lib
+    header = open(os.path.join(ROOT, "include", "cd360_hip.h")).read()
+    declared = set(re.findall(r"\b(cd360_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    lib = _lib.load(check_symbols=True)  # raises if the .so is missing or a symbol is absent
+    for name in declared:
+        assert isinstance(getattr(lib, name), ctypes._CFuncPtr)
+    assert lib.cd360_nerf_k_padded() == 112
+    assert lib.cd360_attn_vt_workspace_bytes(2, 77) == 2 * 64 * 80 * 2
+
+
+# ------------------------------------------------------------------------------------------------ fused-render algebra
+def _emulate_fused_kernel(fw, cams, xref, S, far):
+    """Test-only torch restatement of csrc/nerf_fused.hip + cd360/nerf.py (fp32): validates the weight re-layouts and the algebra."""
+    from cd360 import nerf
+    b, n, hw, C = xref.shape
+    r = int(hw ** 0.5)
+    xs = nerf.patch_positions(r, "cpu")
+    t, dists = nerf.depth_samples(S, far, 0.0, "cpu", hw)
+    rays = O.patch_rays(cams, xs, xs)
+    pts = O.ray_points(rays, t[None, None])  # [b,hw,S,3]
+    Y, lv = nerf.reference_tables(fw, xref)
+    Y, lv = Y.float().reshape(b, n, hw, C), lv.reshape(b, n, hw, 1)
+    # plucker table (kernel cd360_plucker_features) via the oracle's pieces
+    tgt = rays[:, 0]
+    cam_o = O.world_to_view(cams[:, 1:, None, :], tgt[:, None, :, :3])
+    cam_d = O.rotate_to_view(cams[:, 1:, None, :], tgt[:, None, :, 3:])
+    pl = O.plucker(torch.cat([cam_o, cam_d], -1))
+    pf = torch.cat([O.positional_encoding(pl, 8), cam_d, torch.zeros(b, n, hw, 5)], -1)
+    zP = (pf.reshape(-1, 104) @ fw.Wp_t + fw.b1).reshape(b, n, hw, C)
+    cview = nerf.view_constants(fw, cams)
+    grid = O.sample_grid(cams, pts)
+    q = O.world_to_view(cams[:, 1:, None, None, :], pts[:, None])  # [b,n,hw,S,3]
+    feats = torch.zeros(b, n, hw, S, 112)
+    for k, col in enumerate(nerf.xyz_k_columns(C)):
+        ks, h, j = k // 16, (k // 8) % 2, k % 8
+        w = ks * 4 + (j >> 1)
+        if w < 24:
+            rev = q[..., w % 3] * (2.0 if h else 1.0) * 2.0 ** (2 * (w // 3) - 9)
+            feats[..., k] = torch.cos(2 * np.pi * rev) if j & 1 else torch.sin(2 * np.pi * rev)
+        elif col >= 0:
+            feats[..., k] = q[..., col - (C + 96)]
+    z = feats @ fw.Wk.float().t() + zP[:, :, :, None] + O.gather_bilinear(Y, grid)
+    logit = O.gather_bilinear(lv, grid)[..., 0] + cview[:, :, None, None]
+    a = torch.softmax(logit, 1)[..., None]
+    g = (a * torch.nn.functional.silu(z)).sum(1)
+    h = g @ fw.W2_t.float() + fw.b2.float()
+    return h, h @ fw.Wd.t(), a
+
+
+def test_fused_render_algebra_matches_oracle():
+    from cd360 import nerf, synth
+    from cd360.cameras import pack_cameras
+    C, r, n, S, b = 64, 8, 3, 4, 2
+    w = {k[len("model."):]: v for k, v in W.synth_state_dict({
+        "model.plane_coefs.0.weight": (C, C + 198), "model.plane_coefs.0.bias": (C,), "model.plane_coefs.2.weight": (C, C),
+        "model.plane_coefs.2.bias": (C,), "model.nviews.weight": (1, C + 198), "model.nviews.bias": (1,), "model.decoder.weight": (4, C)}, 7).items()}
+    cams = pack_cameras(synth.pose_batch(b, n, seed=13))
+    xref = W.tensor("xref", (b, n, r * r, C), seed=7)
+    fw = nerf.FusedNerfWeights(w["plane_coefs.0.weight"], w["plane_coefs.0.bias"], w["plane_coefs.2.weight"], w["plane_coefs.2.bias"],
+                               w["nviews.weight"], w["nviews.bias"], w["decoder.weight"], dtype=torch.float32)
+    fw.Wk = fw.Wk_f32  # keep the emulation in fp32: this test is about layout/algebra, not bf16 rounding
+    h, dec, a = _emulate_fused_kernel(fw, cams, xref, S, 2.0)
+    feats, sigma, _, attn, rgb, _ = O.nerf_module(w, cams, xref, S, 2.0)
+    assert torch.allclose(a, attn, atol=1e-5)
+    assert torch.allclose(h, feats, atol=2e-4, rtol=1e-3), (h - feats).abs().max()
+    assert torch.allclose(dec[..., 3:], sigma, atol=2e-4) and torch.allclose(dec[..., :3], rgb, atol=2e-4)
+
+
+def test_xyz_k_columns_is_a_bijection_onto_the_99_inputs():
+    from cd360.nerf import xyz_k_columns
+    cols = xyz_k_columns(640)
+    used = [c for c in cols if c >= 0]
+    assert len(cols) == 112 and sorted(used) == list(range(640, 640 + 99))
+
+
+def test_reference_sampling_context_assembly():
+    """_references_as_context == sample.py:89-96 (null image for the unconditional third)."""
+    from sgm.modules.attention import BasicTransformerBlock
+    blk = BasicTransformerBlock(64, 1, 64, context_dim=32, checkpoint=False, attn_mode="softmax-xformers", image_cross=True, num_samples=4,
+                                rgb_predict=True, mode="feature-nerf")
+    refs = torch.arange(5 * 4 * 64, dtype=torch.float32).reshape(5, 4, 64)
+    blk.register_buffer("references", refs)
+    blk.reference_choices = [0, 2]
+    c3 = blk._references_as_context(3)
+    assert c3.shape == (3, 2, 4, 64)
+    assert torch.equal(c3[0, 0], refs[4]) and torch.equal(c3[0, 1], refs[4])
+    assert torch.equal(c3[1, 0], refs[0]) and torch.equal(c3[1, 1], refs[2]) and torch.equal(c3[2], c3[1])
+    c2 = blk._references_as_context(2)
+    assert torch.equal(c2[0, 1], refs[4]) and torch.equal(c2[1, 1], refs[2])
+
+
+def test_pack_cameras_roundtrip_and_cache():
+    from cd360 import synth
+    from cd360.cameras import pack_cameras, unpack_cameras
+    pose = synth.pose_batch(2, 3, seed=5)
+    packed = pack_cameras(pose)
+    assert packed.shape == (2, 4, 16)
+    again = pack_cameras(unpack_cameras(packed))
+    assert torch.equal(packed, again)
+    R = packed[..., :9].reshape(2, 4, 3, 3)
+    assert torch.allclose(R @ R.transpose(-1, -2), torch.eye(3).expand(2, 4, 3, 3), atol=1e-5)

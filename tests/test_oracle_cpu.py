@@ -1,0 +1,196 @@
+"""Oracle (oracle/pose_path.py) pinned against golden vectors captured from the reference's own modules
+(tests/golden/make_golden.py), plus known-answer tests for the pytorch3d conventions the reference relies on
+(the library is not vendored -> "parity unpinned" there).  CPU only."""
+import gzip
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import weights as W
+from oracle import pose_path as O
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = dict(rtol=2e-4, atol=2e-5)  # fp32 round-off: the reference uses bmm/einsum/addmm, the oracle ordered chains
+
+
+def load(name):
+    return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, name + ".npz")).items()}
+
+
+def keys(name):
+    with gzip.open(os.path.join(GOLD, name + ".keys.json.gz"), "rt") as f:
+        return json.load(f)
+
+
+def nerf_weights(C, seed):
+    shapes = {"model.plane_coefs.0.weight": (C, C + 198), "model.plane_coefs.0.bias": (C,), "model.plane_coefs.2.weight": (C, C),
+              "model.plane_coefs.2.bias": (C,), "model.nviews.weight": (1, C + 198), "model.nviews.bias": (1,), "model.decoder.weight": (4, C)}
+    return {k[len("model."):]: v for k, v in W.synth_state_dict(shapes, seed).items()}
+
+
+def close(a, b, **kw):
+    tol = {**TOL, **kw}
+    assert a.shape == b.shape, (a.shape, b.shape)
+    assert torch.allclose(a, b, **tol), f"max abs diff {(a - b).abs().max().item():.3e}"
+
+
+# ------------------------------------------------------------------------------------------- FeatureNeRF (A4-A9)
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_nerf_module_matches_reference(mode):
+    g = load("nerf_" + mode)
+    jit = {} if mode == "eval" else dict(xy_jitter=(g["jit_x"], g["jit_y"]), depth_jitter=g["jit_d"])
+    feats, sigma, dists, attn, rgb, dbg = O.nerf_module(nerf_weights(64, 1), g["cams"], g["xref"], 4, 2.0, **jit)
+    # rays, sample points and grid coordinates are BIT-EXACT (they decide the integer corner indices)
+    assert torch.equal(dbg["rays"], g["rays"])
+    assert torch.equal(dbg["points"][:, None], g["points"])
+    assert torch.equal(dbg["grid"].reshape(g["grid"].shape), g["grid"])
+    assert torch.equal(dists, g["dists"])
+    close(dbg["plane"].permute(0, 1, 4, 2, 3).reshape(g["plane"].shape), g["plane"])
+    close(feats, g["feats"])
+    close(sigma, g["sigma"])
+    close(rgb, g["rgb"])
+    close(attn, g["view_weights"])
+
+
+def test_integer_corner_indices_match_grid_sample():
+    """bilinear_corners + gather_bilinear == F.grid_sample(align_corners=True, zeros) incl. out-of-range and edge samples."""
+    g = load("nerf_eval")
+    grid = g["grid"].clone()
+    grid[0, :4, 0] = torch.tensor([[-1.2, 0.3], [1.2, 1.2], [1.0, -1.0], [-1.0, 1.0]])  # corners / clipped coordinates
+    x = g["xref"].reshape(4, 8, 8, 64).permute(0, 3, 1, 2)
+    want = torch.nn.functional.grid_sample(x, grid, align_corners=True, padding_mode="zeros")
+    got = O.gather_bilinear(g["xref"].reshape(4, 1, 64, 64), grid.reshape(4, 1, 64, 4, 2))
+    close(got.reshape(4, 64, 4, 64).permute(0, 3, 1, 2), want, atol=1e-6)
+    x0, y0, tx, ty, mask = O.bilinear_corners(grid, 8)
+    assert x0.dtype == torch.int32 and int(x0.min()) >= -1 and int(x0.max()) <= 7
+    assert ((mask >= 0) & (mask <= 15)).all()
+
+
+@pytest.mark.parametrize("mode", ["eval", "train"])
+def test_block_matches_reference(mode):
+    g = load("block_" + mode)
+    sd = W.synth_state_dict(keys("block"), seed=2)
+    jit = {} if mode == "eval" else dict(xy_jitter=(g["jit_x"], g["jit_y"]), depth_jitter=g["jit_d"])
+    out, fg, alphas, rgb, _ = O.transformer_block(sd, g["x"], g["ctx"], 1, context_ref=g["cref"], cams=g["cams"], num_samples=4, far=2.0, **jit)
+    close(out, g["out"], atol=1e-4)
+    close(fg, g["fg"])
+    close(alphas, g["alphas"])
+    close(rgb, g["rgb"])
+    if mode == "eval":
+        close(O.transformer_block(sd, g["x"], g["ctx"], 1)[0], g["plain"], atol=1e-4)
+        assert not torch.allclose(g["out"], g["plain"], atol=1e-2), "pose path must not be a no-op (SURVEY.md F7)"
+
+
+def test_spatial_transformer_dual_stream_matches_reference():
+    g = load("st_dual")
+    sd = W.synth_state_dict(keys("st"), seed=3)
+    out, xr, fgs, als, rgbs, _ = O.spatial_transformer(sd, g["x"], g["xr"], g["ctx"], g["ctxr"], g["cams"], 2, 5, num_samples=4, far=2.0)
+    close(out, g["out"], atol=2e-4)
+    close(xr, g["xr_out"], atol=2e-4)
+    for i in range(2):
+        close(fgs[i], g[f"fg{i}"])
+        close(als[i], g[f"alphas{i}"])
+        close(rgbs[i], g[f"rgb{i}"])
+    close(O.spatial_transformer(sd, g["x"], None, g["ctx"], None, None, 2, 5)[0], g["plain"], atol=2e-4)
+
+
+def test_sample_py_cached_render_matches_reference():
+    """sample.py's patched forwards: context_ref from `references[choices]` (null image for the unconditional third), render on
+    the first step, cached `rendered_feat` afterwards."""
+    g = load("customforward_cfg3")
+    sd = W.synth_state_dict(keys("st"), seed=4)
+    choices = g["choices"].tolist()
+    refs = {}
+    for d in (0, 4):
+        r = W.tensor(f"references.{d}", (5, 64, 128), seed=4)
+        sel = r[:-1][choices][None]
+        refs[d] = torch.cat([r[-1:][None].expand(1, 2, -1, -1), sel, sel], 0)
+    out0, _, fgs, _, rgbs, rend = O.spatial_transformer(sd, g["x0"], None, g["ctx"], None, g["cams"], 2, 5, references=refs, num_samples=4, far=2.0)
+    close(out0, g["out0"], atol=2e-4)
+    close(rend[0], g["rend0"], atol=1e-4)
+    close(rend[4], g["rend4"], atol=1e-4)
+    close(fgs[0], g["fg0"]); close(fgs[1], g["fg1"]); close(rgbs[0], g["rgb0"]); close(rgbs[1], g["rgb1"])
+    out1 = O.spatial_transformer(sd, g["x1"], None, g["ctx"], None, g["cams"], 2, 5, rendered=rend)[0]
+    close(out1, g["out1"], atol=2e-4)
+
+
+def test_unet_dual_stream_matches_reference():
+    g = load("unet_tiny")
+    sd = W.synth_state_dict(keys("unet_tiny"), seed=5)
+    out, fgs, als, rgbs = O.unet_forward(sd, g["x"], g["t"], g["ctx"], g["y"], cams=g["cams"], input_ref=g["input_ref"], sigmas_ref=g["sigmas_ref"],
+                                         model_channels=64, num_samples=4, far=2.0)
+    close(out, g["out"], atol=5e-4, rtol=1e-3)
+    assert len(fgs) == 3
+    for i in range(3):
+        close(fgs[i], g[f"fg{i}"], atol=1e-4)
+        close(als[i], g[f"alphas{i}"], atol=1e-4)
+        close(rgbs[i], g[f"rgb{i}"], atol=1e-4)
+
+
+# ------------------------------------------------------------------------------------------- conventions (Appendix B)
+def _cam(R=None, T=(0, 0, 1), f=(1, 1), pp=(0, 0)):
+    R = torch.eye(3) if R is None else R
+    return torch.cat([R.reshape(9), torch.tensor(T, dtype=torch.float32), torch.tensor(f, dtype=torch.float32), torch.tensor(pp, dtype=torch.float32)])
+
+
+def test_known_answer_projection():
+    """identity camera R=I, T=(0,0,1), f=1: world (0.2,-0.1,1) -> view (0.2,-0.1,2) -> NDC (0.1,-0.05)."""
+    ndc = O.project_ndc(_cam(), torch.tensor([0.2, -0.1, 1.0]))
+    assert torch.allclose(ndc, torch.tensor([0.1, -0.05]))
+
+
+def test_project_unproject_roundtrip_and_centre():
+    from cd360 import synth
+    from cd360.cameras import pack_cameras
+    cams = pack_cameras(synth.pose_batch(2, 3, seed=1))
+    xs = O.patch_positions(8)
+    rays = O.patch_rays(cams, xs, xs)
+    pts = O.ray_points(rays, torch.tensor([[[0.5, 1.5]]]))  # two depths along every target ray
+    back = O.project_ndc(cams[:, :1, None, None, :], pts[:, None])[:, 0]
+    hx, hy = torch.meshgrid(xs, xs, indexing="xy")
+    want = torch.stack([hx.reshape(-1), hy.reshape(-1)], -1)[None, :, None].expand_as(back)
+    assert torch.allclose(back, want, atol=1e-5)  # a ray's points project back onto its own patch centre at any depth
+    assert torch.allclose(O.world_to_view(cams, O.camera_center(cams)), torch.zeros(2, 4, 3), atol=1e-6)  # centre -> view origin
+    assert torch.allclose(rays[..., 3:].norm(dim=-1), torch.ones(2, 4, 64), atol=1e-6)
+
+
+def test_same_camera_gives_depth_independent_near_identity_warp():
+    """Appendix B (4): ref camera == target camera -> ray (row i, col j) samples pixel ((j+.5)(r-1)/r, (i+.5)(r-1)/r) at every depth."""
+    from cd360 import synth
+    from cd360.cameras import join_cameras_as_batch, pack_cameras
+    c = synth.ring_cameras(1, seed=3)[0]
+    cams = pack_cameras([join_cameras_as_batch([c, c])])
+    r = 8
+    xs = O.patch_positions(r)
+    rays = O.patch_rays(cams, xs, xs)
+    lengths, _ = O.depth_samples(4, 2.0, num_rays=r * r)
+    grid = O.sample_grid(cams, O.ray_points(rays, lengths))[0, 0]  # [hw, S, 2]
+    ix, iy = (grid[..., 0] + 1) / 2 * (r - 1), (grid[..., 1] + 1) / 2 * (r - 1)
+    j = torch.arange(r).float()
+    want = (j + 0.5) * (r - 1) / r
+    assert torch.allclose(ix.reshape(r, r, 4), want[None, :, None].expand(r, r, 4), atol=2e-5)
+    assert torch.allclose(iy.reshape(r, r, 4), want[:, None, None].expand(r, r, 4), atol=2e-5)
+
+
+def test_torch_norm_is_the_fma_chain_the_kernels_use():
+    """patch_ray normalises with sqrt(fma(z,z,fma(y,y,x*x))); that is what torch's CPU norm over 3 elements computes."""
+    x = torch.randn(4096, 3, generator=torch.Generator().manual_seed(0))
+    d = x.double().numpy()
+    t = np.float32(d[:, 0] * d[:, 0])
+    t = np.float32(d[:, 1] * d[:, 1] + t.astype(np.float64))
+    t = np.float32(d[:, 2] * d[:, 2] + t.astype(np.float64))
+    assert torch.equal(x.norm(dim=-1), torch.from_numpy(np.sqrt(t)))
+
+
+def test_volrender_known_answers():
+    feats = torch.ones(1, 1, 3, 2)
+    dists = torch.full((1, 1, 3, 1), 0.5)
+    out, fg, alphas, w, _ = O.vol_render(feats, torch.zeros(1, 1, 3, 1), dists)  # zero density -> nothing rendered
+    assert torch.all(out == 0) and torch.all(fg == 0) and torch.all(alphas == 0)
+    out, fg, alphas, w, _ = O.vol_render(feats, torch.full((1, 1, 3, 1), 1e4), dists)  # opaque first sample
+    assert torch.allclose(w[0, 0, :, 0], torch.tensor([1.0, 0.0, 0.0])) and torch.allclose(fg, torch.ones(1, 1, 1))
+    out, fg, _, w, _ = O.vol_render(feats, torch.full((1, 1, 3, 1), float("inf")), dists)  # nan_to_num keeps it finite
+    assert torch.isfinite(out).all()
