@@ -1,0 +1,229 @@
+#!/usr/bin/env python
+"""Headline benchmark: UNet denoise steps/s at SDXL 1024^2 with 50 reference views (BASELINE.json configs[1]).
+
+    python bench.py --gpus 1 --steps 50 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload ("sample.py 50-step sampling, SDXL 1024^2, 50-view synthetic cameras"): random-init SDXL UNet from the reference's
+network_config (bf16), latent 128^2, 3-way CFG batch (uncond / image / image+text, sample.py:166-171), 50 reference views
+taken from synthetic per-block `references` buffers, one target pose per GPU.  A "step" is one UNet denoise step over the
+CFG batch plus the CFG combine and Euler update.  The timed region walks the sampler's own schedule: step 0 of every 50-step
+trajectory runs the 12 FeatureNeRF renders, the other 49 use the cached render (sample.py:122-133), so with --steps 50 the
+timed region is exactly one image.  Multi-GPU = independent target poses (weak scaling), one RCCL all-gather of the final
+latents at the end of the job (outside the per-step path).  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "custom-diffusion360_amd"), os.path.join(ROOT, "tests", "golden")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0      # MI355X HBM3E spec (MI355X_MICROARCH.md); ~6300 achievable
+MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
+
+
+def build_model(latent: int, n_ref: int, n_train: int, device, seed: int = 0):
+    from make_golden_params import SDXL_NETWORK_CONFIG
+    from sgm.util import instantiate_from_config
+    from cd360 import sampling
+
+    torch.manual_seed(seed)
+    with torch.device(device):
+        net = instantiate_from_config(SDXL_NETWORK_CONFIG)
+    net = net.to(torch.bfloat16).eval()
+    g = torch.Generator(device=device).manual_seed(seed + 1)
+    with torch.no_grad():
+        for name, blk in sampling.pose_blocks(net):
+            c = blk.pose_emb_layers.weight.shape[0]
+            # the stock init makes the pose path a no-op: perturb pose_emb_layers / decoder / proj_out
+            blk.pose_emb_layers.weight.add_(torch.randn(c, 2 * c, generator=g, device=device, dtype=torch.float32).mul_(0.02).to(torch.bfloat16))
+            blk.pose_featurenerf.model.decoder.weight.copy_(torch.randn(4, c, generator=g, device=device).mul_(0.02))
+        for m in net.modules():
+            if m.__class__.__name__ == "SpatialTransformer":
+                m.proj_out.weight.copy_(torch.randn(m.proj_out.weight.shape, generator=g, device=device).mul_(0.02))
+        refs = {}
+        for name, blk in sampling.pose_blocks(net):
+            c = blk.pose_emb_layers.weight.shape[0]
+            r = latent // 2 if c == 640 else latent // 4
+            refs[name] = torch.randn(n_train + 1, r * r, c, generator=g, device=device).to(torch.bfloat16)
+        sampling.set_references(net, refs)
+        choices = [int(x) for x in torch.linspace(0, n_train - n_train / n_ref, n_ref)]
+        sampling.enable_reference_sampling(net, choices)
+    return net
+
+
+def legacy_ddpm_sigmas(n_steps: int, device):
+    """LegacyDDPMDiscretization (discretizer.py:47-69) sub-sampled like EulerEDMSampler does, sigma descending, + final 0."""
+    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float64) ** 2
+    ac = torch.cumprod(1.0 - betas, 0)
+    sig = ((1 - ac) / ac) ** 0.5
+    idx = torch.linspace(999, 0, n_steps).round().long()
+    return torch.cat([sig[idx], torch.zeros(1, dtype=torch.float64)]).float().to(device), idx.to(device)
+
+
+class Sampler:
+    """Minimal Euler (DDIM-equivalent, EpsScaling) step with the 3-way image/text CFG of guiders.py:102-133."""
+
+    def __init__(self, net, pose, ctx, y, n_steps, scale=7.5, scale_im=3.5):
+        self.net, self.pose, self.ctx, self.y, self.n_steps = net, pose, ctx, y, n_steps
+        self.scale, self.scale_im = scale, scale_im
+        dev = ctx.device
+        self.sigmas, self.tidx = legacy_ddpm_sigmas(n_steps, dev)
+
+    @torch.no_grad()
+    def step(self, x, i):
+        from cd360 import sampling
+        i = i % self.n_steps
+        if i == 0:
+            sampling.clear_rendered_feat(self.net)  # new image: the render runs again
+        s, s_next = self.sigmas[i], self.sigmas[i + 1]
+        c_in = 1.0 / (s * s + 1.0) ** 0.5
+        x3 = (x * c_in).expand(3, -1, -1, -1)
+        t = self.tidx[i].float().expand(3)
+        eps = self.net(x3, timesteps=t, context=self.ctx, y=self.y, pose=self.pose)[0]
+        den = x3 - eps * s  # EpsScaling: c_skip = 1, c_out = -sigma
+        x_u, x_ic, x_c = den[0:1], den[1:2], den[2:3]
+        d0 = x_u + self.scale_im * (x_ic - x_u) + self.scale * (x_c - x_ic)
+        d = (x - d0) / s
+        return x + d * (s_next - s)
+
+
+def cpu_baseline(net, latent: int, threads: int):
+    """CPU oracle (fp32 restatement of the reference) on a bounded sample of the same workload: ONE of the three CFG branches of
+    ONE steady-state denoise step (cached render) at the bench's latent size; scaled by 1/3 to the metric's unit."""
+    from oracle import pose_path as O
+    from cd360 import sampling
+
+    torch.set_num_threads(threads)
+    sd = {k: v.detach().float().cpu() for k, v in net.state_dict().items() if "references" not in k and "raymarcher" not in k}
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(1, 4, latent, latent, generator=g)
+    ctx = torch.randn(1, 77, 2048, generator=g)
+    y = torch.randn(1, 2816, generator=g)
+    rendered = {}
+    for name, blk in sampling.pose_blocks(net):
+        st_key, _, d = name.rpartition(".transformer_blocks.")
+        c = blk.pose_emb_layers.weight.shape[0]
+        r = latent // 2 if c == 640 else latent // 4
+        rendered.setdefault(st_key, {})[int(d)] = torch.randn(1, r * r, c, generator=g) * 0.1
+    cams = torch.zeros(1, 2, 16)  # unused on the cached path, but marks the blocks as pose blocks
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        O.unet_forward(sd, x, torch.tensor([500.0]), ctx, y, cams=cams, st_state={"rendered": rendered})
+    dt = time.perf_counter() - t0
+    return {"value": round(1.0 / (3.0 * dt), 6), "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": f"oracle/pose_path.py unet_forward, fp32: 1 of 3 CFG branches of one steady-state step (cached render), latent {latent}^2, "
+                      f"{dt:.1f} s measured, value = 1/(3*t)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--latent", type=int, default=128, help="latent side (128 = 1024^2 image)")
+    ap.add_argument("--refs", type=int, default=50)
+    ap.add_argument("--traj", type=int, default=50, help="sampler steps per image (render on step 0 of each)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 through torch.distributed.run)"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    from cd360 import ops, synth
+
+    net = build_model(args.latent, args.refs, 50, dev)
+    pose1 = synth.pose_batch(1, args.refs, seed=100 + rank, n_train=50)  # one target pose per rank, 50 shared reference cameras
+    pose = pose1 * 3
+    g = torch.Generator(device=dev).manual_seed(7 + rank)
+    ctx = torch.randn(3, 77, 2048, generator=g, device=dev).to(torch.bfloat16)
+    y = torch.randn(3, 2816, generator=g, device=dev).to(torch.bfloat16)
+    x = torch.randn(1, 4, args.latent, args.latent, generator=g, device=dev)
+    smp = Sampler(net, pose, ctx, y, args.traj)
+
+    def sync():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    xw = x.clone()
+    for i in range(args.warmup):
+        xw = smp.step(xw, i)
+    # individually timed render / steady steps (reported in config, not the headline)
+    sync(); t0 = time.perf_counter(); xw = smp.step(x.clone(), 0); sync(); render_ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter(); xw = smp.step(xw, 1); sync(); steady_ms = (time.perf_counter() - t0) * 1e3
+
+    if not args.no_profile:
+        ops.profile_start()
+    xs = x.clone()
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        xs = smp.step(xs, i)
+    sync()
+    elapsed = time.perf_counter() - t0
+    prof = ops.profile_stop() if not args.no_profile else {}
+
+    tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        gathered = [torch.empty_like(xs) for _ in range(world)]
+        dist.all_gather(gathered, xs)  # the job's one exchange: final latents of every pose
+        assert all(torch.isfinite(t).all() for t in gathered)
+    elapsed = float(tmax.item())
+    assert torch.isfinite(xs).all()
+
+    if rank == 0:
+        roof = None
+        if prof:
+            name = max(prof, key=lambda k: prof[k]["ms"])
+            e = prof[name]
+            if e["flops"] > 0 and name in ("attn_fwd", "nerf_mlp_aggregate"):
+                ach = e["flops"] / (e["ms"] * 1e-3) / 1e12
+                roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
+                        "frac": round(ach / MFMA_BF16_PEAK_TF, 4), "traffic": None, "launches": e["n"], "avg_us": round(e["ms"] * 1e3 / e["n"], 2)}
+            else:
+                ach = e["bytes"] / (e["ms"] * 1e-3) / 1e9
+                roof = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": e["n"], "avg_us": round(e["ms"] * 1e3 / e["n"], 2)}
+        out = {
+            "metric": "UNet denoise steps/sec @ SDXL 1024^2, 50 ref views", "value": round(args.steps * world / elapsed, 4), "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "sample.py 50-step sampling, SDXL UNet (random init), latent %d^2, CFG x3, %d ref views (synthetic ring cameras), "
+                                   "1 target pose per GPU; render on step 0 of each %d-step trajectory, cached afterwards" % (args.latent, args.refs, args.traj),
+                       "render_step_ms": round(render_ms, 2), "steady_step_ms": round(steady_ms, 2), "cfg_batch": 3, "latent": args.latent,
+                       "n_ref": args.refs, "poses_per_gpu": 1,
+                       "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}},
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(net, args.latent, os.cpu_count() or 1)
+            except Exception as e:  # noqa: BLE001  (e.g. not enough host RAM for the fp32 copy)
+                out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -14,6 +14,52 @@ from ._lib import Cd360Error, check
 _I64x3 = ctypes.c_int64 * 3
 
 
+# ----------------------------------------------------------------------------------------------- per-kernel timing
+# bench.py brackets every C-ABI launch with HIP events ON THE LAUNCH STREAM (torch's current stream is the stream every
+# kernel here is enqueued on) and reads them back after the timed region; off by default (zero overhead).
+_PROF = None
+
+
+def profile_start() -> None:
+    global _PROF
+    _PROF = []
+
+
+def profile_stop() -> dict:
+    """-> {kernel: {"ms": total, "n": launches, "flops": algorithmic flops, "bytes": algorithmic HBM bytes}} (synchronises)."""
+    global _PROF
+    rec, _PROF = _PROF or [], None
+    torch.cuda.synchronize()
+    out = {}
+    for name, e0, e1, flops, nbytes in rec:
+        d = out.setdefault(name, {"ms": 0.0, "n": 0, "flops": 0.0, "bytes": 0.0})
+        d["ms"] += e0.elapsed_time(e1)
+        d["n"] += 1
+        d["flops"] += flops
+        d["bytes"] += nbytes
+    return out
+
+
+class _timed:
+    __slots__ = ("name", "flops", "nbytes", "e0")
+
+    def __init__(self, name, flops=0.0, nbytes=0.0):
+        self.name, self.flops, self.nbytes = name, flops, nbytes
+
+    def __enter__(self):
+        if _PROF is not None:
+            self.e0 = torch.cuda.Event(enable_timing=True)
+            self.e0.record()
+        return self
+
+    def __exit__(self, *a):
+        if _PROF is not None:
+            e1 = torch.cuda.Event(enable_timing=True)
+            e1.record()
+            _PROF.append((self.name, self.e0, e1, self.flops, self.nbytes))
+        return False
+
+
 def _stream() -> ctypes.c_void_p:
     return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
 
@@ -45,7 +91,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, nk
     if out is None:
         out = torch.empty(b, nq, inner, dtype=torch.bfloat16, device=q.device)
     lib = _lib.load()
-    check(
+    with _timed("attn_fwd", 4.0 * b * heads * nq * nk * 64, 2.0 * (2 * b * nq * inner + 2 * b * nk * inner)):
+      check(
         lib.cd360_attn_fwd_bf16(
             _ptr(q), _ptr(k), _ptr(vt), _ptr(out), b, heads, nq, nk,
             _I64x3(q.stride(0), 64, q.stride(1)), _I64x3(k.stride(0), 64, k.stride(1)),
@@ -123,7 +170,8 @@ def plucker_features(cams, xs, ys) -> torch.Tensor:
     b, n1, _ = cams.shape
     r = xs.numel()
     out = torch.empty(b, n1 - 1, r * r, 104, dtype=torch.float32, device=cams.device)
-    check(_lib.load().cd360_plucker_features(_ptr(cams), _ptr(xs), _ptr(ys), _ptr(out), b, n1 - 1, r, _stream()), "cd360_plucker_features")
+    with _timed("plucker_features", 0.0, 4.0 * 104 * b * (n1 - 1) * r * r):
+      check(_lib.load().cd360_plucker_features(_ptr(cams), _ptr(xs), _ptr(ys), _ptr(out), b, n1 - 1, r, _stream()), "cd360_plucker_features")
     return out
 
 
@@ -146,7 +194,8 @@ def nerf_mlp_aggregate(cams, xs, ys, t, Y, zP, lv, cview, Wk, want_logits=False)
     g = torch.empty(b, hw * S, C, dtype=torch.bfloat16, device=Y.device)
     logits = torch.empty(b, n, hw * S, dtype=torch.float32, device=Y.device) if want_logits else None
     lse = torch.empty(b, hw * S, 2, dtype=torch.float32, device=Y.device) if want_logits else None
-    check(_lib.load().cd360_nerf_mlp_aggregate(_ptr(cams), _ptr(xs), _ptr(ys), _ptr(t.contiguous()), stride, _ptr(Y), _ptr(zP), _ptr(lv),
+    with _timed("nerf_mlp_aggregate", 2.0 * b * n * hw * S * 99 * C, 2.0 * C * (2 * b * n * hw + b * hw * S)):
+      check(_lib.load().cd360_nerf_mlp_aggregate(_ptr(cams), _ptr(xs), _ptr(ys), _ptr(t.contiguous()), stride, _ptr(Y), _ptr(zP), _ptr(lv),
                                               _ptr(cview), _ptr(Wk), _ptr(g), _ptr(logits), _ptr(lse), b, n, r, S, C, _stream()),
           "cd360_nerf_mlp_aggregate")
     return g, logits, lse
@@ -168,7 +217,8 @@ def volrender(feats, sigma_raw, dists, rgb_raw=None, want_weights=False, sigma_i
     rgb = torch.empty(b, hw, 3, dtype=torch.float32, device=dev) if rgb_raw is not None else None
     dt = {torch.float32: 0, torch.bfloat16: 1}[feats.dtype]
     stride = 0 if dists.dim() == 1 else S
-    check(_lib.load().cd360_volrender(_ptr(feats), _ptr(sigma_raw), _ptr(rgb_raw), _ptr(dists), stride, _ptr(rendered), _ptr(fg),
+    with _timed("volrender", 0.0, feats.element_size() * C * b * hw * (S + 1.0)):
+      check(_lib.load().cd360_volrender(_ptr(feats), _ptr(sigma_raw), _ptr(rgb_raw), _ptr(dists), stride, _ptr(rendered), _ptr(fg),
                                      _ptr(alphas), _ptr(weights), _ptr(rgb), b, hw, S, C, dt, (0 if sigma_is_raw else 1) | (0 if rgb_is_raw else 2),
                                      _stream()), "cd360_volrender")
     return rendered, fg, alphas, weights, rgb
@@ -181,7 +231,8 @@ def rowdot4(h: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     assert h.dtype == torch.bfloat16 and h.is_contiguous() and w.shape == (4, C) and w.dtype == torch.float32 and w.is_contiguous()
     rows = h.numel() // C
     out = torch.empty(*h.shape[:-1], 4, dtype=torch.float32, device=h.device)
-    check(_lib.load().cd360_rowdot4_bf16(_ptr(h), _ptr(w), _ptr(out), rows, C, _stream()), "cd360_rowdot4_bf16")
+    with _timed("rowdot4", 0.0, 2.0 * rows * C):
+      check(_lib.load().cd360_rowdot4_bf16(_ptr(h), _ptr(w), _ptr(out), rows, C, _stream()), "cd360_rowdot4_bf16")
     return out
 
 
@@ -196,6 +247,7 @@ def gn_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: in
     ws = torch.empty(lib.cd360_gn_workspace_bytes(N, P, C), dtype=torch.uint8, device=x.device)
     if out is None:
         out = torch.empty_like(x)
-    check(lib.cd360_gn_silu_bf16(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(ws), N, P, C, groups, float(eps), int(silu), _stream()),
+    with _timed("gn_silu", 0.0, 2.0 * 3 * N * P * C):
+      check(lib.cd360_gn_silu_bf16(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(ws), N, P, C, groups, float(eps), int(silu), _stream()),
           "cd360_gn_silu_bf16")
     return out
