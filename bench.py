@@ -185,9 +185,9 @@ def main():
     tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        gathered = [torch.empty_like(xs) for _ in range(world)]
-        dist.all_gather(gathered, xs)  # the job's one exchange: final latents of every pose
-        assert all(torch.isfinite(t).all() for t in gathered)
+        from cd360 import shard
+        gathered = shard.gather_latents(xs, world)  # the job's one exchange: final latents of every pose
+        assert gathered.shape[0] == world and torch.isfinite(gathered).all()
     elapsed = float(tmax.item())
     assert torch.isfinite(xs).all()
 
@@ -217,7 +217,8 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(net, args.latent, os.cpu_count() or 1)
+                # 32 threads: PyTorch's CPU kernels stop scaling (and regress badly) beyond one socket's worth of cores
+                out["cpu_baseline"] = cpu_baseline(net, args.latent, min(os.cpu_count() or 1, 32))
             except Exception as e:  # noqa: BLE001  (e.g. not enough host RAM for the fp32 copy)
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
         print(json.dumps(out), flush=True)

@@ -52,28 +52,36 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const uint16_t* __restr
   }
 }
 
+// grid (N): per-channel totals over the slabs (coalesced, fixed order), then per-group mean / rstd -> stat [N, G, 2]
+__global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stat, int P, int C, int G,
+                                                          float eps, int nslab) {
+  __shared__ float tot[2 * MAX_C];
+  const int n = blockIdx.x, cpg = C / G;
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    float acc = 0.f;
+    for (int sl = 0; sl < nslab; ++sl) acc += partial[((long)n * nslab + sl) * 2 * C + i];
+    tot[i] = acc;
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < G; g += 256) {
+    float s = 0.f, ss = 0.f;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += tot[2 * c]; ss += tot[2 * c + 1]; }
+    const float cnt = (float)cpg * (float)P;
+    const float mean = s / cnt;
+    const float var = fmaxf(ss / cnt - mean * mean, 0.f);
+    stat[((long)n * G + g) * 2] = mean;
+    stat[((long)n * G + g) * 2 + 1] = 1.f / sqrtf(var + eps);
+  }
+}
+
 template <bool SILU>
 __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restrict__ x, const float* __restrict__ partial,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        uint16_t* __restrict__ y, int P, int C, int G, float eps, int nslab,
                                                        int nslab_apply) {
   __shared__ float ab[2 * MAX_C];  // per channel: scale, shift
-  __shared__ float gstat[2 * 64];
   const int n = blockIdx.y, slab = blockIdx.x, cpg = C / G, CV = C >> 3;
-  // group statistics from the per-channel partial sums (fixed summation order: deterministic)
-  for (int g = threadIdx.x; g < G; g += blockDim.x) {
-    float s = 0.f, ss = 0.f;
-    for (int sl = 0; sl < nslab; ++sl) {
-      const float* src = partial + ((long)n * nslab + sl) * 2 * C + 2 * g * cpg;
-      for (int c = 0; c < cpg; ++c) { s += src[2 * c]; ss += src[2 * c + 1]; }
-    }
-    const float cnt = (float)cpg * (float)P;
-    const float mean = s / cnt;
-    const float var = fmaxf(ss / cnt - mean * mean, 0.f);
-    gstat[2 * g] = mean;
-    gstat[2 * g + 1] = 1.f / sqrtf(var + eps);
-  }
-  __syncthreads();
+  const float* gstat = partial + (long)n * 2 * G;  // here `partial` is the finalised [N, G, 2] = (mean, rstd)
   for (int c = threadIdx.x; c < C; c += blockDim.x) {
     const int g = c / cpg;
     const float a = gstat[2 * g + 1] * gamma[c];
@@ -104,9 +112,13 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const uint16_t* __restric
 
 }  // namespace
 
+static inline int gn_num_slabs(int P) {
+  const int n = (P + 63) / 64;  // ~64 pixels per workgroup: >= 256 workgroups per image at 128^2
+  return n < 1 ? 1 : (n > 256 ? 256 : n);
+}
+
 extern "C" int64_t cd360_gn_workspace_bytes(int N, int P, int C) {
-  const int nslab = P >= 4096 ? 32 : (P >= 1024 ? 16 : (P >= 256 ? 4 : 1));
-  return (int64_t)N * nslab * 2 * C * 4;
+  return ((int64_t)N * gn_num_slabs(P) * 2 * C + (int64_t)N * 2 * 64) * 4;
 }
 
 // x, y: [N, P, C] bf16 channels-last (y may alias x); gamma, beta: [C] fp32; ws: cd360_gn_workspace_bytes(N, P, C) bytes
@@ -114,16 +126,20 @@ extern "C" int cd360_gn_silu_bf16(const void* x, const void* gamma, const void* 
                                   float eps, int silu, void* stream) {
   if (!x || !gamma || !beta || !y || !ws || N <= 0 || P <= 0 || C <= 0 || G <= 0) return CD360_ERR_ARG;
   if (C % 8 || C % G || C > MAX_C || G > 64) return CD360_ERR_SHAPE;
-  const int nslab = P >= 4096 ? 32 : (P >= 1024 ? 16 : (P >= 256 ? 4 : 1));
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(nslab, N), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (float*)ws, P, C, nslab);
+  const int nslab = gn_num_slabs(P);
+  float* partial = (float*)ws;
+  float* stat = partial + (long)N * nslab * 2 * C;
+  hipLaunchKernelGGL(gn_partial_kernel, dim3(nslab, N), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, partial, P, C, nslab);
+  CD360_LAUNCH_CHECK();
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (const float*)partial, stat, P, C, G, eps, nslab);
   CD360_LAUNCH_CHECK();
   const int nslab_apply = (int)(((long)P * (C / 8) + 256 * 8 - 1) / (256 * 8));
   const int na = nslab_apply < 1 ? 1 : (nslab_apply > 1024 ? 1024 : nslab_apply);
   if (silu)
-    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(na, N), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (const float*)ws,
+    hipLaunchKernelGGL(gn_apply_kernel<true>, dim3(na, N), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (const float*)stat,
                        (const float*)gamma, (const float*)beta, (uint16_t*)y, P, C, G, eps, nslab, na);
   else
-    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(na, N), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (const float*)ws,
+    hipLaunchKernelGGL(gn_apply_kernel<false>, dim3(na, N), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, (const float*)stat,
                        (const float*)gamma, (const float*)beta, (uint16_t*)y, P, C, G, eps, nslab, na);
   CD360_LAUNCH_CHECK();
   return CD360_OK;

@@ -168,8 +168,7 @@ def gather_bilinear(xref: Tensor, grid: Tensor) -> Tensor:
     out = torch.zeros(*grid.shape[:-1], C, dtype=xref.dtype)
     wts = [(1 - tx) * (1 - ty), tx * (1 - ty), (1 - tx) * ty, tx * ty]
     offs = [(0, 0), (1, 0), (0, 1), (1, 1)]
-    S = grid.shape[3]
-    bn = torch.arange(b * n).reshape(b, n, 1, 1).expand(b, n, hw, S)
+    bn = torch.arange(b * n).reshape(b, n, 1, 1).expand(b, n, grid.shape[2], grid.shape[3])
     for bit, ((dx, dy), w) in enumerate(zip(offs, wts)):
         ok = ((mask >> bit) & 1).bool()
         idx = ((y0l + dy).clamp(0, r - 1) * r + (x0l + dx).clamp(0, r - 1))
