@@ -251,3 +251,29 @@ def gn_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: in
       check(lib.cd360_gn_silu_bf16(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(ws), N, P, C, groups, float(eps), int(silu), _stream()),
           "cd360_gn_silu_bf16")
     return out
+
+
+# ----------------------------------------------------------------------------------------------- epilogues
+def geglu(proj: torch.Tensor) -> torch.Tensor:
+    """proj [..., 2*inner] bf16 = [x | gate] -> [..., inner] = x * gelu(gate)."""
+    _need_gpu(proj)
+    inner = proj.shape[-1] // 2
+    assert proj.dtype == torch.bfloat16 and proj.is_contiguous()
+    rows = proj.numel() // (2 * inner)
+    out = torch.empty(*proj.shape[:-1], inner, dtype=torch.bfloat16, device=proj.device)
+    with _timed("geglu", 0.0, 2.0 * 3 * rows * inner):
+        check(_lib.load().cd360_geglu_bf16(_ptr(proj), _ptr(out), rows, inner, _stream()), "cd360_geglu_bf16")
+    return out
+
+
+def concat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """torch.cat([a, b], dim=1) for channels-last bf16 images [N, C, H, W]; returns a channels-last [N, Ca+Cb, H, W]."""
+    _need_gpu(a, b)
+    N, ca, H, W = a.shape
+    cb = b.shape[1]
+    at, bt = a.permute(0, 2, 3, 1), b.permute(0, 2, 3, 1)
+    assert a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and at.is_contiguous() and bt.is_contiguous() and b.shape[0] == N
+    out = torch.empty(N, H, W, ca + cb, dtype=torch.bfloat16, device=a.device)
+    with _timed("concat_channels", 0.0, 2.0 * 2 * N * H * W * (ca + cb)):
+        check(_lib.load().cd360_concat_channels_bf16(_ptr(at), _ptr(bt), _ptr(out), N * H * W, ca, cb, _stream()), "cd360_concat_channels_bf16")
+    return out.permute(0, 3, 1, 2)

@@ -16,6 +16,7 @@
 //   * all tensors are addressed through explicit strides, so the kernel reads the projection outputs
 //     [b, N, H*64] in place and writes [b, N, H*64] directly: no head split/merge copies.
 #include "cd360_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -33,15 +34,60 @@ struct AttnParams {
   int n_qtiles;
 };
 
-constexpr int BM = 128;       // queries per workgroup
 constexpr int BN = 64;        // keys per tile
 constexpr int K_PITCH = 128;  // bytes per K row in LDS (64 d * 2 B), XOR-swizzled
 constexpr int V_PITCH = 136;  // bytes per V^T row in LDS (64 keys * 2 B + 8 B pad)
+constexpr int TILE_BYTES = BN * K_PITCH + 64 * V_PITCH;
 
+// One K/V tile on its way from HBM to LDS: every thread carries 2 x 16 B of K and 2 x 16 B of V^T in registers, so the
+// loads of tile t+1 are in flight while tile t is being consumed (split issue / write, LDS double-buffered).
+struct TileRegs {
+  u32x4 k[2], v[2];
+};
+
+__device__ __forceinline__ void tile_load(const AttnParams& p, const uint16_t* kp, const uint16_t* vp, int kt0, int tid, TileRegs& r) {
+  const bool ragged = kt0 + BN > p.Nk;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int row = (tid >> 3) + 32 * pass, chunk = tid & 7;
+    u32x4 kv = {0u, 0u, 0u, 0u};
+    const int key = kt0 + row;
+    if (key < p.Nk) kv = *reinterpret_cast<const u32x4*>(kp + (long)key * p.k_sn + chunk * 8);
+    r.k[pass] = kv;
+    const int key0 = kt0 + chunk * 8;
+    u32x4 vv = {0u, 0u, 0u, 0u};
+    if (key0 < p.Nk) {
+      vv = *reinterpret_cast<const u32x4*>(vp + (long)row * p.v_sd + key0);
+      if (ragged) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          uint32_t w = vv[e];
+          if (key0 + 2 * e >= p.Nk) w &= 0xffff0000u;
+          if (key0 + 2 * e + 1 >= p.Nk) w &= 0x0000ffffu;
+          vv[e] = w;
+        }
+      }
+    }
+    r.v[pass] = vv;
+  }
+}
+
+__device__ __forceinline__ void tile_store(unsigned char* Ks, unsigned char* Vs, int tid, const TileRegs& r) {
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int row = (tid >> 3) + 32 * pass, chunk = tid & 7;
+    *reinterpret_cast<u32x4*>(Ks + row * K_PITCH + ((chunk ^ ((row >> 1) & 7)) << 4)) = r.k[pass];
+    u32x2 lo = {r.v[pass][0], r.v[pass][1]}, hi = {r.v[pass][2], r.v[pass][3]};
+    *reinterpret_cast<u32x2*>(Vs + row * V_PITCH + chunk * 16) = lo;
+    *reinterpret_cast<u32x2*>(Vs + row * V_PITCH + chunk * 16 + 8) = hi;
+  }
+}
+
+// QB = 32-query blocks per wave (1: 128 queries per workgroup, 2: 256).  QB = 2 halves the LDS fragment traffic and the
+// barriers per MFMA and is used whenever the grid still fills the chip.
+template <int QB>
 __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[BN * K_PITCH + 64 * V_PITCH];
-  unsigned char* Ks = lds;
-  unsigned char* Vs = lds + BN * K_PITCH;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TILE_BYTES];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -52,136 +98,147 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
   const uint16_t* vp = p.vt + b * p.v_sb + h * p.v_sh;
   uint16_t* op = p.o + b * p.o_sb + h * p.o_sh;
 
-  const int qrow = qt * BM + wave * 32 + l31;
-  const bool qok = qrow < p.Nq;
-
-  bf16x8 qf[4];
+  int qrow[QB];
+  bf16x8 qf[QB][4];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    u32x4 v = {0u, 0u, 0u, 0u};
-    if (qok) v = *reinterpret_cast<const u32x4*>(qp + (long)qrow * p.q_sn + 16 * ks + 8 * hh);
-    qf[ks] = __builtin_bit_cast(bf16x8, v);
+  for (int qb = 0; qb < QB; ++qb) {
+    qrow[qb] = qt * (128 * QB) + (wave * QB + qb) * 32 + l31;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (qrow[qb] < p.Nq) v = *reinterpret_cast<const u32x4*>(qp + (long)qrow[qb] * p.q_sn + 16 * ks + 8 * hh);
+      qf[qb][ks] = __builtin_bit_cast(bf16x8, v);
+    }
   }
 
-  f32x16 oT[2];
+  f32x16 oT[QB][2];
+  float m_run[QB], l_run[QB];
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { oT[0][i] = 0.f; oT[1][i] = 0.f; }
-  float m_run = -INFINITY, l_run = 0.f;
+  for (int qb = 0; qb < QB; ++qb) {
+    m_run[qb] = -INFINITY;
+    l_run[qb] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { oT[qb][0][i] = 0.f; oT[qb][1][i] = 0.f; }
+  }
+  const float c = p.scale_log2e;
 
-  for (int kt0 = 0; kt0 < p.Nk; kt0 += BN) {
-    __syncthreads();  // previous tile fully consumed
+  TileRegs tr;
+  tile_load(p, kp, vp, 0, tid, tr);
+  tile_store(lds, lds + BN * K_PITCH, tid, tr);
+  __syncthreads();
+
+  int buf = 0;
+  for (int kt0 = 0; kt0 < p.Nk; kt0 += BN, buf ^= 1) {
+    const unsigned char* Ks = lds + buf * TILE_BYTES;
+    const unsigned char* Vs = Ks + BN * K_PITCH;
+    const bool more = kt0 + BN < p.Nk;
+    if (more) tile_load(p, kp, vp, kt0 + BN, tid, tr);  // in flight during this tile's MFMAs
+
     const bool ragged = kt0 + BN > p.Nk;
-    // ---- stage K tile [64 keys][64 d] and V^T tile [64 d][64 keys] ----
-#pragma unroll
-    for (int pass = 0; pass < 2; ++pass) {
-      const int row = (tid >> 3) + 32 * pass, chunk = tid & 7;
-      u32x4 kv = {0u, 0u, 0u, 0u};
-      const int key = kt0 + row;
-      if (key < p.Nk) kv = *reinterpret_cast<const u32x4*>(kp + (long)key * p.k_sn + chunk * 8);
-      *reinterpret_cast<u32x4*>(Ks + row * K_PITCH + ((chunk ^ ((row >> 1) & 7)) << 4)) = kv;
-
-      const int key0 = kt0 + chunk * 8;
-      u32x4 vv = {0u, 0u, 0u, 0u};
-      if (key0 < p.Nk) {
-        vv = *reinterpret_cast<const u32x4*>(vp + (long)row * p.v_sd + key0);
-        if (ragged) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            uint32_t w = vv[e];
-            if (key0 + 2 * e >= p.Nk) w &= 0xffff0000u;
-            if (key0 + 2 * e + 1 >= p.Nk) w &= 0x0000ffffu;
-            vv[e] = w;
-          }
-        }
-      }
-      u32x2 lo = {vv[0], vv[1]}, hi = {vv[2], vv[3]};
-      *reinterpret_cast<u32x2*>(Vs + row * V_PITCH + chunk * 16) = lo;
-      *reinterpret_cast<u32x2*>(Vs + row * V_PITCH + chunk * 16 + 8) = hi;
-    }
-    __syncthreads();
-
     const int nkb = (p.Nk - kt0 > 32) ? 2 : 1;  // 32-key blocks with at least one valid key
     // ---- S^T = K Q^T ----
-    f32x16 sT[2];
+    f32x16 sT[QB][2];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { sT[qb][0][i] = 0.f; sT[qb][1][i] = 0.f; }
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int i = 0; i < 16; ++i) sT[kb][i] = 0.f;
       if (kb < nkb) {
         const int krow = kb * 32 + l31;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
           const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ks + krow * K_PITCH + (((2 * ks + hh) ^ ((krow >> 1) & 7)) << 4));
-          sT[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[ks], sT[kb], 0, 0, 0);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) sT[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[qb][ks], sT[qb][kb], 0, 0, 0);
         }
       }
     }
-    // ---- online softmax (this lane: one query column; keys spread over registers and lane^32) ----
-    float mx = -INFINITY;
+    __builtin_amdgcn_s_setprio(0);
+
+    // ---- online softmax (this lane: one query column per q-block; keys spread over registers and lane^32) ----
+    uint32_t pk[QB][16];
 #pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
+    for (int qb = 0; qb < QB; ++qb) {
+      if (ragged || nkb < 2) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        float s = sT[kb][r] * p.scale_log2e;
-        if (ragged) {
-          const int key = kt0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-          if (key >= p.Nk) s = -INFINITY;
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kt0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+            if (key >= p.Nk) sT[qb][kb][r] = -INFINITY;
+          }
+      }
+      float mx = sT[qb][0][0];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sT[qb][kb][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run[qb], mx);  // raw (unscaled) score units
+      const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c);
+      const float mc = -m_new * c;
+      float rs = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+          const float p0 = __builtin_amdgcn_exp2f(fmaf(sT[qb][kb][r], c, mc));
+          const float p1 = __builtin_amdgcn_exp2f(fmaf(sT[qb][kb][r + 1], c, mc));
+          rs += p0 + p1;
+          pk[qb][kb * 8 + (r >> 1)] = pack_bf16x2(p0, p1);
         }
-        if (kb >= nkb) s = -INFINITY;
-        sT[kb][r] = s;
-        mx = fmaxf(mx, s);
-      }
+      rs += __shfl_xor(rs, 32);
+      l_run[qb] = l_run[qb] * alpha + rs;
+      m_run[qb] = m_new;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { oT[qb][0][i] *= alpha; oT[qb][1][i] *= alpha; }
     }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    float rs = 0.f;
-    uint32_t pk[16];
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-      for (int r = 0; r < 16; r += 2) {
-        const float p0 = __builtin_amdgcn_exp2f(sT[kb][r] - m_new);
-        const float p1 = __builtin_amdgcn_exp2f(sT[kb][r + 1] - m_new);
-        rs += p0 + p1;
-        pk[kb * 8 + (r >> 1)] = pack_bf16x2(p0, p1);
-      }
-    }
-    rs += __shfl_xor(rs, 32);
-    l_run = l_run * alpha + rs;
-    m_run = m_new;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { oT[0][i] *= alpha; oT[1][i] *= alpha; }
 
     // ---- O^T += V^T P^T ----
+    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       if (kk < 2 * nkb) {
-        u32x4 pw = {pk[kk * 4 + 0], pk[kk * 4 + 1], pk[kk * 4 + 2], pk[kk * 4 + 3]};
-        const bf16x8 pb = __builtin_bit_cast(bf16x8, pw);
 #pragma unroll
         for (int db = 0; db < 2; ++db) {
           const unsigned char* vrow = Vs + (db * 32 + l31) * V_PITCH + (16 * kk + 4 * hh) * 2;
           const u32x2 v0 = *reinterpret_cast<const u32x2*>(vrow);
           const u32x2 v1 = *reinterpret_cast<const u32x2*>(vrow + 16);
           u32x4 vw = {v0[0], v0[1], v1[0], v1[1]};
-          oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vw), pb, oT[db], 0, 0, 0);
+          const bf16x8 va = __builtin_bit_cast(bf16x8, vw);
+#pragma unroll
+          for (int qb = 0; qb < QB; ++qb) {
+            u32x4 pw = {pk[qb][kk * 4 + 0], pk[qb][kk * 4 + 1], pk[qb][kk * 4 + 2], pk[qb][kk * 4 + 3]};
+            oT[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, __builtin_bit_cast(bf16x8, pw), oT[qb][db], 0, 0, 0);
+          }
         }
       }
     }
+    __builtin_amdgcn_s_setprio(0);
+
+    if (more) {
+      unsigned char* Kn = lds + (buf ^ 1) * TILE_BYTES;
+      tile_store(Kn, Kn + BN * K_PITCH, tid, tr);  // the other buffer was last read before the previous barrier
+    }
+    __syncthreads();
   }
 
-  if (qok) {
-    const float inv = 1.f / l_run;
-    uint16_t* orow = op + (long)qrow * p.o_sn;
 #pragma unroll
-    for (int db = 0; db < 2; ++db) {
+  for (int qb = 0; qb < QB; ++qb) {
+    if (qrow[qb] < p.Nq) {
+      const float inv = 1.f / l_run[qb];
+      uint16_t* orow = op + (long)qrow[qb] * p.o_sn;
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = db * 32 + 8 * g + 4 * hh;
-        u32x2 w = {pack_bf16x2(oT[db][4 * g + 0] * inv, oT[db][4 * g + 1] * inv),
-                   pack_bf16x2(oT[db][4 * g + 2] * inv, oT[db][4 * g + 3] * inv)};
-        *reinterpret_cast<u32x2*>(orow + d) = w;
+      for (int db = 0; db < 2; ++db) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = db * 32 + 8 * g + 4 * hh;
+          u32x2 w = {pack_bf16x2(oT[qb][db][4 * g + 0] * inv, oT[qb][db][4 * g + 1] * inv),
+                     pack_bf16x2(oT[qb][db][4 * g + 2] * inv, oT[qb][db][4 * g + 3] * inv)};
+          *reinterpret_cast<u32x2*>(orow + d) = w;
+        }
       }
     }
   }
@@ -224,10 +281,20 @@ extern "C" int cd360_attn_fwd_bf16(const void* q, const void* k, const void* vt,
   if (p.v_sd < ((Nk + 7) / 8) * 8) return CD360_ERR_SHAPE;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) % 16 || (uintptr_t)o % 8) return CD360_ERR_ARG;
   p.scale_log2e = scale * 1.4426950408889634f;
-  p.n_qtiles = (Nq + BM - 1) / BM;
+  // 256 queries per workgroup (2 q-blocks per wave) when that still gives every CU work; else 128
+  const long wg256 = (long)((Nq + 255) / 256) * B * H;
+  int qb = wg256 >= 384 ? 2 : 1;
+  if (const char* e = getenv("CD360_ATTN_QB")) {  // tuning override: 1 or 2
+    if (e[0] == '1') qb = 1;
+    if (e[0] == '2') qb = 2;
+  }
+  p.n_qtiles = (Nq + 128 * qb - 1) / (128 * qb);
   const long nwg = (long)p.n_qtiles * B * H;
   if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
-  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+  if (qb == 2)
+    hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
   CD360_LAUNCH_CHECK();
   return CD360_OK;
 }

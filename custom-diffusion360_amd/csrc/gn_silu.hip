@@ -52,23 +52,29 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const uint16_t* __restr
   }
 }
 
-// grid (N): per-channel totals over the slabs (coalesced, fixed order), then per-group mean / rstd -> stat [N, G, 2]
+// grid (G, N): one workgroup reduces the nslab x cpg x (sum, sumsq) partials of one group (fixed tree order: deterministic)
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stat, int P, int C, int G,
                                                           float eps, int nslab) {
-  __shared__ float tot[2 * MAX_C];
-  const int n = blockIdx.x, cpg = C / G;
-  for (int i = threadIdx.x; i < 2 * C; i += 256) {
-    float acc = 0.f;
-    for (int sl = 0; sl < nslab; ++sl) acc += partial[((long)n * nslab + sl) * 2 * C + i];
-    tot[i] = acc;
+  __shared__ float red[2 * 256];
+  const int g = blockIdx.x, n = blockIdx.y, cpg = C / G, tid = threadIdx.x;
+  float s = 0.f, ss = 0.f;
+  for (int i = tid; i < nslab * cpg; i += 256) {
+    const int sl = i / cpg, c = g * cpg + (i - sl * cpg);
+    const float* src = partial + (((long)n * nslab + sl) * C + c) * 2;
+    s += src[0];
+    ss += src[1];
   }
+  red[2 * tid] = s;
+  red[2 * tid + 1] = ss;
   __syncthreads();
-  for (int g = threadIdx.x; g < G; g += 256) {
-    float s = 0.f, ss = 0.f;
-    for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s += tot[2 * c]; ss += tot[2 * c + 1]; }
+  for (int off = 128; off > 0; off >>= 1) {
+    if (tid < off) { red[2 * tid] += red[2 * (tid + off)]; red[2 * tid + 1] += red[2 * (tid + off) + 1]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
     const float cnt = (float)cpg * (float)P;
-    const float mean = s / cnt;
-    const float var = fmaxf(ss / cnt - mean * mean, 0.f);
+    const float mean = red[0] / cnt;
+    const float var = fmaxf(red[1] / cnt - mean * mean, 0.f);
     stat[((long)n * G + g) * 2] = mean;
     stat[((long)n * G + g) * 2 + 1] = 1.f / sqrtf(var + eps);
   }
@@ -131,7 +137,7 @@ extern "C" int cd360_gn_silu_bf16(const void* x, const void* gamma, const void* 
   float* stat = partial + (long)N * nslab * 2 * C;
   hipLaunchKernelGGL(gn_partial_kernel, dim3(nslab, N), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, partial, P, C, nslab);
   CD360_LAUNCH_CHECK();
-  hipLaunchKernelGGL(gn_finalize_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, (const float*)partial, stat, P, C, G, eps, nslab);
+  hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, N), dim3(256), 0, (hipStream_t)stream, (const float*)partial, stat, P, C, G, eps, nslab);
   CD360_LAUNCH_CHECK();
   const int nslab_apply = (int)(((long)P * (C / 8) + 256 * 8 - 1) / (256 * 8));
   const int na = nslab_apply < 1 ? 1 : (nslab_apply > 1024 ? 1024 : nslab_apply);

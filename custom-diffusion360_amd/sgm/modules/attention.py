@@ -60,7 +60,10 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, x):
-        x, gate = self.proj(x).chunk(2, dim=-1)
+        p = self.proj(x)
+        if p.dtype == torch.bfloat16 and p.is_cuda:
+            return ops.geglu(p)  # one fused pass (cd360_geglu_bf16)
+        x, gate = p.chunk(2, dim=-1)
         return x * F.gelu(gate)
 
 
@@ -83,6 +86,12 @@ def Normalize(in_channels):
 def _pad_tokens(ctx: torch.Tensor, mult: int = 8) -> torch.Tensor:
     pad = (-ctx.shape[1]) % mult
     return ctx if pad == 0 else F.pad(ctx, (0, 0, 0, pad))
+
+
+def _project_transposed(w: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """(x @ w^T)^T = w @ x^T as ONE batched GEMM writing [b, out, N] directly (x^T is consumed as a transposed BLAS operand;
+    torch.matmul(w, x^T) would compute x @ w^T and then copy-transpose it)."""
+    return torch.bmm(w.unsqueeze(0).expand(x.shape[0], -1, -1), x.transpose(1, 2))
 
 
 class MemoryEfficientCrossAttention(nn.Module):
@@ -116,7 +125,7 @@ class MemoryEfficientCrossAttention(nn.Module):
         """K [b, Nk_pad, inner] and V^T [b, inner, Nk_pad] for a cross-attention context (reusable across query sets)."""
         ctx = _pad_tokens(context)
         k = F.linear(ctx, self.to_k.weight)
-        vt = torch.matmul(self.to_v.weight, ctx.transpose(1, 2))
+        vt = _project_transposed(self.to_v.weight, ctx)
         return k, vt, context.shape[1]
 
     def attend(self, x: torch.Tensor, kv) -> torch.Tensor:
@@ -144,7 +153,7 @@ class MemoryEfficientCrossAttention(nn.Module):
             if x.shape[1] % 8 == 0:
                 qk = F.linear(x, self._qk_weight())
                 q, k = qk[..., :inner], qk[..., inner:]
-                vt = torch.matmul(self.to_v.weight, x.transpose(1, 2))
+                vt = _project_transposed(self.to_v.weight, x)
                 return self._finish(x, q, k, vt, x.shape[1])
             context = x
         return self.attend(x, self.project_context(context))

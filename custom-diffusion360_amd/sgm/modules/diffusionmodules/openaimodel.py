@@ -19,6 +19,7 @@ import torch as th
 import torch.nn as nn
 import torch.nn.functional as F
 
+from cd360 import ops
 from ...modules.attention import SpatialTransformer
 from ...modules.diffusionmodules.util import (
     conv_nd,
@@ -30,6 +31,14 @@ from ...modules.diffusionmodules.util import (
     zero_module,
 )
 from ...util import default, exists
+
+
+def _cat_channels(a, b):
+    """th.cat([a, b], dim=1) (openaimodel.py:1074-1076); channels-last bf16 goes through cd360_concat_channels_bf16."""
+    if a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.shape[1] % 8 == 0 and b.shape[1] % 8 == 0:
+        cl = torch.channels_last
+        return ops.concat_channels(a.contiguous(memory_format=cl), b.contiguous(memory_format=cl))
+    return th.cat([a, b], dim=1)
 
 
 class TimestepBlock(nn.Module):
@@ -277,10 +286,10 @@ class UNetModel(nn.Module):
         h, hr, fg, _, al, rgb = self.middle_block(h, emb, context, hr, embr, contextr, pose, mask_ref=mask_ref, prev_weights=None)
         collect(fg, al, rgb)
         for module in self.output_blocks:
-            h = th.cat([h, hs.pop()], dim=1)
+            h = _cat_channels(h, hs.pop())
             hrp = hrs.pop()
             if reference_image:
-                hr = th.cat([hr, hrp], dim=1)
+                hr = _cat_channels(hr, hrp)
             h, hr, fg, _, al, rgb = module(h, emb, context, hr, embr, contextr, pose, mask_ref=mask_ref, prev_weights=None)
             collect(fg, al, rgb)
         out = self.out[2](tokens_to_image(group_norm_tokens(self.out[0], h, silu=True), h.shape[2], h.shape[3]))

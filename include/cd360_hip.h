@@ -102,6 +102,14 @@ int64_t cd360_gn_workspace_bytes(int N, int P, int C);
 int cd360_gn_silu_bf16(const void* x, const void* gamma, const void* beta, void* y, void* ws, int N, int P, int C, int G, float eps,
                        int silu, void* stream);
 
+/* ---- epilogues around the transformer blocks -------------------------------------------------------------------------
+ * replaces GEGLU.forward's chunk / F.gelu / multiply (sgm/modules/attention.py:94-96): in [rows, 2*inner] bf16 = [x | gate]
+ * -> out [rows, inner] = x * gelu(gate) (erf form).  inner % 8 == 0. */
+int cd360_geglu_bf16(const void* in, void* out, int64_t rows, int inner, void* stream);
+/* replaces th.cat([h, hs.pop()], dim=1) (sgm/modules/diffusionmodules/openaimodel.py:1074-1076) on channels-last activations:
+ * a [pixels, ca], b [pixels, cb] -> out [pixels, ca + cb].  ca, cb % 8 == 0. */
+int cd360_concat_channels_bf16(const void* a, const void* b, void* out, int64_t pixels, int ca, int cb, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

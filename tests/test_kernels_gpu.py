@@ -175,6 +175,18 @@ def test_rowdot4():
     assert rel(ops.rowdot4(h.to(DEV, torch.bfloat16), w.to(DEV)), h @ w.t()) < 1e-5
 
 
+def test_geglu_and_concat():
+    from cd360 import ops
+    g = torch.Generator().manual_seed(10)
+    p = bf(torch.randn(3, 50, 2 * 320, generator=g) * 2)
+    x, gate = p.chunk(2, dim=-1)
+    assert rel(ops.geglu(p.to(DEV, torch.bfloat16)), x * torch.nn.functional.gelu(gate)) < 8e-3
+    a, b = bf(torch.randn(2, 64, 5, 7, generator=g)), bf(torch.randn(2, 24, 5, 7, generator=g))
+    cl = torch.channels_last
+    got = ops.concat_channels(a.to(DEV, torch.bfloat16).contiguous(memory_format=cl), b.to(DEV, torch.bfloat16).contiguous(memory_format=cl))
+    assert got.shape == (2, 88, 5, 7) and torch.equal(got.float().cpu(), torch.cat([a, b], 1))
+
+
 # ------------------------------------------------------------------------------------------------ GroupNorm + SiLU (K7)
 @pytest.mark.parametrize("N,P,C,silu", [(2, 64, 64, True), (3, 1024, 320, True), (1, 4096, 640, False), (2, 256, 2560, True), (1, 100, 960, False)])
 def test_gn_silu(N, P, C, silu):

@@ -1,0 +1,84 @@
+"""Micro-benchmarks of the cd360 kernels at the bench workload's shapes (cfg-B: latent 128^2, b=3, n=50).  GPU only."""
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "custom-diffusion360_amd"), os.path.join(ROOT, "tests", "golden")):
+    sys.path.insert(0, p)
+import torch
+
+from cd360 import nerf, ops, synth
+from cd360.cameras import pack_cameras
+
+dev = "cuda"
+BF = torch.bfloat16
+
+
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / iters * 1e3  # us
+
+
+def attn(tag, b, H, nq, nk):
+    q = torch.randn(b, nq, H * 64, device=dev).to(BF)
+    k = torch.randn(b, (nk + 7) // 8 * 8, H * 64, device=dev).to(BF)
+    vt = torch.randn(b, H * 64, (nk + 7) // 8 * 8, device=dev).to(BF)
+    us = timeit(lambda: ops.attention(q, k, vt, H, nk))
+    fl = 4.0 * b * H * nq * nk * 64
+    by = 2.0 * (2 * b * nq * H * 64 + 2 * b * nk * H * 64)
+    print(f"attn {tag:12s} b{b} H{H} Nq{nq} Nk{nk}: {us:9.1f} us  {fl / us / 1e6:8.1f} TF/s  {by / us / 1e3:8.1f} GB/s", flush=True)
+
+
+def nerf_block(tag, C, r, n=50, b=3, S=24):
+    import weights as W
+    shapes = {"model.plane_coefs.0.weight": (C, C + 198), "model.plane_coefs.0.bias": (C,), "model.plane_coefs.2.weight": (C, C),
+              "model.plane_coefs.2.bias": (C,), "model.nviews.weight": (1, C + 198), "model.nviews.bias": (1,), "model.decoder.weight": (4, C)}
+    w = {k[len("model."):]: v.to(dev) for k, v in W.synth_state_dict(shapes, 1).items()}
+    fw = nerf.FusedNerfWeights(w["plane_coefs.0.weight"], w["plane_coefs.0.bias"], w["plane_coefs.2.weight"], w["plane_coefs.2.bias"],
+                               w["nviews.weight"], w["nviews.bias"], w["decoder.weight"])
+    cams = pack_cameras(synth.pose_batch(1, n, seed=1) * b).to(dev)
+    hw = r * r
+    xref = torch.randn(b, n, hw, C, device=dev).to(BF)
+    xs = nerf.patch_positions(r, dev)
+    t, dists = nerf.depth_samples(S, 2.0, 0.0, dev, hw)
+    Y, lv = nerf.reference_tables(fw, xref)
+    zP = torch.randn(b * n, hw, C, device=dev).to(BF)
+    cview = nerf.view_constants(fw, cams)
+    us = timeit(lambda: ops.nerf_mlp_aggregate(cams, xs, xs, t, Y, zP, lv, cview, fw.Wk), iters=5, warm=1)
+    M = b * n * hw * S
+    print(f"nerf {tag}: C{C} r{r} n{n} b{b}: {us:9.1f} us  rows {M / 1e6:.1f}M  {M * C / us / 1e3:8.1f} G(row*ch)/s  mfma {2.0 * M * 99 * C / us / 1e6:7.1f} TF/s", flush=True)
+    us2 = timeit(lambda: nerf.reference_tables(fw, xref), iters=5, warm=1)
+    print(f"     tables (Y GEMM + lv): {us2:9.1f} us", flush=True)
+
+
+def gn(tag, N, P, C):
+    x = torch.randn(N, P, C, device=dev).to(BF)
+    g, bta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+    us = timeit(lambda: ops.gn_silu(x, g, bta, 32, 1e-5, True))
+    print(f"gn_silu {tag}: N{N} P{P} C{C}: {us:8.1f} us  {3.0 * 2 * N * P * C / us / 1e3:8.1f} GB/s", flush=True)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["attn", "nerf", "gn"]
+    print("env CD360_ATTN_QB =", os.environ.get("CD360_ATTN_QB"))
+    if "attn" in which:
+        attn("L1 self", 3, 10, 4096, 4096)
+        attn("L2 self", 3, 20, 1024, 1024)
+        attn("L1 cross", 3, 10, 4096, 77)
+        attn("L2 cross", 3, 20, 1024, 77)
+        attn("L1 pose", 3, 10, 98304, 77)
+        attn("L2 pose", 3, 20, 24576, 77)
+    if "gn" in which:
+        gn("L0", 3, 16384, 320); gn("L1", 3, 4096, 640); gn("L2", 3, 1024, 1280); gn("up", 3, 1024, 2560); gn("up0", 3, 16384, 960)
+    if "nerf" in which:
+        nerf_block("L2", 1280, 32)
+        nerf_block("L1", 640, 64)
