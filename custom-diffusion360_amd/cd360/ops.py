@@ -277,3 +277,24 @@ def concat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     with _timed("concat_channels", 0.0, 2.0 * 2 * N * H * W * (ca + cb)):
         check(_lib.load().cd360_concat_channels_bf16(_ptr(at), _ptr(bt), _ptr(out), N * H * W, ca, cb, _stream()), "cd360_concat_channels_bf16")
     return out.permute(0, 3, 1, 2)
+
+
+# ----------------------------------------------------------------------------------------------- conv3x3 / GEMM (implicit GEMM)
+def conv_igemm(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], N: int, H: int, W: int, taps: int = 9,
+               emb: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [N*H*W, Cin] (or [N, H*W, Cin]) channels-last bf16; w_packed [Cout, taps*Cin] bf16; bias fp32 [Cout]; emb bf16 [N, Cout];
+    res bf16 [N*H*W, Cout] -> [N, H*W, Cout] bf16 = conv3x3 (taps=9) or x @ w^T (taps=1) + bias + emb[n] + res."""
+    _need_gpu(x, w_packed, bias, emb, res)
+    cin = x.shape[-1]
+    cout = w_packed.shape[0]
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.numel() == N * H * W * cin
+    assert w_packed.dtype == torch.bfloat16 and w_packed.is_contiguous() and w_packed.shape[1] == taps * cin
+    assert bias is None or (bias.dtype == torch.float32 and bias.is_contiguous())
+    assert emb is None or (emb.dtype == torch.bfloat16 and emb.is_contiguous() and emb.shape == (N, cout))
+    assert res is None or (res.dtype == torch.bfloat16 and res.is_contiguous() and res.numel() == N * H * W * cout)
+    out = torch.empty(N, H * W, cout, dtype=torch.bfloat16, device=x.device)
+    m = N * H * W
+    with _timed("conv_igemm", 2.0 * m * taps * cin * cout, 2.0 * (m * cin + m * cout + taps * cin * cout)):
+        check(_lib.load().cd360_conv_igemm_bf16(_ptr(x), _ptr(w_packed), _ptr(bias), _ptr(emb), _ptr(res), _ptr(out), N, H, W, cin, cout, taps,
+                                               _stream()), "cd360_conv_igemm_bf16")
+    return out

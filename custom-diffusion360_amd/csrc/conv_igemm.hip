@@ -1,0 +1,199 @@
+// 3x3 (stride 1, pad 1) convolution and plain GEMM on channels-last bf16 as ONE implicit-GEMM MFMA kernel with fused
+// epilogues -- the convs that bracket the injected transformer blocks:
+//   ResBlock  in_layers[2]  : conv3x3(SiLU(GN(x))) + bias + emb[n, :]          (sgm/modules/diffusionmodules/openaimodel.py:352-374)
+//   ResBlock  out_layers[3] : conv3x3(SiLU(GN(h))) + bias + skip               (openaimodel.py:375-376)
+//   Upsample.conv, UNet.out : conv3x3 + bias                                    (openaimodel.py:161-164, 967-973)
+// MIOpen serves these shapes with split-K asm kernels (fp32 atomics + separate zero-fill and cast passes, ~270 TF/s effective
+// at SDXL sizes, see profiles/r01a_*); here the 9 taps are 9 shifted views of the same NHWC tensor accumulated into one MFMA
+// accumulator, bias / time-embedding / residual are applied in registers and the bf16 result is written once.
+//
+//   out^T[co, pixel] = sum_{tap, ci} Wp[co][tap][ci] * x[pixel + shift(tap)][ci]       (zero outside the image)
+// Tile 128 co x 128 pixels x 64 ci per step, 4 waves (2 x 2), each 64 x 64 on v_mfma_f32_32x32x16_bf16; the weight operand
+// rows are loaded through the permutation `chan_pos` so that a lane ends up with 16 CONSECUTIVE output channels of one pixel
+// (32-byte stores); both LDS tiles use the 16-B XOR swizzle of attn_fwd.hip (conflict-free ds_read_b128); the next K-step's
+// tiles travel HBM -> registers while the current one is multiplied (LDS double-buffered, one barrier per step).
+#include "cd360_common.h"
+
+namespace {
+
+struct ConvParams {
+  const uint16_t* x;      // [M, Cin] pixels (n, y, x) row-major, channels contiguous
+  const uint16_t* w;      // [Cout, taps * Cin] packed: k = tap * Cin + ci, tap = ky * 3 + kx
+  const float* bias;      // [Cout] or null
+  const uint16_t* emb;    // [N, Cout] bf16 per-image addend or null
+  const uint16_t* res;    // [M, Cout] bf16 residual or null
+  uint16_t* out;          // [M, Cout]
+  int N, H, W, Cin, Cout, taps;
+  long M;
+  int n_mtiles, n_ntiles;
+};
+
+constexpr int BM = 128, BNC = 128, BK = 64, PITCH = 128;  // bytes per LDS row (64 ch x 2 B)
+constexpr int STAGE = (BM + BNC) * PITCH;
+
+__device__ __forceinline__ int chan_pos(int i) { return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3); }
+__device__ __forceinline__ int swz(int row, int chunk) { return row * PITCH + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wco = wave >> 1, wpx = wave & 1;  // wave tile: 64 channels x 64 pixels
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int nt = tile % p.n_ntiles, mt = tile / p.n_ntiles;  // neighbouring workgroups share the pixel tile (L2 reuse)
+  const long m0 = (long)mt * BM;
+  const int co0 = nt * BNC;
+  const int HW = p.H * p.W;
+  const int chunk = tid & 7, lrow = tid >> 3;
+
+  // ---- per-thread staging geometry: 4 weight rows and 4 pixel rows (fixed for the whole K loop) ----
+  const uint16_t* wsrc[4];
+  bool wok[4];
+  long pbase[4];
+  int py[4], px[4];
+  bool pok[4];
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const int row = lrow + 32 * ps;
+    const int co = co0 + row;
+    wok[ps] = co < p.Cout;
+    wsrc[ps] = p.w + (long)(wok[ps] ? co : 0) * p.taps * p.Cin + chunk * 8;
+    const long m = m0 + row;
+    pok[ps] = m < p.M;
+    const long mc = pok[ps] ? m : 0;
+    const int rem = (int)(mc % HW);
+    py[ps] = rem / p.W;
+    px[ps] = rem - py[ps] * p.W;
+    pbase[ps] = mc * p.Cin + chunk * 8;
+  }
+
+  const int kchunks = p.Cin / BK;
+  const int nsteps = p.taps * kchunks;
+
+  u32x4 wreg[4], xreg[4];
+  auto load_step = [&](int step) {
+    const int tap = step / kchunks, kc = step - tap * kchunks;
+    const int dy = p.taps == 9 ? tap / 3 - 1 : 0, dx = p.taps == 9 ? tap % 3 - 1 : 0;
+    const long woff = (long)tap * p.Cin + kc * BK;
+    const long xoff = ((long)dy * p.W + dx) * p.Cin + kc * BK;
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      u32x4 z = {0u, 0u, 0u, 0u};
+      wreg[ps] = wok[ps] ? *reinterpret_cast<const u32x4*>(wsrc[ps] + woff) : z;
+      const bool ok = pok[ps] && (unsigned)(py[ps] + dy) < (unsigned)p.H && (unsigned)(px[ps] + dx) < (unsigned)p.W;
+      xreg[ps] = ok ? *reinterpret_cast<const u32x4*>(p.x + pbase[ps] + xoff) : z;
+    }
+  };
+  auto store_step = [&](unsigned char* base) {
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) {
+      const int row = lrow + 32 * ps;
+      *reinterpret_cast<u32x4*>(base + swz(row, chunk)) = wreg[ps];
+      *reinterpret_cast<u32x4*>(base + BNC * PITCH + swz(row, chunk)) = xreg[ps];
+    }
+  };
+
+  f32x16 acc[2][2];  // [channel block][pixel block]
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { acc[0][0][i] = 0.f; acc[0][1][i] = 0.f; acc[1][0][i] = 0.f; acc[1][1][i] = 0.f; }
+
+  load_step(0);
+  store_step(lds);
+  __syncthreads();
+
+  const int wrow0 = wco * 64 + chan_pos(l31);  // + 32 * cb : weight-tile row feeding MFMA A-operand row l31
+  const int prow0 = wpx * 64 + l31;            // + 32 * pb : pixel-tile row feeding MFMA B-operand column l31
+  for (int step = 0; step < nsteps; ++step) {
+    const unsigned char* Ws = lds + (step & 1) * STAGE;
+    const unsigned char* Xs = Ws + BNC * PITCH;
+    const bool more = step + 1 < nsteps;
+    if (more) load_step(step + 1);
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        a[i] = *reinterpret_cast<const bf16x8*>(Ws + swz(wrow0 + 32 * i, 2 * ks + hh));
+        b[i] = *reinterpret_cast<const bf16x8*>(Xs + swz(prow0 + 32 * i, 2 * ks + hh));
+      }
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+        for (int pb = 0; pb < 2; ++pb) acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cb], b[pb], acc[cb][pb], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+    if (more) store_step(lds + ((step + 1) & 1) * STAGE);
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane = pixel (l31), registers = 16 consecutive channels (16*hh + r) of each 32-channel block ----
+#pragma unroll
+  for (int pb = 0; pb < 2; ++pb) {
+    const long m = m0 + wpx * 64 + pb * 32 + l31;
+    if (m >= p.M) continue;
+    const int img = (int)(m / HW);
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb) {
+      const int co = co0 + wco * 64 + cb * 32 + 16 * hh;
+      if (co >= p.Cout) continue;  // Cout is a multiple of 16
+      float v[16];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) v[r] = acc[cb][pb][r];
+      if (p.bias) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] += p.bias[co + r];
+      }
+      if (p.emb) {
+        const u32x4 e0 = *reinterpret_cast<const u32x4*>(p.emb + (long)img * p.Cout + co);
+        const u32x4 e1 = *reinterpret_cast<const u32x4*>(p.emb + (long)img * p.Cout + co + 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[2 * e] += bf16lo_to_f32(e0[e]); v[2 * e + 1] += bf16hi_to_f32(e0[e]);
+          v[8 + 2 * e] += bf16lo_to_f32(e1[e]); v[8 + 2 * e + 1] += bf16hi_to_f32(e1[e]);
+        }
+      }
+      if (p.res) {
+        const u32x4 e0 = *reinterpret_cast<const u32x4*>(p.res + m * p.Cout + co);
+        const u32x4 e1 = *reinterpret_cast<const u32x4*>(p.res + m * p.Cout + co + 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[2 * e] += bf16lo_to_f32(e0[e]); v[2 * e + 1] += bf16hi_to_f32(e0[e]);
+          v[8 + 2 * e] += bf16lo_to_f32(e1[e]); v[8 + 2 * e + 1] += bf16hi_to_f32(e1[e]);
+        }
+      }
+      u32x4 o0, o1;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        o0[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+        o1[e] = pack_bf16x2(v[8 + 2 * e], v[8 + 2 * e + 1]);
+      }
+      uint16_t* dst = p.out + m * p.Cout + co;
+      *reinterpret_cast<u32x4*>(dst) = o0;
+      *reinterpret_cast<u32x4*>(dst + 8) = o1;
+    }
+  }
+}
+
+}  // namespace
+
+// x [N*H*W, Cin] channels-last bf16; w_packed [Cout, taps*Cin] bf16 (taps = 9: k = (ky*3+kx)*Cin + ci, 3x3 / stride 1 / pad 1;
+// taps = 1: plain GEMM out = x @ w^T with H = W = 1 ignored); bias fp32 [Cout] | NULL; emb bf16 [N, Cout] | NULL (added per image);
+// res bf16 [N*H*W, Cout] | NULL; out bf16 [N*H*W, Cout].  Cin % 64 == 0, Cout % 16 == 0.
+extern "C" int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const void* bias, const void* emb, const void* res, void* out,
+                                     int N, int H, int W, int Cin, int Cout, int taps, void* stream) {
+  if (!x || !w_packed || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return CD360_ERR_ARG;
+  if ((taps != 9 && taps != 1) || Cin % BK || Cout % 16) return CD360_ERR_SHAPE;
+  if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)out | (uintptr_t)emb | (uintptr_t)res) % 16) return CD360_ERR_ARG;
+  ConvParams p;
+  p.x = (const uint16_t*)x; p.w = (const uint16_t*)w_packed; p.bias = (const float*)bias; p.emb = (const uint16_t*)emb;
+  p.res = (const uint16_t*)res; p.out = (uint16_t*)out;
+  p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.taps = taps;
+  p.M = (long)N * H * W;
+  p.n_mtiles = (int)((p.M + BM - 1) / BM);
+  p.n_ntiles = (Cout + BNC - 1) / BNC;
+  const long nwg = (long)p.n_mtiles * p.n_ntiles;
+  if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
+  hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+  CD360_LAUNCH_CHECK();
+  return CD360_OK;
+}

@@ -23,6 +23,7 @@ from cd360 import ops
 from ...modules.attention import SpatialTransformer
 from ...modules.diffusionmodules.util import (
     conv_nd,
+    conv_tokens,
     group_norm_tokens,
     linear,
     normalization,
@@ -80,7 +81,12 @@ class Upsample(nn.Module):
     def forward(self, x):
         assert x.shape[1] == self.channels
         x = F.interpolate(x, scale_factor=self.scale_factor, mode="nearest")
-        return self.conv(x) if self.use_conv else x
+        if not self.use_conv:
+            return x
+        N, _, H, W = x.shape
+        xt = x.permute(0, 2, 3, 1)
+        xt = (xt if xt.is_contiguous() else xt.contiguous()).reshape(N, H * W, -1)
+        return tokens_to_image(conv_tokens(self.conv, xt, N, H, W), H, W)
 
 
 class Downsample(nn.Module):
@@ -134,11 +140,21 @@ class ResBlock(TimestepBlock):
         return self._forward(x, emb)
 
     def _forward(self, x, emb):
-        h = self.in_layers[2](self._gn_silu(self.in_layers[0], x))
-        emb_out = self.emb_layers(emb).type(h.dtype)
-        h = h + emb_out[:, :, None, None]
-        h = self.out_layers[3](self._gn_silu(self.out_layers[0], h))
-        return self.skip_connection(x) + h
+        """Works on channels-last tokens: GN+SiLU kernel -> implicit-GEMM conv with `+ emb` fused -> GN+SiLU -> conv with the skip
+        connection fused as residual.  No elementwise kernels are left between the four launches."""
+        N, _, H, W = x.shape
+        t = group_norm_tokens(self.in_layers[0], x, silu=True)  # [N, HW, Cin]
+        emb_out = self.emb_layers(emb).type(t.dtype)
+        h = conv_tokens(self.in_layers[2], t, N, H, W, emb=emb_out.contiguous())
+        t2 = group_norm_tokens(self.out_layers[0], tokens_to_image(h, H, W), silu=True)
+        xt = x.permute(0, 2, 3, 1)
+        xt = (xt if xt.is_contiguous() else xt.contiguous()).reshape(N, H * W, -1)
+        if isinstance(self.skip_connection, nn.Identity):
+            skip = xt
+        else:
+            skip = conv_tokens(self.skip_connection, xt, N, H, W)
+        out = conv_tokens(self.out_layers[3], t2, N, H, W, res=skip if skip.dtype == t2.dtype else skip.to(t2.dtype))
+        return tokens_to_image(out, H, W)
 
 
 class UNetModel(nn.Module):

@@ -83,6 +83,38 @@ def tokens_to_image(t: torch.Tensor, H: int, W: int) -> torch.Tensor:
     return t.reshape(N, H, W, C).permute(0, 3, 1, 2)
 
 
+def packed_conv(conv: nn.Conv2d):
+    """(w_packed [Cout, taps*Cin] bf16 with k = (ky*3+kx)*Cin + ci, bias fp32 | None) for cd360_conv_igemm_bf16, cached on the
+    module and rebuilt when the parameters change.  Returns None if the conv is outside the kernel's envelope."""
+    w = conv.weight
+    k = conv.kernel_size
+    if not (w.is_cuda and k in ((3, 3), (1, 1)) and conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
+            and conv.padding == ((1, 1) if k == (3, 3) else (0, 0)) and w.shape[1] % 64 == 0 and w.shape[0] % 16 == 0):
+        return None
+    key = (w.data_ptr(), w._version, w.dtype, w.device, None if conv.bias is None else conv.bias._version)
+    cache = getattr(conv, "_cd360_packed", None)
+    if cache is None or cache[0] != key:
+        wp = w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(torch.bfloat16).contiguous()
+        bias = None if conv.bias is None else conv.bias.detach().float().contiguous()
+        cache = (key, wp, bias)
+        conv._cd360_packed = cache
+    return cache[1], cache[2]
+
+
+def conv_tokens(conv: nn.Conv2d, tokens: torch.Tensor, N: int, H: int, W: int, emb=None, res=None):
+    """conv(3x3 pad 1 | 1x1) on channels-last tokens [N, H*W, Cin] -> [N, H*W, Cout], with the per-image addend `emb` [N, Cout] and the
+    residual `res` [N, H*W, Cout] fused into the epilogue (cd360_conv_igemm_bf16); falls back to MIOpen outside the envelope."""
+    pk = packed_conv(conv) if tokens.dtype == torch.bfloat16 else None
+    if pk is None:
+        y = conv(tokens_to_image(tokens, H, W))
+        if emb is not None:
+            y = y + emb[:, :, None, None]
+        y = y.permute(0, 2, 3, 1).reshape(N, H * W, -1)
+        return y if res is None else y + res
+    taps = 9 if conv.kernel_size == (3, 3) else 1
+    return ops.conv_igemm(tokens, pk[0], pk[1], N, H, W, taps, emb, res)
+
+
 class GroupNorm32(nn.GroupNorm):
     """fp32-statistics GroupNorm (util.py:309-311) on the HIP kernel."""
 

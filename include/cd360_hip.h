@@ -110,6 +110,15 @@ int cd360_geglu_bf16(const void* in, void* out, int64_t rows, int inner, void* s
  * a [pixels, ca], b [pixels, cb] -> out [pixels, ca + cb].  ca, cb % 8 == 0. */
 int cd360_concat_channels_bf16(const void* a, const void* b, void* out, int64_t pixels, int ca, int cb, void* stream);
 
+/* ---- 3x3 convolution / GEMM with fused epilogue -----------------------------------------------------------------------
+ * replaces nn.Conv2d(3x3, stride 1, padding 1) + the adds around it in ResBlock._forward (openaimodel.py:350-376:
+ * `h + emb_out`, `skip_connection(x) + h`) and Upsample.conv (:161-164) on channels-last bf16; taps = 1 gives out = x @ w^T
+ * (the 1x1 skip_connection conv, :337).  x [N*H*W, Cin]; w_packed [Cout, taps*Cin] with k = (ky*3+kx)*Cin + ci;
+ * bias fp32 [Cout] | NULL; emb bf16 [N, Cout] | NULL (per-image addend); res bf16 [N*H*W, Cout] | NULL; out bf16 [N*H*W, Cout].
+ * Cin % 64 == 0, Cout % 16 == 0, 16-byte aligned pointers. */
+int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const void* bias, const void* emb, const void* res, void* out, int N, int H,
+                          int W, int Cin, int Cout, int taps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -187,6 +187,28 @@ def test_geglu_and_concat():
     assert got.shape == (2, 88, 5, 7) and torch.equal(got.float().cpu(), torch.cat([a, b], 1))
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout,taps,extras", [(2, 9, 7, 64, 48, 9, False), (1, 16, 16, 128, 320, 9, True), (3, 32, 32, 320, 640, 9, True),
+                                                       (2, 5, 5, 192, 64, 1, True), (1, 1, 1, 64, 16, 9, False)])
+def test_conv_igemm(N, H, W, Cin, Cout, taps, extras):
+    """implicit-GEMM conv3x3 / GEMM with fused bias + per-image addend + residual vs torch's fp32 conv2d on the same bf16 inputs."""
+    from cd360 import ops
+    g = torch.Generator().manual_seed(N * 100 + H + Cin + Cout)
+    k = 3 if taps == 9 else 1
+    x = bf(torch.randn(N, Cin, H, W, generator=g))
+    w = bf(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5)
+    bias = torch.randn(Cout, generator=g)
+    emb = bf(torch.randn(N, Cout, generator=g)) if extras else None
+    res = bf(torch.randn(N, Cout, H, W, generator=g)) if extras else None
+    want = torch.nn.functional.conv2d(x, w, bias, padding=k // 2)
+    if extras:
+        want = want + emb[:, :, None, None] + res
+    xt = x.permute(0, 2, 3, 1).reshape(N, H * W, Cin).contiguous().to(DEV, torch.bfloat16)
+    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(DEV, torch.bfloat16)
+    rt = None if res is None else res.permute(0, 2, 3, 1).reshape(N, H * W, Cout).contiguous().to(DEV, torch.bfloat16)
+    got = ops.conv_igemm(xt, wp, bias.to(DEV), N, H, W, taps, None if emb is None else emb.to(DEV, torch.bfloat16), rt)
+    assert rel(got.reshape(N, H, W, Cout).permute(0, 3, 1, 2), want) < 8e-3
+
+
 # ------------------------------------------------------------------------------------------------ GroupNorm + SiLU (K7)
 @pytest.mark.parametrize("N,P,C,silu", [(2, 64, 64, True), (3, 1024, 320, True), (1, 4096, 640, False), (2, 256, 2560, True), (1, 100, 960, False)])
 def test_gn_silu(N, P, C, silu):

@@ -67,8 +67,20 @@ def gn(tag, N, P, C):
     print(f"gn_silu {tag}: N{N} P{P} C{C}: {us:8.1f} us  {3.0 * 2 * N * P * C / us / 1e3:8.1f} GB/s", flush=True)
 
 
+def conv(tag, N, H, W, cin, cout):
+    x = torch.randn(N, H * W, cin, device=dev).to(BF)
+    wp = (torch.randn(cout, 9 * cin, device=dev) / (9 * cin) ** 0.5).to(BF)
+    bias = torch.randn(cout, device=dev)
+    us = timeit(lambda: ops.conv_igemm(x, wp, bias, N, H, W, 9))
+    fl = 2.0 * N * H * W * 9 * cin * cout
+    xi = x.reshape(N, H, W, cin).permute(0, 3, 1, 2)
+    w4 = wp.reshape(cout, 3, 3, cin).permute(0, 3, 1, 2).contiguous(memory_format=torch.channels_last)
+    us2 = timeit(lambda: torch.nn.functional.conv2d(xi, w4, bias.to(BF), padding=1))
+    print(f"conv {tag}: N{N} {H}x{W} {cin}->{cout}: cd360 {us:8.1f} us {fl / us / 1e6:7.1f} TF/s | MIOpen {us2:8.1f} us {fl / us2 / 1e6:7.1f} TF/s", flush=True)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["attn", "nerf", "gn"]
+    which = sys.argv[1:] or ["attn", "nerf", "gn", "conv"]
     print("env CD360_ATTN_QB =", os.environ.get("CD360_ATTN_QB"))
     if "attn" in which:
         attn("L1 self", 3, 10, 4096, 4096)
@@ -79,6 +91,10 @@ if __name__ == "__main__":
         attn("L2 pose", 3, 20, 24576, 77)
     if "gn" in which:
         gn("L0", 3, 16384, 320); gn("L1", 3, 4096, 640); gn("L2", 3, 1024, 1280); gn("up", 3, 1024, 2560); gn("up0", 3, 16384, 960)
+    if "conv" in which:
+        conv("L0", 3, 128, 128, 320, 320); conv("L0 up", 3, 128, 128, 960, 320); conv("L0 ups", 3, 128, 128, 640, 640)
+        conv("L1", 3, 64, 64, 640, 640); conv("L1 up", 3, 64, 64, 1920, 640); conv("L1 ups", 3, 64, 64, 1280, 1280)
+        conv("L2", 3, 32, 32, 1280, 1280); conv("L2 up", 3, 32, 32, 2560, 1280)
     if "nerf" in which:
         nerf_block("L2", 1280, 32)
         nerf_block("L1", 640, 64)
