@@ -283,7 +283,8 @@ extern "C" int cd360_attn_fwd_bf16(const void* q, const void* k, const void* vt,
   p.scale_log2e = scale * 1.4426950408889634f;
   // 256 queries per workgroup (2 q-blocks per wave) when that still gives every CU work; else 128
   const long wg256 = (long)((Nq + 255) / 256) * B * H;
-  int qb = wg256 >= 384 ? 2 : 1;
+  int qb = 1;  // measured on MI355X: 2 q-blocks/wave (1 wave/SIMD) is 15 % slower than 1 (2 waves/SIMD) at every SDXL shape
+  (void)wg256;
   if (const char* e = getenv("CD360_ATTN_QB")) {  // tuning override: 1 or 2
     if (e[0] == '1') qb = 1;
     if (e[0] == '2') qb = 2;

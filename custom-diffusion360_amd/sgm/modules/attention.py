@@ -112,6 +112,8 @@ class MemoryEfficientCrossAttention(nn.Module):
         self.to_out = nn.Sequential(nn.Linear(inner_dim, query_dim), nn.Dropout(dropout))
         self.attention_op = None
         self._merged = None
+        self._kv_cache = None
+        self.cache_context_kv = False
 
     def _qk_weight(self):
         """[to_q.weight; to_k.weight] for the self-attention GEMM, rebuilt when either changes."""
@@ -123,10 +125,21 @@ class MemoryEfficientCrossAttention(nn.Module):
 
     def project_context(self, context: torch.Tensor):
         """K [b, Nk_pad, inner] and V^T [b, inner, Nk_pad] for a cross-attention context (reusable across query sets)."""
+        # The text context is constant over a whole sampling trajectory (and K/V do not depend on x or the timestep).  When the
+        # caller opts in (cd360.sampling.enable_reference_sampling(cache_context=True): "this context buffer stays put until
+        # clear_rendered_feat()"), the projections are kept resident and reused by every step and by the pose-token attention.
+        wk, wv = self.to_k.weight, self.to_v.weight
+        use_cache = self.cache_context_kv and not torch.is_grad_enabled()
+        if use_cache:
+            key = (context.data_ptr(), context._version, tuple(context.shape), context.dtype, wk.data_ptr(), wk._version, wv._version)
+            if self._kv_cache is not None and self._kv_cache[0] == key:
+                return self._kv_cache[1]
         ctx = _pad_tokens(context)
-        k = F.linear(ctx, self.to_k.weight)
-        vt = _project_transposed(self.to_v.weight, ctx)
-        return k, vt, context.shape[1]
+        k = F.linear(ctx, wk)
+        vt = _project_transposed(wv, ctx)
+        out = (k, vt, context.shape[1])
+        self._kv_cache = (key, out) if use_cache else None
+        return out
 
     def attend(self, x: torch.Tensor, kv) -> torch.Tensor:
         """softmax(q k^T / sqrt(d)) v and the output projection for precomputed (k, vt, nk)."""

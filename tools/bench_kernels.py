@@ -79,6 +79,19 @@ def conv(tag, N, H, W, cin, cout):
     print(f"conv {tag}: N{N} {H}x{W} {cin}->{cout}: cd360 {us:8.1f} us {fl / us / 1e6:7.1f} TF/s | MIOpen {us2:8.1f} us {fl / us2 / 1e6:7.1f} TF/s", flush=True)
 
 
+def gemm(tag, M, K, N):
+    x = torch.randn(1, M, K, device=dev).to(BF)
+    w = (torch.randn(N, K, device=dev) / K ** 0.5).to(BF)
+    bias = torch.randn(N, device=dev)
+    res = torch.randn(1, M, N, device=dev).to(BF)
+    us = timeit(lambda: ops.conv_igemm(x, w, bias, M, 1, 1, 1, None, res))
+    bb = bias.to(BF)
+    us2 = timeit(lambda: torch.nn.functional.linear(x, w, bb) + res)
+    us3 = timeit(lambda: torch.nn.functional.linear(x, w, bb))
+    fl = 2.0 * M * K * N
+    print(f"gemm {tag}: M{M} K{K} N{N}: cd360(+bias+res) {us:8.1f} us {fl / us / 1e6:7.1f} TF/s | hipBLASLt+add {us2:8.1f} us {fl / us2 / 1e6:7.1f} TF/s | hipBLASLt {us3:8.1f} us {fl / us3 / 1e6:7.1f} TF/s", flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["attn", "nerf", "gn", "conv"]
     print("env CD360_ATTN_QB =", os.environ.get("CD360_ATTN_QB"))
@@ -95,6 +108,9 @@ if __name__ == "__main__":
         conv("L0", 3, 128, 128, 320, 320); conv("L0 up", 3, 128, 128, 960, 320); conv("L0 ups", 3, 128, 128, 640, 640)
         conv("L1", 3, 64, 64, 640, 640); conv("L1 up", 3, 64, 64, 1920, 640); conv("L1 ups", 3, 64, 64, 1280, 1280)
         conv("L2", 3, 32, 32, 1280, 1280); conv("L2 up", 3, 32, 32, 2560, 1280)
+    if "gemm" in which:
+        gemm("L1 qk", 12288, 640, 1280); gemm("L1 out", 12288, 640, 640); gemm("L1 ff1", 12288, 640, 5120); gemm("L1 ff2", 12288, 2560, 640)
+        gemm("L2 qk", 3072, 1280, 2560); gemm("L2 out", 3072, 1280, 1280); gemm("L2 ff1", 3072, 1280, 10240); gemm("L2 ff2", 3072, 5120, 1280)
     if "nerf" in which:
         nerf_block("L2", 1280, 32)
         nerf_block("L1", 640, 64)
