@@ -262,6 +262,18 @@ def main():
                 ach = e["bytes"] / (e["ms"] * 1e-3) / 1e9
                 roof = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": e["n"], "avg_us": round(e["ms"] * 1e3 / e["n"], 2)}
+            # HBM traffic per launch of that kernel comes from the committed rocprofv3 PMC passes over this same command
+            # (profiles/*_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 1/2-FETCH correction applied).
+            roof["alg_bytes_per_launch"] = round(e["bytes"] / e["n"])
+            roof["alg_flops_per_launch"] = round(e["flops"] / e["n"])
+            try:
+                import glob
+                pm_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]
+                with open(pm_file) as f:
+                    roof["traffic"] = json.load(f)["kernels"][name]["hbm_bytes_per_launch"]
+                roof["traffic_source"] = os.path.relpath(pm_file, ROOT)
+            except Exception:  # noqa: BLE001
+                roof["traffic"] = None
         out = {
             "metric": "UNet denoise steps/sec @ SDXL 1024^2, 50 ref views", "value": round(args.steps * world / elapsed, 4), "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),

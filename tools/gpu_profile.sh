@@ -1,22 +1,24 @@
 #!/bin/bash
-# rocprofv3 kernel trace of the bench workload + (optionally) the gpu tests.  Outputs under gpurun_out/.
+# rocprofv3 passes over the bench workload: (1) kernel trace + stats, (2) PMC FETCH_SIZE, (3) PMC WRITE_SIZE (separate passes, as
+# MI355X_MICROARCH.md prescribes; never combined with sys/runtime tracing).  Outputs under gpurun_out/prof_$TAG.
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
-mkdir -p gpurun_out
 TAG=${1:-r1}
 STEPS=${2:-6}
-if [ "$3" == "tests" ]; then
-  timeout 1500 python -m pytest tests -m gpu -q --tb=short -p no:cacheprovider > gpurun_out/pytest_gpu.log 2>&1; echo "pytest exit $?" >> gpurun_out/pytest_gpu.log; tail -15 gpurun_out/pytest_gpu.log
-fi
+OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
+mkdir -p $OUT
+BENCH="python $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --no-profile --no-graph"
 cd /tmp
 rm -rf /tmp/prof_$TAG
-timeout 1200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --no-profile > $GRAFT_REPO_ROOT/gpurun_out/bench_prof_$TAG.log 2>&1
-echo "rocprof exit $?"
+timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG/kt -o bench -- $BENCH > $OUT/bench_kt.log 2>&1; echo "kt exit $?"
+find /tmp/prof_$TAG/kt -name "*kernel_stats.csv" -exec cp {} $OUT/ \;
+TRACE=$(find /tmp/prof_$TAG/kt -name "*kernel_trace.csv" | head -1)
+python $GRAFT_REPO_ROOT/tools/prof_summary.py $TRACE 70 > $OUT/kernel_by_shape.csv
+head -42 $OUT/kernel_by_shape.csv | cut -c1-200
+for C in FETCH_SIZE WRITE_SIZE; do
+  timeout 900 rocprofv3 --pmc $C --output-format csv -d /tmp/prof_$TAG/$C -o bench -- $BENCH > $OUT/bench_$C.log 2>&1; echo "$C exit $?"
+  CC=$(find /tmp/prof_$TAG/$C -name "*counter_collection.csv" | head -1)
+  python $GRAFT_REPO_ROOT/tools/pmc_summary.py $CC $C conv_igemm attn_fwd nerf_fused gn_ geglu volrender > $OUT/pmc_$C.csv
+  cat $OUT/pmc_$C.csv
+done
 cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out/prof_$TAG
-find /tmp/prof_$TAG -name "*stats*.csv" -exec cp {} gpurun_out/prof_$TAG/ \;
-TRACE=$(find /tmp/prof_$TAG -name "*kernel_trace.csv" | head -1)
-python tools/prof_summary.py $TRACE 80 > gpurun_out/prof_$TAG/kernel_by_shape.csv
-ls -la gpurun_out/prof_$TAG
-head -45 gpurun_out/prof_$TAG/kernel_by_shape.csv
-tail -3 gpurun_out/bench_prof_$TAG.log
-if [ "$4" == "bench" ]; then timeout 900 python bench.py --steps 50 --warmup 3 > gpurun_out/bench_$TAG.log 2>&1; echo "bench exit $?"; tail -2 gpurun_out/bench_$TAG.log; fi
+if [ "$3" == "bench" ]; then timeout 900 python bench.py --steps 50 --warmup 3 > gpurun_out/bench_$TAG.log 2>&1; echo "bench exit $?"; tail -1 gpurun_out/bench_$TAG.log; fi
