@@ -86,7 +86,7 @@ __device__ __forceinline__ void tile_store(unsigned char* Ks, unsigned char* Vs,
 // QB = 32-query blocks per wave (1: 128 queries per workgroup, 2: 256).  QB = 2 halves the LDS fragment traffic and the
 // barriers per MFMA and is used whenever the grid still fills the chip.
 template <int QB>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(AttnParams p) {
+__global__ __launch_bounds__(256, QB == 1 ? 3 : 1) void attn_fwd_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TILE_BYTES];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;

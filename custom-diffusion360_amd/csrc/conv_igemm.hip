@@ -13,6 +13,7 @@
 // (32-byte stores); both LDS tiles use the 16-B XOR swizzle of attn_fwd.hip (conflict-free ds_read_b128); the next K-step's
 // tiles travel HBM -> registers while the current one is multiplied (LDS double-buffered, one barrier per step).
 #include "cd360_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -28,14 +29,23 @@ struct ConvParams {
   int n_mtiles, n_ntiles;
 };
 
-constexpr int BM = 128, BNC = 128, BK = 64, PITCH = 128;  // bytes per LDS row (64 ch x 2 B)
-constexpr int STAGE = (BM + BNC) * PITCH;
+constexpr int BM = 128, BNC = 128;
 
 __device__ __forceinline__ int chan_pos(int i) { return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3); }
-__device__ __forceinline__ int swz(int row, int chunk) { return row * PITCH + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
+// BK = input channels per K-step (64: 2 x 32 KB LDS stages, 2 workgroups per CU; 32: 2 x 16 KB, up to 4 per CU).
+template <int BK>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
+  constexpr int PITCH = BK * 2;             // bytes per LDS row
+  constexpr int CPR = BK / 8;               // 16-byte chunks per row
+  constexpr int SH = BK == 64 ? 1 : 2;      // rows per 256-byte bank row = 1 << SH
+  constexpr int RPP = 256 / CPR;            // rows staged per pass
+  constexpr int NPASS = 128 / RPP;          // passes per 128-row tile
+  constexpr int STAGE = (BM + BNC) * PITCH;
+  constexpr int KS = BK / 16;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+  auto swz = [](int row, int chunk) { return row * PITCH + ((chunk ^ ((row >> SH) & (CPR - 1))) << 4); };
+
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wco = wave >> 1, wpx = wave & 1;  // wave tile: 64 channels x 64 pixels
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -43,50 +53,65 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
   const long m0 = (long)mt * BM;
   const int co0 = nt * BNC;
   const int HW = p.H * p.W;
-  const int chunk = tid & 7, lrow = tid >> 3;
+  const int chunk = tid % CPR, lrow = tid / CPR;
 
-  // ---- per-thread staging geometry: 4 weight rows and 4 pixel rows (fixed for the whole K loop) ----
-  const uint16_t* wsrc[4];
-  bool wok[4];
-  long pbase[4];
-  int py[4], px[4];
-  bool pok[4];
+  // ---- per-thread staging geometry: NPASS weight rows and NPASS pixel rows (fixed for the whole K loop) ----
+  const uint16_t* wsrc[NPASS];
+  const uint16_t* xsrc[NPASS];
+  int py[NPASS], px[NPASS];
+  bool pok[NPASS];
 #pragma unroll
-  for (int ps = 0; ps < 4; ++ps) {
-    const int row = lrow + 32 * ps;
+  for (int ps = 0; ps < NPASS; ++ps) {
+    const int row = lrow + RPP * ps;
     const int co = co0 + row;
-    wok[ps] = co < p.Cout;
-    wsrc[ps] = p.w + (long)(wok[ps] ? co : 0) * p.taps * p.Cin + chunk * 8;
+    wsrc[ps] = co < p.Cout ? p.w + (long)co * p.taps * p.Cin + chunk * 8 : nullptr;
     const long m = m0 + row;
     pok[ps] = m < p.M;
     const long mc = pok[ps] ? m : 0;
     const int rem = (int)(mc % HW);
     py[ps] = rem / p.W;
     px[ps] = rem - py[ps] * p.W;
-    pbase[ps] = mc * p.Cin + chunk * 8;
+    xsrc[ps] = p.x + mc * p.Cin + chunk * 8;
   }
 
   const int kchunks = p.Cin / BK;
   const int nsteps = p.taps * kchunks;
 
-  u32x4 wreg[4], xreg[4];
-  auto load_step = [&](int step) {
-    const int tap = step / kchunks, kc = step - tap * kchunks;
-    const int dy = p.taps == 9 ? tap / 3 - 1 : 0, dx = p.taps == 9 ? tap % 3 - 1 : 0;
-    const long woff = (long)tap * p.Cin + kc * BK;
-    const long xoff = ((long)dy * p.W + dx) * p.Cin + kc * BK;
+  // running (tap, kc) of the NEXT step to load; per-tap source pointers are refreshed only when the tap changes
+  int ld_tap = 0, ld_kc = 0;
+  const uint16_t* xtap[NPASS];
+  auto set_tap = [&](int tap) {
+    const int dy = p.taps == 9 ? tap / 3 - 1 : 0, dx = p.taps == 9 ? tap - (tap / 3) * 3 - 1 : 0;
+    const long xoff = ((long)dy * p.W + dx) * p.Cin;
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      u32x4 z = {0u, 0u, 0u, 0u};
-      wreg[ps] = wok[ps] ? *reinterpret_cast<const u32x4*>(wsrc[ps] + woff) : z;
+    for (int ps = 0; ps < NPASS; ++ps) {
       const bool ok = pok[ps] && (unsigned)(py[ps] + dy) < (unsigned)p.H && (unsigned)(px[ps] + dx) < (unsigned)p.W;
-      xreg[ps] = ok ? *reinterpret_cast<const u32x4*>(p.x + pbase[ps] + xoff) : z;
+      xtap[ps] = ok ? xsrc[ps] + xoff : nullptr;
+    }
+  };
+  set_tap(0);
+
+  // One register set in flight: the loads of step t+1 are issued before step t's MFMAs and written to the other LDS buffer after
+  // them.  (A second set -- loads two steps ahead -- was measured 10-25 % SLOWER on MI355X: 256 VGPRs, worse MFMA interleave.)
+  u32x4 wreg[NPASS], xreg[NPASS];
+  auto load_next = [&]() {
+    const long woff = (long)ld_tap * p.Cin + ld_kc * BK;
+    const int koff = ld_kc * BK;
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) {
+      u32x4 z = {0u, 0u, 0u, 0u};
+      wreg[ps] = wsrc[ps] ? *reinterpret_cast<const u32x4*>(wsrc[ps] + woff) : z;
+      xreg[ps] = xtap[ps] ? *reinterpret_cast<const u32x4*>(xtap[ps] + koff) : z;
+    }
+    if (++ld_kc == kchunks) {
+      ld_kc = 0;
+      if (++ld_tap < p.taps) set_tap(ld_tap);
     }
   };
   auto store_step = [&](unsigned char* base) {
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) {
-      const int row = lrow + 32 * ps;
+    for (int ps = 0; ps < NPASS; ++ps) {
+      const int row = lrow + RPP * ps;
       *reinterpret_cast<u32x4*>(base + swz(row, chunk)) = wreg[ps];
       *reinterpret_cast<u32x4*>(base + BNC * PITCH + swz(row, chunk)) = xreg[ps];
     }
@@ -96,7 +121,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) { acc[0][0][i] = 0.f; acc[0][1][i] = 0.f; acc[1][0][i] = 0.f; acc[1][1][i] = 0.f; }
 
-  load_step(0);
+  load_next();
   store_step(lds);
   __syncthreads();
 
@@ -106,10 +131,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
     const unsigned char* Ws = lds + (step & 1) * STAGE;
     const unsigned char* Xs = Ws + BNC * PITCH;
     const bool more = step + 1 < nsteps;
-    if (more) load_step(step + 1);
+    if (more) load_next();
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
+    for (int ks = 0; ks < KS; ++ks) {
       bf16x8 a[2], b[2];
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -182,7 +207,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 extern "C" int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const void* bias, const void* emb, const void* res, void* out,
                                      int N, int H, int W, int Cin, int Cout, int taps, void* stream) {
   if (!x || !w_packed || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return CD360_ERR_ARG;
-  if ((taps != 9 && taps != 1) || Cin % BK || Cout % 16) return CD360_ERR_SHAPE;
+  if ((taps != 9 && taps != 1) || Cin % 64 || Cout % 16) return CD360_ERR_SHAPE;
   if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)out | (uintptr_t)emb | (uintptr_t)res) % 16) return CD360_ERR_ARG;
   ConvParams p;
   p.x = (const uint16_t*)x; p.w = (const uint16_t*)w_packed; p.bias = (const float*)bias; p.emb = (const uint16_t*)emb;
@@ -193,7 +218,14 @@ extern "C" int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const 
   p.n_ntiles = (Cout + BNC - 1) / BNC;
   const long nwg = (long)p.n_mtiles * p.n_ntiles;
   if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
-  hipLaunchKernelGGL(conv_igemm_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+  int bk = 64;
+  if (const char* e = getenv("CD360_CONV_BK")) {  // tuning override
+    if (e[0] == '3') bk = 32;
+  }
+  if (bk == 32)
+    hipLaunchKernelGGL(conv_igemm_kernel<32>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+  else
+    hipLaunchKernelGGL(conv_igemm_kernel<64>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
   CD360_LAUNCH_CHECK();
   return CD360_OK;
 }

@@ -108,6 +108,12 @@ if __name__ == "__main__":
         conv("L0", 3, 128, 128, 320, 320); conv("L0 up", 3, 128, 128, 960, 320); conv("L0 ups", 3, 128, 128, 640, 640)
         conv("L1", 3, 64, 64, 640, 640); conv("L1 up", 3, 64, 64, 1920, 640); conv("L1 ups", 3, 64, 64, 1280, 1280)
         conv("L2", 3, 32, 32, 1280, 1280); conv("L2 up", 3, 32, 32, 2560, 1280)
+    if "conv1" in which:
+        conv("L1", 3, 64, 64, 640, 640)
+    if "attn1" in which:
+        attn("L1 self", 3, 10, 4096, 4096)
+    if "nerf1" in which:
+        nerf_block("L2", 1280, 32)
     if "gemm" in which:
         gemm("L1 qk", 12288, 640, 1280); gemm("L1 out", 12288, 640, 640); gemm("L1 ff1", 12288, 640, 5120); gemm("L1 ff2", 12288, 2560, 640)
         gemm("L2 qk", 3072, 1280, 2560); gemm("L2 out", 3072, 1280, 1280); gemm("L2 ff1", 3072, 1280, 10240); gemm("L2 ff2", 3072, 5120, 1280)
