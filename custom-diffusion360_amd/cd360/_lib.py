@@ -24,11 +24,12 @@ SIGNATURES = {
     "cd360_feature_gather": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "cd360_plucker_features": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "cd360_nerf_k_padded": (c_int, []),
-    "cd360_nerf_mlp_aggregate": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "cd360_nerf_mlp_aggregate": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "cd360_volrender": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cd360_rowdot4_bf16": (c_int, [_P, _P, _P, c_int64, c_int, _P]),
     "cd360_geglu_bf16": (c_int, [_P, _P, c_int64, c_int, _P]),
     "cd360_concat_channels_bf16": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P]),
+    "cd360_add_layernorm_bf16": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, c_float, _P]),
     "cd360_conv_igemm_bf16": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cd360_gn_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "cd360_gn_silu_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),

@@ -128,22 +128,24 @@ def view_constants(fw: FusedNerfWeights, cams: torch.Tensor) -> torch.Tensor:
     return ((o * fw.v_otgt).sum(-1) + (positional_encoding(o, NUM_FREQS) * fw.v_otgt_enc).sum(-1) + fw.bv).contiguous()
 
 
-def fused_feature_nerf(fw: FusedNerfWeights, cams: torch.Tensor, xref: torch.Tensor, num_samples: int, far: float, near: float = 0.0,
-                       xy_jitter=None, depth_jitter=None, want_view_weights: bool = False, tables=None):
-    """cams [b, n+1, 16] fp32 (device), xref [b, n, hw, C] -> (h [b,hw,S,C] bf16, dec [b,hw,S,4] fp32, dists, view_weights|None)."""
-    b, n, hw, C = xref.shape
+def fused_feature_nerf(fw: FusedNerfWeights, cams: torch.Tensor, xref: Optional[torch.Tensor], num_samples: int, far: float,
+                       near: float = 0.0, xy_jitter=None, depth_jitter=None, want_view_weights: bool = False, tables=None, dims=None):
+    """cams [b, n+1, 16] fp32 (device), xref [b, n, hw, C] -> (h [b,hw,S,C] bf16, dec [b,hw,S,4] fp32, dists, view_weights|None).
+    With precomputed `tables` = (Y, lv, img_map) xref may be None and `dims` = (b, n, hw, C)."""
+    b, n, hw, C = xref.shape if dims is None else dims
     r = int(math.isqrt(hw))
-    dev = xref.device
+    dev = cams.device
     xs = patch_positions(r, dev, None if xy_jitter is None else xy_jitter[0])
     ys = patch_positions(r, dev, None if xy_jitter is None else xy_jitter[1])
     t, dists = depth_samples(num_samples, far, near, dev, hw, depth_jitter)
     if tables is None:
         tables = reference_tables(fw, xref)
-    Y, lv = tables
+    Y, lv = tables[0], tables[1]
+    img_map = tables[2] if len(tables) > 2 else None
     pf = ops.plucker_features(cams, xs, ys).reshape(b * n * hw, 104)
     zP = torch.addmm(fw.b1, pf, fw.Wp_t).to(torch.bfloat16).reshape(b * n, hw, C)
     cview = view_constants(fw, cams)
-    g, logits, lse = ops.nerf_mlp_aggregate(cams, xs, ys, t, Y, zP, lv, cview, fw.Wk, want_logits=want_view_weights)
+    g, logits, lse = ops.nerf_mlp_aggregate(cams, xs, ys, t, Y, zP, lv, cview, fw.Wk, want_logits=want_view_weights, img_map=img_map)
     h = torch.addmm(fw.b2, g.reshape(-1, C), fw.W2_t).reshape(b, hw, num_samples, C)
     dec = ops.rowdot4(h, fw.Wd)
     vw = None

@@ -179,14 +179,17 @@ def nerf_k_padded() -> int:
     return _lib.load().cd360_nerf_k_padded()
 
 
-def nerf_mlp_aggregate(cams, xs, ys, t, Y, zP, lv, cview, Wk, want_logits=False):
-    _need_gpu(cams, xs, ys, t, Y, zP, lv, cview, Wk)
+def nerf_mlp_aggregate(cams, xs, ys, t, Y, zP, lv, cview, Wk, want_logits=False, img_map=None):
+    """img_map (int32 [b*n], optional): Y / lv hold only distinct table images [n_tab, hw, ...]; (batch, view) reads image img_map[b*n_idx]."""
+    _need_gpu(cams, xs, ys, t, Y, zP, lv, cview, Wk, img_map)
     b, n1, _ = cams.shape
     n, r = n1 - 1, xs.numel()
     hw, S = r * r, t.shape[-1]
     C = Y.shape[-1]
-    assert Y.shape == (b * n, hw, C) and zP.shape == (b * n, hw, C) and Y.dtype == torch.bfloat16 and zP.dtype == torch.bfloat16
-    assert lv.shape == (b * n, hw) and lv.dtype == torch.float32 and cview.shape == (b, n) and cview.dtype == torch.float32
+    ntab = b * n if img_map is None else Y.shape[0]
+    assert Y.shape == (ntab, hw, C) and zP.shape == (b * n, hw, C) and Y.dtype == torch.bfloat16 and zP.dtype == torch.bfloat16
+    assert lv.shape == (ntab, hw) and lv.dtype == torch.float32 and cview.shape == (b, n) and cview.dtype == torch.float32
+    assert img_map is None or (img_map.dtype == torch.int32 and img_map.numel() == b * n and img_map.is_contiguous())
     assert Wk.shape == (C, nerf_k_padded()) and Wk.dtype == torch.bfloat16
     for x in (Y, zP, lv, cview, Wk):
         assert x.is_contiguous()
@@ -196,7 +199,7 @@ def nerf_mlp_aggregate(cams, xs, ys, t, Y, zP, lv, cview, Wk, want_logits=False)
     lse = torch.empty(b, hw * S, 2, dtype=torch.float32, device=Y.device) if want_logits else None
     with _timed("nerf_mlp_aggregate", 2.0 * b * n * hw * S * 99 * C, 2.0 * C * (2 * b * n * hw + b * hw * S)):
       check(_lib.load().cd360_nerf_mlp_aggregate(_ptr(cams), _ptr(xs), _ptr(ys), _ptr(t.contiguous()), stride, _ptr(Y), _ptr(zP), _ptr(lv),
-                                              _ptr(cview), _ptr(Wk), _ptr(g), _ptr(logits), _ptr(lse), b, n, r, S, C, _stream()),
+                                              _ptr(cview), _ptr(Wk), _ptr(img_map), _ptr(g), _ptr(logits), _ptr(lse), b, n, r, S, C, _stream()),
           "cd360_nerf_mlp_aggregate")
     return g, logits, lse
 
@@ -298,3 +301,18 @@ def conv_igemm(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Ten
         check(_lib.load().cd360_conv_igemm_bf16(_ptr(x), _ptr(w_packed), _ptr(bias), _ptr(emb), _ptr(res), _ptr(out), N, H, W, cin, cout, taps,
                                                _stream()), "cd360_conv_igemm_bf16")
     return out
+
+
+def add_layernorm(a: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor, eps: float, want_sum: bool = True):
+    """(a + b, LayerNorm(a + b) * gamma + beta) in one pass; b None -> (None, LayerNorm(a)).  All bf16, last dim C."""
+    _need_gpu(a, b, gamma, beta)
+    C = a.shape[-1]
+    assert a.dtype == torch.bfloat16 and a.is_contiguous() and gamma.dtype == torch.bfloat16 and beta.dtype == torch.bfloat16
+    assert b is None or (b.dtype == torch.bfloat16 and b.is_contiguous() and b.shape == a.shape)
+    rows = a.numel() // C
+    s = torch.empty_like(a) if (b is not None and want_sum) else None
+    ln = torch.empty_like(a)
+    with _timed("add_layernorm", 0.0, 2.0 * rows * C * (2 + (b is not None) + (s is not None))):
+        check(_lib.load().cd360_add_layernorm_bf16(_ptr(a), _ptr(b), _ptr(gamma), _ptr(beta), _ptr(s), _ptr(ln), rows, C, float(eps), _stream()),
+              "cd360_add_layernorm_bf16")
+    return s, ln

@@ -64,3 +64,86 @@ extern "C" int cd360_concat_channels_bf16(const void* a, const void* b, void* ou
   CD360_LAUNCH_CHECK();
   return CD360_OK;
 }
+
+// ---- residual add + LayerNorm in one pass (sgm/modules/attention.py:609-636: `x = attn(norm(x)) + x` followed by the next norm) ----
+// sum = a + b (written once, bf16) and ln = LayerNorm(sum) * gamma + beta from the fp32 sum: 2 reads + 2 writes instead of the
+// 5 passes of add-kernel + LayerNorm-kernel.  One wave per row, row held in registers (C <= 2048), two-pass statistics.
+namespace {
+constexpr int LN_MAX_IT = 4;  // 64 lanes x 8 channels x 4 = 2048 channels
+
+__global__ __launch_bounds__(256) void add_layernorm_kernel(const uint16_t* __restrict__ a, const uint16_t* __restrict__ b,
+                                                            const uint16_t* __restrict__ gamma, const uint16_t* __restrict__ beta,
+                                                            uint16_t* __restrict__ sum_out, uint16_t* __restrict__ ln_out, long rows, int C,
+                                                            float eps) {
+  const int lane = threadIdx.x & 63;
+  const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  const int nchunk = C >> 3;
+  for (long row = wave0; row < rows; row += nwaves) {
+    float v[LN_MAX_IT][8];
+    float s = 0.f;
+#pragma unroll
+    for (int it = 0; it < LN_MAX_IT; ++it) {
+      const int ch = lane + 64 * it;
+      if (ch < nchunk) {
+        const u32x4 av = *reinterpret_cast<const u32x4*>(a + row * C + ch * 8);
+        u32x4 bv = {0u, 0u, 0u, 0u};
+        if (b) bv = *reinterpret_cast<const u32x4*>(b + row * C + ch * 8);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[it][2 * e] = bf16lo_to_f32(av[e]) + bf16lo_to_f32(bv[e]);
+          v[it][2 * e + 1] = bf16hi_to_f32(av[e]) + bf16hi_to_f32(bv[e]);
+        }
+        if (sum_out) {
+          u32x4 o = {pack_bf16x2(v[it][0], v[it][1]), pack_bf16x2(v[it][2], v[it][3]), pack_bf16x2(v[it][4], v[it][5]),
+                     pack_bf16x2(v[it][6], v[it][7])};
+          *reinterpret_cast<u32x4*>(sum_out + row * C + ch * 8) = o;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[it][e];
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s / (float)C;
+    float ss = 0.f;
+#pragma unroll
+    for (int it = 0; it < LN_MAX_IT; ++it) {
+      if (lane + 64 * it < nchunk) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[it][e] - mean; ss = fmaf(d, d, ss); }
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    const float rstd = 1.f / sqrtf(ss / (float)C + eps);
+#pragma unroll
+    for (int it = 0; it < LN_MAX_IT; ++it) {
+      const int ch = lane + 64 * it;
+      if (ch < nchunk) {
+        const u32x4 gv = *reinterpret_cast<const u32x4*>(gamma + ch * 8);
+        const u32x4 bv = *reinterpret_cast<const u32x4*>(beta + ch * 8);
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o[e] = pack_bf16x2(fmaf((v[it][2 * e] - mean) * rstd, bf16lo_to_f32(gv[e]), bf16lo_to_f32(bv[e])),
+                             fmaf((v[it][2 * e + 1] - mean) * rstd, bf16hi_to_f32(gv[e]), bf16hi_to_f32(bv[e])));
+        *reinterpret_cast<u32x4*>(ln_out + row * C + ch * 8) = o;
+      }
+    }
+  }
+}
+}  // namespace
+
+// a, b [rows, C] bf16 (b may be NULL: plain LayerNorm of a); gamma, beta [C] bf16; sum_out [rows, C] bf16 = a + b (may be NULL);
+// ln_out [rows, C] bf16 = LayerNorm(a + b) * gamma + beta.  C % 8 == 0, C <= 2048.
+extern "C" int cd360_add_layernorm_bf16(const void* a, const void* b, const void* gamma, const void* beta, void* sum_out, void* ln_out,
+                                        int64_t rows, int C, float eps, void* stream) {
+  if (!a || !gamma || !beta || !ln_out || rows <= 0 || C <= 0) return CD360_ERR_ARG;
+  if (C % 8 || C > 64 * 8 * LN_MAX_IT) return CD360_ERR_SHAPE;
+  const long blocks = (rows + 3) / 4;
+  hipLaunchKernelGGL(add_layernorm_kernel, dim3((unsigned)(blocks > 256L * 32 ? 256L * 32 : blocks)), dim3(256), 0, (hipStream_t)stream,
+                     (const uint16_t*)a, (const uint16_t*)b, (const uint16_t*)gamma, (const uint16_t*)beta, (uint16_t*)sum_out,
+                     (uint16_t*)ln_out, (long)rows, C, eps);
+  CD360_LAUNCH_CHECK();
+  return CD360_OK;
+}

@@ -36,6 +36,7 @@ struct NerfParams {
   const float* lv;        // [b*n, hw]
   const float* cview;     // [b, n]
   const uint16_t* Wk;     // [C, KP] bf16, k-permuted (see nerf.py: xyz_k_columns)
+  const int* img_map;     // optional [b*n]: index of the (Y, lv) table image used by (batch, view); NULL = identity
   uint16_t* g;            // [b, hw*S, C] bf16 out: sum_i softmax_i * silu(z_i)
   float* logits;          // optional [b, n, hw*S]
   float* lse;             // optional [b, hw*S, 2] = (max, sum)
@@ -97,8 +98,9 @@ __global__ __launch_bounds__(256, 2) void nerf_fused_kernel(NerfParams p) {
       const int x0 = min(max(cr.x0, 0), p.r - 1), x1 = min(max(cr.x0 + 1, 0), p.r - 1);
       const int y0 = min(max(cr.y0, 0), p.r - 1), y1 = min(max(cr.y0 + 1, 0), p.r - 1);
       const long img = (long)bi * p.n + iv;
-      const long pix[4] = {img * hw + (long)y0 * p.r + x0, img * hw + (long)y0 * p.r + x1, img * hw + (long)y1 * p.r + x0,
-                           img * hw + (long)y1 * p.r + x1};
+      const long yimg = p.img_map ? (long)p.img_map[img] : img;  // which table image (Y, lv) this (batch, view) reads
+      const long pix[4] = {yimg * hw + (long)y0 * p.r + x0, yimg * hw + (long)y0 * p.r + x1, yimg * hw + (long)y1 * p.r + x0,
+                           yimg * hw + (long)y1 * p.r + x1};
       float w[4] = {(1.f - cr.tx) * (1.f - cr.ty), cr.tx * (1.f - cr.ty), (1.f - cr.tx) * cr.ty, cr.tx * cr.ty};
 #pragma unroll
       for (int c = 0; c < 4; ++c) if (!((cr.mask >> c) & 1)) w[c] = 0.f;
@@ -259,10 +261,10 @@ extern "C" int cd360_plucker_features(const void* cams, const void* xs, const vo
 
 extern "C" int cd360_nerf_k_padded(void) { return KP; }
 
-// See NerfParams for layouts.  C must be a multiple of 64.  logits / lse may be NULL.
+// See NerfParams for layouts.  C must be a multiple of 64.  img_map / logits / lse may be NULL.
 extern "C" int cd360_nerf_mlp_aggregate(const void* cams, const void* xs, const void* ys, const void* t, int t_ray_stride, const void* Y,
-                                        const void* zP, const void* lv, const void* cview, const void* Wk, void* g, void* logits,
-                                        void* lse, int b, int n, int r, int S, int C, void* stream) {
+                                        const void* zP, const void* lv, const void* cview, const void* Wk, const void* img_map, void* g,
+                                        void* logits, void* lse, int b, int n, int r, int S, int C, void* stream) {
   if (!cams || !xs || !ys || !t || !Y || !zP || !lv || !cview || !Wk || !g) return CD360_ERR_ARG;
   if (b <= 0 || n <= 0 || r <= 0 || S <= 0 || C <= 0 || C % CN) return CD360_ERR_SHAPE;
   if (t_ray_stride != 0 && t_ray_stride != S) return CD360_ERR_SHAPE;
@@ -270,7 +272,7 @@ extern "C" int cd360_nerf_mlp_aggregate(const void* cams, const void* xs, const 
   NerfParams p;
   p.cams = (const float*)cams; p.xs = (const float*)xs; p.ys = (const float*)ys; p.t = (const float*)t;
   p.Y = (const uint16_t*)Y; p.zP = (const uint16_t*)zP; p.lv = (const float*)lv; p.cview = (const float*)cview;
-  p.Wk = (const uint16_t*)Wk; p.g = (uint16_t*)g; p.logits = (float*)logits; p.lse = (float*)lse;
+  p.Wk = (const uint16_t*)Wk; p.img_map = (const int*)img_map; p.g = (uint16_t*)g; p.logits = (float*)logits; p.lse = (float*)lse;
   p.b = b; p.n = n; p.r = r; p.S = S; p.C = C; p.t_ray_stride = t_ray_stride;
   p.ncc = C / CN;
   const long npts = (long)r * r * S;

@@ -228,12 +228,12 @@ class BasicTransformerBlock(nn.Module):
         out.addmm_(xref.reshape(-1, c).to(out.dtype), wb)
         return out.reshape(b, n, c)
 
-    def reference_attn(self, x, context_ref, context, pose, prev_weights, mask_ref, tables=None):
+    def reference_attn(self, x, context_ref, context, pose, prev_weights, mask_ref, tables=None, dims=None):
         """FeatureNeRF render of the reference features at the target pose (attention.py:571-598).
         context_ref [b, n, hw, C].  -> (xref [b,hw,C], fg [b,hw,1], prev_weights(None), alphas [b,hw,S,1], rgb [b,hw,3])"""
         if prev_weights is not None and self.use_prev_weights_imp_sample:
             raise NotImplementedError("importance sampling is dead code in the reference (SURVEY.md F3)")
-        h, dec, dists, _ = self.pose_featurenerf.render_inputs(pose, context_ref, mask_ref, tables=tables)
+        h, dec, dists, _ = self.pose_featurenerf.render_inputs(pose, context_ref, mask_ref, tables=tables, dims=dims)
         b, hw, S, C = h.shape
         tok = h.reshape(b, hw * S, C)
         if tok.dtype != x.dtype:
@@ -257,6 +257,26 @@ class BasicTransformerBlock(nn.Module):
         cond = sel[None].expand(bs, -1, -1, -1)
         return torch.cat([refs[-1:][None].expand(bs, n, -1, -1), cond], 0)
 
+    def _sampling_tables(self, batch_size: int):
+        """(Y, lv, img_map), dims for the CFG batch of sample.py:89-96 built from the DISTINCT images only: table image 0 = the null
+        image `references[-1]`, images 1..n = `references[choices]`.  They depend on (references, choices, weights) alone, so they are
+        computed once and reused for every target pose and image (the reference recomputes the equivalent work in every render)."""
+        from cd360 import nerf as _nerf
+        refs, choices = self.references, self.reference_choices
+        fw = self.pose_featurenerf.model.fused_weights()
+        key = (refs.data_ptr(), refs._version, tuple(choices), batch_size, id(fw))
+        if self._ref_tables is None or self._ref_tables[0] != key:
+            n = len(choices)
+            uniq = torch.cat([refs[-1:], refs[:-1][torch.as_tensor(choices, device=refs.device)]], 0)  # [1+n, hw, C]
+            Y, lv = _nerf.reference_tables(fw, uniq[None])
+            groups = 3 if batch_size % 3 == 0 else 2
+            bs = batch_size // groups
+            cond = torch.arange(1, n + 1, dtype=torch.int32, device=refs.device)
+            rows = [torch.zeros(n, dtype=torch.int32, device=refs.device)] * bs + [cond] * (bs * (groups - 1))
+            img_map = torch.stack(rows).reshape(-1).contiguous()
+            self._ref_tables = (key, (Y, lv, img_map), (batch_size, n, refs.shape[1], refs.shape[2]))
+        return self._ref_tables[1], self._ref_tables[2]
+
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self, x, context=None, context_ref=None, pose=None, mask_ref=None, prev_weights=None, additional_tokens=None,
                 n_times_crossframe_attn_in_self=0):
@@ -267,13 +287,31 @@ class BasicTransformerBlock(nn.Module):
     def _forward(self, x, context=None, context_ref=None, pose=None, mask_ref=None, prev_weights=None, additional_tokens=None,
                  n_times_crossframe_attn_in_self=0):
         fg_mask = weights = alphas = predicted_rgb = None
-        x = self.attn1(self.norm1(x), context=None) + x
-        x = self.attn2(self.norm2(x), context=context) + x
+        pose_active = context_ref is not None
+        fused = x.is_cuda and x.dtype == torch.bfloat16 and self.norm1.weight.dtype == torch.bfloat16 and x.shape[-1] <= 2048
+        n3 = None
+        if fused:  # residual adds fused into the following LayerNorm (cd360_add_layernorm_bf16)
+            x = x.contiguous()
+            _, n1 = ops.add_layernorm(x, None, self.norm1.weight, self.norm1.bias, self.norm1.eps)
+            x, n2 = ops.add_layernorm(self.attn1(n1, context=None), x, self.norm2.weight, self.norm2.bias, self.norm2.eps)
+            a2 = self.attn2(n2, context=context)
+            if pose_active:
+                x = a2 + x  # pose_emb_layers sits between this add and norm3
+            else:
+                x, n3 = ops.add_layernorm(a2, x, self.norm3.weight, self.norm3.bias, self.norm3.eps)
+        else:
+            x = self.attn1(self.norm1(x), context=None) + x
+            x = self.attn2(self.norm2(x), context=context) + x
         if context_ref is not None:
             if self.reference_choices is not None:  # native equivalent of sample.py's _customforward (sample.py:82-136)
                 if self.rendered_feat is None:
-                    cref = self._references_as_context(x.size(0))
-                    xref, fg_mask, weights, alphas, predicted_rgb = self.reference_attn(x, cref, context, pose, prev_weights, mask_ref)
+                    if mask_ref is None:  # tables of the DISTINCT reference images, kept across images / poses
+                        tables, dims = self._sampling_tables(x.size(0))
+                        xref, fg_mask, weights, alphas, predicted_rgb = self.reference_attn(x, None, context, pose, prev_weights, None,
+                                                                                            tables=tables, dims=dims)
+                    else:
+                        cref = self._references_as_context(x.size(0))
+                        xref, fg_mask, weights, alphas, predicted_rgb = self.reference_attn(x, cref, context, pose, prev_weights, mask_ref)
                     self.rendered_feat = xref
                 x = self.pose_embed(x, self.rendered_feat)
             else:
@@ -281,7 +319,9 @@ class BasicTransformerBlock(nn.Module):
                 cref = context_ref if context_ref.dim() == 4 else context_ref.reshape(b, context_ref.size(0) // b, *context_ref.shape[1:])
                 xref, fg_mask, weights, alphas, predicted_rgb = self.reference_attn(x, cref, context, pose, prev_weights, mask_ref)
                 x = self.pose_embed(x, xref)
-        x = self.ff(self.norm3(x)) + x
+        if n3 is None:
+            n3 = self.norm3(x)
+        x = self.ff(n3) + x
         return x, fg_mask, weights, alphas, predicted_rgb
 
 

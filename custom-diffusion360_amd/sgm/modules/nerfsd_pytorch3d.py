@@ -143,21 +143,22 @@ class NerfSDModule(nn.Module):
                                          average=average, num_freqs=num_freqs)
         self.return_view_weights = True  # the reference returns plane_features_attn; its only caller drops it
 
-    def render_inputs(self, pose, xref, mask_ref=None, tables=None, want_view_weights=False):
+    def render_inputs(self, pose, xref, mask_ref=None, tables=None, want_view_weights=False, dims=None):
         """Fast path used by BasicTransformerBlock: -> (h [b,hw,S,C] bf16, dec [b,hw,S,4] fp32 = (rgb_raw 0..2, sigma_raw 3),
         dists [S]|[hw,S], view_weights|None)."""
-        if xref.dim() == 5:
+        if xref is not None and xref.dim() == 5:
             xref = xref.reshape(*xref.shape[:2], -1, xref.shape[-1])
-        b, n, hw, C = xref.shape
+        b, n, hw, C = xref.shape if xref is not None else dims
+        device = xref.device if xref is not None else tables[0].device
         if mask_ref is not None:  # nerfsd_pytorch3d.py:61-70
             r = int(math.isqrt(hw))
             m = torch.nn.functional.interpolate(mask_ref.reshape(b * n, *mask_ref.shape[2:]).float(), size=[r, r], mode="nearest")
             xref = xref * m.reshape(b, n, -1, 1).to(xref.dtype)
             tables = None
-        cams = packed_pose(pose, xref.device)
-        xy, jd = self.raymarcher.jitter(int(math.isqrt(hw)), xref.device)
+        cams = packed_pose(pose, device)
+        xy, jd = self.raymarcher.jitter(int(math.isqrt(hw)), device)
         return _nerf.fused_feature_nerf(self.model.fused_weights(), cams, xref, self.num_samples, self.far, self.near, xy, jd,
-                                        want_view_weights, tables)
+                                        want_view_weights, tables, (b, n, hw, C))
 
     def forward(self, pose, xref=None, mask_ref=None, prev_weights=None, imp_sample_next_step=False):
         """-> (features [b,hw,S,C], sigma_raw [b,hw,S,1], dists [1,hw,S,1], view_weights [b,n,hw,S,1], rgb_raw [b,hw,S,3]|None,

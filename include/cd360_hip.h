@@ -72,13 +72,15 @@ int cd360_feature_gather(const void* xref, const void* grid, void* out, int n_im
  *   lv    [b*n, hw] fp32    = xref @ w_v[:C]                cview [b, n] fp32 per-view logit constant
  *   Wk    [C, cd360_nerf_k_padded()] bf16 = W1[:, C:C+99] with columns permuted to the kernel's input order
  *   g out [b, hw*S, C] bf16 = sum_i softmax_i(logit_i) * SiLU(z_i)   (plane_coefs.2 is applied to g by the caller)
+ *   img_map [b*n] int32 (optional): Y / lv may then hold only the DISTINCT reference images [n_tab, hw, C] and (batch, view)
+ *   reads table image img_map[batch*n + view] -- the CFG batch of sample.py:89-96 repeats the same views three times;
  *   logits [b, n, hw*S] fp32 and lse [b, hw*S, 2] = (max, sum) are optional (NULL to skip).  C % 64 == 0. */
 int cd360_plucker_features(const void* cams, const void* xs, const void* ys, void* out /* [b, n, hw, 104] fp32 */, int b, int n, int r,
                            void* stream);
 int cd360_nerf_k_padded(void);
 int cd360_nerf_mlp_aggregate(const void* cams, const void* xs, const void* ys, const void* t, int t_ray_stride, const void* Y,
-                             const void* zP, const void* lv, const void* cview, const void* Wk, void* g, void* logits, void* lse, int b,
-                             int n, int r, int S, int C, void* stream);
+                             const void* zP, const void* lv, const void* cview, const void* Wk, const void* img_map, void* g, void* logits,
+                             void* lse, int b, int n, int r, int S, int C, void* stream);
 
 /* ---- volume rendering --------------------------------------------------------------------------------------------
  * replaces _TruncExp.forward (sgm/modules/attention.py:192-199) + VolRender.forward/get_weights
@@ -109,6 +111,11 @@ int cd360_geglu_bf16(const void* in, void* out, int64_t rows, int inner, void* s
 /* replaces th.cat([h, hs.pop()], dim=1) (sgm/modules/diffusionmodules/openaimodel.py:1074-1076) on channels-last activations:
  * a [pixels, ca], b [pixels, cb] -> out [pixels, ca + cb].  ca, cb % 8 == 0. */
 int cd360_concat_channels_bf16(const void* a, const void* b, void* out, int64_t pixels, int ca, int cb, void* stream);
+
+/* replaces the residual add followed by the next nn.LayerNorm in BasicTransformerBlock._forward (sgm/modules/attention.py:609-636):
+ * sum_out = a + b (NULL to skip; b NULL = plain LayerNorm), ln_out = LayerNorm(a + b) * gamma + beta.  All bf16, C % 8 == 0, C <= 2048. */
+int cd360_add_layernorm_bf16(const void* a, const void* b, const void* gamma, const void* beta, void* sum_out, void* ln_out, int64_t rows,
+                             int C, float eps, void* stream);
 
 /* ---- 3x3 convolution / GEMM with fused epilogue -----------------------------------------------------------------------
  * replaces nn.Conv2d(3x3, stride 1, padding 1) + the adds around it in ResBlock._forward (openaimodel.py:350-376:

@@ -187,6 +187,19 @@ def test_geglu_and_concat():
     assert got.shape == (2, 88, 5, 7) and torch.equal(got.float().cpu(), torch.cat([a, b], 1))
 
 
+@pytest.mark.parametrize("rows,C", [(37, 64), (1000, 640), (513, 1280), (5, 2048)])
+def test_add_layernorm(rows, C):
+    from cd360 import ops
+    g = torch.Generator().manual_seed(rows + C)
+    a, b = bf(torch.randn(rows, C, generator=g) * 2), bf(torch.randn(rows, C, generator=g) + 0.3)
+    gamma, beta = bf(torch.randn(C, generator=g)), bf(torch.randn(C, generator=g))
+    s, ln = ops.add_layernorm(a.to(DEV, torch.bfloat16), b.to(DEV, torch.bfloat16), gamma.to(DEV, torch.bfloat16), beta.to(DEV, torch.bfloat16), 1e-5)
+    assert rel(s, a + b) < 5e-3
+    assert rel(ln, torch.nn.functional.layer_norm(a + b, (C,), gamma, beta, 1e-5)) < 8e-3
+    s2, ln2 = ops.add_layernorm(a.to(DEV, torch.bfloat16), None, gamma.to(DEV, torch.bfloat16), beta.to(DEV, torch.bfloat16), 1e-5)
+    assert s2 is None and rel(ln2, torch.nn.functional.layer_norm(a, (C,), gamma, beta, 1e-5)) < 8e-3
+
+
 @pytest.mark.parametrize("N,H,W,Cin,Cout,taps,extras", [(2, 9, 7, 64, 48, 9, False), (1, 16, 16, 128, 320, 9, True), (3, 32, 32, 320, 640, 9, True),
                                                        (2, 5, 5, 192, 64, 1, True), (1, 1, 1, 64, 16, 9, False)])
 def test_conv_igemm(N, H, W, Cin, Cout, taps, extras):
