@@ -62,36 +62,35 @@ def build_model(latent: int, n_ref: int, n_train: int, device, seed: int = 0):
     return net
 
 
-def legacy_ddpm_sigmas(n_steps: int, device):
-    """LegacyDDPMDiscretization (discretizer.py:47-69) sub-sampled like EulerEDMSampler does, sigma descending, + final 0."""
-    betas = torch.linspace(0.00085 ** 0.5, 0.012 ** 0.5, 1000, dtype=torch.float64) ** 2
-    ac = torch.cumprod(1.0 - betas, 0)
-    sig = ((1 - ac) / ac) ** 0.5
-    idx = torch.linspace(999, 0, n_steps).round().long()
-    return torch.cat([sig[idx], torch.zeros(1, dtype=torch.float64)]).float().to(device), idx.to(device)
-
-
 class Sampler:
     """Minimal Euler (DDIM-equivalent, EpsScaling) step with the 3-way image/text CFG of guiders.py:102-133.
     With `use_graph` the steady-state step (cached render) is captured once into a hipGraph and replayed: ~3000 launches per step
     are then issued by the GPU front end instead of the Python interpreter."""
 
     def __init__(self, net, pose, ctx, y, n_steps, scale=7.5, scale_im=3.5, use_graph=False):
-        self.net, self.pose, self.ctx, self.y, self.n_steps = net, pose, ctx, y, n_steps
+        from cd360 import sampler as S
+        self.net, self.pose, self.n_steps = net, pose, n_steps
         self.scale, self.scale_im = scale, scale_im
         dev = ctx.device
-        self.sigmas, self.tidx = legacy_ddpm_sigmas(n_steps, dev)
+        # the reference's own stack (cd360/sampler.py mirrors sampling.py / guiders.py / denoiser.py; parity: tests/test_sampler_cpu.py)
+        self.denoiser = S.DiscreteDenoiser().to(dev)
+        self.guider = S.ScheduledCFGImgTextRef(scale, scale_im)
+        self.sigmas = S.LegacyDDPMDiscretization()(n_steps, device=dev)  # n_steps + 1 values, last = 0
+        # conditioning is constant over a trajectory: the guider's (uc, uc, c) batch is assembled once per image, not per step
+        c = {"crossattn": ctx[2:3], "vector": y[2:3]}
+        uc = {"crossattn": ctx[0:1], "vector": y[0:1]}
+        _, _, cond3 = self.guider.prepare_inputs(ctx.new_zeros(1, 1), ctx.new_zeros(1), c, uc)
+        self.ctx, self.y = cond3["crossattn"].contiguous(), cond3["vector"].contiguous()
         self.use_graph, self.graph = use_graph, None
 
-    def _math(self, x, s, s_next, t):
-        c_in = 1.0 / (s * s + 1.0) ** 0.5
-        x3 = (x * c_in).expand(3, -1, -1, -1)
-        eps = self.net(x3, timesteps=t, context=self.ctx, y=self.y, pose=self.pose)[0]
-        den = x3 - eps * s  # EpsScaling: c_skip = 1, c_out = -sigma
-        x_u, x_ic, x_c = den[0:1], den[1:2], den[2:3]
-        d0 = x_u + self.scale_im * (x_ic - x_u) + self.scale * (x_c - x_ic)
-        d = (x - d0) / s
-        return x + d * (s_next - s)
+    def _math(self, x, s, s_next, t_unused=None):
+        """One sampler step = guider.prepare_inputs -> DiscreteDenoiser (sigma -> table index, c_in) -> UNet -> fused
+        [c_out, 3-way CFG, to_d, Euler] kernel."""
+        from cd360.sampler import cfg_euler_update
+        x3 = x.expand(3, -1, -1, -1)
+        x_in, c_noise, _, _, _ = self.denoiser.network_inputs(x3, s.expand(3), {})
+        eps = self.net(x_in, timesteps=c_noise, context=self.ctx, y=self.y, pose=self.pose)[0]
+        return cfg_euler_update(x, eps.contiguous(), s.reshape(1), s_next.reshape(1), self.scale, self.scale_im)
 
     def _pin_rendered(self):
         """Keep every block's cached render in a fixed buffer so a captured graph keeps reading the current image's render."""
@@ -119,7 +118,7 @@ class Sampler:
     def step(self, x, i):
         from cd360 import sampling
         i = i % self.n_steps
-        s, s_next, t = self.sigmas[i], self.sigmas[i + 1], self.tidx[i].float().expand(3)
+        s, s_next, t = self.sigmas[i], self.sigmas[i + 1], self.sigmas[i:i + 1]
         if i == 0:
             sampling.clear_rendered_feat(self.net)  # new image: the render runs again
             out = self._math(x, s, s_next, t)

@@ -316,3 +316,14 @@ def add_layernorm(a: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tenso
         check(_lib.load().cd360_add_layernorm_bf16(_ptr(a), _ptr(b), _ptr(gamma), _ptr(beta), _ptr(s), _ptr(ln), rows, C, float(eps), _stream()),
               "cd360_add_layernorm_bf16")
     return s, ln
+
+
+def cfg_euler_step(x: torch.Tensor, eps: torch.Tensor, sigma: torch.Tensor, sigma_next: torch.Tensor, scale: float, scale_im: float):
+    """x [n,...] fp32, eps [3n,...] fp32 (u | ic | c), sigma / sigma_next 0-d fp32 device tensors -> Euler-updated x (one kernel)."""
+    _need_gpu(x, eps, sigma, sigma_next)
+    assert x.dtype == torch.float32 and eps.dtype == torch.float32 and eps.numel() == 3 * x.numel() and x.is_contiguous() and eps.is_contiguous()
+    assert sigma.dtype == torch.float32 and sigma_next.dtype == torch.float32 and sigma.numel() == 1 and sigma_next.numel() == 1
+    out = torch.empty_like(x)
+    check(_lib.load().cd360_cfg_euler_step_f32(_ptr(x), _ptr(eps), _ptr(sigma), _ptr(sigma_next), float(scale), float(scale_im), _ptr(out),
+                                              x.numel(), _stream()), "cd360_cfg_euler_step_f32")
+    return out

@@ -147,3 +147,28 @@ extern "C" int cd360_add_layernorm_bf16(const void* a, const void* b, const void
   CD360_LAUNCH_CHECK();
   return CD360_OK;
 }
+
+// ---- tail of one 3-way-CFG Euler step: EpsScaling c_out (denoiser.py:41-44, denoiser_scaling.py:26-32),
+// ScheduledCFGImgTextRef combine (guiders.py:111-114), to_d + Euler update (sampling.py:101-106, sampling_utils.py:39-40) ----
+namespace {
+__global__ void cfg_euler_step_kernel(const float* __restrict__ x, const float* __restrict__ eps, const float* __restrict__ sigma,
+                                      const float* __restrict__ sigma_next, float scale, float scale_im, float* __restrict__ out, long n) {
+  const float s = *sigma, sn = *sigma_next;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+    const float xv = x[i];
+    const float du = xv - s * eps[i], dic = xv - s * eps[n + i], dc = xv - s * eps[2 * n + i];
+    const float d0 = du + scale * (dc - dic) + scale_im * (dic - du);
+    out[i] = xv + (xv - d0) / s * (sn - s);
+  }
+}
+}  // namespace
+
+// x [n] fp32 latent, eps [3n] fp32 network output (uncond | image-cond | image+text-cond), sigma / sigma_next: device scalars
+extern "C" int cd360_cfg_euler_step_f32(const void* x, const void* eps, const void* sigma, const void* sigma_next, float scale,
+                                        float scale_im, void* out, int64_t n, void* stream) {
+  if (!x || !eps || !sigma || !sigma_next || !out || n <= 0) return CD360_ERR_ARG;
+  hipLaunchKernelGGL(cfg_euler_step_kernel, dim3(grid_for(n)), dim3(256), 0, (hipStream_t)stream, (const float*)x, (const float*)eps,
+                     (const float*)sigma, (const float*)sigma_next, scale, scale_im, (float*)out, (long)n);
+  CD360_LAUNCH_CHECK();
+  return CD360_OK;
+}

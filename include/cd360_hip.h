@@ -117,6 +117,12 @@ int cd360_concat_channels_bf16(const void* a, const void* b, void* out, int64_t 
 int cd360_add_layernorm_bf16(const void* a, const void* b, const void* gamma, const void* beta, void* sum_out, void* ln_out, int64_t rows,
                              int C, float eps, void* stream);
 
+/* replaces the elementwise tail of one sampling step: DiscreteDenoiser's c_out/c_skip (denoiser.py:41-44), ScheduledCFGImgTextRef.__call__
+ * (guiders.py:111-114), to_d and the Euler update (sampling.py:101-106).  x [n] fp32, eps [3n] fp32 (u | ic | c), sigma / sigma_next
+ * device scalars; out [n] = x + (x - d0)/sigma * (sigma_next - sigma), d0 = den_u + scale (den_c - den_ic) + scale_im (den_ic - den_u). */
+int cd360_cfg_euler_step_f32(const void* x, const void* eps, const void* sigma, const void* sigma_next, float scale, float scale_im,
+                             void* out, int64_t n, void* stream);
+
 /* ---- 3x3 convolution / GEMM with fused epilogue -----------------------------------------------------------------------
  * replaces nn.Conv2d(3x3, stride 1, padding 1) + the adds around it in ResBlock._forward (openaimodel.py:350-376:
  * `h + emb_out`, `skip_connection(x) + h`) and Upsample.conv (:161-164) on channels-last bf16; taps = 1 gives out = x @ w^T

@@ -224,6 +224,46 @@ def case_unet():
     keyfile("unet_tiny", net)
 
 
+def dummy_network(x_in, c_noise, cond, **kw):
+    """Deterministic stand-in for OpenAIWrapper(UNet): depends on every input the sampler stack prepares."""
+    b = x_in.shape[0]
+    ctx = cond["crossattn"][:b].float().mean((1, 2)).view(-1, 1, 1, 1)
+    vec = cond["vector"][:b].float().mean(1).view(-1, 1, 1, 1)
+    pred = 0.3 * torch.tanh(x_in) + 0.001 * c_noise.float().view(-1, 1, 1, 1) / 10 + 0.1 * ctx + 0.05 * vec
+    return pred, [], [], [torch.zeros(b, 4, 3)]
+
+
+def case_sampler():
+    """EulerEDMSampler + ScheduledCFGImgTextRef + DiscreteDenoiser(EpsScaling, LegacyDDPM) exactly as sample.py configures them
+    (sample.py:230-240, configs/train_co3d_concept.yaml:14-25,119-131), around a deterministic dummy network."""
+    den = ns.denoiser.DiscreteDenoiser(
+        weighting_config={"target": "sgm.modules.diffusionmodules.denoiser_weighting.EpsWeighting"},
+        scaling_config={"target": "sgm.modules.diffusionmodules.denoiser_scaling.EpsScaling"}, num_idx=1000,
+        discretization_config={"target": "sgm.modules.diffusionmodules.discretizer.LegacyDDPMDiscretization"})
+    out = {}
+    for name, gcfg in (("cfg3", {"target": "sgm.modules.diffusionmodules.guiders.ScheduledCFGImgTextRef", "params": {"scale": 7.5, "scale_im": 3.5}}),
+                       ("cfg2", {"target": "sgm.modules.diffusionmodules.guiders.VanillaCFGImgRef", "params": {"scale": 7.5}})):
+        smp = ns.sampling.EulerEDMSampler(discretization_config={"target": "sgm.modules.diffusionmodules.discretizer.LegacyDDPMDiscretization"},
+                                          num_steps=50, guider_config=gcfg, device="cpu")
+        b, n = 1, 2
+        x = W.tensor("x", (b, 4, 8, 8), seed=8)
+        c = {"crossattn": W.tensor("c_ctx", (b + b * n, 7, 16), seed=8), "vector": W.tensor("c_vec", (b + b * n, 12), seed=8)}
+        uc = {"crossattn": W.tensor("uc_ctx", (b + b * n, 7, 16), seed=8), "vector": W.tensor("uc_vec", (b + b * n, 12), seed=8)}
+        denoiser = lambda inp, sigma, cc: den(dummy_network, inp, sigma, cc)  # noqa: E731
+        res, _ = smp(denoiser, x.clone(), c, uc=uc, num_steps=12)
+        out[name] = res
+        if name == "cfg3":
+            out.update(x=x, **{"c_" + k: v for k, v in c.items()}, **{"uc_" + k: v for k, v in uc.items()})
+            out["sigmas50"] = smp.discretization(50, device="cpu")
+            out["sigmas12"] = smp.discretization(12, device="cpu")
+            out["table"] = den.sigmas
+            xin, sin, cin = smp.guider.prepare_inputs(x, torch.full((b,), 3.3), c, uc)
+            out["prep_ctx"], out["prep_vec"] = cin["crossattn"], cin["vector"]
+            d1, _, _, _ = den(dummy_network, xin, sin, cin)
+            out["denoised_first"] = d1
+    npz("sampler", **out)
+
+
 def case_sdxl_keys():
     """state_dict names/shapes of the full SDXL-config UNet (configs/train_co3d_concept.yaml:27-54), built on the meta device."""
     import yaml
@@ -243,5 +283,6 @@ if __name__ == "__main__":
     case_st_dual()
     case_customforward()
     case_unet()
+    case_sampler()
     case_sdxl_keys()
     assert not os.path.exists(os.path.join(refshim.REF_ROOT, "sgm", "__pycache__")), "bytecode leaked into the reference tree"

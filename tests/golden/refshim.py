@@ -106,6 +106,7 @@ def _stub_third_party():
         pass
 
     oc.ListConfig = ListConfig
+    oc.OmegaConf = type("OmegaConf", (), {})
     lc = types.ModuleType("omegaconf.listconfig")
     lc.ListConfig = ListConfig
     oc.listconfig = lc
@@ -142,4 +143,8 @@ def import_reference():
     ns.nerf = importlib.import_module("sgm.modules.nerfsd_pytorch3d")
     ns.attention = importlib.import_module("sgm.modules.attention")
     ns.openaimodel = importlib.import_module("sgm.modules.diffusionmodules.openaimodel")
+    ns.sampling = importlib.import_module("sgm.modules.diffusionmodules.sampling")
+    ns.guiders = importlib.import_module("sgm.modules.diffusionmodules.guiders")
+    ns.denoiser = importlib.import_module("sgm.modules.diffusionmodules.denoiser")
+    ns.discretizer = importlib.import_module("sgm.modules.diffusionmodules.discretizer")
     return ns

@@ -187,6 +187,15 @@ def test_geglu_and_concat():
     assert got.shape == (2, 88, 5, 7) and torch.equal(got.float().cpu(), torch.cat([a, b], 1))
 
 
+def test_cfg_euler_step_kernel_matches_sampler_chain():
+    from cd360.sampler import cfg_euler_update
+    x, eps = W.tensor("x", (2, 4, 16, 16), seed=3), W.tensor("eps", (6, 4, 16, 16), seed=3)
+    s, sn = torch.tensor([3.3]), torch.tensor([2.9])
+    want = cfg_euler_update(x, eps, s, sn, 7.5, 3.5, fused=False)
+    got = cfg_euler_update(x.to(DEV), eps.to(DEV), s.to(DEV), sn.to(DEV), 7.5, 3.5, fused=True)
+    assert rel(got, want) < 1e-6
+
+
 @pytest.mark.parametrize("rows,C", [(37, 64), (1000, 640), (513, 1280), (5, 2048)])
 def test_add_layernorm(rows, C):
     from cd360 import ops
