@@ -56,37 +56,41 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
   const int chunk = tid % CPR, lrow = tid / CPR;
 
   // ---- per-thread staging geometry: NPASS weight rows and NPASS pixel rows (fixed for the whole K loop) ----
-  const uint16_t* wsrc[NPASS];
-  const uint16_t* xsrc[NPASS];
+  // Loads go through buffer descriptors: a row that does not exist (channel >= Cout, pixel >= M, tap outside the image) gets an
+  // offset beyond num_records and the hardware returns zeros -- no branches, no zero-fill moves in the K loop.
+  constexpr uint32_t OOB = 0x80000000u;
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)((long)p.Cout * p.taps * p.Cin * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(p.M * p.Cin * 2), 0x00020000);
+  uint32_t woff[NPASS], xbase[NPASS];
   int py[NPASS], px[NPASS];
   bool pok[NPASS];
 #pragma unroll
   for (int ps = 0; ps < NPASS; ++ps) {
     const int row = lrow + RPP * ps;
     const int co = co0 + row;
-    wsrc[ps] = co < p.Cout ? p.w + (long)co * p.taps * p.Cin + chunk * 8 : nullptr;
+    woff[ps] = co < p.Cout ? (uint32_t)(((long)co * p.taps * p.Cin + chunk * 8) * 2) : OOB;
     const long m = m0 + row;
     pok[ps] = m < p.M;
     const long mc = pok[ps] ? m : 0;
     const int rem = (int)(mc % HW);
     py[ps] = rem / p.W;
     px[ps] = rem - py[ps] * p.W;
-    xsrc[ps] = p.x + mc * p.Cin + chunk * 8;
+    xbase[ps] = (uint32_t)((mc * p.Cin + chunk * 8) * 2);
   }
 
   const int kchunks = p.Cin / BK;
   const int nsteps = p.taps * kchunks;
 
-  // running (tap, kc) of the NEXT step to load; per-tap source pointers are refreshed only when the tap changes
+  // running (tap, kc) of the NEXT step to load; per-tap byte offsets are refreshed only when the tap changes
   int ld_tap = 0, ld_kc = 0;
-  const uint16_t* xtap[NPASS];
+  uint32_t xtap[NPASS];
   auto set_tap = [&](int tap) {
     const int dy = p.taps == 9 ? tap / 3 - 1 : 0, dx = p.taps == 9 ? tap - (tap / 3) * 3 - 1 : 0;
-    const long xoff = ((long)dy * p.W + dx) * p.Cin;
+    const int xoff = (dy * p.W + dx) * p.Cin * 2;
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       const bool ok = pok[ps] && (unsigned)(py[ps] + dy) < (unsigned)p.H && (unsigned)(px[ps] + dx) < (unsigned)p.W;
-      xtap[ps] = ok ? xsrc[ps] + xoff : nullptr;
+      xtap[ps] = ok ? (uint32_t)((int)xbase[ps] + xoff) : OOB;
     }
   };
   set_tap(0);
@@ -95,13 +99,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
   // them.  (A second set -- loads two steps ahead -- was measured 10-25 % SLOWER on MI355X: 256 VGPRs, worse MFMA interleave.)
   u32x4 wreg[NPASS], xreg[NPASS];
   auto load_next = [&]() {
-    const long woff = (long)ld_tap * p.Cin + ld_kc * BK;
-    const int koff = ld_kc * BK;
+    const uint32_t koff = (uint32_t)(ld_kc * BK * 2);
+    const uint32_t wstep = (uint32_t)(ld_tap * p.Cin * 2) + koff;
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
-      u32x4 z = {0u, 0u, 0u, 0u};
-      wreg[ps] = wsrc[ps] ? *reinterpret_cast<const u32x4*>(wsrc[ps] + woff) : z;
-      xreg[ps] = xtap[ps] ? *reinterpret_cast<const u32x4*>(xtap[ps] + koff) : z;
+      wreg[ps] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, woff[ps] + wstep, 0, 0);
+      xreg[ps] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xtap[ps] + koff, 0, 0);
     }
     if (++ld_kc == kchunks) {
       ld_kc = 0;
@@ -209,6 +212,7 @@ extern "C" int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const 
   if (!x || !w_packed || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return CD360_ERR_ARG;
   if ((taps != 9 && taps != 1) || Cin % 64 || Cout % 16) return CD360_ERR_SHAPE;
   if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)out | (uintptr_t)emb | (uintptr_t)res) % 16) return CD360_ERR_ARG;
+  if ((long)N * H * W * Cin * 2 >= (1L << 31) || (long)Cout * taps * Cin * 2 >= (1L << 31)) return CD360_ERR_SHAPE;  // 32-bit buffer offsets
   ConvParams p;
   p.x = (const uint16_t*)x; p.w = (const uint16_t*)w_packed; p.bias = (const float*)bias; p.emb = (const uint16_t*)emb;
   p.res = (const uint16_t*)res; p.out = (uint16_t*)out;
