@@ -192,7 +192,7 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 through torch.distributed.run)"
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:  # launched through torch.distributed.run (also with a single rank)
         dist.init_process_group("nccl", device_id=dev)
 
     from cd360 import ops, synth
@@ -291,7 +291,8 @@ def main():
             except Exception as e:  # noqa: BLE001  (e.g. not enough host RAM for the fp32 copy)
                 out["cpu_baseline"] = {"value": None, "unit": "steps/s", "cores": os.cpu_count(), "kind": "port", "sample": f"failed: {e!r}"}
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
+        dist.barrier()  # rank 0 may still be in its per-kernel event pass: leave together
         dist.destroy_process_group()
 
 

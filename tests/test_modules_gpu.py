@@ -148,3 +148,34 @@ def test_sdxl_width_pose_block_properties():
     assert torch.equal(fg, fg3)  # the FeatureNeRF render does not read x (attention.py:571-598)
     out4 = blk(x, context=ctx, context_ref=cref * 0.5, pose=pose)[0]
     assert not torch.allclose(out.float(), out4.float(), atol=1e-2)
+
+
+@torch.no_grad()
+def test_cfgB_level1_sampling_block_cached_equals_uncached():
+    """BASELINE configs[1] shape for one level-1 pose block: C=640, r=64 (hw=4096), S=24, n=50 references, CFG batch 3.
+    Too large for the CPU oracle, so size-independent properties of the sampling path (sample.py:82-136):
+      * a step that reuses the cached render equals a step that re-renders (the render does not depend on x or the step);
+      * the unconditional third (null image for every view) differs from the conditional thirds, which are identical;
+      * render outputs are finite, fg in [0, 1]; re-running is bit-identical."""
+    from cd360 import sampling, synth
+    blk = make_block(11, C=640, heads=10, cd=2048, S=24)
+    n_train, n, hw = 50, 50, 4096
+    refs = dev(W.tensor("references", (n_train + 1, hw, 640), seed=11))
+    sampling.set_references(blk, {"": refs})
+    sampling.enable_reference_sampling(blk, list(range(n)))
+    pose = synth.pose_batch(1, n, seed=9, n_train=n_train) * 3
+    ctx1 = dev(W.tensor("ctx", (1, 77, 2048), seed=11))
+    ctx = ctx1.expand(3, -1, -1).contiguous()
+    x1 = dev(W.tensor("x", (1, hw, 640), seed=11))
+    x = x1.expand(3, -1, -1).contiguous()
+    out_a, fg, _, alphas, rgb = blk(x, context=ctx, context_ref=x, pose=pose)  # renders
+    rend = blk.rendered_feat.clone()
+    out_b = blk(x, context=ctx, context_ref=x, pose=pose)[0]  # cached
+    assert torch.equal(out_a, out_b)
+    sampling.clear_rendered_feat(blk)
+    out_c = blk(x * 0.5, context=ctx, context_ref=x, pose=pose)[0]  # different x, re-render
+    assert torch.equal(blk.rendered_feat, rend)  # render independent of x, bit-reproducible
+    assert torch.isfinite(out_c.float()).all()
+    assert float(fg.min()) >= -1e-5 and float(fg.max()) <= 1 + 1e-4 and float(alphas.min()) >= 0 and float(alphas.max()) <= 1
+    assert torch.equal(rend[1], rend[2]) and not torch.allclose(rend[0].float(), rend[1].float(), atol=1e-3)
+    assert torch.equal(out_a[1], out_a[2])
