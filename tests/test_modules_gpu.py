@@ -177,5 +177,7 @@ def test_cfgB_level1_sampling_block_cached_equals_uncached():
     assert torch.equal(blk.rendered_feat, rend)  # render independent of x, bit-reproducible
     assert torch.isfinite(out_c.float()).all()
     assert float(fg.min()) >= -1e-5 and float(fg.max()) <= 1 + 1e-4 and float(alphas.min()) >= 0 and float(alphas.max()) <= 1
-    assert torch.equal(rend[1], rend[2]) and not torch.allclose(rend[0].float(), rend[1].float(), atol=1e-3)
-    assert torch.equal(out_a[1], out_a[2])
+    # the two conditional thirds see identical inputs; hipBLASLt's stream-K GEMMs may round their rows differently, so "equal"
+    # is asserted to bf16 round-off rather than bitwise
+    assert rel(rend[1], rend[2]) < 2e-2 and rel(rend[0], rend[1]) > 5e-2
+    assert rel(out_a[1], out_a[2]) < 2e-2
