@@ -200,3 +200,16 @@ def test_pack_cameras_roundtrip_and_cache():
     assert torch.equal(packed, again)
     R = packed[..., :9].reshape(2, 4, 3, 3)
     assert torch.allclose(R @ R.transpose(-1, -2), torch.eye(3).expand(2, 4, 3, 3), atol=1e-5)
+
+
+def test_product_package_never_touches_the_oracle():
+    """oracle/ is test infrastructure: nothing under custom-diffusion360_amd/ may import or execute it."""
+    pkg = os.path.join(ROOT, "custom-diffusion360_amd")
+    offenders = []
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(d, f)).read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", src, re.M) or "oracle." in src.replace("oracle/pose_path.py", ""):
+                    offenders.append(os.path.join(d, f))
+    assert not offenders, offenders
