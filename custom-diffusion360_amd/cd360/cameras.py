@@ -112,12 +112,70 @@ class PerspectiveCameras:
         R, T = self.R[:, None], self.T[:, None]
         return ((p[..., 0:1] * R[..., 0, :] + p[..., 1:2] * R[..., 1, :]) + p[..., 2:3] * R[..., 2, :]) + T
 
+    def get_world_to_view_transform(self) -> "Transform3d":
+        """pytorch3d's row-vector 4x4: [[R, 0], [T, 1]] so that [X_world, 1] @ M = [X_view, 1]."""
+        n = len(self)
+        m = torch.zeros(n, 4, 4, dtype=torch.float32, device=self.device)
+        m[:, :3, :3], m[:, 3, :3], m[:, 3, 3] = self.R, self.T, 1.0
+        return Transform3d(m)
+
     def transform_points_ndc(self, points, **_ignored) -> torch.Tensor:
         v = self.get_world_to_view_points(points)
         f, c = self.focal_length[:, None, :], self.principal_point[:, None, :]
         x = (f[..., 0:1] * v[..., 0:1]) / v[..., 2:3] + c[..., 0:1]
         y = (f[..., 1:2] * v[..., 1:2]) / v[..., 2:3] + c[..., 1:2]
         return torch.cat([x, y, 1.0 / v[..., 2:3]], -1)
+
+
+class Transform3d:
+    """The slice of pytorch3d.transforms.Transform3d the reference's camera utilities use (data_co3d.py:94-160,
+    utils_cameraray.py:317-375): row-vector 4x4 matrices, `a.compose(b)` = apply a then b = a.M @ b.M."""
+
+    def __init__(self, matrix=None, device="cpu"):
+        self._m = torch.eye(4, dtype=torch.float32, device=device)[None] if matrix is None else matrix.to(torch.float32)
+
+    def get_matrix(self) -> torch.Tensor:
+        return self._m
+
+    @property
+    def device(self):
+        return self._m.device
+
+    def compose(self, *others: "Transform3d") -> "Transform3d":
+        m = self._m
+        for o in others:
+            m = m @ o.get_matrix()
+        return Transform3d(m)
+
+    def inverse(self) -> "Transform3d":
+        return Transform3d(torch.linalg.inv(self._m))
+
+    def transform_points(self, points: torch.Tensor) -> torch.Tensor:
+        p = points.to(self._m.device, torch.float32)
+        squeeze = p.dim() == 2
+        if squeeze:
+            p = p[None]
+        h = torch.cat([p, torch.ones_like(p[..., :1])], -1) @ self._m
+        out = h[..., :3] / h[..., 3:]
+        return out[0] if squeeze and out.shape[0] == 1 else out  # pytorch3d: (P,3) in, one transform -> (P,3) out
+
+    def __len__(self):
+        return self._m.shape[0]
+
+
+def Translate(xyz: torch.Tensor) -> Transform3d:
+    xyz = torch.as_tensor(xyz, dtype=torch.float32).reshape(-1, 3)
+    m = torch.eye(4, dtype=torch.float32, device=xyz.device)[None].repeat(xyz.shape[0], 1, 1)
+    m[:, 3, :3] = xyz
+    return Transform3d(m)
+
+
+def Rotate(R: torch.Tensor) -> Transform3d:
+    R = torch.as_tensor(R, dtype=torch.float32)
+    R = R[None] if R.dim() == 2 else R
+    m = torch.eye(4, dtype=torch.float32, device=R.device)[None].repeat(R.shape[0], 1, 1)
+    m[:, :3, :3] = R
+    return Transform3d(m)
 
 
 def join_cameras_as_batch(cameras: Sequence[PerspectiveCameras]) -> PerspectiveCameras:

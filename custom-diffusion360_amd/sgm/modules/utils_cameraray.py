@@ -55,3 +55,48 @@ def get_plucker_parameterization(ray):
 def positional_encoding(ray, n_freqs=10, start_freq=0):
     """[sin(f_k x)]_k || [cos(f_k x)]_k with f_k = 2^(k - n/2) pi (:222-242)."""
     return _nerf.positional_encoding(ray, n_freqs)
+
+
+# ---- novel-view camera paths used by sample.py:311-319 (reference :317-391), pytorch3d-free ----
+def _translated_along_view_axis(cam1, axis: int, interp_start, interp_end, interp_step):
+    """Slide the target camera's centre along one of its own VIEW axes: the new centre is the view-frame point
+    `i * e_axis` mapped back to the world, the rotation is kept, and T is recomputed as `-C R` (reference :317-375).
+    Steps follow `np.arange(start, end, step)` exactly as the reference does (float64 arange, then a float32 point)."""
+    import numpy as np
+
+    from cd360.cameras import PerspectiveCameras
+
+    cameras = []
+    view_to_world = cam1.get_world_to_view_transform().inverse()
+    for i in np.arange(interp_start, interp_end, interp_step):
+        p = np.zeros(3)
+        p[axis] = i
+        point = torch.from_numpy(p).reshape(1, 3).float().to(cam1.device)
+        centre = view_to_world.transform_points(point)  # [1, 3]
+        rt = cam1.R[0]
+        new_t = -rt.T @ centre.T  # [3, 1]  ( = -(C R)^T )
+        cameras.append(PerspectiveCameras(R=cam1.R, T=new_t.T, focal_length=cam1.focal_length, principal_point=cam1.principal_point,
+                                          image_size=512, device=cam1.device))
+    return cameras
+
+
+def interpolate_translate_interpolate_xaxis(cam1, interp_start, interp_end, interp_step):
+    return _translated_along_view_axis(cam1, 0, interp_start, interp_end, interp_step)
+
+
+def interpolate_translate_interpolate_yaxis(cam1, interp_start, interp_end, interp_step):
+    return _translated_along_view_axis(cam1, 1, interp_start, interp_end, interp_step)
+
+
+def interpolate_translate_interpolate_zaxis(cam1, interp_start, interp_end, interp_step):
+    return _translated_along_view_axis(cam1, 2, interp_start, interp_end, interp_step)
+
+
+def interpolatefocal(cam1, interp_start, interp_end, interp_step):
+    """Same pose, focal length scaled by each step of `np.arange(start, end, step)` (reference :378-391)."""
+    import numpy as np
+
+    from cd360.cameras import PerspectiveCameras
+
+    return [PerspectiveCameras(R=cam1.R, T=cam1.T, focal_length=cam1.focal_length * i, principal_point=cam1.principal_point, image_size=512,
+                               device=cam1.device) for i in np.arange(interp_start, interp_end, interp_step)]

@@ -275,7 +275,68 @@ def case_sdxl_keys():
     print("sdxl keys:", len(listing), "params(M):", sum(int(np.prod(s)) for s in listing.values()) / 1e6)
 
 
+def _data_co3d_functions():
+    """The camera functions of sgm/data/data_co3d.py (:27-185), compiled from the reference file in place; the module itself
+    cannot be imported here (pytorch_lightning / torchvision / pytorch3d.implicitron are absent)."""
+    from cd360 import cameras as cams
+    src = open(os.path.join(refshim.REF_ROOT, "sgm", "data", "data_co3d.py")).read()
+    names = ("intersect_skew_line_groups", "intersect_skew_lines_high_dim", "_point_line_distance", "compute_optical_axis_intersection",
+             "normalize_cameras", "centerandalign", "square_bbox")
+    wanted = [n for n in ast.parse(src).body if isinstance(n, ast.FunctionDef) and n.name in names]
+    assert len(wanted) == len(names)
+    env = {"torch": torch, "np": np, "join_cameras_as_batch": cams.join_cameras_as_batch, "Rotate": cams.Rotate, "Translate": cams.Translate}
+    exec(compile(ast.Module(body=wanted, type_ignores=[]), "data_co3d.py", "exec"), env)
+    return env
+
+
+def _off_centre_rig(n, seed):
+    """A ring of cameras around a point that is NOT the origin, at a scale that is NOT 1, with perturbed look-at directions and
+    principal points: what normalize_cameras exists to fix."""
+    g = torch.Generator().manual_seed(seed)
+    base = synth.ring_cameras(n, seed=seed)
+    cams_ = []
+    for i in range(n):
+        c = base[i]
+        centre = c.get_camera_center()[0] * 3.7 + torch.tensor([0.4, -1.1, 2.3])
+        at = torch.tensor([0.4, -1.1, 2.3]) + 0.05 * torch.randn(3, generator=g)
+        pp = 0.03 * torch.randn(2, generator=g)
+        cams_.append(synth.look_at_camera(centre.tolist(), at=at.tolist(), focal=float(c.focal_length[0, 0]), pp=pp.tolist()))
+    from cd360.cameras import join_cameras_as_batch
+    return join_cameras_as_batch(cams_)
+
+
+def case_cameras():
+    env = _data_co3d_functions()
+    rig = _off_centre_rig(12, seed=21)
+    out = {"rig": pack_cameras([rig])[0]}
+    new, p_int, p_line, pp, r = env["normalize_cameras"](rig)
+    out.update(norm=pack_cameras([new])[0], p_intersect=p_int, p_line_intersect=p_line, pp=pp, r=r)
+    aligned = env["centerandalign"]([new[i] for i in range(len(new))])
+    out["aligned"] = pack_cameras([aligned])[0]
+    boxes = np.array([[10, 20, 211, 300], [0, 0, 64, 64], [5.5, 7.25, 100.5, 31.0]], dtype=np.float64)
+    out["bbox_in"] = boxes
+    out["bbox_out"] = np.stack([env["square_bbox"](b, padding=0.1) for b in boxes])
+    out["bbox_out_int"] = np.stack([env["square_bbox"](b.astype(np.int64), padding=0.0, astype=int) for b in boxes])
+    cam1 = new[3]
+    for axis in "xyz":
+        fn = getattr(ns.cameraray, f"interpolate_translate_interpolate_{axis}axis")
+        lst = fn(cam1, -0.2, 0.21, 0.1)
+        out[f"interp_{axis}"] = pack_cameras([refshim_join(lst)])[0]
+    out["interp_focal"] = pack_cameras([refshim_join(ns.cameraray.interpolatefocal(cam1, 0.8, 1.25, 0.1))])[0]
+    npz("cameras", **out)
+
+
+def refshim_join(lst):
+    from cd360.cameras import join_cameras_as_batch
+    return join_cameras_as_batch(lst)
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1:  # regenerate selected cases only: make_golden.py case_cameras ...
+        for name in sys.argv[1:]:
+            globals()[name]()
+        sys.exit(0)
+    case_cameras()
     case_nerf(False)
     case_nerf(True)
     case_block(False)

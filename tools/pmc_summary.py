@@ -4,7 +4,7 @@ import sys
 from collections import defaultdict
 
 path, counter = sys.argv[1], sys.argv[2]
-want = sys.argv[3:]
+want = [a for a in sys.argv[3:] if not a.startswith('--')]
 agg = defaultdict(lambda: [0, 0.0])
 with open(path) as f:
     for r in csv.DictReader(f):
@@ -13,6 +13,8 @@ with open(path) as f:
         name = r.get("Kernel_Name", "")
         if want and not any(w in name for w in want):
             continue
+        if "--by-grid" in sys.argv:
+            name = name[:60] + " grid=" + r.get("Grid_Size", r.get("Grid_Size_X", "?"))
         a = agg[name[:100]]
         a[0] += 1
         a[1] += float(r["Counter_Value"])
