@@ -1,0 +1,154 @@
+"""Fine-tuning glue around the pose path: what the reference's Lightning engine and callbacks do to the UNet between training
+steps and the sampling path.  pytorch_lightning is not part of the drop-in; these are plain functions on the
+UNet module that an engine (or a test) calls.
+
+  select_trainable          diffusion.py:117-150   which parameters train for trainkeys in {poseattn, pose, all}
+  combine_losses            diffusion.py:226-241   lambda-weighted total of the four loss terms, gated by drop_im
+  register_reference_hooks  diffusion.py:28-41,151-163   forward hooks that keep the pose blocks' outputs on reference images
+  harvest_references        main.py:596-607        concatenate, all-gather over ranks (RCCL `nccl` / gloo), interleave, register
+                                                   the `references` buffer the sampling path reads (sample.py:91)
+  delta_state_dict          main.py:611-624        the delta checkpoint: pose parameters (no raymarcher buffers) + references
+  load_delta_state_dict     sgm/util.py:227-240    its inverse on a freshly built UNet
+
+The all-gather in harvest_references is the one exchange step of the training side: each rank holds the features of its share
+of the reference images ([N_local, hw, C] per pose block, 12 blocks) and every rank needs all of them in dataset order
+(DistributedSampler gives sample i to rank i % world, hence the transpose before flattening).  It is issued once per
+validation epoch on ~2 GB of bf16 features at 1024^2, as ONE collective per block over xGMI.
+"""
+from __future__ import annotations
+
+import collections
+from typing import Dict, List, Optional
+
+import torch
+import torch.distributed as dist
+
+from .sampling import pose_blocks
+
+
+# ---------------------------------------------------------------- which parameters train
+def select_trainable(unet: torch.nn.Module, trainkeys: str = "pose") -> List[str]:
+    """Sets requires_grad exactly as diffusion.py:117-150 and returns the names left trainable."""
+    named = list(unet.named_parameters())
+    if trainkeys == "poseattn":
+        blocks = []
+        for name, p in named:
+            if not ("pose" in name or "transformer_blocks" in name):
+                p.requires_grad = False
+            elif "pose" in name:
+                p.requires_grad = True
+                blocks.append(name.split(".pose")[0])
+        blocks = set(blocks)
+        for name, p in named:
+            if "transformer_blocks" in name:
+                hit = any(b in name and ("attn1" in name or "attn2" in name or "pose" in name) for b in blocks)
+                p.requires_grad = bool(hit)
+    elif trainkeys == "pose":
+        for name, p in named:
+            p.requires_grad = "pose" in name
+    elif trainkeys == "all":
+        for _, p in named:
+            p.requires_grad = True
+    else:
+        raise ValueError(f"unknown trainkeys {trainkeys!r}")
+    return [n for n, p in named if p.requires_grad]
+
+
+# ---------------------------------------------------------------- loss weighting
+def combine_losses(loss, loss_fg, loss_bg, loss_rgb, drop_im, *, rgb: bool = True, rgb_predict: bool = True, global_step: int = 1,
+                   loss_fg_lambda: float = 10.0, loss_bg_lambda: float = 10.0, loss_rgb_lambda: float = 5.0):
+    """DiffusionEngine.forward (diffusion.py:226-241).  `drop_im` [b] is 1 where the sample kept its reference images; the
+    render losses only count those samples.  Defaults are configs/train_co3d_concept.yaml:9-11."""
+    total = loss.mean()
+    out = {"loss": float(total)}
+    den = drop_im.sum() + 1e-12
+    if rgb and global_step > 0:
+        fg = (loss_fg.mean(1) * drop_im.reshape(-1)).sum() / den
+        bg = (loss_bg.mean(1) * drop_im.reshape(-1)).sum() / den
+        total = total + loss_fg_lambda * fg + loss_bg_lambda * bg
+        out["loss_fg"], out["loss_bg"] = float(fg), float(bg)
+    if rgb_predict and loss_rgb.mean() > 0:
+        lr = (loss_rgb.mean(1) * drop_im.reshape(-1)).sum() / den
+        total = total + loss_rgb_lambda * lr
+        out["loss_rgb"] = float(lr)
+    return total, out
+
+
+# ---------------------------------------------------------------- references harvest
+def _is_pose_block_name(name: str) -> bool:
+    parts = name.split(".")
+    return len(parts) > 1 and parts[-2] == "transformer_blocks"
+
+
+def register_reference_hooks(unet: torch.nn.Module):
+    """-> (activations, handles).  A pose block called WITHOUT a pose (the `onlyref` validation pass over the reference images)
+    returns `(x, None, None, None, None)`; the hook keeps `x` (diffusion.py:28-41: only when out[1] is None)."""
+    activations: Dict[str, list] = collections.defaultdict(list)
+    handles = []
+
+    def hook(name, _module, _inp, out):
+        if isinstance(out, tuple) and out[1] is None:
+            activations[name].append(out[0].detach())
+
+    for name, module in unet.named_modules():
+        if _is_pose_block_name(name) and hasattr(module, "pose_emb_layers"):
+            handles.append(module.register_forward_hook(lambda m, i, o, name=name: hook(name, m, i, o)))
+    return activations, handles
+
+
+def remove_hooks(handles) -> None:
+    for h in handles:
+        h.remove()
+
+
+def harvest_references(unet: torch.nn.Module, activations: Dict[str, list], group: Optional[dist.ProcessGroup] = None) -> Dict[str, torch.Tensor]:
+    """main.py:596-607.  Every rank must have run the same number of reference images.  Returns {block name: references}."""
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    out = {}
+    for name, module in unet.named_modules():
+        if not (_is_pose_block_name(name) and hasattr(module, "pose_emb_layers")):
+            continue
+        if not activations.get(name):
+            raise RuntimeError(f"no reference activations were recorded for {name} (run the reference images with pose=None first)")
+        local = torch.cat(activations[name]).contiguous()
+        if world > 1:
+            gathered = [torch.empty_like(local) for _ in range(world)]
+            dist.all_gather(gathered, local, group=group)
+            refs = torch.stack(gathered).transpose(0, 1).reshape(-1, *local.shape[1:])  # "(b n) ..." with n = rank
+        else:
+            refs = local
+        if "references" in module._buffers:
+            module._buffers["references"] = refs
+        else:
+            module.register_buffer("references", refs)
+        out[name] = refs
+    return out
+
+
+# ---------------------------------------------------------------- delta checkpoint
+def delta_state_dict(state_dict: Dict[str, torch.Tensor], embeds: Optional[list] = None) -> Dict[str, object]:
+    """main.py:611-624: keys containing 'pose' (but not the raymarcher buffers) and the `references` buffers; `embed` carries
+    the two new-token embedding rows of the text encoders when the caller has them (they live outside the UNet)."""
+    delta = {k: v for k, v in state_dict.items() if ("pose" in k and "raymarcher" not in k) or "references" in k}
+    if embeds is not None:
+        delta["embed"] = list(embeds)
+    return delta
+
+
+def load_delta_state_dict(unet: torch.nn.Module, sd_delta: Dict[str, object], prefix: str = "model.diffusion_model.") -> List[str]:
+    """sgm/util.py:227-240 for the UNet part: registers each pose block's `references` buffer, loads the pose parameters,
+    returns the unexpected keys.  `sd_delta` is not modified."""
+    sd = {k: v for k, v in sd_delta.items() if k != "embed"}
+    for name, module in unet.named_modules():
+        if _is_pose_block_name(name) and hasattr(module, "pose_emb_layers"):
+            key = f"{prefix}{name}.references"
+            if key not in sd:
+                raise KeyError(f"delta checkpoint has no {key}")
+            ref = sd.pop(key).to(next(module.parameters()).device)
+            if "references" in module._buffers:
+                module._buffers["references"] = ref
+            else:
+                module.register_buffer("references", ref)
+    stripped = {k[len(prefix):] if k.startswith(prefix) else k: v for k, v in sd.items()}
+    _missing, unexpected = unet.load_state_dict(stripped, strict=False)
+    return list(unexpected)

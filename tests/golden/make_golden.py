@@ -326,6 +326,33 @@ def case_cameras():
     npz("cameras", **out)
 
 
+from make_golden_params import LOSS_CFG, LossDenoiser as _LossDenoiser, loss_inputs  # noqa: E402
+
+
+def case_loss():
+    rns = refshim.import_reference_loss()
+    d = loss_inputs()
+    out = {}
+    loss_fn = rns.loss.StandardDiffusionLossImgRef(**LOSS_CFG)
+    den = _LossDenoiser(d)
+    torch.manual_seed(77)
+    l2, lfg, lbg, lrgb = loss_fn(None, den, lambda batch: {}, d["x0"], d["x_rgb"], d["xr"], None, d["mask"], None, d["opacity"], {})
+    out.update(l2=l2, lfg=lfg, lbg=lbg, lrgb=lrgb, **{"seen_" + k: v for k, v in den.seen.items()})
+    # no-mask / l1 variants through get_loss directly
+    w = torch.tensor([0.5, 2.0, 1.0]).view(-1, 1, 1, 1)
+    mo = W.tensor("loss.mo", (3, 4, 16, 16), seed=31)
+    l2n, _, _, _ = loss_fn.get_loss(mo, [], [], d["x0"], d["x_rgb"], w, None, None, d["opacity"], [])
+    out["l2_nomask"] = l2n
+    l1 = rns.loss.StandardDiffusionLossImgRef(type="l1", **LOSS_CFG).get_loss(mo, [], [], d["x0"], d["x_rgb"], w, None, None, d["opacity"], [])
+    out["l1"] = l1[0]
+    # sigma samplers on a fixed RNG stream
+    torch.manual_seed(5)
+    out["cubic"] = rns.sigma_sampling.CubicSampling(**LOSS_CFG["sigma_sampler_config"]["params"])(16)
+    out["discrete"] = rns.sigma_sampling.DiscreteSampling(**LOSS_CFG["sigma_sampler_config_ref"]["params"])(16)
+    out["edm"] = rns.sigma_sampling.EDMSampling()(16)
+    npz("loss", **out)
+
+
 def refshim_join(lst):
     from cd360.cameras import join_cameras_as_batch
     return join_cameras_as_batch(lst)
@@ -337,6 +364,7 @@ if __name__ == "__main__":
             globals()[name]()
         sys.exit(0)
     case_cameras()
+    case_loss()
     case_nerf(False)
     case_nerf(True)
     case_block(False)

@@ -148,3 +148,21 @@ def import_reference():
     ns.denoiser = importlib.import_module("sgm.modules.diffusionmodules.denoiser")
     ns.discretizer = importlib.import_module("sgm.modules.diffusionmodules.discretizer")
     return ns
+
+
+def import_reference_loss():
+    """sgm.modules.diffusionmodules.{loss, sigma_sampling} of the reference.  loss.py:6-7 imports LPIPS (torchvision) and
+    GeneralConditioner (open_clip / kornia), neither installed nor on the l2 path: both names are stubbed."""
+    ns = import_reference()
+    for name, attr in (("sgm.modules.autoencoding.lpips.loss.lpips", "LPIPS"), ("sgm.modules.encoders.modules", "GeneralConditioner")):
+        parts = name.split(".")
+        for i in range(3, len(parts) + 1):
+            sub = ".".join(parts[:i])
+            if sub not in sys.modules:
+                m = types.ModuleType(sub)
+                m.__path__ = []
+                sys.modules[sub] = m
+        setattr(sys.modules[name], attr, type(attr, (torch.nn.Module,), {}))
+    ns.loss = importlib.import_module("sgm.modules.diffusionmodules.loss")
+    ns.sigma_sampling = importlib.import_module("sgm.modules.diffusionmodules.sigma_sampling")
+    return ns

@@ -181,3 +181,76 @@ def test_cfgB_level1_sampling_block_cached_equals_uncached():
     # is asserted to bf16 round-off rather than bitwise
     assert rel(rend[1], rend[2]) < 2e-2 and rel(rend[0], rend[1]) > 5e-2
     assert rel(out_a[1], out_a[2]) < 2e-2
+
+
+@torch.no_grad()
+def test_references_harvest_delta_checkpoint_and_sampling_round_trip():
+    """§8 f3 on the HIP path: run the reference images through the UNet WITHOUT a pose with the harvest hooks on
+    (diffusion.py:151-163), build `references` (main.py:596-607), save/load the delta checkpoint into a second UNet
+    (main.py:611-624, sgm/util.py:227-240) and sample from it with the native reference-sampling mode (sample.py:82-136):
+    both UNets must give the same step output, and the harvested rows must equal the blocks' plain outputs."""
+    from cd360 import finetune, sampling, synth
+    from make_golden_params import UNET_TINY
+    from sgm.modules.diffusionmodules.openaimodel import UNetModel
+    src, dst = UNetModel(**UNET_TINY).eval(), UNetModel(**UNET_TINY).eval()
+    W.load_into(src, seed=5)
+    W.load_into(dst, seed=5)
+    for n, p in dst.named_parameters():
+        if "pose" in n:
+            p.zero_()  # so that only the delta checkpoint can make dst agree with src
+    src, dst = src.to(DEV, BF), dst.to(DEV, BF)
+    n_train, L = 3, 16
+    imgs = W.tensor("ft.refs", (n_train + 1, 4, L, L), seed=12).to(DEV)
+    imgs[-1] = 0  # last row: the null image (data_co3d.py:469-472)
+    ctx = W.tensor("ft.ctx", (1, 77, 32), seed=12).to(DEV)
+    y = W.tensor("ft.y", (1, 16), seed=12).to(DEV)
+    t = torch.full((1,), 10.0, device=DEV)
+    acts, handles = finetune.register_reference_hooks(src)
+    for i in range(n_train + 1):
+        src(imgs[i:i + 1], timesteps=t, context=ctx, y=y)
+    refs = finetune.harvest_references(src, acts)
+    finetune.remove_hooks(handles)
+    assert len(refs) == 3 and all(r.shape[0] == n_train + 1 and r.dtype == BF for r in refs.values())
+    full = {"model.diffusion_model." + k: v for k, v in src.state_dict().items()}
+    delta = finetune.delta_state_dict(full)
+    assert finetune.load_delta_state_dict(dst, delta) == []
+    pose = synth.pose_batch(1, n_train, seed=4, n_train=n_train) * 3
+    x = W.tensor("ft.x", (3, 4, L, L), seed=12).to(DEV)
+    outs = []
+    for net in (src, dst):
+        sampling.enable_reference_sampling(net, list(range(n_train)))
+        o = net(x, timesteps=t.expand(3), context=ctx.expand(3, -1, -1).contiguous(), y=y.expand(3, -1).contiguous(), pose=pose)
+        outs.append(o)
+        sampling.clear_rendered_feat(net)
+    assert torch.isfinite(outs[0][0]).all() and len(outs[0][1]) == 3
+    assert rel(outs[1][0], outs[0][0]) < 1e-3 and rel(outs[1][3][0], outs[0][3][0]) < 1e-3
+    assert rel(outs[0][0][0], outs[0][0][2]) > 1e-4  # conditional vs null-image third differ: the references are in use
+
+
+@torch.no_grad()
+def test_training_loss_on_hip_outputs_matches_loss_on_reference_outputs():
+    """§8 f3: StandardDiffusionLossImgRef.get_loss (loss.py:177-209) evaluated on the HIP UNet's dual-stream outputs vs on the
+    reference's own outputs for the same inputs (unet_tiny golden): every term within the module tolerance."""
+    from make_golden_params import LOSS_CFG, UNET_TINY
+    from sgm.modules.diffusionmodules.openaimodel import UNetModel
+    from sgm.util import instantiate_from_config
+    g = load("unet_tiny")
+    net = UNetModel(**UNET_TINY).eval()
+    W.load_into(net, seed=5)
+    net = net.to(DEV, BF)
+    out, fgs, alphas, rgbs = net(g["x"].to(DEV), timesteps=g["t"].to(DEV), context=g["ctx"].to(DEV), y=g["y"].to(DEV),
+                                 pose=unpack_cameras(g["cams"]), input_ref=g["input_ref"].to(DEV), sigmas_ref=g["sigmas_ref"].to(DEV), mask_ref=None)
+    b, L = g["x"].shape[0], g["x"].shape[-1]
+    target = W.tensor("lt.x0", (b, 4, L, L), seed=2).to(DEV)
+    rgb_t = W.tensor("lt.rgb", (b, 3, 8 * L, 8 * L), seed=2).clamp(-1, 1).to(DEV)
+    mask = torch.ones(b, 1, L, L, device=DEV)
+    opacity = torch.sigmoid(3 * W.tensor("lt.op", (b, 1, 8 * L, 8 * L), seed=2)).to(DEV)
+    w = torch.full((b, 1, 1, 1), 0.7, device=DEV)
+    loss_fn = instantiate_from_config({"target": "sgm.modules.diffusionmodules.loss.StandardDiffusionLossImgRef", "params": LOSS_CFG})
+    got = loss_fn.get_loss(out, fgs, rgbs, target, rgb_t, w, mask, None, opacity, alphas)
+    ref_f = [g[f"fg{i}"].to(DEV) for i in range(3)]
+    ref_r = [g[f"rgb{i}"].to(DEV) for i in range(3)]
+    want = loss_fn.get_loss(g["out"].to(DEV), ref_f, ref_r, target, rgb_t, w, mask, None, opacity, [a.float() for a in alphas])
+    for a, bb in zip(got, want):
+        assert a.dtype == torch.float32 and torch.isfinite(a).all() and rel(a, bb) < 4e-2
+    assert got[1].shape == (b, 3) and got[3].shape == (b, 3)

@@ -60,3 +60,53 @@ def test_assign_poses_partition():
         for P in (1, 7, 8, 50):
             parts = [assign_poses(P, world, r) for r in range(world)]
             assert sum(parts, []) == list(range(P))
+
+
+class _Blk(torch.nn.Module):
+    """Just enough of a pose block for the harvest: lives under `transformer_blocks.N` and has `pose_emb_layers`."""
+
+    def __init__(self):
+        super().__init__()
+        self.pose_emb_layers = torch.nn.Linear(4, 2, bias=False)
+
+
+class _Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.transformer_blocks = torch.nn.ModuleList([_Blk(), torch.nn.Identity(), _Blk()])
+
+
+def _harvest_worker(rank, world, port, n_images, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "custom-diffusion360_amd"))
+    from cd360 import finetune
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    net = _Net()
+    # DistributedSampler order: reference image i is processed by rank i % world, in increasing i, one per forward
+    acts = {}
+    for name in ("transformer_blocks.0", "transformer_blocks.2"):
+        acts[name] = [torch.full((1, 3, 2), float(i)) for i in range(rank, n_images, world)]
+    refs = finetune.harvest_references(net, acts)
+    ok = all(r.shape == (n_images, 3, 2) and all(torch.all(r[i] == i) for i in range(n_images)) for r in refs.values())
+    ok = ok and torch.equal(net.transformer_blocks[2].references, refs["transformer_blocks.2"]) and len(refs) == 2
+    q.put((rank, bool(ok)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_images", [(2, 6), (3, 6)])
+def test_references_harvest_allgather_restores_dataset_order(world, n_images):
+    """main.py:596-607: per-rank features -> all_gather -> transpose(0, 1) -> flatten gives rows in dataset order."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_harvest_worker, args=(r, world, port, n_images, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(ok for _, ok in res)
