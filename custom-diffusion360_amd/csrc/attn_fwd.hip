@@ -5,7 +5,7 @@
 // for all three call shapes of the pose path:
 //   self-attn  Nq = Nk = hw,  text cross-attn Nk = 77,  pose-token cross-attn Nq = hw*S (up to 98 304), Nk = 77.
 //
-// CDNA4 design (one wave = 32 query rows, 4 waves per workgroup, 64-key tiles):
+// CDNA4 design (one wave = 32 query rows, 4 waves per workgroup, 64-key tiles, 3 workgroups per CU):
 //   * "swapped" scores  S^T = K Q^T  with v_mfma_f32_32x32x16_bf16, so every lane owns ONE query column:
 //     the row max / row sum of the online softmax are in-register reductions plus one exchange with lane^32.
 //   * O^T = V^T P^T: the P^T B-operand is taken straight from the lane's own S^T accumulator registers
@@ -32,6 +32,7 @@ struct AttnParams {
   long o_sb, o_sh, o_sn;
   float scale_log2e;
   int n_qtiles;
+  int fast;  // 1: full tiles may use 32-bit buffer offsets (K and V^T of one head span < 2 GiB)
 };
 
 constexpr int BN = 64;        // keys per tile
@@ -83,10 +84,134 @@ __device__ __forceinline__ void tile_store(unsigned char* Ks, unsigned char* Vs,
   }
 }
 
-// QB = 32-query blocks per wave (1: 128 queries per workgroup, 2: 256).  QB = 2 halves the LDS fragment traffic and the
-// barriers per MFMA and is used whenever the grid still fills the chip.
-template <int QB>
-__global__ __launch_bounds__(256, QB == 1 ? 3 : 1) void attn_fwd_kernel(AttnParams p) {
+// Fast path of tile_load for a tile whose 64 keys all exist: buffer loads with per-thread byte offsets computed once and a
+// scalar tile offset, so the K-loop spends no VALU on addresses or bounds.
+__device__ __forceinline__ void tile_load_full(__amdgpu_buffer_rsrc_t krsrc, __amdgpu_buffer_rsrc_t vrsrc, int kgo, int vgo, int ksoff,
+                                               int vsoff, int kpass, int vpass, TileRegs& r) {
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {  // the second pass (rows + 32) is a scalar offset as well
+    r.k[pass] = __builtin_amdgcn_raw_buffer_load_b128(krsrc, kgo, ksoff + pass * kpass, 0);
+    r.v[pass] = __builtin_amdgcn_raw_buffer_load_b128(vrsrc, vgo, vsoff + pass * vpass, 0);
+  }
+}
+
+template <int BUF>
+__device__ __forceinline__ void tile_store_to(unsigned char* lds, int kso, int vso, const TileRegs& r) {
+  unsigned char* Ks = lds + BUF * TILE_BYTES;
+  unsigned char* Vs = Ks + BN * K_PITCH;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {  // rows + 32: the swizzle term ((row >> 1) & 7) is unchanged, so a constant offset
+    *reinterpret_cast<u32x4*>(Ks + kso + pass * 32 * K_PITCH) = r.k[pass];
+    u32x2 lo = {r.v[pass][0], r.v[pass][1]}, hi = {r.v[pass][2], r.v[pass][3]};
+    *reinterpret_cast<u32x2*>(Vs + vso + pass * 32 * V_PITCH) = lo;
+    *reinterpret_cast<u32x2*>(Vs + vso + pass * 32 * V_PITCH + 8) = hi;
+  }
+}
+
+struct WaveState {
+  bf16x8 qf[4];    // this wave's 32 query rows as MFMA B fragments
+  f32x16 oT[2];    // O^T accumulator: 64 d x 32 queries
+  float m_run, l_run;
+};
+
+// One 64-key tile from LDS buffer BUF against the wave's 32 queries.  FULL = every key of the tile exists (no masking, both
+// 32-key halves multiplied); the ragged last tile takes the other instantiation.  BUF is a template parameter so that every LDS
+// address is `per-lane offset computed before the loop + immediate`.
+template <int BUF, bool FULL>
+__device__ __forceinline__ void consume_tile(const AttnParams& p, const unsigned char* lds, int kt0, const int (&koff)[4], int voff,
+                                             int hh, float c, WaveState& w) {
+  const unsigned char* Ks = lds + BUF * TILE_BYTES;
+  const unsigned char* Vs = Ks + BN * K_PITCH;
+  const int nkb = FULL ? 2 : ((p.Nk - kt0 > 32) ? 2 : 1);  // 32-key blocks with at least one valid key
+  // ---- S^T = K Q^T ----
+  f32x16 sT[2];
+  __builtin_amdgcn_s_setprio(1);
+  if (FULL) {
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ks + kb * 32 * K_PITCH + koff[ks]);
+        sT[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w.qf[ks], ks == 0 ? zero : sT[kb], 0, 0, 0);
+      }
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { sT[0][i] = 0.f; sT[1][i] = 0.f; }
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      if (kb < nkb) {
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ks + kb * 32 * K_PITCH + koff[ks]);
+          sT[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, w.qf[ks], sT[kb], 0, 0, 0);
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_s_setprio(0);
+
+  // ---- online softmax (this lane: one query column; keys spread over registers and lane^32) ----
+  if (!FULL) {
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
+        if (key >= p.Nk) sT[kb][r] = -INFINITY;
+      }
+  }
+  float mx = sT[0][0];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sT[kb][r]);
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  const float m_new = fmaxf(w.m_run, mx);  // raw (unscaled) score units
+  const float alpha = __builtin_amdgcn_exp2f((w.m_run - m_new) * c);
+  const float mc = -m_new * c;
+  float rs = 0.f;
+  uint32_t pk[16];
+#pragma unroll
+  for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const float p0 = __builtin_amdgcn_exp2f(fmaf(sT[kb][r], c, mc));
+      const float p1 = __builtin_amdgcn_exp2f(fmaf(sT[kb][r + 1], c, mc));
+      rs += p0 + p1;
+      pk[kb * 8 + (r >> 1)] = pack_bf16x2(p0, p1);
+    }
+  rs += __shfl_xor(rs, 32);
+  w.l_run = w.l_run * alpha + rs;
+  w.m_run = m_new;
+  // (skipping this rescale when no running max moved -- `if (__any(m_new > m_old))` -- measured 3-7 % SLOWER: the branch
+  // breaks the MFMA/VALU interleave; the 32 multiplies stay unconditional)
+#pragma unroll
+  for (int i = 0; i < 16; ++i) { w.oT[0][i] *= alpha; w.oT[1][i] *= alpha; }
+
+  // ---- O^T += V^T P^T ----
+  __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    if (FULL || kk < 2 * nkb) {
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const unsigned char* vrow = Vs + db * 32 * V_PITCH + 32 * kk + voff;
+        const u32x2 v0 = *reinterpret_cast<const u32x2*>(vrow);
+        const u32x2 v1 = *reinterpret_cast<const u32x2*>(vrow + 16);
+        u32x4 vw = {v0[0], v0[1], v1[0], v1[1]};
+        u32x4 pw = {pk[kk * 4 + 0], pk[kk * 4 + 1], pk[kk * 4 + 2], pk[kk * 4 + 3]};
+        w.oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vw), __builtin_bit_cast(bf16x8, pw), w.oT[db], 0, 0, 0);
+      }
+    }
+  }
+  __builtin_amdgcn_s_setprio(0);
+}
+
+// 4 waves x 32 queries per workgroup, 3 workgroups per CU.  (A 2-q-block-per-wave variant -- half the LDS fragment traffic, one
+// wave per SIMD -- measured 15 % slower at every SDXL shape and was removed.)
+__global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams p) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * TILE_BYTES];
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -98,149 +223,73 @@ __global__ __launch_bounds__(256, QB == 1 ? 3 : 1) void attn_fwd_kernel(AttnPara
   const uint16_t* vp = p.vt + b * p.v_sb + h * p.v_sh;
   uint16_t* op = p.o + b * p.o_sb + h * p.o_sh;
 
-  int qrow[QB];
-  bf16x8 qf[QB][4];
+  WaveState w;
+  const int qrow = qt * 128 + wave * 32 + l31;
 #pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    qrow[qb] = qt * (128 * QB) + (wave * QB + qb) * 32 + l31;
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (qrow[qb] < p.Nq) v = *reinterpret_cast<const u32x4*>(qp + (long)qrow[qb] * p.q_sn + 16 * ks + 8 * hh);
-      qf[qb][ks] = __builtin_bit_cast(bf16x8, v);
-    }
+  for (int ks = 0; ks < 4; ++ks) {
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (qrow < p.Nq) v = *reinterpret_cast<const u32x4*>(qp + (long)qrow * p.q_sn + 16 * ks + 8 * hh);
+    w.qf[ks] = __builtin_bit_cast(bf16x8, v);
   }
-
-  f32x16 oT[QB][2];
-  float m_run[QB], l_run[QB];
+  w.m_run = -INFINITY;
+  w.l_run = 0.f;
 #pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    m_run[qb] = -INFINITY;
-    l_run[qb] = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) { oT[qb][0][i] = 0.f; oT[qb][1][i] = 0.f; }
-  }
+  for (int i = 0; i < 16; ++i) { w.oT[0][i] = 0.f; w.oT[1][i] = 0.f; }
   const float c = p.scale_log2e;
+
+  // per-lane LDS offsets, constant over the K-loop
+  int koff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koff[ks] = l31 * K_PITCH + (((2 * ks + hh) ^ ((l31 >> 1) & 7)) << 4);
+  const int voff = l31 * V_PITCH + 8 * hh;
+  const int srow = tid >> 3, schunk = tid & 7;  // staging: thread -> (row, 16-byte chunk), rows + 32 on the second pass
+  const int kso = srow * K_PITCH + ((schunk ^ ((srow >> 1) & 7)) << 4), vso = srow * V_PITCH + schunk * 16;
+  const int kgo = (int)(srow * p.k_sn * 2) + schunk * 16, vgo = (int)(srow * p.v_sd * 2) + schunk * 16;
+  const int kpass = (int)(32 * p.k_sn * 2), vpass = (int)(32 * p.v_sd * 2);
+  const int n_tiles = (p.Nk + BN - 1) / BN;
+  const int n_full = p.fast ? p.Nk / BN : 0;  // tiles that take the unguarded buffer-load / unmasked path
+  const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, p.fast ? (int)((long)p.Nk * p.k_sn * 2) : 0, 0x00020000);
+  const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vp, 0, p.fast ? (int)(64 * p.v_sd * 2) : 0, 0x00020000);
+  const int kstep = (int)(BN * p.k_sn * 2);
 
   TileRegs tr;
   tile_load(p, kp, vp, 0, tid, tr);
-  tile_store(lds, lds + BN * K_PITCH, tid, tr);
+  tile_store_to<0>(lds, kso, vso, tr);
   __syncthreads();
 
-  int buf = 0;
-  for (int kt0 = 0; kt0 < p.Nk; kt0 += BN, buf ^= 1) {
-    const unsigned char* Ks = lds + buf * TILE_BYTES;
-    const unsigned char* Vs = Ks + BN * K_PITCH;
-    const bool more = kt0 + BN < p.Nk;
-    if (more) tile_load(p, kp, vp, kt0 + BN, tid, tr);  // in flight during this tile's MFMAs
-
-    const bool ragged = kt0 + BN > p.Nk;
-    const int nkb = (p.Nk - kt0 > 32) ? 2 : 1;  // 32-key blocks with at least one valid key
-    // ---- S^T = K Q^T ----
-    f32x16 sT[QB][2];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { sT[qb][0][i] = 0.f; sT[qb][1][i] = 0.f; }
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      if (kb < nkb) {
-        const int krow = kb * 32 + l31;
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ks + krow * K_PITCH + (((2 * ks + hh) ^ ((krow >> 1) & 7)) << 4));
-#pragma unroll
-          for (int qb = 0; qb < QB; ++qb) sT[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[qb][ks], sT[qb][kb], 0, 0, 0);
-        }
-      }
-    }
-    __builtin_amdgcn_s_setprio(0);
-
-    // ---- online softmax (this lane: one query column per q-block; keys spread over registers and lane^32) ----
-    uint32_t pk[QB][16];
-#pragma unroll
-    for (int qb = 0; qb < QB; ++qb) {
-      if (ragged || nkb < 2) {
-#pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) {
-            const int key = kt0 + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh;
-            if (key >= p.Nk) sT[qb][kb][r] = -INFINITY;
-          }
-      }
-      float mx = sT[qb][0][0];
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sT[qb][kb][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 32));
-      const float m_new = fmaxf(m_run[qb], mx);  // raw (unscaled) score units
-      const float alpha = __builtin_amdgcn_exp2f((m_run[qb] - m_new) * c);
-      const float mc = -m_new * c;
-      float rs = 0.f;
-#pragma unroll
-      for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-        for (int r = 0; r < 16; r += 2) {
-          const float p0 = __builtin_amdgcn_exp2f(fmaf(sT[qb][kb][r], c, mc));
-          const float p1 = __builtin_amdgcn_exp2f(fmaf(sT[qb][kb][r + 1], c, mc));
-          rs += p0 + p1;
-          pk[qb][kb * 8 + (r >> 1)] = pack_bf16x2(p0, p1);
-        }
-      rs += __shfl_xor(rs, 32);
-      l_run[qb] = l_run[qb] * alpha + rs;
-      m_run[qb] = m_new;
-      // (skipping this rescale when no running max moved -- `if (__any(m_new > m_old))` -- measured 3-7 % SLOWER: the branch
-      // breaks the MFMA/VALU interleave; the 32 multiplies stay unconditional)
-#pragma unroll
-      for (int i = 0; i < 16; ++i) { oT[qb][0][i] *= alpha; oT[qb][1][i] *= alpha; }
-    }
-
-    // ---- O^T += V^T P^T ----
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      if (kk < 2 * nkb) {
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          const unsigned char* vrow = Vs + (db * 32 + l31) * V_PITCH + (16 * kk + 4 * hh) * 2;
-          const u32x2 v0 = *reinterpret_cast<const u32x2*>(vrow);
-          const u32x2 v1 = *reinterpret_cast<const u32x2*>(vrow + 16);
-          u32x4 vw = {v0[0], v0[1], v1[0], v1[1]};
-          const bf16x8 va = __builtin_bit_cast(bf16x8, vw);
-#pragma unroll
-          for (int qb = 0; qb < QB; ++qb) {
-            u32x4 pw = {pk[qb][kk * 4 + 0], pk[qb][kk * 4 + 1], pk[qb][kk * 4 + 2], pk[qb][kk * 4 + 3]};
-            oT[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, __builtin_bit_cast(bf16x8, pw), oT[qb][db], 0, 0, 0);
-          }
-        }
-      }
-    }
-    __builtin_amdgcn_s_setprio(0);
-
-    if (more) {
-      unsigned char* Kn = lds + (buf ^ 1) * TILE_BYTES;
-      tile_store(Kn, Kn + BN * K_PITCH, tid, tr);  // the other buffer was last read before the previous barrier
-    }
-    __syncthreads();
+  // the loads of tile t+1 are in flight during tile t's MFMAs and land in the other LDS buffer (last read before the previous
+  // barrier); the loop is unrolled over the two buffers so BUF is a compile-time constant
+#define CD360_ATTN_STEP(BUF, T)                                                                         \
+  {                                                                                                     \
+    const int t_ = (T), kt0 = t_ * BN;                                                                  \
+    const bool more = t_ + 1 < n_tiles;                                                                 \
+    if (more) {                                                                                         \
+      if (t_ + 1 < n_full) tile_load_full(krsrc, vrsrc, kgo, vgo, (t_ + 1) * kstep, (kt0 + BN) * 2, kpass, vpass, tr); \
+      else tile_load(p, kp, vp, kt0 + BN, tid, tr);                                                     \
+    }                                                                                                   \
+    if (t_ < n_full) consume_tile<BUF, true>(p, lds, kt0, koff, voff, hh, c, w);                        \
+    else consume_tile<BUF, false>(p, lds, kt0, koff, voff, hh, c, w);                                   \
+    if (more) tile_store_to<(BUF) ^ 1>(lds, kso, vso, tr);                                              \
+    __syncthreads();                                                                                    \
   }
+  for (int t = 0; t < n_tiles; t += 2) {
+    CD360_ATTN_STEP(0, t)
+    if (t + 1 >= n_tiles) break;
+    CD360_ATTN_STEP(1, t + 1)
+  }
+#undef CD360_ATTN_STEP
 
+  if (qrow < p.Nq) {
+    const float inv = 1.f / w.l_run;
+    uint16_t* orow = op + (long)qrow * p.o_sn;
 #pragma unroll
-  for (int qb = 0; qb < QB; ++qb) {
-    if (qrow[qb] < p.Nq) {
-      const float inv = 1.f / l_run[qb];
-      uint16_t* orow = op + (long)qrow[qb] * p.o_sn;
+    for (int db = 0; db < 2; ++db) {
 #pragma unroll
-      for (int db = 0; db < 2; ++db) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int d = db * 32 + 8 * g + 4 * hh;
-          u32x2 w = {pack_bf16x2(oT[qb][db][4 * g + 0] * inv, oT[qb][db][4 * g + 1] * inv),
-                     pack_bf16x2(oT[qb][db][4 * g + 2] * inv, oT[qb][db][4 * g + 3] * inv)};
-          *reinterpret_cast<u32x2*>(orow + d) = w;
-        }
+      for (int g = 0; g < 4; ++g) {
+        const int d = db * 32 + 8 * g + 4 * hh;
+        u32x2 wv = {pack_bf16x2(w.oT[db][4 * g + 0] * inv, w.oT[db][4 * g + 1] * inv),
+                    pack_bf16x2(w.oT[db][4 * g + 2] * inv, w.oT[db][4 * g + 3] * inv)};
+        *reinterpret_cast<u32x2*>(orow + d) = wv;
       }
     }
   }
@@ -283,21 +332,12 @@ extern "C" int cd360_attn_fwd_bf16(const void* q, const void* k, const void* vt,
   if (p.v_sd < ((Nk + 7) / 8) * 8) return CD360_ERR_SHAPE;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) % 16 || (uintptr_t)o % 8) return CD360_ERR_ARG;
   p.scale_log2e = scale * 1.4426950408889634f;
-  // 256 queries per workgroup (2 q-blocks per wave) when that still gives every CU work; else 128
-  const long wg256 = (long)((Nq + 255) / 256) * B * H;
-  int qb = 1;  // measured on MI355X: 2 q-blocks/wave (1 wave/SIMD) is 15 % slower than 1 (2 waves/SIMD) at every SDXL shape
-  (void)wg256;
-  if (const char* e = getenv("CD360_ATTN_QB")) {  // tuning override: 1 or 2
-    if (e[0] == '1') qb = 1;
-    if (e[0] == '2') qb = 2;
-  }
-  p.n_qtiles = (Nq + 128 * qb - 1) / (128 * qb);
+  p.n_qtiles = (Nq + 127) / 128;
+  p.fast = ((long)Nk * p.k_sn * 2 < (1L << 31) && 64 * p.v_sd * 2 < (1L << 31)) ? 1 : 0;
+  if (const char* e = getenv("CD360_ATTN_FAST")) p.fast = p.fast && e[0] != '0';  // tuning/debug: 0 forces the guarded path
   const long nwg = (long)p.n_qtiles * B * H;
   if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
-  if (qb == 2)
-    hipLaunchKernelGGL(attn_fwd_kernel<2>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
-  else
-    hipLaunchKernelGGL(attn_fwd_kernel<1>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
   CD360_LAUNCH_CHECK();
   return CD360_OK;
 }

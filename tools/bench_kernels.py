@@ -94,7 +94,7 @@ def gemm(tag, M, K, N):
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["attn", "nerf", "gn", "conv"]
-    print("env CD360_ATTN_QB =", os.environ.get("CD360_ATTN_QB"))
+    print("env CD360_ATTN_FAST =", os.environ.get("CD360_ATTN_FAST"))
     if "attn" in which:
         attn("L1 self", 3, 10, 4096, 4096)
         attn("L2 self", 3, 20, 1024, 1024)

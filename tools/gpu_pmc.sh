@@ -7,7 +7,7 @@ mkdir -p $OUT
 cd /tmp
 P1="SQ_WAVE_CYCLES SQ_BUSY_CU_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_BF16 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE"
 P2="SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVES TCC_HIT_sum TCC_MISS_sum"
-for K in conv1 attn1 nerf1; do
+for K in ${2:-conv1 attn1 nerf1}; do
   i=0
   for P in "$P1" "$P2"; do
     i=$((i+1))
