@@ -13,6 +13,7 @@
 // (32-byte stores); both LDS tiles use the 16-B XOR swizzle of attn_fwd.hip (conflict-free ds_read_b128); the next K-step's
 // tiles travel HBM -> registers while the current one is multiplied (LDS double-buffered, one barrier per step).
 #include "cd360_common.h"
+#include <type_traits>
 #include <stdlib.h>
 
 namespace {
@@ -33,20 +34,27 @@ constexpr int BM = 128, BNC = 128;
 
 __device__ __forceinline__ int chan_pos(int i) { return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3); }
 
-// BK = input channels per K-step (64: 2 x 32 KB LDS stages, 2 workgroups per CU; 32: 2 x 16 KB, up to 4 per CU).
-template <int BK>
-__global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
+// BK = 64 input channels per K-step: 2 x 32 KB LDS stages per 256-thread group (BK = 32 with more workgroups per CU measured slower).
+// SPLIT = 1: 256 threads own the tile.  SPLIT = 2: 512 threads; the second group of 4 waves runs the ODD K-steps of the same
+// tile through its own LDS stages and the two accumulators are summed through LDS at the end -- an in-workgroup split-K for
+// launches with no more tiles than CUs (the 32x32 level: 240 tiles), where one 4-wave workgroup per CU leaves one wave per SIMD
+// and nothing to hide LDS / MFMA latency behind.  No atomics, no workspace, deterministic.
+template <int SPLIT>
+__global__ __launch_bounds__(256 * SPLIT) void conv_igemm_kernel(ConvParams p) {
+  constexpr int BK = 64;
   constexpr int PITCH = BK * 2;             // bytes per LDS row
   constexpr int CPR = BK / 8;               // 16-byte chunks per row
-  constexpr int SH = BK == 64 ? 1 : 2;      // rows per 256-byte bank row = 1 << SH
+  constexpr int SH = 1;                     // rows per 256-byte bank row = 1 << SH
   constexpr int RPP = 256 / CPR;            // rows staged per pass
   constexpr int NPASS = 128 / RPP;          // passes per 128-row tile
   constexpr int STAGE = (BM + BNC) * PITCH;
   constexpr int KS = BK / 16;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];  // SPLIT * 2 * STAGE bytes (64 KB / 128 KB)
   auto swz = [](int row, int chunk) { return row * PITCH + ((chunk ^ ((row >> SH) & (CPR - 1))) << 4); };
 
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int grp = SPLIT == 1 ? 0 : (int)(threadIdx.x >> 8);  // K-split group
+  unsigned char* lds = lds_all + grp * 2 * STAGE;
+  const int tid = threadIdx.x & 255, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wco = wave >> 1, wpx = wave & 1;  // wave tile: 64 channels x 64 pixels
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   // tile order: each XCD walks a contiguous range of tiles; keep the LARGER operand's tile fixed between neighbours so that the
@@ -82,10 +90,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
   }
 
   const int kchunks = p.Cin / BK;
-  const int nsteps = p.taps * kchunks;
+  const int nsteps_all = p.taps * kchunks;                       // K-steps of the tile
+  const int nsteps = (nsteps_all - grp + SPLIT - 1) / SPLIT;     // ... of which this group runs grp, grp + SPLIT, ...
+  const int niter = (nsteps_all + SPLIT - 1) / SPLIT;            // barrier count, the same for both groups
 
   // running (tap, kc) of the NEXT step to load; per-tap byte offsets are refreshed only when the tap changes
-  int ld_tap = 0, ld_kc = 0;
+  int ld_tap = grp / kchunks, ld_kc = grp % kchunks;
   uint32_t xtap[NPASS];
   auto set_tap = [&](int tap) {
     const int dy = p.taps == 9 ? tap / 3 - 1 : 0, dx = p.taps == 9 ? tap - (tap / 3) * 3 - 1 : 0;
@@ -96,7 +106,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
       xtap[ps] = ok ? (uint32_t)((int)xbase[ps] + xoff) : OOB;
     }
   };
-  set_tap(0);
+  set_tap(ld_tap);
 
   // One register set in flight: the loads of step t+1 are issued before step t's MFMAs and written to the other LDS buffer after
   // them.  (A second set -- loads two steps ahead -- was measured 10-25 % SLOWER on MI355X: 256 VGPRs, worse MFMA interleave.)
@@ -109,8 +119,9 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
       wreg[ps] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, woff[ps] + wstep, 0, 0);
       xreg[ps] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xtap[ps] + koff, 0, 0);
     }
-    if (++ld_kc == kchunks) {
-      ld_kc = 0;
+    ld_kc += SPLIT;  // the host only selects SPLIT = 2 when kchunks >= 2
+    if (ld_kc >= kchunks) {
+      ld_kc -= kchunks;
       if (++ld_tap < p.taps) set_tap(ld_tap);
     }
   };
@@ -127,34 +138,71 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvParams p) {
 #pragma unroll
   for (int i = 0; i < 16; ++i) { acc[0][0][i] = 0.f; acc[0][1][i] = 0.f; acc[1][0][i] = 0.f; acc[1][1][i] = 0.f; }
 
+  // Schedule: the registers hold tile t+1 when iteration t starts (its loads were issued one whole iteration earlier).  They
+  // are written to the other LDS buffer FIRST -- that buffer's last readers passed the previous barrier -- and re-issued at once
+  // for tile t+2, so the ds_writes drain under this iteration's MFMAs and the single barrier at the end of the iteration never
+  // waits for a load or a write pass.  (Load-at-the-top / write-before-the-barrier measured the same within 2 % at 2
+  // workgroups per CU and 1-2 % slower at 1.)
   load_next();
   store_step(lds);
+  if (nsteps > 1) load_next();
   __syncthreads();
 
+  // Cout = 320 leaves the upper 64 channels of the third 128-channel tile empty: those two waves only help staging and skip
+  // the fragment reads and MFMAs, which hands their SIMDs' matrix pipes to the co-resident workgroup
+  const bool wave_has_channels = co0 + wco * 64 < p.Cout;
   const int wrow0 = wco * 64 + chan_pos(l31);  // + 32 * cb : weight-tile row feeding MFMA A-operand row l31
   const int prow0 = wpx * 64 + l31;            // + 32 * pb : pixel-tile row feeding MFMA B-operand column l31
-  for (int step = 0; step < nsteps; ++step) {
-    const unsigned char* Ws = lds + (step & 1) * STAGE;
-    const unsigned char* Xs = Ws + BNC * PITCH;
-    const bool more = step + 1 < nsteps;
-    if (more) load_next();
-    __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      bf16x8 a[2], b[2];
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        a[i] = *reinterpret_cast<const bf16x8*>(Ws + swz(wrow0 + 32 * i, 2 * ks + hh));
-        b[i] = *reinterpret_cast<const bf16x8*>(Xs + swz(prow0 + 32 * i, 2 * ks + hh));
+  auto k_loop = [&](auto compute_tag) {
+    constexpr bool COMPUTE = decltype(compute_tag)::value;
+    for (int step = 0; step < nsteps; ++step) {
+      const unsigned char* Ws = lds + (step & 1) * STAGE;
+      const unsigned char* Xs = Ws + BNC * PITCH;
+      if (step + 1 < nsteps) {
+        store_step(lds + ((step + 1) & 1) * STAGE);
+        if (step + 2 < nsteps) load_next();
       }
+      if (COMPUTE) {
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          bf16x8 a[2], b[2];
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            a[i] = *reinterpret_cast<const bf16x8*>(Ws + swz(wrow0 + 32 * i, 2 * ks + hh));
+            b[i] = *reinterpret_cast<const bf16x8*>(Xs + swz(prow0 + 32 * i, 2 * ks + hh));
+          }
+#pragma unroll
+          for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+            for (int pb = 0; pb < 2; ++pb) acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cb], b[pb], acc[cb][pb], 0, 0, 0);
+        }
+        __builtin_amdgcn_s_setprio(0);
+      }
+      __syncthreads();
+    }
+  };
+  if (wave_has_channels) k_loop(std::true_type{}); else k_loop(std::false_type{});
+  if (SPLIT == 2 && nsteps < niter) __syncthreads();  // odd step count: the other group had one more iteration
+
+  if (SPLIT == 2) {  // sum the two K-halves through LDS (64 fp32 per thread = 64 KB, in the now idle stages), group 0 finishes
+    float* red = reinterpret_cast<float*>(lds_all);
+    if (grp == 1) {
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb)
 #pragma unroll
-        for (int pb = 0; pb < 2; ++pb) acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cb], b[pb], acc[cb][pb], 0, 0, 0);
+        for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) red[((cb * 2 + pb) * 16 + r) * 256 + tid] = acc[cb][pb][r];
     }
-    __builtin_amdgcn_s_setprio(0);
-    if (more) store_step(lds + ((step + 1) & 1) * STAGE);
     __syncthreads();
+    if (grp == 1) return;
+#pragma unroll
+    for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+      for (int pb = 0; pb < 2; ++pb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[cb][pb][r] += red[((cb * 2 + pb) * 16 + r) * 256 + tid];
   }
 
   // ---- epilogue: lane = pixel (l31), registers = 16 consecutive channels (16*hh + r) of each 32-channel block ----
@@ -227,14 +275,26 @@ extern "C" int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const 
   if (const char* e = getenv("CD360_CONV_WMAJOR")) p.w_major = e[0] == '1';
   const long nwg = (long)p.n_mtiles * p.n_ntiles;
   if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
-  int bk = 64;
-  if (const char* e = getenv("CD360_CONV_BK")) {  // tuning override
-    if (e[0] == '3') bk = 32;
+  // in-workgroup split-K when the launch has no more tiles than CUs (one 4-wave workgroup per CU otherwise)
+  static const int cus = [] {
+    int dev = 0, n = 256;
+    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    return n;
+  }();
+  int split = (nwg <= cus && Cin / 64 >= 2 && taps * (Cin / 64) >= 8) ? 2 : 1;
+  if (const char* e = getenv("CD360_CONV_SPLIT")) {  // tuning override: 1 or 2
+    if (e[0] == '1') split = 1;
+    if (e[0] == '2' && Cin / 64 >= 2) split = 2;
   }
-  if (bk == 32)
-    hipLaunchKernelGGL(conv_igemm_kernel<32>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
-  else
-    hipLaunchKernelGGL(conv_igemm_kernel<64>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+  constexpr int kStageBytes = (BM + BNC) * 64 * 2;
+  if (split == 2) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<2>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kStageBytes);  // 128 KB > the 64 KB default
+    if (attr != hipSuccess) return CD360_ERR_LAUNCH;
+    hipLaunchKernelGGL(conv_igemm_kernel<2>, dim3((unsigned)nwg), dim3(512), 4 * kStageBytes, (hipStream_t)stream, p);
+  } else {
+    hipLaunchKernelGGL(conv_igemm_kernel<1>, dim3((unsigned)nwg), dim3(256), 2 * kStageBytes, (hipStream_t)stream, p);
+  }
   CD360_LAUNCH_CHECK();
   return CD360_OK;
 }
