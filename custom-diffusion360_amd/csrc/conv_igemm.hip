@@ -28,6 +28,7 @@ struct ConvParams {
   int N, H, W, Cin, Cout, taps;
   long M;
   int n_mtiles, n_ntiles, w_major;
+  int chunk_outer;  // K order: 1 = 64-channel chunk outer / tap inner, 0 = tap outer / chunk inner (cd360_conv_k_order)
 };
 
 constexpr int BM = 128, BNC = 128;
@@ -94,35 +95,45 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_igemm_kernel(ConvParams p) {
   const int nsteps = (nsteps_all - grp + SPLIT - 1) / SPLIT;     // ... of which this group runs grp, grp + SPLIT, ...
   const int niter = (nsteps_all + SPLIT - 1) / SPLIT;            // barrier count, the same for both groups
 
-  // running (tap, kc) of the NEXT step to load; per-tap byte offsets are refreshed only when the tap changes
-  int ld_tap = grp / kchunks, ld_kc = grp % kchunks;
-  uint32_t xtap[NPASS];
-  auto set_tap = [&](int tap) {
-    const int dy = p.taps == 9 ? tap / 3 - 1 : 0, dx = p.taps == 9 ? tap - (tap / 3) * 3 - 1 : 0;
-    const int xoff = (dy * p.W + dx) * p.Cin * 2;
+  // K order (chunk_outer): 64-channel chunk OUTER, tap INNER -- the nine taps of one chunk re-read the same (128 + halo) pixels
+  // x 64 channels (20 KB per pixel tile) back to back, so eight of the nine reads are L1/L2 hits; tap-outer order re-streams the
+  // whole pixel tile from the fabric for every tap (measured: 2-4x the fetch traffic).  Step s <-> (kc, tap) = (s / taps, s % taps).
+  // (Time: within 2 % of tap-outer order on every SDXL shape; tap-outer stays selectable through cd360_conv_k_order.)
+  // Per staged pixel row a 9-bit mask says which taps stay inside the image; the tap's byte shift is wave-uniform.
+  uint32_t tapmask[NPASS];
 #pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
+  for (int ps = 0; ps < NPASS; ++ps) {
+    uint32_t mbits = 0;
+    for (int tap = 0; tap < p.taps; ++tap) {
+      const int dy = p.taps == 9 ? tap / 3 - 1 : 0, dx = p.taps == 9 ? tap - (tap / 3) * 3 - 1 : 0;
       const bool ok = pok[ps] && (unsigned)(py[ps] + dy) < (unsigned)p.H && (unsigned)(px[ps] + dx) < (unsigned)p.W;
-      xtap[ps] = ok ? (uint32_t)((int)xbase[ps] + xoff) : OOB;
+      mbits |= (ok ? 1u : 0u) << tap;
     }
-  };
-  set_tap(ld_tap);
+    tapmask[ps] = mbits;
+  }
+  int ld_tap = p.chunk_outer ? grp % p.taps : grp / kchunks;  // (tap, kc) of the NEXT step this group loads
+  int ld_kc = p.chunk_outer ? grp / p.taps : grp % kchunks;
 
-  // One register set in flight: the loads of step t+1 are issued before step t's MFMAs and written to the other LDS buffer after
-  // them.  (A second set -- loads two steps ahead -- was measured 10-25 % SLOWER on MI355X: 256 VGPRs, worse MFMA interleave.)
+  // One register set in flight (a second set -- loads two steps ahead -- was measured 10-25 % SLOWER: 256 VGPRs, worse interleave)
   u32x4 wreg[NPASS], xreg[NPASS];
   auto load_next = [&]() {
+    const int dy = p.taps == 9 ? ld_tap / 3 - 1 : 0, dx = p.taps == 9 ? ld_tap - (ld_tap / 3) * 3 - 1 : 0;
     const uint32_t koff = (uint32_t)(ld_kc * BK * 2);
-    const uint32_t wstep = (uint32_t)(ld_tap * p.Cin * 2) + koff;
+    // weights are packed in the same K order: consecutive steps read consecutive 128 B of a weight row
+    const uint32_t wstep = (uint32_t)((p.chunk_outer ? ld_kc * p.taps + ld_tap : ld_tap * kchunks + ld_kc) * BK * 2);
+    const uint32_t xstep = (uint32_t)((dy * p.W + dx) * p.Cin * 2) + koff;  // wraps mod 2^32 for negative shifts, as intended
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
       wreg[ps] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, woff[ps] + wstep, 0, 0);
-      xreg[ps] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xtap[ps] + koff, 0, 0);
+      const uint32_t xo = ((tapmask[ps] >> ld_tap) & 1u) ? xbase[ps] + xstep : OOB;
+      xreg[ps] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xo, 0, 0);
     }
-    ld_kc += SPLIT;  // the host only selects SPLIT = 2 when kchunks >= 2
-    if (ld_kc >= kchunks) {
-      ld_kc -= kchunks;
-      if (++ld_tap < p.taps) set_tap(ld_tap);
+    if (p.chunk_outer) {
+      ld_tap += SPLIT;
+      while (ld_tap >= p.taps) { ld_tap -= p.taps; ++ld_kc; }
+    } else {
+      ld_kc += SPLIT;
+      while (ld_kc >= kchunks) { ld_kc -= kchunks; ++ld_tap; }
     }
   };
   auto store_step = [&](unsigned char* base) {
@@ -255,9 +266,17 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_igemm_kernel(ConvParams p) {
 
 }  // namespace
 
-// x [N*H*W, Cin] channels-last bf16; w_packed [Cout, taps*Cin] bf16 (taps = 9: k = (ky*3+kx)*Cin + ci, 3x3 / stride 1 / pad 1;
-// taps = 1: plain GEMM out = x @ w^T with H = W = 1 ignored); bias fp32 [Cout] | NULL; emb bf16 [N, Cout] | NULL (added per image);
+// x [N*H*W, Cin] channels-last bf16; w_packed [Cout, taps*Cin] bf16 in the kernel's K order (tap = ky*3+kx, 3x3 / stride 1 / pad 1):
+// cd360_conv_k_order(Cin, taps) == 1: k = ((ci / 64) * taps + tap) * 64 + ci % 64 (chunk outer); == 0: k = tap * Cin + ci (tap outer);
+// taps = 1: the plain [Cout, Cin] matrix either way, out = x @ w^T; bias fp32 [Cout] | NULL; emb bf16 [N, Cout] | NULL (added per image);
 // res bf16 [N*H*W, Cout] | NULL; out bf16 [N*H*W, Cout].  Cin % 64 == 0, Cout % 16 == 0.
+// K order of w_packed for a conv with `Cin` input channels: 1 = chunk outer / tap inner, 0 = tap outer / chunk inner.
+extern "C" int cd360_conv_k_order(int Cin, int taps) {
+  if (const char* e = getenv("CD360_CONV_KORDER")) return e[0] == '1';  // tuning override (must be set before weights are packed)
+  (void)Cin;
+  return taps == 9;
+}
+
 extern "C" int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const void* bias, const void* emb, const void* res, void* out,
                                      int N, int H, int W, int Cin, int Cout, int taps, void* stream) {
   if (!x || !w_packed || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return CD360_ERR_ARG;
@@ -271,6 +290,7 @@ extern "C" int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const 
   p.M = (long)N * H * W;
   p.n_mtiles = (int)((p.M + BM - 1) / BM);
   p.n_ntiles = (Cout + BNC - 1) / BNC;
+  p.chunk_outer = cd360_conv_k_order(Cin, taps);
   p.w_major = 0;  // weight-tile-major order measured within noise of pixel-tile-major on every SDXL shape; kept as a tuning knob
   if (const char* e = getenv("CD360_CONV_WMAJOR")) p.w_major = e[0] == '1';
   const long nwg = (long)p.n_mtiles * p.n_ntiles;

@@ -84,7 +84,7 @@ def tokens_to_image(t: torch.Tensor, H: int, W: int) -> torch.Tensor:
 
 
 def packed_conv(conv: nn.Conv2d):
-    """(w_packed [Cout, taps*Cin] bf16 with k = (ky*3+kx)*Cin + ci, bias fp32 | None) for cd360_conv_igemm_bf16, cached on the
+    """(w_packed [Cout, taps*Cin] bf16 in the kernel's K order (ops.pack_conv_weight), bias fp32 | None) for cd360_conv_igemm_bf16, cached on the
     module and rebuilt when the parameters change.  Returns None if the conv is outside the kernel's envelope."""
     w = conv.weight
     k = conv.kernel_size
@@ -94,7 +94,7 @@ def packed_conv(conv: nn.Conv2d):
     key = (w.data_ptr(), w._version, w.dtype, w.device, None if conv.bias is None else conv.bias._version)
     cache = getattr(conv, "_cd360_packed", None)
     if cache is None or cache[0] != key:
-        wp = w.detach().permute(0, 2, 3, 1).reshape(w.shape[0], -1).to(torch.bfloat16).contiguous()
+        wp = ops.pack_conv_weight(w)
         bias = None if conv.bias is None else conv.bias.detach().float().contiguous()
         cache = (key, wp, bias)
         conv._cd360_packed = cache

@@ -230,7 +230,7 @@ def test_conv_igemm(N, H, W, Cin, Cout, taps, extras, split, monkeypatch):
     if extras:
         want = want + emb[:, :, None, None] + res
     xt = x.permute(0, 2, 3, 1).reshape(N, H * W, Cin).contiguous().to(DEV, torch.bfloat16)
-    wp = w.permute(0, 2, 3, 1).reshape(Cout, -1).contiguous().to(DEV, torch.bfloat16)
+    wp = ops.pack_conv_weight(w).to(DEV)
     rt = None if res is None else res.permute(0, 2, 3, 1).reshape(N, H * W, Cout).contiguous().to(DEV, torch.bfloat16)
     got = ops.conv_igemm(xt, wp, bias.to(DEV), N, H, W, taps, None if emb is None else emb.to(DEV, torch.bfloat16), rt)
     assert rel(got.reshape(N, H, W, Cout).permute(0, 3, 1, 2), want) < 8e-3
