@@ -58,8 +58,7 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_igemm_kernel(ConvParams p) {
   const int tid = threadIdx.x & 255, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wco = wave >> 1, wpx = wave & 1;  // wave tile: 64 channels x 64 pixels
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
-  // tile order: each XCD walks a contiguous range of tiles; keep the LARGER operand's tile fixed between neighbours so that the
-  // XCD's 4 MB L2 re-streams the smaller one (weights dominate on the 32x32 level: 59 MB of W vs 16 MB of pixels)
+  // tile order: each XCD walks a contiguous range of tiles (see the host side for which operand is re-streamed)
   const int nt = p.w_major ? tile / p.n_mtiles : tile % p.n_ntiles;
   const int mt = p.w_major ? tile % p.n_mtiles : tile / p.n_ntiles;
   const long m0 = (long)mt * BM;
@@ -291,8 +290,12 @@ extern "C" int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const 
   p.n_mtiles = (int)((p.M + BM - 1) / BM);
   p.n_ntiles = (Cout + BNC - 1) / BNC;
   p.chunk_outer = cd360_conv_k_order(Cin, taps);
-  p.w_major = 0;  // weight-tile-major order measured within noise of pixel-tile-major on every SDXL shape; kept as a tuning knob
-  if (const char* e = getenv("CD360_CONV_WMAJOR")) p.w_major = e[0] == '1';
+  // Tile order across the 8 XCDs (each walks a contiguous range of tiles and has its own L2): pixel-tile-major makes every XCD
+  // stream ALL weights once per resident set, weight-tile-major makes every XCD stream all pixels.  Pick the order that re-streams
+  // the SMALLER operand: weight-major when the weights are at least ~0.9x the pixels (the 32x32 level and 1280->1280 at 64x64).
+  // Measured FETCH_SIZE: 1280->1280 @32^2 180 -> 81 MB, @64^2 287 -> 191 MB; time unchanged (the kernel is not traffic-bound).
+  p.w_major = (long)Cout * taps * 10 >= p.M * 9;
+  if (const char* e = getenv("CD360_CONV_WMAJOR")) p.w_major = e[0] == '1';  // tuning override
   const long nwg = (long)p.n_mtiles * p.n_ntiles;
   if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
   // in-workgroup split-K when the launch has no more tiles than CUs (one 4-wave workgroup per CU otherwise)
