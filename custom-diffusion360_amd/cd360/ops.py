@@ -285,16 +285,14 @@ def concat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
 # ----------------------------------------------------------------------------------------------- conv3x3 / GEMM (implicit GEMM)
 def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
     """nn.Conv2d weight [Cout, Cin, k, k] (k = 3 | 1) or a Linear weight [Cout, Cin] -> the bf16 [Cout, taps*Cin] matrix
-    cd360_conv_igemm_bf16 reads, in the K order cd360_conv_k_order(Cin, taps) names: 1 = 64-channel chunk outer / tap inner
-    (k = ((ci//64)*taps + ky*3+kx)*64 + ci%64), 0 = tap outer (k = (ky*3+kx)*Cin + ci)."""
+    cd360_conv_igemm_bf16 reads.  K order: G = cd360_conv_k_order(Cin, taps) 64-channel chunks per group; group outer, tap middle,
+    chunk-in-group inner: k = ((cg*taps + ky*3+kx)*G + j)*64 + ci%64 with ci//64 = cg*G + j."""
     if w.dim() == 2:
         return w.detach().to(torch.bfloat16).contiguous()
     cout, cin, kh, kw = w.shape
     assert cin % 64 == 0 and kh == kw and kh in (1, 3)
-    if _lib.load().cd360_conv_k_order(cin, kh * kw):
-        wp = w.detach().reshape(cout, cin // 64, 64, kh * kw).permute(0, 1, 3, 2)  # [co, chunk, tap, 64]
-    else:
-        wp = w.detach().permute(0, 2, 3, 1)  # [co, ky, kx, ci]
+    g = _lib.load().cd360_conv_k_order(cin, kh * kw)
+    wp = w.detach().reshape(cout, cin // (64 * g), g, 64, kh * kw).permute(0, 1, 4, 2, 3)  # [co, group, tap, chunk-in-group, 64]
     return wp.reshape(cout, -1).to(torch.bfloat16).contiguous()
 
 

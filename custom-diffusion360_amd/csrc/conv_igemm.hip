@@ -28,10 +28,10 @@ struct ConvParams {
   int N, H, W, Cin, Cout, taps;
   long M;
   int n_mtiles, n_ntiles, w_major;
-  int chunk_outer;  // K order: 1 = 64-channel chunk outer / tap inner, 0 = tap outer / chunk inner (cd360_conv_k_order)
+  int kgroup;  // K order: 64-channel chunks per group (cd360_conv_k_order): group outer, tap middle, chunk-in-group inner
 };
 
-constexpr int BM = 128, BNC = 128;
+constexpr int BM = 128;  // pixels per tile (both tilings)
 
 __device__ __forceinline__ int chan_pos(int i) { return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3); }
 
@@ -40,14 +40,22 @@ __device__ __forceinline__ int chan_pos(int i) { return 16 * ((i >> 2) & 1) + (i
 // tile through its own LDS stages and the two accumulators are summed through LDS at the end -- an in-workgroup split-K for
 // launches with no more tiles than CUs (the 32x32 level: 240 tiles), where one 4-wave workgroup per CU leaves one wave per SIMD
 // and nothing to hide LDS / MFMA latency behind.  No atomics, no workspace, deterministic.
-template <int SPLIT>
+// Wave tiling: WAVES_CO x (4 / WAVES_CO) waves, each NCB x NPB MFMA tiles of 32 channels x 32 pixels.
+//   <2, 2, 2>: 128 channels x 128 pixels, waves 2 x 2 of 64 x 64 -- the default;
+//   <1, 5, 1>: 160 channels x 128 pixels, 4 waves of 160 x 32 -- for Cout = 320 (2 exact tiles instead of 2.5 of 128: no
+//              half-empty third tile, a third fewer workgroups for the same pixels, weights read from LDS once per 32 pixels).
+template <int SPLIT, int WAVES_CO, int NCB, int NPB>
 __global__ __launch_bounds__(256 * SPLIT) void conv_igemm_kernel(ConvParams p) {
+  constexpr int WAVES_PX = 4 / WAVES_CO;
+  constexpr int BNC = WAVES_CO * NCB * 32;  // channels per tile
+  static_assert(WAVES_PX * NPB * 32 == BM, "pixel tile is 128");
   constexpr int BK = 64;
   constexpr int PITCH = BK * 2;             // bytes per LDS row
   constexpr int CPR = BK / 8;               // 16-byte chunks per row
   constexpr int SH = 1;                     // rows per 256-byte bank row = 1 << SH
   constexpr int RPP = 256 / CPR;            // rows staged per pass
-  constexpr int NPASS = 128 / RPP;          // passes per 128-row tile
+  constexpr int NPASS = BM / RPP;           // staging passes of the pixel tile
+  constexpr int WPASS = BNC / RPP;          // ... of the weight tile
   constexpr int STAGE = (BM + BNC) * PITCH;
   constexpr int KS = BK / 16;
   extern __shared__ __attribute__((aligned(16))) unsigned char lds_all[];  // SPLIT * 2 * STAGE bytes (64 KB / 128 KB)
@@ -56,7 +64,7 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_igemm_kernel(ConvParams p) {
   const int grp = SPLIT == 1 ? 0 : (int)(threadIdx.x >> 8);  // K-split group
   unsigned char* lds = lds_all + grp * 2 * STAGE;
   const int tid = threadIdx.x & 255, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
-  const int wco = wave >> 1, wpx = wave & 1;  // wave tile: 64 channels x 64 pixels
+  const int wco = wave / WAVES_PX, wpx = wave % WAVES_PX;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   // tile order: each XCD walks a contiguous range of tiles (see the host side for which operand is re-streamed)
   const int nt = p.w_major ? tile / p.n_mtiles : tile % p.n_ntiles;
@@ -72,15 +80,17 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_igemm_kernel(ConvParams p) {
   constexpr uint32_t OOB = 0x80000000u;
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)((long)p.Cout * p.taps * p.Cin * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(p.M * p.Cin * 2), 0x00020000);
-  uint32_t woff[NPASS], xbase[NPASS];
+  uint32_t woff[WPASS], xbase[NPASS];
   int py[NPASS], px[NPASS];
   bool pok[NPASS];
 #pragma unroll
-  for (int ps = 0; ps < NPASS; ++ps) {
-    const int row = lrow + RPP * ps;
-    const int co = co0 + row;
+  for (int ps = 0; ps < WPASS; ++ps) {
+    const int co = co0 + lrow + RPP * ps;
     woff[ps] = co < p.Cout ? (uint32_t)(((long)co * p.taps * p.Cin + chunk * 8) * 2) : OOB;
-    const long m = m0 + row;
+  }
+#pragma unroll
+  for (int ps = 0; ps < NPASS; ++ps) {
+    const long m = m0 + lrow + RPP * ps;
     pok[ps] = m < p.M;
     const long mc = pok[ps] ? m : 0;
     const int rem = (int)(mc % HW);
@@ -94,59 +104,57 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_igemm_kernel(ConvParams p) {
   const int nsteps = (nsteps_all - grp + SPLIT - 1) / SPLIT;     // ... of which this group runs grp, grp + SPLIT, ...
   const int niter = (nsteps_all + SPLIT - 1) / SPLIT;            // barrier count, the same for both groups
 
-  // K order (chunk_outer): 64-channel chunk OUTER, tap INNER -- the nine taps of one chunk re-read the same (128 + halo) pixels
-  // x 64 channels (20 KB per pixel tile) back to back, so eight of the nine reads are L1/L2 hits; tap-outer order re-streams the
-  // whole pixel tile from the fabric for every tap (measured: 2-4x the fetch traffic).  Step s <-> (kc, tap) = (s / taps, s % taps).
-  // (Time: within 2 % of tap-outer order on every SDXL shape; tap-outer stays selectable through cd360_conv_k_order.)
-  // Per staged pixel row a 9-bit mask says which taps stay inside the image; the tap's byte shift is wave-uniform.
-  uint32_t tapmask[NPASS];
-#pragma unroll
-  for (int ps = 0; ps < NPASS; ++ps) {
-    uint32_t mbits = 0;
-    for (int tap = 0; tap < p.taps; ++tap) {
-      const int dy = p.taps == 9 ? tap / 3 - 1 : 0, dx = p.taps == 9 ? tap - (tap / 3) * 3 - 1 : 0;
-      const bool ok = pok[ps] && (unsigned)(py[ps] + dy) < (unsigned)p.H && (unsigned)(px[ps] + dx) < (unsigned)p.W;
-      mbits |= (ok ? 1u : 0u) << tap;
-    }
-    tapmask[ps] = mbits;
-  }
-  int ld_tap = p.chunk_outer ? grp % p.taps : grp / kchunks;  // (tap, kc) of the NEXT step this group loads
-  int ld_kc = p.chunk_outer ? grp / p.taps : grp % kchunks;
-
-  // One register set in flight (a second set -- loads two steps ahead -- was measured 10-25 % SLOWER: 256 VGPRs, worse interleave)
-  u32x4 wreg[NPASS], xreg[NPASS];
-  auto load_next = [&]() {
-    const int dy = p.taps == 9 ? ld_tap / 3 - 1 : 0, dx = p.taps == 9 ? ld_tap - (ld_tap / 3) * 3 - 1 : 0;
-    const uint32_t koff = (uint32_t)(ld_kc * BK * 2);
-    // weights are packed in the same K order: consecutive steps read consecutive 128 B of a weight row
-    const uint32_t wstep = (uint32_t)((p.chunk_outer ? ld_kc * p.taps + ld_tap : ld_tap * kchunks + ld_kc) * BK * 2);
-    const uint32_t xstep = (uint32_t)((dy * p.W + dx) * p.Cin * 2) + koff;  // wraps mod 2^32 for negative shifts, as intended
+  // K order: groups of G = p.kgroup 64-channel chunks OUTER, tap MIDDLE, chunk-in-group INNER (step s = (cg * taps + tap) * G + j).
+  // The nine taps of one group re-read the same (128 + halo) pixels x G*64 channels (<= 100 KB per pixel tile) back to back, so
+  // eight of the nine reads are L2 hits -- pure tap-outer order (G = all chunks) re-streamed the whole pixel tile from the fabric
+  // for every tap (2-4x the fetch traffic) -- while the per-tap shifts / image-border tests are still hoisted out of G
+  // consecutive steps and each pixel row is read G*128 contiguous bytes at a time (G = 1, tap innermost, measured 7 % slower).
+  const int G = p.kgroup;
+  uint32_t xtap[NPASS];
+  auto set_tap = [&](int tap) {
+    const int dy = p.taps == 9 ? tap / 3 - 1 : 0, dx = p.taps == 9 ? tap - (tap / 3) * 3 - 1 : 0;
+    const int xoff = (dy * p.W + dx) * p.Cin * 2;
 #pragma unroll
     for (int ps = 0; ps < NPASS; ++ps) {
-      wreg[ps] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, woff[ps] + wstep, 0, 0);
-      const uint32_t xo = ((tapmask[ps] >> ld_tap) & 1u) ? xbase[ps] + xstep : OOB;
-      xreg[ps] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xo, 0, 0);
+      const bool ok = pok[ps] && (unsigned)(py[ps] + dy) < (unsigned)p.H && (unsigned)(px[ps] + dx) < (unsigned)p.W;
+      xtap[ps] = ok ? (uint32_t)((int)xbase[ps] + xoff) : OOB;
     }
-    if (p.chunk_outer) {
-      ld_tap += SPLIT;
-      while (ld_tap >= p.taps) { ld_tap -= p.taps; ++ld_kc; }
-    } else {
-      ld_kc += SPLIT;
-      while (ld_kc >= kchunks) { ld_kc -= kchunks; ++ld_tap; }
+  };
+  // (cg, tap, j) and the linear index of the NEXT step this K-split group loads: steps grp, grp + SPLIT, ...
+  int ld_s = grp, ld_j = grp % G, ld_tap = (grp / G) % p.taps, ld_cg = grp / (G * p.taps);
+  set_tap(ld_tap);
+
+  // One register set in flight (a second set -- loads two steps ahead -- was measured 10-25 % SLOWER: 256 VGPRs, worse interleave)
+  u32x4 wreg[WPASS], xreg[NPASS];
+  auto load_next = [&]() {
+    const uint32_t wstep = (uint32_t)(ld_s * BK * 2);                 // weights are packed in step order: consecutive 128 B
+    const uint32_t koff = (uint32_t)((ld_cg * G + ld_j) * BK * 2);    // channel chunk of the pixel rows
+#pragma unroll
+    for (int ps = 0; ps < WPASS; ++ps) wreg[ps] = __builtin_amdgcn_raw_buffer_load_b128(wrsrc, woff[ps] + wstep, 0, 0);
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) xreg[ps] = __builtin_amdgcn_raw_buffer_load_b128(xrsrc, xtap[ps] + koff, 0, 0);
+    ld_s += SPLIT;
+    ld_j += SPLIT;
+    if (ld_j >= G) {
+      do { ld_j -= G; ++ld_tap; } while (ld_j >= G);
+      while (ld_tap >= p.taps) { ld_tap -= p.taps; ++ld_cg; }
+      set_tap(ld_tap);
     }
   };
   auto store_step = [&](unsigned char* base) {
 #pragma unroll
-    for (int ps = 0; ps < NPASS; ++ps) {
-      const int row = lrow + RPP * ps;
-      *reinterpret_cast<u32x4*>(base + swz(row, chunk)) = wreg[ps];
-      *reinterpret_cast<u32x4*>(base + BNC * PITCH + swz(row, chunk)) = xreg[ps];
-    }
+    for (int ps = 0; ps < WPASS; ++ps) *reinterpret_cast<u32x4*>(base + swz(lrow + RPP * ps, chunk)) = wreg[ps];
+#pragma unroll
+    for (int ps = 0; ps < NPASS; ++ps) *reinterpret_cast<u32x4*>(base + BNC * PITCH + swz(lrow + RPP * ps, chunk)) = xreg[ps];
   };
 
-  f32x16 acc[2][2];  // [channel block][pixel block]
+  f32x16 acc[NCB][NPB];  // [channel block][pixel block]
 #pragma unroll
-  for (int i = 0; i < 16; ++i) { acc[0][0][i] = 0.f; acc[0][1][i] = 0.f; acc[1][0][i] = 0.f; acc[1][1][i] = 0.f; }
+  for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[cb][pb][i] = 0.f;
 
   // Schedule: the registers hold tile t+1 when iteration t starts (its loads were issued one whole iteration earlier).  They
   // are written to the other LDS buffer FIRST -- that buffer's last readers passed the previous barrier -- and re-issued at once
@@ -160,9 +168,9 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_igemm_kernel(ConvParams p) {
 
   // Cout = 320 leaves the upper 64 channels of the third 128-channel tile empty: those two waves only help staging and skip
   // the fragment reads and MFMAs, which hands their SIMDs' matrix pipes to the co-resident workgroup
-  const bool wave_has_channels = co0 + wco * 64 < p.Cout;
-  const int wrow0 = wco * 64 + chan_pos(l31);  // + 32 * cb : weight-tile row feeding MFMA A-operand row l31
-  const int prow0 = wpx * 64 + l31;            // + 32 * pb : pixel-tile row feeding MFMA B-operand column l31
+  const bool wave_has_channels = co0 + wco * NCB * 32 < p.Cout;
+  const int wrow0 = wco * NCB * 32 + chan_pos(l31);  // + 32 * cb : weight-tile row feeding MFMA A-operand row l31
+  const int prow0 = wpx * NPB * 32 + l31;            // + 32 * pb : pixel-tile row feeding MFMA B-operand column l31
   auto k_loop = [&](auto compute_tag) {
     constexpr bool COMPUTE = decltype(compute_tag)::value;
     for (int step = 0; step < nsteps; ++step) {
@@ -176,16 +184,15 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_igemm_kernel(ConvParams p) {
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) {
-          bf16x8 a[2], b[2];
+          bf16x8 a[NCB], b[NPB];
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            a[i] = *reinterpret_cast<const bf16x8*>(Ws + swz(wrow0 + 32 * i, 2 * ks + hh));
-            b[i] = *reinterpret_cast<const bf16x8*>(Xs + swz(prow0 + 32 * i, 2 * ks + hh));
-          }
+          for (int i = 0; i < NCB; ++i) a[i] = *reinterpret_cast<const bf16x8*>(Ws + swz(wrow0 + 32 * i, 2 * ks + hh));
 #pragma unroll
-          for (int cb = 0; cb < 2; ++cb)
+          for (int i = 0; i < NPB; ++i) b[i] = *reinterpret_cast<const bf16x8*>(Xs + swz(prow0 + 32 * i, 2 * ks + hh));
 #pragma unroll
-            for (int pb = 0; pb < 2; ++pb) acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cb], b[pb], acc[cb][pb], 0, 0, 0);
+          for (int cb = 0; cb < NCB; ++cb)
+#pragma unroll
+            for (int pb = 0; pb < NPB; ++pb) acc[cb][pb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[cb], b[pb], acc[cb][pb], 0, 0, 0);
         }
         __builtin_amdgcn_s_setprio(0);
       }
@@ -199,31 +206,31 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_igemm_kernel(ConvParams p) {
     float* red = reinterpret_cast<float*>(lds_all);
     if (grp == 1) {
 #pragma unroll
-      for (int cb = 0; cb < 2; ++cb)
+      for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-        for (int pb = 0; pb < 2; ++pb)
+        for (int pb = 0; pb < NPB; ++pb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) red[((cb * 2 + pb) * 16 + r) * 256 + tid] = acc[cb][pb][r];
+          for (int r = 0; r < 16; ++r) red[((cb * NPB + pb) * 16 + r) * 256 + tid] = acc[cb][pb][r];
     }
     __syncthreads();
     if (grp == 1) return;
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb)
+    for (int cb = 0; cb < NCB; ++cb)
 #pragma unroll
-      for (int pb = 0; pb < 2; ++pb)
+      for (int pb = 0; pb < NPB; ++pb)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[cb][pb][r] += red[((cb * 2 + pb) * 16 + r) * 256 + tid];
+        for (int r = 0; r < 16; ++r) acc[cb][pb][r] += red[((cb * NPB + pb) * 16 + r) * 256 + tid];
   }
 
   // ---- epilogue: lane = pixel (l31), registers = 16 consecutive channels (16*hh + r) of each 32-channel block ----
 #pragma unroll
-  for (int pb = 0; pb < 2; ++pb) {
-    const long m = m0 + wpx * 64 + pb * 32 + l31;
+  for (int pb = 0; pb < NPB; ++pb) {
+    const long m = m0 + wpx * NPB * 32 + pb * 32 + l31;
     if (m >= p.M) continue;
     const int img = (int)(m / HW);
 #pragma unroll
-    for (int cb = 0; cb < 2; ++cb) {
-      const int co = co0 + wco * 64 + cb * 32 + 16 * hh;
+    for (int cb = 0; cb < NCB; ++cb) {
+      const int co = co0 + wco * NCB * 32 + cb * 32 + 16 * hh;
       if (co >= p.Cout) continue;  // Cout is a multiple of 16
       float v[16];
 #pragma unroll
@@ -266,14 +273,20 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_igemm_kernel(ConvParams p) {
 }  // namespace
 
 // x [N*H*W, Cin] channels-last bf16; w_packed [Cout, taps*Cin] bf16 in the kernel's K order (tap = ky*3+kx, 3x3 / stride 1 / pad 1):
-// cd360_conv_k_order(Cin, taps) == 1: k = ((ci / 64) * taps + tap) * 64 + ci % 64 (chunk outer); == 0: k = tap * Cin + ci (tap outer);
-// taps = 1: the plain [Cout, Cin] matrix either way, out = x @ w^T; bias fp32 [Cout] | NULL; emb bf16 [N, Cout] | NULL (added per image);
+// with G = cd360_conv_k_order(Cin, taps), k = ((cg * taps + tap) * G + j) * 64 + ci % 64 where ci / 64 = cg * G + j;
+// taps = 1: the plain [Cout, Cin] matrix, out = x @ w^T; bias fp32 [Cout] | NULL; emb bf16 [N, Cout] | NULL (added per image);
 // res bf16 [N*H*W, Cout] | NULL; out bf16 [N*H*W, Cout].  Cin % 64 == 0, Cout % 16 == 0.
-// K order of w_packed for a conv with `Cin` input channels: 1 = chunk outer / tap inner, 0 = tap outer / chunk inner.
+// K order of w_packed for a conv with `Cin` input channels: returns G, the number of 64-channel chunks per group; the K index of
+// (tap, ci) is k = ((cg * taps + tap) * G + j) * 64 + ci % 64 with chunk = ci / 64 = cg * G + j.  G = Cin / 64 is plain tap-major
+// order (k = tap * Cin + ci), G = 1 chunk-major.  Default: the largest divisor of Cin / 64 that is <= 5 (5 for every SDXL width).
 extern "C" int cd360_conv_k_order(int Cin, int taps) {
-  if (const char* e = getenv("CD360_CONV_KORDER")) return e[0] == '1';  // tuning override (must be set before weights are packed)
-  (void)Cin;
-  return taps == 9;
+  const int kchunks = Cin / 64;
+  if (taps != 9 || kchunks <= 0) return kchunks > 0 ? kchunks : 1;
+  int gmax = 5;
+  if (const char* e = getenv("CD360_CONV_KGROUP")) gmax = atoi(e) > 0 ? atoi(e) : gmax;  // tuning override (set before weights are packed)
+  for (int g = gmax < kchunks ? gmax : kchunks; g > 1; --g)
+    if (kchunks % g == 0) return g;
+  return 1;
 }
 
 extern "C" int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const void* bias, const void* emb, const void* res, void* out,
@@ -288,35 +301,45 @@ extern "C" int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const 
   p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.taps = taps;
   p.M = (long)N * H * W;
   p.n_mtiles = (int)((p.M + BM - 1) / BM);
-  p.n_ntiles = (Cout + BNC - 1) / BNC;
-  p.chunk_outer = cd360_conv_k_order(Cin, taps);
-  // Tile order across the 8 XCDs (each walks a contiguous range of tiles and has its own L2): pixel-tile-major makes every XCD
-  // stream ALL weights once per resident set, weight-tile-major makes every XCD stream all pixels.  Pick the order that re-streams
-  // the SMALLER operand: weight-major when the weights are at least ~0.9x the pixels (the 32x32 level and 1280->1280 at 64x64).
-  // Measured FETCH_SIZE: 1280->1280 @32^2 180 -> 81 MB, @64^2 287 -> 191 MB; time unchanged (the kernel is not traffic-bound).
-  p.w_major = (long)Cout * taps * 10 >= p.M * 9;
+  // 160-channel tiles (4 waves of 160 x 32) when Cout is a multiple of 160 but not of 128 (Cout = 320): exact tiling
+  bool wide = Cout % 160 == 0 && Cout % 128 != 0;
+  if (const char* e = getenv("CD360_CONV_WIDE")) wide = wide && e[0] != '0';  // tuning override: 0 = always 128-channel tiles
+  const int bnc = wide ? 160 : 128;
+  p.n_ntiles = (Cout + bnc - 1) / bnc;
+  p.kgroup = cd360_conv_k_order(Cin, taps);
+  // Tile order across the 8 XCDs (each walks a contiguous range of tiles and has its own 4 MB L2): pixel-tile-major makes every
+  // XCD stream ALL weights once per resident set, weight-tile-major makes every XCD stream all pixels, nine taps per K group --
+  // which only stays in L2 while the group footprint of ALL pixel tiles (n_mtiles x G x 20 KB) fits.  So: weight-major when the
+  // weights are at least ~0.9x the pixels AND that footprint is < ~3 MB (the 32x32 level: FETCH_SIZE 180 -> 81 MB per launch);
+  // 1280->1280 at 64x64 (96 pixel tiles) went 287 -> 1080 MB weight-major with G = 5 and stays pixel-major.  Time is unaffected.
+  p.w_major = (long)Cout * taps * 10 >= p.M * 9 && (long)p.n_mtiles * p.kgroup <= 160;
   if (const char* e = getenv("CD360_CONV_WMAJOR")) p.w_major = e[0] == '1';  // tuning override
   const long nwg = (long)p.n_mtiles * p.n_ntiles;
   if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
   // in-workgroup split-K when the launch has no more tiles than CUs (one 4-wave workgroup per CU otherwise)
   static const int cus = [] {
     int dev = 0, n = 256;
-    if (hipGetDevice(&dev) == hipSuccess) hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 256;
     return n;
   }();
-  int split = (nwg <= cus && Cin / 64 >= 2 && taps * (Cin / 64) >= 8) ? 2 : 1;
+  int split = (!wide && nwg <= cus && taps * (Cin / 64) >= 8) ? 2 : 1;
   if (const char* e = getenv("CD360_CONV_SPLIT")) {  // tuning override: 1 or 2
     if (e[0] == '1') split = 1;
-    if (e[0] == '2' && Cin / 64 >= 2) split = 2;
+    if (e[0] == '2' && !wide) split = 2;
   }
-  constexpr int kStageBytes = (BM + BNC) * 64 * 2;
-  if (split == 2) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<2>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * kStageBytes);  // 128 KB > the 64 KB default
+  const int stage_bytes = (BM + bnc) * 64 * 2;
+  if (wide) {  // 2 x 36 KB stages = 72 KB: above the 64 KB default, still two workgroups per CU
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<1, 1, 5, 1>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * (BM + 160) * 64 * 2);
     if (attr != hipSuccess) return CD360_ERR_LAUNCH;
-    hipLaunchKernelGGL(conv_igemm_kernel<2>, dim3((unsigned)nwg), dim3(512), 4 * kStageBytes, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<1, 1, 5, 1>), dim3((unsigned)nwg), dim3(256), 2 * stage_bytes, (hipStream_t)stream, p);
+  } else if (split == 2) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<2, 2, 2, 2>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, 4 * (BM + 128) * 64 * 2);  // 128 KB
+    if (attr != hipSuccess) return CD360_ERR_LAUNCH;
+    hipLaunchKernelGGL((conv_igemm_kernel<2, 2, 2, 2>), dim3((unsigned)nwg), dim3(512), 4 * stage_bytes, (hipStream_t)stream, p);
   } else {
-    hipLaunchKernelGGL(conv_igemm_kernel<1>, dim3((unsigned)nwg), dim3(256), 2 * kStageBytes, (hipStream_t)stream, p);
+    hipLaunchKernelGGL((conv_igemm_kernel<1, 2, 2, 2>), dim3((unsigned)nwg), dim3(256), 2 * stage_bytes, (hipStream_t)stream, p);
   }
   CD360_LAUNCH_CHECK();
   return CD360_OK;

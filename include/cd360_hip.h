@@ -127,8 +127,8 @@ int cd360_cfg_euler_step_f32(const void* x, const void* eps, const void* sigma, 
  * replaces nn.Conv2d(3x3, stride 1, padding 1) + the adds around it in ResBlock._forward (openaimodel.py:350-376:
  * `h + emb_out`, `skip_connection(x) + h`) and Upsample.conv (:161-164) on channels-last bf16; taps = 1 gives out = x @ w^T
  * (the 1x1 skip_connection conv, :337).  x [N*H*W, Cin]; w_packed [Cout, taps*Cin] in the kernel's K order:
- * cd360_conv_k_order(Cin, taps) == 1 -> k = ((ci/64)*taps + ky*3+kx)*64 + ci%64 (64-channel chunk outer, tap inner),
- * == 0 -> k = (ky*3+kx)*Cin + ci (tap outer); taps = 1: the plain [Cout, Cin] matrix;
+ * with G = cd360_conv_k_order(Cin, taps) 64-channel chunks per group, k = ((cg*taps + ky*3+kx)*G + j)*64 + ci%64 where
+ * ci/64 = cg*G + j (group outer, tap middle, chunk inner; G = Cin/64 is plain tap-major k = tap*Cin + ci); taps = 1: the plain [Cout, Cin] matrix;
  * bias fp32 [Cout] | NULL; emb bf16 [N, Cout] | NULL (per-image addend); res bf16 [N*H*W, Cout] | NULL; out bf16 [N*H*W, Cout].
  * Cin % 64 == 0, Cout % 16 == 0, 16-byte aligned pointers. */
 int cd360_conv_k_order(int Cin, int taps);

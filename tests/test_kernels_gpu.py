@@ -210,12 +210,13 @@ def test_add_layernorm(rows, C):
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,taps,extras", [(2, 9, 7, 64, 48, 9, False), (1, 16, 16, 128, 320, 9, True), (3, 32, 32, 320, 640, 9, True),
-                                                       (2, 5, 5, 192, 64, 1, True), (1, 1, 1, 64, 16, 9, False)])
+                                                       (2, 5, 5, 192, 64, 1, True), (1, 1, 1, 64, 16, 9, False), (2, 9, 7, 128, 320, 9, True), (1, 12, 12, 64, 160, 9, False)])
 @pytest.mark.parametrize("split", ["auto", "1", "2"])
 def test_conv_igemm(N, H, W, Cin, Cout, taps, extras, split, monkeypatch):
     """implicit-GEMM conv3x3 / GEMM with fused bias + per-image addend + residual vs torch's fp32 conv2d on the same bf16 inputs.
     `split`: the in-workgroup split-K variant (512 threads, odd K-steps on the second 4 waves) forced on / off / chosen by the
-    launch heuristic; (3,32,32,320,640) has an ODD number of K-steps (45), (1,16,16,128,320) the minimum of 2 chunks per tap."""
+    launch heuristic; (3,32,32,320,640) has an ODD number of K-steps (45), (1,16,16,128,320) the minimum of 2 chunks per tap.
+    Cout = 320 / 160 take the 160-channel tiling (4 waves of 160 x 32), with ragged pixel tiles in (2,9,7,...)."""
     from cd360 import ops
     if split != "auto":
         monkeypatch.setenv("CD360_CONV_SPLIT", split)
