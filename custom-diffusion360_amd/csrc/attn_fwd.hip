@@ -279,6 +279,8 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams p) {
   }
 #undef CD360_ATTN_STEP
 
+  // (routing these stores through LDS as full 128-byte rows, as attn_smallk_kernel does, measured no gain here -- the epilogue is
+  // a percent of a 16-64 tile K-loop -- and cost a register spill)
   if (qrow < p.Nq) {
     const float inv = 1.f / w.l_run;
     uint16_t* orow = op + (long)qrow * p.o_sn;
@@ -290,6 +292,178 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams p) {
         u32x2 wv = {pack_bf16x2(w.oT[db][4 * g + 0] * inv, w.oT[db][4 * g + 1] * inv),
                     pack_bf16x2(w.oT[db][4 * g + 2] * inv, w.oT[db][4 * g + 3] * inv)};
         *reinterpret_cast<u32x2*>(orow + d) = wv;
+      }
+    }
+  }
+}
+
+// ---- Nk <= 96 (the text context: 77 keys) -------------------------------------------------------------------------------------
+// Cross-attention over the text tokens (A2) and over the pose tokens (A3, up to 98 304 queries per head against the same 77 keys)
+// is a streaming problem: 256 B of Q/O traffic per (query, head) against 2 x 12 MFMAs.  The whole K and V^T of a head fit in
+// REGISTERS as MFMA A-fragments (NKB*4 + NKB*4 fragments of 4 VGPRs), so after one staging pass through LDS the loop over query
+// blocks has no LDS traffic, no barrier and no online-softmax state: S^T for all keys at once, one max / exp2 / sum, P straight
+// from the accumulator registers into the PV MFMAs, the next block's Q rows already in flight.  Keys >= Nk are masked for free:
+// the accumulator of the last 32-key block starts at -1e30 in the masked rows instead of 0.
+template <int NKB>
+__global__ __launch_bounds__(256, 2) void attn_smallk_kernel(AttnParams p) {
+  constexpr int NKEYS = NKB * 32;
+  constexpr int VP = NKEYS * 2 + 16;  // V^T row pitch in bytes (conflict-free ds_read_b64, as V_PITCH)
+  // K / V^T staging (read once into registers) + per wave one 32 x 128 B block each for Q (in) and O (out): rows move between
+  // HBM and LDS as FULL 128-byte lines (8 lanes x 16 B per row) and are re-read in MFMA fragment shape from LDS -- loading the
+  // fragments straight from global memory touches every line four times with 32-byte pieces and capped the kernel at 2.5 TB/s.
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NKEYS * K_PITCH + 64 * VP + 4 * 2 * 32 * K_PITCH];
+  unsigned char* Ks = lds;
+  unsigned char* Vs = lds + NKEYS * K_PITCH;
+  unsigned char* Qs = lds + NKEYS * K_PITCH + 64 * VP + (threadIdx.x >> 6) * (2 * 32 * K_PITCH);  // this wave's Q block
+  unsigned char* Os = Qs + 32 * K_PITCH;                                                          // ... and O block
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int bh = blockIdx.x / p.n_qtiles, chunk_id = blockIdx.x - bh * p.n_qtiles;  // n_qtiles = query chunks per head here
+  const int b = bh / p.H, h = bh - b * p.H;
+  const uint16_t* qp = p.q + b * p.q_sb + h * p.q_sh;
+  const uint16_t* kp = p.k + b * p.k_sb + h * p.k_sh;
+  const uint16_t* vp = p.vt + b * p.v_sb + h * p.v_sh;
+  uint16_t* op = p.o + b * p.o_sb + h * p.o_sh;
+
+  // ---- stage K [Nk, 64] (rows >= Nk zero) and V^T [64, Nk] (keys >= Nk zero) ----
+  for (int i = tid; i < NKEYS * 8; i += 256) {
+    const int row = i >> 3, chunk = i & 7;
+    u32x4 kv = {0u, 0u, 0u, 0u};
+    if (row < p.Nk) kv = *reinterpret_cast<const u32x4*>(kp + (long)row * p.k_sn + chunk * 8);
+    *reinterpret_cast<u32x4*>(Ks + row * K_PITCH + ((chunk ^ ((row >> 1) & 7)) << 4)) = kv;
+  }
+  for (int i = tid; i < 64 * (NKEYS / 8); i += 256) {
+    const int row = i / (NKEYS / 8), chunk = i - row * (NKEYS / 8), key0 = chunk * 8;
+    u32x4 vv = {0u, 0u, 0u, 0u};
+    if (key0 < p.Nk) {
+      vv = *reinterpret_cast<const u32x4*>(vp + (long)row * p.v_sd + key0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        uint32_t w = vv[e];
+        if (key0 + 2 * e >= p.Nk) w &= 0xffff0000u;
+        if (key0 + 2 * e + 1 >= p.Nk) w &= 0x0000ffffu;
+        vv[e] = w;
+      }
+    }
+    u32x2 lo = {vv[0], vv[1]}, hi = {vv[2], vv[3]};
+    *reinterpret_cast<u32x2*>(Vs + row * VP + chunk * 16) = lo;
+    *reinterpret_cast<u32x2*>(Vs + row * VP + chunk * 16 + 8) = hi;
+  }
+  __syncthreads();
+
+  // ---- K and V^T fragments into registers, mask vector for the last key block ----
+  bf16x8 kf[NKB][4], vf[2][2 * NKB];
+#pragma unroll
+  for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const int krow = kb * 32 + l31;
+      kf[kb][ks] = *reinterpret_cast<const bf16x8*>(Ks + krow * K_PITCH + (((2 * ks + hh) ^ ((krow >> 1) & 7)) << 4));
+    }
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int kk = 0; kk < 2 * NKB; ++kk) {
+      const unsigned char* vrow = Vs + (db * 32 + l31) * VP + (16 * kk + 4 * hh) * 2;
+      const u32x2 v0 = *reinterpret_cast<const u32x2*>(vrow);
+      const u32x2 v1 = *reinterpret_cast<const u32x2*>(vrow + 16);
+      u32x4 vw = {v0[0], v0[1], v1[0], v1[1]};
+      vf[db][kk] = __builtin_bit_cast(bf16x8, vw);
+    }
+  f32x16 init_last;  // accumulator start of the last key block: 0 for real keys, -1e30 for padding
+#pragma unroll
+  for (int r = 0; r < 16; ++r) init_last[r] = ((NKB - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh < p.Nk) ? 0.f : -1e30f;
+  const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  const float c = p.scale_log2e;
+
+  // ---- this wave's 32-query blocks: first, first + 4, ... inside the workgroup's chunk ----
+  const int nqb = (p.Nq + 31) >> 5;
+  const int per = (nqb + p.n_qtiles - 1) / p.n_qtiles;  // blocks per chunk
+  const int qb_end = min(nqb, (chunk_id + 1) * per);
+  int qb = chunk_id * per + wave;
+  // line-shaped access: pass i moves rows 8 i + lane / 8, 16-byte chunk lane % 8
+  const int lrow = lane >> 3, lchunk = lane & 7;
+  auto load_q = [&](int blk, u32x4 (&dst)[4]) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int qrow = blk * 32 + 8 * i + lrow;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (blk < qb_end && qrow < p.Nq) v = *reinterpret_cast<const u32x4*>(qp + (long)qrow * p.q_sn + lchunk * 8);
+      dst[i] = v;
+    }
+  };
+  u32x4 qn[4];
+  load_q(qb, qn);
+  for (; qb < qb_end; qb += 4) {
+    // rows -> this wave's LDS block (16-B XOR swizzle) -> B fragments (row l31, chunk 2 ks + hh); wave-private, no barrier
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 8 * i + lrow;
+      *reinterpret_cast<u32x4*>(Qs + row * K_PITCH + ((lchunk ^ ((row >> 1) & 7)) << 4)) = qn[i];
+    }
+    load_q(qb + 4, qn);  // next block's rows travel during this block's MFMAs
+    bf16x8 qf[4];
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks)
+      qf[ks] = *reinterpret_cast<const bf16x8*>(Qs + l31 * K_PITCH + (((2 * ks + hh) ^ ((l31 >> 1) & 7)) << 4));
+
+    f32x16 sT[NKB];
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        sT[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb][ks], qf[ks], ks == 0 ? (kb == NKB - 1 ? init_last : zero) : sT[kb], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+
+    float mx = sT[0][0];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sT[kb][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float mc = -mx * c;
+    float rs = 0.f;
+    uint32_t pk[NKB * 8];
+#pragma unroll
+    for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(fmaf(sT[kb][r], c, mc));
+        const float p1 = __builtin_amdgcn_exp2f(fmaf(sT[kb][r + 1], c, mc));
+        rs += p0 + p1;
+        pk[kb * 8 + (r >> 1)] = pack_bf16x2(p0, p1);
+      }
+    rs += __shfl_xor(rs, 32);
+
+    f32x16 oT[2];
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int kk = 0; kk < 2 * NKB; ++kk) {
+      u32x4 pw = {pk[kk * 4 + 0], pk[kk * 4 + 1], pk[kk * 4 + 2], pk[kk * 4 + 3]};
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+        oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][kk], __builtin_bit_cast(bf16x8, pw), kk == 0 ? zero : oT[db], 0, 0, 0);
+    }
+    __builtin_amdgcn_s_setprio(0);
+
+    // O^T registers (lane = query, 4 consecutive d per group) -> this wave's LDS block -> full 128-byte rows to HBM
+    {
+      const float inv = 1.f / rs;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int dbyte = (db * 32 + 8 * g + 4 * hh) * 2;  // byte offset in the row: chunk = dbyte >> 4, half = dbyte & 8
+          u32x2 wv = {pack_bf16x2(oT[db][4 * g + 0] * inv, oT[db][4 * g + 1] * inv),
+                      pack_bf16x2(oT[db][4 * g + 2] * inv, oT[db][4 * g + 3] * inv)};
+          *reinterpret_cast<u32x2*>(Os + l31 * K_PITCH + ((((dbyte >> 4)) ^ ((l31 >> 1) & 7)) << 4) + (dbyte & 8)) = wv;
+        }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = 8 * i + lrow, qrow = qb * 32 + row;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(Os + row * K_PITCH + ((lchunk ^ ((row >> 1) & 7)) << 4));
+        if (qrow < p.Nq) *reinterpret_cast<u32x4*>(op + (long)qrow * p.o_sn + lchunk * 8) = v;
       }
     }
   }
@@ -332,6 +506,26 @@ extern "C" int cd360_attn_fwd_bf16(const void* q, const void* k, const void* vt,
   if (p.v_sd < ((Nk + 7) / 8) * 8) return CD360_ERR_SHAPE;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) % 16 || (uintptr_t)o % 8) return CD360_ERR_ARG;
   p.scale_log2e = scale * 1.4426950408889634f;
+  // (its 16-byte output stores need 16-byte aligned output rows; otherwise the tiled kernel with 8-byte stores serves the call)
+  bool smallk = Nk <= 96 && !(p.o_sb % 8 || p.o_sh % 8 || p.o_sn % 8 || (uintptr_t)o % 16);
+  if (const char* e = getenv("CD360_ATTN_SMALLK")) smallk = smallk && e[0] != '0';  // tuning override: 0 = always the tiled kernel
+  if (smallk) {
+    // one workgroup = one (batch, head) x one chunk of 32-query blocks; ~8 workgroups per CU in total, at least one block per wave
+    const int nqb = (Nq + 31) / 32;
+    long chunks = (2048 + (long)B * H - 1) / ((long)B * H);
+    const long max_chunks = (nqb + 3) / 4;
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks < 1) chunks = 1;
+    p.n_qtiles = (int)chunks;
+    p.fast = 0;
+    const long nwg = chunks * B * H;
+    if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
+    if (Nk <= 32) hipLaunchKernelGGL(attn_smallk_kernel<1>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+    else if (Nk <= 64) hipLaunchKernelGGL(attn_smallk_kernel<2>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL(attn_smallk_kernel<3>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+    CD360_LAUNCH_CHECK();
+    return CD360_OK;
+  }
   p.n_qtiles = (Nq + 127) / 128;
   p.fast = ((long)Nk * p.k_sn * 2 < (1L << 31) && 64 * p.v_sd * 2 < (1L << 31)) ? 1 : 0;
   if (const char* e = getenv("CD360_ATTN_FAST")) p.fast = p.fast && e[0] != '0';  // tuning/debug: 0 forces the guarded path

@@ -33,7 +33,8 @@ def cams_for(b, n, seed):
 
 
 # ------------------------------------------------------------------------------------------------ attention (A1-A3)
-@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 2, 128, 128), (1, 3, 200, 77), (1, 1, 1024, 1024), (2, 2, 96, 40), (1, 10, 6144, 77), (1, 2, 333, 333)])
+@pytest.mark.parametrize("B,H,Nq,Nk", [(2, 2, 128, 128), (1, 3, 200, 77), (1, 1, 1024, 1024), (2, 2, 96, 40), (1, 10, 6144, 77), (1, 2, 333, 333),
+                                        (1, 2, 50, 20), (1, 1, 33, 96), (1, 2, 100, 97), (3, 2, 4100, 77)])
 def test_attention_strided(B, H, Nq, Nk):
     from cd360 import ops
     g = torch.Generator().manual_seed(B * 1000 + Nq + Nk)
