@@ -12,11 +12,13 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libcd360_hip.so")
 
 _P = c_void_p
+_F32P = ctypes.POINTER(ctypes.c_float)
 _I64P = ctypes.POINTER(c_int64)
 
 # name -> (restype, argtypes); must list every symbol of include/cd360_hip.h
 SIGNATURES = {
     "cd360_attn_fwd_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _I64P, _I64P, _I64P, _I64P, c_float, _P]),
+    "cd360_attn_fwd_fp8mfma_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _I64P, _I64P, _I64P, _I64P, c_float, _F32P, _P]),
     "cd360_attn_vt_workspace_bytes": (c_int64, [c_int, c_int]),
     "cd360_attn_fwd_xformers_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "cd360_patch_rays": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),

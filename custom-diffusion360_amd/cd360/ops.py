@@ -102,6 +102,29 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, nk
     return out
 
 
+def attention_fp8mfma(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, nk: Optional[int] = None, amax=None) -> torch.Tensor:
+    """`attention` with both contractions on fp8 (e4m3) MFMA -- BASELINE configs[4], Nk <= 96 only.  Same bf16 tensors; the
+    per-tensor scales come from `amax` = (max|q|, max|k|, max|v|), measured here (one host sync) when not given."""
+    _need_gpu(q, k, vt)
+    b, nq, inner = q.shape
+    assert inner == heads * 64 and q.dtype == k.dtype == vt.dtype == torch.bfloat16
+    assert q.stride(2) == 1 and k.stride(2) == 1 and vt.stride(2) == 1
+    nk = k.shape[1] if nk is None else nk
+    if amax is None:
+        amax = torch.stack([q.abs().amax(), k[:, :nk].abs().amax(), vt[:, :, :nk].abs().amax()]).float().tolist()
+    out = torch.empty(b, nq, inner, dtype=torch.bfloat16, device=q.device)
+    arr = (ctypes.c_float * 3)(*[float(a) for a in amax])
+    with _timed("attn_fp8mfma", 4.0 * b * heads * nq * nk * 64, 2.0 * (2 * b * nq * inner + 2 * b * nk * inner)):
+      check(
+        _lib.load().cd360_attn_fwd_fp8mfma_bf16(
+            _ptr(q), _ptr(k), _ptr(vt), _ptr(out), b, heads, nq, nk,
+            _I64x3(q.stride(0), 64, q.stride(1)), _I64x3(k.stride(0), 64, k.stride(1)),
+            _I64x3(vt.stride(0), 64 * vt.stride(1), vt.stride(1)), _I64x3(out.stride(0), 64, out.stride(1)),
+            64 ** -0.5, arr, _stream()),
+        "cd360_attn_fwd_fp8mfma_bf16")
+    return out
+
+
 def memory_efficient_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, attn_bias=None, op=None) -> torch.Tensor:
     """Same contract as xformers.ops.memory_efficient_attention for the layout the reference uses:
     q, k, v contiguous [B*H, N, 64] (sgm/modules/attention.py:393-408)."""

@@ -33,6 +33,7 @@ struct AttnParams {
   float scale_log2e;
   int n_qtiles;
   int fast;  // 1: full tiles may use 32-bit buffer offsets (K and V^T of one head span < 2 GiB)
+  float inv_sq, inv_sk, inv_sv, o_scale;  // fp8-MFMA variant: 1 / per-tensor e4m3 scales, and sv / 256 for the output
 };
 
 constexpr int BN = 64;        // keys per tile
@@ -304,7 +305,22 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams p) {
 // blocks has no LDS traffic, no barrier and no online-softmax state: S^T for all keys at once, one max / exp2 / sum, P straight
 // from the accumulator registers into the PV MFMAs, the next block's Q rows already in flight.  Keys >= Nk are masked for free:
 // the accumulator of the last 32-key block starts at -1e30 in the masked rows instead of 0.
-template <int NKB>
+//
+// FP8 = true is the fp8-MFMA variant (BASELINE config 5): the same bf16 tensors in and out, but Q, K, V^T and P are rounded to
+// OCP e4m3 in registers (per-tensor scales amax / 448 supplied by the caller, P scaled by 256 into the e4m3 normal range) and both
+// contractions run on v_mfma_f32_32x32x16_fp8_fp8.  It exists to measure what fp8 QK^T / PV costs in accuracy; HBM traffic is
+// unchanged (bf16 rows), so it is not faster on this HBM-bound shape.
+__device__ __forceinline__ long bf16x8_to_fp8x8(bf16x8 v, float inv_scale) {
+  const u32x4 w = __builtin_bit_cast(u32x4, v);
+  int lo = 0, hi = 0;
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf16lo_to_f32(w[0]) * inv_scale, bf16hi_to_f32(w[0]) * inv_scale, lo, false);
+  lo = __builtin_amdgcn_cvt_pk_fp8_f32(bf16lo_to_f32(w[1]) * inv_scale, bf16hi_to_f32(w[1]) * inv_scale, lo, true);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf16lo_to_f32(w[2]) * inv_scale, bf16hi_to_f32(w[2]) * inv_scale, hi, false);
+  hi = __builtin_amdgcn_cvt_pk_fp8_f32(bf16lo_to_f32(w[3]) * inv_scale, bf16hi_to_f32(w[3]) * inv_scale, hi, true);
+  return (long)(((unsigned long)(unsigned)hi << 32) | (unsigned)lo);
+}
+
+template <int NKB, bool FP8>
 __global__ __launch_bounds__(256, 2) void attn_smallk_kernel(AttnParams p) {
   constexpr int NKEYS = NKB * 32;
   constexpr int VP = NKEYS * 2 + 16;  // V^T row pitch in bytes (conflict-free ds_read_b64, as V_PITCH)
@@ -353,12 +369,14 @@ __global__ __launch_bounds__(256, 2) void attn_smallk_kernel(AttnParams p) {
 
   // ---- K and V^T fragments into registers, mask vector for the last key block ----
   bf16x8 kf[NKB][4], vf[2][2 * NKB];
+  long kf8[NKB][4], vf8[2][2 * NKB];  // the e4m3 copies (FP8 only; dead otherwise)
 #pragma unroll
   for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       const int krow = kb * 32 + l31;
       kf[kb][ks] = *reinterpret_cast<const bf16x8*>(Ks + krow * K_PITCH + (((2 * ks + hh) ^ ((krow >> 1) & 7)) << 4));
+      if (FP8) kf8[kb][ks] = bf16x8_to_fp8x8(kf[kb][ks], p.inv_sk);
     }
 #pragma unroll
   for (int db = 0; db < 2; ++db)
@@ -369,6 +387,7 @@ __global__ __launch_bounds__(256, 2) void attn_smallk_kernel(AttnParams p) {
       const u32x2 v1 = *reinterpret_cast<const u32x2*>(vrow + 16);
       u32x4 vw = {v0[0], v0[1], v1[0], v1[1]};
       vf[db][kk] = __builtin_bit_cast(bf16x8, vw);
+      if (FP8) vf8[db][kk] = bf16x8_to_fp8x8(vf[db][kk], p.inv_sv);
     }
   f32x16 init_last;  // accumulator start of the last key block: 0 for real keys, -1e30 for padding
 #pragma unroll
@@ -408,12 +427,20 @@ __global__ __launch_bounds__(256, 2) void attn_smallk_kernel(AttnParams p) {
       qf[ks] = *reinterpret_cast<const bf16x8*>(Qs + l31 * K_PITCH + (((2 * ks + hh) ^ ((l31 >> 1) & 7)) << 4));
 
     f32x16 sT[NKB];
+    long qf8[4];
+    if (FP8) {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) qf8[ks] = bf16x8_to_fp8x8(qf[ks], p.inv_sq);
+    }
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-        sT[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb][ks], qf[ks], ks == 0 ? (kb == NKB - 1 ? init_last : zero) : sT[kb], 0, 0, 0);
+      for (int ks = 0; ks < 4; ++ks) {
+        const f32x16 acc0 = ks == 0 ? (kb == NKB - 1 ? init_last : zero) : sT[kb];
+        sT[kb] = FP8 ? __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(kf8[kb][ks], qf8[ks], acc0, 0, 0, 0)
+                     : __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[kb][ks], qf[ks], acc0, 0, 0, 0);
+      }
     __builtin_amdgcn_s_setprio(0);
 
     float mx = sT[0][0];
@@ -424,15 +451,24 @@ __global__ __launch_bounds__(256, 2) void attn_smallk_kernel(AttnParams p) {
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     const float mc = -mx * c;
     float rs = 0.f;
-    uint32_t pk[NKB * 8];
+    uint32_t pk[NKB * 8];   // bf16 pairs
+    int pk8[NKB * 4];       // e4m3 quads of 256 p (FP8)
 #pragma unroll
     for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-      for (int r = 0; r < 16; r += 2) {
+      for (int r = 0; r < 16; r += 4) {
         const float p0 = __builtin_amdgcn_exp2f(fmaf(sT[kb][r], c, mc));
         const float p1 = __builtin_amdgcn_exp2f(fmaf(sT[kb][r + 1], c, mc));
-        rs += p0 + p1;
-        pk[kb * 8 + (r >> 1)] = pack_bf16x2(p0, p1);
+        const float p2 = __builtin_amdgcn_exp2f(fmaf(sT[kb][r + 2], c, mc));
+        const float p3 = __builtin_amdgcn_exp2f(fmaf(sT[kb][r + 3], c, mc));
+        rs += (p0 + p1) + (p2 + p3);
+        if (FP8) {
+          int d8 = __builtin_amdgcn_cvt_pk_fp8_f32(p0 * 256.f, p1 * 256.f, 0, false);
+          pk8[kb * 4 + (r >> 2)] = __builtin_amdgcn_cvt_pk_fp8_f32(p2 * 256.f, p3 * 256.f, d8, true);
+        } else {
+          pk[kb * 8 + (r >> 1)] = pack_bf16x2(p0, p1);
+          pk[kb * 8 + (r >> 1) + 1] = pack_bf16x2(p2, p3);
+        }
       }
     rs += __shfl_xor(rs, 32);
 
@@ -440,16 +476,20 @@ __global__ __launch_bounds__(256, 2) void attn_smallk_kernel(AttnParams p) {
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int kk = 0; kk < 2 * NKB; ++kk) {
-      u32x4 pw = {pk[kk * 4 + 0], pk[kk * 4 + 1], pk[kk * 4 + 2], pk[kk * 4 + 3]};
+      u32x4 pw = {0u, 0u, 0u, 0u};
+      long pw8 = 0;
+      if (FP8) pw8 = (long)(((unsigned long)(unsigned)pk8[kk * 2 + 1] << 32) | (unsigned)pk8[kk * 2]);
+      else pw = u32x4{pk[kk * 4 + 0], pk[kk * 4 + 1], pk[kk * 4 + 2], pk[kk * 4 + 3]};
 #pragma unroll
       for (int db = 0; db < 2; ++db)
-        oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][kk], __builtin_bit_cast(bf16x8, pw), kk == 0 ? zero : oT[db], 0, 0, 0);
+        oT[db] = FP8 ? __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(vf8[db][kk], pw8, kk == 0 ? zero : oT[db], 0, 0, 0)
+                     : __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[db][kk], __builtin_bit_cast(bf16x8, pw), kk == 0 ? zero : oT[db], 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(0);
 
     // O^T registers (lane = query, 4 consecutive d per group) -> this wave's LDS block -> full 128-byte rows to HBM
     {
-      const float inv = 1.f / rs;
+      const float inv = (FP8 ? p.o_scale : 1.f) / rs;
 #pragma unroll
       for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -488,9 +528,10 @@ __global__ void transpose_v_kernel(const uint16_t* v, uint16_t* vt, int N, int l
 
 }  // namespace
 
-extern "C" int cd360_attn_fwd_bf16(const void* q, const void* k, const void* vt, void* o, int B, int H, int Nq, int Nk,
-                                   const int64_t* q_strides, const int64_t* k_strides, const int64_t* vt_strides,
-                                   const int64_t* o_strides, float scale, void* stream) {
+// fp8_amax = {max|q|, max|k|, max|v|} selects the fp8-MFMA variant (Nk <= 96 only); NULL = bf16 MFMA
+static int attn_launch(const void* q, const void* k, const void* vt, void* o, int B, int H, int Nq, int Nk, const int64_t* q_strides,
+                       const int64_t* k_strides, const int64_t* vt_strides, const int64_t* o_strides, float scale, const float* fp8_amax,
+                       void* stream) {
   if (!q || !k || !vt || !o || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return CD360_ERR_ARG;
   AttnParams p;
   p.q = (const uint16_t*)q; p.k = (const uint16_t*)k; p.vt = (const uint16_t*)vt; p.o = (uint16_t*)o;
@@ -508,7 +549,16 @@ extern "C" int cd360_attn_fwd_bf16(const void* q, const void* k, const void* vt,
   p.scale_log2e = scale * 1.4426950408889634f;
   // (its 16-byte output stores need 16-byte aligned output rows; otherwise the tiled kernel with 8-byte stores serves the call)
   bool smallk = Nk <= 96 && !(p.o_sb % 8 || p.o_sh % 8 || p.o_sn % 8 || (uintptr_t)o % 16);
-  if (const char* e = getenv("CD360_ATTN_SMALLK")) smallk = smallk && e[0] != '0';  // tuning override: 0 = always the tiled kernel
+  if (fp8_amax) {
+    if (!smallk) return CD360_ERR_SHAPE;
+    for (int i = 0; i < 3; ++i) if (!(fp8_amax[i] > 0.f)) return CD360_ERR_ARG;
+    const float sq = fp8_amax[0] / 448.f, sk = fp8_amax[1] / 448.f, sv = fp8_amax[2] / 448.f;  // OCP e4m3: largest finite value 448
+    p.inv_sq = 1.f / sq; p.inv_sk = 1.f / sk; p.inv_sv = 1.f / sv;
+    p.scale_log2e *= sq * sk;     // scores come out in units of sq * sk
+    p.o_scale = sv / 256.f;       // V in units of sv, P in units of 1 / 256
+  } else if (const char* e = getenv("CD360_ATTN_SMALLK")) {
+    smallk = smallk && e[0] != '0';  // tuning override: 0 = always the tiled kernel
+  }
   if (smallk) {
     // one workgroup = one (batch, head) x one chunk of 32-query blocks; ~8 workgroups per CU in total, at least one block per wave
     const int nqb = (Nq + 31) / 32;
@@ -520,9 +570,15 @@ extern "C" int cd360_attn_fwd_bf16(const void* q, const void* k, const void* vt,
     p.fast = 0;
     const long nwg = chunks * B * H;
     if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
-    if (Nk <= 32) hipLaunchKernelGGL(attn_smallk_kernel<1>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
-    else if (Nk <= 64) hipLaunchKernelGGL(attn_smallk_kernel<2>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
-    else hipLaunchKernelGGL(attn_smallk_kernel<3>, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+#define CD360_SMALLK(NKB_) \
+  do { \
+    if (fp8_amax) hipLaunchKernelGGL((attn_smallk_kernel<NKB_, true>), dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p); \
+    else hipLaunchKernelGGL((attn_smallk_kernel<NKB_, false>), dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p); \
+  } while (0)
+    if (Nk <= 32) CD360_SMALLK(1);
+    else if (Nk <= 64) CD360_SMALLK(2);
+    else CD360_SMALLK(3);
+#undef CD360_SMALLK
     CD360_LAUNCH_CHECK();
     return CD360_OK;
   }
@@ -534,6 +590,21 @@ extern "C" int cd360_attn_fwd_bf16(const void* q, const void* k, const void* vt,
   hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
   CD360_LAUNCH_CHECK();
   return CD360_OK;
+}
+
+extern "C" int cd360_attn_fwd_bf16(const void* q, const void* k, const void* vt, void* o, int B, int H, int Nq, int Nk,
+                                   const int64_t* q_strides, const int64_t* k_strides, const int64_t* vt_strides,
+                                   const int64_t* o_strides, float scale, void* stream) {
+  return attn_launch(q, k, vt, o, B, H, Nq, Nk, q_strides, k_strides, vt_strides, o_strides, scale, nullptr, stream);
+}
+
+// fp8-MFMA variant for Nk <= 96 (BASELINE config 5): same bf16 tensors, Q / K / V^T / P rounded to e4m3 in registers.
+// amax = {max|q|, max|k|, max|v|} (host floats) define the per-tensor scales.  CD360_ERR_SHAPE when Nk > 96.
+extern "C" int cd360_attn_fwd_fp8mfma_bf16(const void* q, const void* k, const void* vt, void* o, int B, int H, int Nq, int Nk,
+                                           const int64_t* q_strides, const int64_t* k_strides, const int64_t* vt_strides,
+                                           const int64_t* o_strides, float scale, const float* amax, void* stream) {
+  if (!amax) return CD360_ERR_ARG;
+  return attn_launch(q, k, vt, o, B, H, Nq, Nk, q_strides, k_strides, vt_strides, o_strides, scale, amax, stream);
 }
 
 // xformers-layout convenience entry: q,k,v,o all contiguous [BH, N, 64]; `vt_ws` is caller-provided workspace

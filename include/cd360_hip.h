@@ -38,6 +38,14 @@ extern "C" {
 int cd360_attn_fwd_bf16(const void* q, const void* k, const void* vt, void* o, int B, int H, int Nq, int Nk,
                         const int64_t* q_strides, const int64_t* k_strides, const int64_t* vt_strides, const int64_t* o_strides,
                         float scale, void* stream);
+/* fp8-MFMA variant of cd360_attn_fwd_bf16 for Nk <= 96 -- the text / pose-token cross-attention of attention.py:578-588,620-625
+ * (BASELINE.json configs[4]): same bf16 tensors and strides; Q, K, V^T and the softmax probabilities are rounded to OCP e4m3 in
+ * registers with per-tensor scales amax[i] / 448 (amax = {max|q|, max|k|, max|v|}, host floats) and both contractions run on
+ * v_mfma_f32_32x32x16_fp8_fp8.  Returns CD360_ERR_SHAPE for Nk > 96 or output rows that are not 16-byte aligned. */
+int cd360_attn_fwd_fp8mfma_bf16(const void* q, const void* k, const void* vt, void* o, int B, int H, int Nq, int Nk,
+                                const int64_t* q_strides, const int64_t* k_strides, const int64_t* vt_strides,
+                                const int64_t* o_strides, float scale, const float* amax, void* stream);
+
 /* xformers layout: q, k, v, o contiguous [B*H, N, 64]; vt_ws = workspace of cd360_attn_vt_workspace_bytes(BH, Nk). */
 int64_t cd360_attn_vt_workspace_bytes(int BH, int Nk);
 int cd360_attn_fwd_xformers_bf16(const void* q, const void* k, const void* v, void* o, void* vt_ws, int BH, int Nq, int Nk, float scale,
