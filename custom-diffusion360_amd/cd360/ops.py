@@ -264,18 +264,24 @@ def rowdot4(h: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
 
 # ----------------------------------------------------------------------------------------------- GroupNorm (+SiLU)
 def gn_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, silu: bool,
-            out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """x: channels-last bf16 viewed as [N, P, C] (contiguous).  gamma/beta fp32 [C]."""
-    _need_gpu(x, gamma, beta)
+            out: Optional[torch.Tensor] = None, tile_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x: channels-last bf16 viewed as [N, P, C] (contiguous).  gamma/beta fp32 [C].
+    tile_stats: the fp32 [N, slabs, C, 2] per-slab channel sums conv_igemm(..., want_stats=True) returned for this very tensor
+    (the statistics read pass is skipped)."""
+    _need_gpu(x, gamma, beta, tile_stats)
     N, P, C = x.shape
+    slabs = 0
+    if tile_stats is not None:
+        assert tile_stats.dtype == torch.float32 and tile_stats.is_contiguous() and tile_stats.shape[0] == N and tile_stats.shape[2:] == (C, 2)
+        slabs = tile_stats.shape[1]
     assert x.dtype == torch.bfloat16 and x.is_contiguous() and gamma.dtype == torch.float32 and beta.dtype == torch.float32
     lib = _lib.load()
     ws = torch.empty(lib.cd360_gn_workspace_bytes(N, P, C), dtype=torch.uint8, device=x.device)
     if out is None:
         out = torch.empty_like(x)
-    with _timed("gn_silu", 0.0, 2.0 * 3 * N * P * C):
-      check(lib.cd360_gn_silu_bf16(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(ws), N, P, C, groups, float(eps), int(silu), _stream()),
-          "cd360_gn_silu_bf16")
+    with _timed("gn_silu", 0.0, 2.0 * (3 if tile_stats is None else 2) * N * P * C):
+      check(lib.cd360_gn_silu_bf16(_ptr(x), _ptr(gamma), _ptr(beta), _ptr(out), _ptr(ws), N, P, C, groups, float(eps), int(silu),
+                                   _ptr(tile_stats), slabs, _stream()), "cd360_gn_silu_bf16")
     return out
 
 
@@ -320,9 +326,11 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
 
 
 def conv_igemm(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], N: int, H: int, W: int, taps: int = 9,
-               emb: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+               emb: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, want_stats: bool = False):
     """x [N*H*W, Cin] (or [N, H*W, Cin]) channels-last bf16; w_packed [Cout, taps*Cin] bf16; bias fp32 [Cout]; emb bf16 [N, Cout];
-    res bf16 [N*H*W, Cout] -> [N, H*W, Cout] bf16 = conv3x3 (taps=9) or x @ w^T (taps=1) + bias + emb[n] + res."""
+    res bf16 [N*H*W, Cout] -> [N, H*W, Cout] bf16 = conv3x3 (taps=9) or x @ w^T (taps=1) + bias + emb[n] + res.
+    want_stats=True (H*W % 128 == 0): returns (out, tile_stats) with tile_stats fp32 [N, slabs, Cout, 2] = per pixel slab the channel
+    sums / sums of squares of `out`, for gn_silu(out, ..., tile_stats=tile_stats)."""
     _need_gpu(x, w_packed, bias, emb, res)
     cin = x.shape[-1]
     cout = w_packed.shape[0]
@@ -333,10 +341,16 @@ def conv_igemm(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Ten
     assert res is None or (res.dtype == torch.bfloat16 and res.is_contiguous() and res.numel() == N * H * W * cout)
     out = torch.empty(N, H * W, cout, dtype=torch.bfloat16, device=x.device)
     m = N * H * W
+    lib = _lib.load()
+    stats = None
+    if want_stats:
+        if (H * W) % 128:
+            raise Cd360Error("conv_igemm(want_stats=True) needs H*W % 128 == 0")
+        stats = torch.empty(N, (H * W) // 128 * lib.cd360_conv_stats_slabs(cout), cout, 2, dtype=torch.float32, device=x.device)
     with _timed("conv_igemm", 2.0 * m * taps * cin * cout, 2.0 * (m * cin + m * cout + taps * cin * cout)):
-        check(_lib.load().cd360_conv_igemm_bf16(_ptr(x), _ptr(w_packed), _ptr(bias), _ptr(emb), _ptr(res), _ptr(out), N, H, W, cin, cout, taps,
-                                               _stream()), "cd360_conv_igemm_bf16")
-    return out
+        check(lib.cd360_conv_igemm_bf16(_ptr(x), _ptr(w_packed), _ptr(bias), _ptr(emb), _ptr(res), _ptr(out), N, H, W, cin, cout, taps,
+                                       _ptr(stats), _stream()), "cd360_conv_igemm_bf16")
+    return (out, stats) if want_stats else out
 
 
 def add_layernorm(a: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor, eps: float, want_sum: bool = True):

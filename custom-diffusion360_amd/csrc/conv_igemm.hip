@@ -25,6 +25,7 @@ struct ConvParams {
   const uint16_t* emb;    // [N, Cout] bf16 per-image addend or null
   const uint16_t* res;    // [M, Cout] bf16 residual or null
   uint16_t* out;          // [M, Cout]
+  float* stats;           // optional [n_mtiles * slabs_per_tile, Cout, 2]: per-slab channel sums / sums of squares of `out`
   int N, H, W, Cin, Cout, taps;
   long M;
   int n_mtiles, n_ntiles, w_major;
@@ -223,15 +224,21 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_igemm_kernel(ConvParams p) {
   }
 
   // ---- epilogue: lane = pixel (l31), registers = 16 consecutive channels (16*hh + r) of each 32-channel block ----
+  // Optional GroupNorm pre-pass (p.stats): per (pixel slab, channel) sum and sum of squares of the bf16 outputs this wave writes,
+  // slab = (pixel tile, wpx) = NPB*32 pixels -- exactly the [N, nslab, C, 2] partials gn_finalize_kernel consumes, so the
+  // GroupNorm that follows the conv skips its own read pass over the tensor.  Fixed reduction order: deterministic.
 #pragma unroll
-  for (int pb = 0; pb < NPB; ++pb) {
-    const long m = m0 + wpx * NPB * 32 + pb * 32 + l31;
-    if (m >= p.M) continue;
-    const int img = (int)(m / HW);
+  for (int cb = 0; cb < NCB; ++cb) {
+    const int co = co0 + wco * NCB * 32 + cb * 32 + 16 * hh;
+    const bool co_ok = co < p.Cout;  // Cout is a multiple of 16
+    float ssum[16], ssq[16];
 #pragma unroll
-    for (int cb = 0; cb < NCB; ++cb) {
-      const int co = co0 + wco * NCB * 32 + cb * 32 + 16 * hh;
-      if (co >= p.Cout) continue;  // Cout is a multiple of 16
+    for (int r = 0; r < 16; ++r) { ssum[r] = 0.f; ssq[r] = 0.f; }
+#pragma unroll
+    for (int pb = 0; pb < NPB; ++pb) {
+      const long m = m0 + wpx * NPB * 32 + pb * 32 + l31;
+      if (m >= p.M || !co_ok) continue;
+      const int img = (int)(m / HW);
       float v[16];
 #pragma unroll
       for (int r = 0; r < 16; ++r) v[r] = acc[cb][pb][r];
@@ -266,6 +273,46 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_igemm_kernel(ConvParams p) {
       uint16_t* dst = p.out + m * p.Cout + co;
       *reinterpret_cast<u32x4*>(dst) = o0;
       *reinterpret_cast<u32x4*>(dst + 8) = o1;
+      if (p.stats) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float a0 = bf16lo_to_f32(o0[e]), a1 = bf16hi_to_f32(o0[e]), b0 = bf16lo_to_f32(o1[e]), b1 = bf16hi_to_f32(o1[e]);
+          ssum[2 * e] += a0; ssq[2 * e] = fmaf(a0, a0, ssq[2 * e]);
+          ssum[2 * e + 1] += a1; ssq[2 * e + 1] = fmaf(a1, a1, ssq[2 * e + 1]);
+          ssum[8 + 2 * e] += b0; ssq[8 + 2 * e] = fmaf(b0, b0, ssq[8 + 2 * e]);
+          ssum[8 + 2 * e + 1] += b1; ssq[8 + 2 * e + 1] = fmaf(b1, b1, ssq[8 + 2 * e + 1]);
+        }
+      }
+    }
+    if (p.stats) {  // wave-uniform
+      // Sum over this wave's 32 pixel lanes through LDS (the K-loop stages are idle after the last barrier): every lane stores its
+      // 16 channel sums / sums of squares as one padded row (36 floats: conflict-free ds_write_b128), then lane j adds half a
+      // column -- 16 ds_read_b32 per quantity -- and one exchange with lane ^ 32 finishes it.  (Butterfly shuffles: 160 per
+      // quantity, measured 3x the cost.)  Fixed order: deterministic.
+      // (SPLIT = 2: the first 64 KB may still be read by slower waves finishing the K-split reduction -- use the second half)
+      float* red = reinterpret_cast<float*>(lds_all + (SPLIT == 2 ? 2 * STAGE : 0)) + wave * (2 * 32 * 36);
+      float* mine = red + l31 * 36 + 16 * hh;
+#pragma unroll
+      for (int r = 0; r < 16; r += 4) {
+        *reinterpret_cast<f32x4*>(mine + r) = f32x4{ssum[r], ssum[r + 1], ssum[r + 2], ssum[r + 3]};
+        *reinterpret_cast<f32x4*>(mine + 32 * 36 + r) = f32x4{ssq[r], ssq[r + 1], ssq[r + 2], ssq[r + 3]};
+      }
+      // wave-private region: no workgroup barrier; the compiler's lgkmcnt wait orders the ds_write before the ds_read
+      const int c = lane & 31, half = lane >> 5;
+      float ts = 0.f, tq = 0.f;
+#pragma unroll
+      for (int row = 0; row < 16; ++row) {
+        ts += red[(half * 16 + row) * 36 + c];
+        tq += red[32 * 36 + (half * 16 + row) * 36 + c];
+      }
+      ts += __shfl_xor(ts, 32);
+      tq += __shfl_xor(tq, 32);
+      const int cch = co0 + wco * NCB * 32 + cb * 32 + c;
+      if (half == 0 && cch < p.Cout) {
+        float* dst = p.stats + (((long)mt * WAVES_PX + wpx) * p.Cout + cch) * 2;
+        dst[0] = ts;
+        dst[1] = tq;
+      }
     }
   }
 }
@@ -289,15 +336,22 @@ extern "C" int cd360_conv_k_order(int Cin, int taps) {
   return 1;
 }
 
+// Pixel slabs per 128-pixel tile of the optional `tile_stats` output (the wave tiling the launch will use for this Cout)
+extern "C" int cd360_conv_stats_slabs(int Cout) { return (Cout % 160 == 0 && Cout % 128 != 0 && !(getenv("CD360_CONV_WIDE") && getenv("CD360_CONV_WIDE")[0] == '0')) ? 4 : 2; }
+
+// tile_stats (optional): fp32 [N*H*W / 128 * cd360_conv_stats_slabs(Cout), Cout, 2] = per pixel slab (32 or 64 consecutive pixels)
+// and channel, the sum and the sum of squares of the bf16 outputs -- the first pass of the GroupNorm that follows the conv
+// (cd360_gn_silu_bf16's `tile_stats`).  Requires H*W % 128 == 0 (slabs must not straddle images).
 extern "C" int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const void* bias, const void* emb, const void* res, void* out,
-                                     int N, int H, int W, int Cin, int Cout, int taps, void* stream) {
+                                     int N, int H, int W, int Cin, int Cout, int taps, void* tile_stats, void* stream) {
   if (!x || !w_packed || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return CD360_ERR_ARG;
   if ((taps != 9 && taps != 1) || Cin % 64 || Cout % 16) return CD360_ERR_SHAPE;
   if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)out | (uintptr_t)emb | (uintptr_t)res) % 16) return CD360_ERR_ARG;
   if ((long)N * H * W * Cin * 2 >= (1L << 31) || (long)Cout * taps * Cin * 2 >= (1L << 31)) return CD360_ERR_SHAPE;  // 32-bit buffer offsets
   ConvParams p;
   p.x = (const uint16_t*)x; p.w = (const uint16_t*)w_packed; p.bias = (const float*)bias; p.emb = (const uint16_t*)emb;
-  p.res = (const uint16_t*)res; p.out = (uint16_t*)out;
+  p.res = (const uint16_t*)res; p.out = (uint16_t*)out; p.stats = (float*)tile_stats;
+  if (tile_stats && ((long)H * W) % BM) return CD360_ERR_SHAPE;
   p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.taps = taps;
   p.M = (long)N * H * W;
   p.n_mtiles = (int)((p.M + BM - 1) / BM);

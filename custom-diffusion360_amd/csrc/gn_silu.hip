@@ -127,16 +127,21 @@ extern "C" int64_t cd360_gn_workspace_bytes(int N, int P, int C) {
   return ((int64_t)N * gn_num_slabs(P) * 2 * C + (int64_t)N * 2 * 64) * 4;
 }
 
-// x, y: [N, P, C] bf16 channels-last (y may alias x); gamma, beta: [C] fp32; ws: cd360_gn_workspace_bytes(N, P, C) bytes
+// x, y: [N, P, C] bf16 channels-last (y may alias x); gamma, beta: [C] fp32; ws: cd360_gn_workspace_bytes(N, P, C) bytes.
+// tile_stats (optional) = the per-slab channel sums a producer already computed while writing x -- cd360_conv_igemm_bf16's
+// `tile_stats`, fp32 [N, stats_slabs, C, 2] with stats_slabs equal slabs per image: the statistics read pass over x is skipped.
 extern "C" int cd360_gn_silu_bf16(const void* x, const void* gamma, const void* beta, void* y, void* ws, int N, int P, int C, int G,
-                                  float eps, int silu, void* stream) {
+                                  float eps, int silu, const void* tile_stats, int stats_slabs, void* stream) {
   if (!x || !gamma || !beta || !y || !ws || N <= 0 || P <= 0 || C <= 0 || G <= 0) return CD360_ERR_ARG;
   if (C % 8 || C % G || C > MAX_C || G > 64) return CD360_ERR_SHAPE;
-  const int nslab = gn_num_slabs(P);
-  float* partial = (float*)ws;
-  float* stat = partial + (long)N * nslab * 2 * C;
-  hipLaunchKernelGGL(gn_partial_kernel, dim3(nslab, N), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, partial, P, C, nslab);
-  CD360_LAUNCH_CHECK();
+  if (tile_stats && stats_slabs <= 0) return CD360_ERR_ARG;
+  const int nslab = tile_stats ? stats_slabs : gn_num_slabs(P);
+  float* partial = tile_stats ? (float*)tile_stats : (float*)ws;
+  float* stat = (float*)ws + (long)N * gn_num_slabs(P) * 2 * C;
+  if (!tile_stats) {
+    hipLaunchKernelGGL(gn_partial_kernel, dim3(nslab, N), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x, partial, P, C, nslab);
+    CD360_LAUNCH_CHECK();
+  }
   hipLaunchKernelGGL(gn_finalize_kernel, dim3(G, N), dim3(256), 0, (hipStream_t)stream, (const float*)partial, stat, P, C, G, eps, nslab);
   CD360_LAUNCH_CHECK();
   const int nslab_apply = (int)(((long)P * (C / 8) + 256 * 8 - 1) / (256 * 8));

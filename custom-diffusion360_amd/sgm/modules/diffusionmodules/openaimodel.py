@@ -27,6 +27,7 @@ from ...modules.diffusionmodules.util import (
     group_norm_tokens,
     linear,
     normalization,
+    tag_gn_stats,
     timestep_embedding,
     tokens_to_image,
     zero_module,
@@ -145,16 +146,16 @@ class ResBlock(TimestepBlock):
         N, _, H, W = x.shape
         t = group_norm_tokens(self.in_layers[0], x, silu=True)  # [N, HW, Cin]
         emb_out = self.emb_layers(emb).type(t.dtype)
-        h = conv_tokens(self.in_layers[2], t, N, H, W, emb=emb_out.contiguous())
-        t2 = group_norm_tokens(self.out_layers[0], tokens_to_image(h, H, W), silu=True)
+        h, h_stats = conv_tokens(self.in_layers[2], t, N, H, W, emb=emb_out.contiguous(), want_stats=True)
+        t2 = group_norm_tokens(self.out_layers[0], tokens_to_image(h, H, W), silu=True, stats=h_stats)  # statistics from the conv epilogue
         xt = x.permute(0, 2, 3, 1)
         xt = (xt if xt.is_contiguous() else xt.contiguous()).reshape(N, H * W, -1)
         if isinstance(self.skip_connection, nn.Identity):
             skip = xt
         else:
             skip = conv_tokens(self.skip_connection, xt, N, H, W)
-        out = conv_tokens(self.out_layers[3], t2, N, H, W, res=skip if skip.dtype == t2.dtype else skip.to(t2.dtype))
-        return tokens_to_image(out, H, W)
+        out, out_stats = conv_tokens(self.out_layers[3], t2, N, H, W, res=skip if skip.dtype == t2.dtype else skip.to(t2.dtype), want_stats=True)
+        return tag_gn_stats(tokens_to_image(out, H, W), out_stats)  # the next module's GroupNorm (if any) reuses them
 
 
 class UNetModel(nn.Module):

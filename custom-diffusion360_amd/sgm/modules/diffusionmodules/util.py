@@ -6,6 +6,7 @@ import them by name."""
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -61,10 +62,32 @@ def _fp32_affine(norm: nn.GroupNorm):
     return cache[1], cache[2]
 
 
-def group_norm_tokens(norm: nn.GroupNorm, x: torch.Tensor, silu: bool) -> torch.Tensor:
+def tag_gn_stats(img: torch.Tensor, stats) -> torch.Tensor:
+    """Attach the conv epilogue's GroupNorm slab statistics to the image VIEW a module returns, so that a GroupNorm in the NEXT
+    module (SpatialTransformer.norm, the following ResBlock's in_layers, UNet.out) can skip its statistics pass.  The tag is a
+    plain attribute of this Python object: it does not survive any tensor op, and the consumer re-checks address, shape and
+    version counter before trusting it."""
+    if stats is not None:
+        img._cd360_gn_stats = (stats, img.data_ptr(), img._version, tuple(img.shape))
+    return img
+
+
+def _tagged_gn_stats(x: torch.Tensor):
+    tag = getattr(x, "_cd360_gn_stats", None)
+    if tag is None:
+        return None
+    stats, ptr, version, shape = tag
+    return stats if (x.data_ptr() == ptr and x._version == version and tuple(x.shape) == shape) else None
+
+
+def group_norm_tokens(norm: nn.GroupNorm, x: torch.Tensor, silu: bool, stats=None) -> torch.Tensor:
     """GroupNorm(+SiLU) of an image tensor [N, C, H, W]; returns channels-last tokens [N, H*W, C] in x's dtype.
-    The token tensor aliases a channels-last image: `.reshape(N, H, W, C).permute(0, 3, 1, 2)` is free."""
+    The token tensor aliases a channels-last image: `.reshape(N, H, W, C).permute(0, 3, 1, 2)` is free.
+    `stats`: per-slab channel sums the producing conv already computed (conv_tokens(..., want_stats=True)); also picked up from
+    a tag left by tag_gn_stats."""
     N, C, H, W = x.shape
+    if stats is None:
+        stats = _tagged_gn_stats(x)
     xt = x.permute(0, 2, 3, 1)
     if not xt.is_contiguous():
         xt = xt.contiguous()  # NCHW-contiguous input: one layout change, then everything stays channels-last
@@ -72,8 +95,9 @@ def group_norm_tokens(norm: nn.GroupNorm, x: torch.Tensor, silu: bool) -> torch.
     dt = xt.dtype
     if dt != torch.bfloat16:
         xt = xt.to(torch.bfloat16)
+        stats = None  # the statistics were taken of the bf16 tensor the conv wrote; x is something else
     g, b = _fp32_affine(norm)
-    y = ops.gn_silu(xt, g, b, norm.num_groups, norm.eps, silu)
+    y = ops.gn_silu(xt, g, b, norm.num_groups, norm.eps, silu, tile_stats=stats)
     return y if dt == torch.bfloat16 else y.to(dt)
 
 
@@ -101,18 +125,23 @@ def packed_conv(conv: nn.Conv2d):
     return cache[1], cache[2]
 
 
-def conv_tokens(conv: nn.Conv2d, tokens: torch.Tensor, N: int, H: int, W: int, emb=None, res=None):
+def conv_tokens(conv: nn.Conv2d, tokens: torch.Tensor, N: int, H: int, W: int, emb=None, res=None, want_stats: bool = False):
     """conv(3x3 pad 1 | 1x1) on channels-last tokens [N, H*W, Cin] -> [N, H*W, Cout], with the per-image addend `emb` [N, Cout] and the
-    residual `res` [N, H*W, Cout] fused into the epilogue (cd360_conv_igemm_bf16); falls back to MIOpen outside the envelope."""
+    residual `res` [N, H*W, Cout] fused into the epilogue (cd360_conv_igemm_bf16); falls back to MIOpen outside the envelope.
+    want_stats=True returns (tokens, stats): the GroupNorm slab statistics of the output, or None when the kernel cannot give them."""
     pk = packed_conv(conv) if tokens.dtype == torch.bfloat16 else None
     if pk is None:
         y = conv(tokens_to_image(tokens, H, W))
         if emb is not None:
             y = y + emb[:, :, None, None]
         y = y.permute(0, 2, 3, 1).reshape(N, H * W, -1)
-        return y if res is None else y + res
+        y = y if res is None else y + res
+        return (y, None) if want_stats else y
     taps = 9 if conv.kernel_size == (3, 3) else 1
-    return ops.conv_igemm(tokens, pk[0], pk[1], N, H, W, taps, emb, res)
+    if want_stats and (H * W) % 128 == 0 and not os.environ.get("CD360_NO_GN_STATS"):  # (tuning knob: GroupNorm does its own pass)
+        return ops.conv_igemm(tokens, pk[0], pk[1], N, H, W, taps, emb, res, want_stats=True)
+    y = ops.conv_igemm(tokens, pk[0], pk[1], N, H, W, taps, emb, res)
+    return (y, None) if want_stats else y
 
 
 class GroupNorm32(nn.GroupNorm):

@@ -110,7 +110,9 @@ int cd360_rowdot4_bf16(const void* h, const void* w, void* out, int64_t rows, in
  * ws = cd360_gn_workspace_bytes(N, P, C) bytes; y may alias x.  C % 8 == 0, C <= 4096, G <= 64. */
 int64_t cd360_gn_workspace_bytes(int N, int P, int C);
 int cd360_gn_silu_bf16(const void* x, const void* gamma, const void* beta, void* y, void* ws, int N, int P, int C, int G, float eps,
-                       int silu, void* stream);
+                       int silu, const void* tile_stats, int stats_slabs, void* stream);
+/* tile_stats / stats_slabs (optional, NULL / 0): per-slab channel sums [N, stats_slabs, C, 2] already produced by the conv that
+ * wrote x (cd360_conv_igemm_bf16); the statistics read pass over x is then skipped. */
 
 /* ---- epilogues around the transformer blocks -------------------------------------------------------------------------
  * replaces GEGLU.forward's chunk / F.gelu / multiply (sgm/modules/attention.py:94-96): in [rows, 2*inner] bf16 = [x | gate]
@@ -141,7 +143,11 @@ int cd360_cfg_euler_step_f32(const void* x, const void* eps, const void* sigma, 
  * Cin % 64 == 0, Cout % 16 == 0, 16-byte aligned pointers. */
 int cd360_conv_k_order(int Cin, int taps);
 int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const void* bias, const void* emb, const void* res, void* out, int N, int H,
-                          int W, int Cin, int Cout, int taps, void* stream);
+                          int W, int Cin, int Cout, int taps, void* tile_stats, void* stream);
+/* tile_stats (optional, NULL to skip): fp32 [N*H*W/128 * cd360_conv_stats_slabs(Cout), Cout, 2] = per pixel slab and channel the
+ * sum and the sum of squares of the bf16 outputs: the statistics pass of the GroupNorm that follows the conv (openaimodel.py:
+ * 352-376 h = out_layers(GN -> SiLU -> conv)), handed to cd360_gn_silu_bf16.  Requires H*W % 128 == 0. */
+int cd360_conv_stats_slabs(int Cout);
 
 #ifdef __cplusplus
 }

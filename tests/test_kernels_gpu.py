@@ -238,6 +238,33 @@ def test_conv_igemm(N, H, W, Cin, Cout, taps, extras, split, monkeypatch):
     assert rel(got.reshape(N, H, W, Cout).permute(0, 3, 1, 2), want) < 8e-3
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 16, 128, 256), (1, 32, 32, 64, 320), (3, 32, 32, 320, 640), (2, 16, 8, 128, 160)])
+def test_conv_epilogue_groupnorm_statistics(N, H, W, Cin, Cout):
+    """conv_igemm(want_stats=True) hands the GroupNorm that follows its per-slab channel sums (openaimodel.py:352-376: conv ->
+    GN -> SiLU -> conv): GN from those statistics must equal GN with its own statistics pass, in every launch shape (default
+    128-channel tiles, 160-channel tiles for Cout = 320 / 160, in-workgroup split-K for (3,32,32,320,640)), with emb + residual."""
+    from cd360 import ops
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = bf(torch.randn(N, H * W, Cin, generator=g)).to(DEV, torch.bfloat16)
+    wp = ops.pack_conv_weight(bf(torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5)).to(DEV)
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    emb = bf(torch.randn(N, Cout, generator=g)).to(DEV, torch.bfloat16)
+    res = bf(torch.randn(N, H * W, Cout, generator=g)).to(DEV, torch.bfloat16)
+    out, stats = ops.conv_igemm(x, wp, bias, N, H, W, 9, emb, res, want_stats=True)
+    assert torch.equal(out, ops.conv_igemm(x, wp, bias, N, H, W, 9, emb, res))  # same output with and without the statistics
+    slabs = stats.shape[1]
+    assert stats.shape == (N, slabs, Cout, 2) and (H * W) % slabs == 0
+    want = out.float().reshape(N, slabs, H * W // slabs, Cout)
+    assert rel(stats[..., 0], want.sum(2)) < 1e-5 and rel(stats[..., 1], (want * want).sum(2)) < 1e-5
+    gamma, beta = torch.randn(Cout, generator=g).to(DEV), torch.randn(Cout, generator=g).to(DEV)
+    a = ops.gn_silu(out, gamma, beta, 32, 1e-5, True, tile_stats=stats)
+    b = ops.gn_silu(out, gamma, beta, 32, 1e-5, True)
+    assert rel(a, b) < 4e-3  # bf16 outputs; statistics differ only in summation order
+    assert torch.equal(a, ops.gn_silu(out, gamma, beta, 32, 1e-5, True, tile_stats=stats))  # deterministic
+    with pytest.raises(Exception):
+        ops.conv_igemm(x[:, :100].contiguous(), wp, bias, N, 10, 10, 9, want_stats=True)  # H*W % 128 != 0
+
+
 # ------------------------------------------------------------------------------------------------ GroupNorm + SiLU (K7)
 @pytest.mark.parametrize("N,P,C,silu", [(2, 64, 64, True), (3, 1024, 320, True), (1, 4096, 640, False), (2, 256, 2560, True), (1, 100, 960, False)])
 def test_gn_silu(N, P, C, silu):
@@ -459,6 +486,33 @@ def test_conv_igemm(N, H, W, Cin, Cout, taps, extras, split, monkeypatch):
     rt = None if res is None else res.permute(0, 2, 3, 1).reshape(N, H * W, Cout).contiguous().to(DEV, torch.bfloat16)
     got = ops.conv_igemm(xt, wp, bias.to(DEV), N, H, W, taps, None if emb is None else emb.to(DEV, torch.bfloat16), rt)
     assert rel(got.reshape(N, H, W, Cout).permute(0, 3, 1, 2), want) < 8e-3
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 16, 128, 256), (1, 32, 32, 64, 320), (3, 32, 32, 320, 640), (2, 16, 8, 128, 160)])
+def test_conv_epilogue_groupnorm_statistics(N, H, W, Cin, Cout):
+    """conv_igemm(want_stats=True) hands the GroupNorm that follows its per-slab channel sums (openaimodel.py:352-376: conv ->
+    GN -> SiLU -> conv): GN from those statistics must equal GN with its own statistics pass, in every launch shape (default
+    128-channel tiles, 160-channel tiles for Cout = 320 / 160, in-workgroup split-K for (3,32,32,320,640)), with emb + residual."""
+    from cd360 import ops
+    g = torch.Generator().manual_seed(Cin + Cout)
+    x = bf(torch.randn(N, H * W, Cin, generator=g)).to(DEV, torch.bfloat16)
+    wp = ops.pack_conv_weight(bf(torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5)).to(DEV)
+    bias = torch.randn(Cout, generator=g).to(DEV)
+    emb = bf(torch.randn(N, Cout, generator=g)).to(DEV, torch.bfloat16)
+    res = bf(torch.randn(N, H * W, Cout, generator=g)).to(DEV, torch.bfloat16)
+    out, stats = ops.conv_igemm(x, wp, bias, N, H, W, 9, emb, res, want_stats=True)
+    assert torch.equal(out, ops.conv_igemm(x, wp, bias, N, H, W, 9, emb, res))  # same output with and without the statistics
+    slabs = stats.shape[1]
+    assert stats.shape == (N, slabs, Cout, 2) and (H * W) % slabs == 0
+    want = out.float().reshape(N, slabs, H * W // slabs, Cout)
+    assert rel(stats[..., 0], want.sum(2)) < 1e-5 and rel(stats[..., 1], (want * want).sum(2)) < 1e-5
+    gamma, beta = torch.randn(Cout, generator=g).to(DEV), torch.randn(Cout, generator=g).to(DEV)
+    a = ops.gn_silu(out, gamma, beta, 32, 1e-5, True, tile_stats=stats)
+    b = ops.gn_silu(out, gamma, beta, 32, 1e-5, True)
+    assert rel(a, b) < 4e-3  # bf16 outputs; statistics differ only in summation order
+    assert torch.equal(a, ops.gn_silu(out, gamma, beta, 32, 1e-5, True, tile_stats=stats))  # deterministic
+    with pytest.raises(Exception):
+        ops.conv_igemm(x[:, :100].contiguous(), wp, bias, N, 10, 10, 9, want_stats=True)  # H*W % 128 != 0
 
 
 # ------------------------------------------------------------------------------------------------ GroupNorm + SiLU (K7)
