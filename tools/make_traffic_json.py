@@ -1,0 +1,39 @@
+"""profiles/<tag>_pmc_traffic.json from the FETCH_SIZE / WRITE_SIZE summaries tools/gpu_profile.sh wrote (pmc_FETCH_SIZE.csv,
+pmc_WRITE_SIZE.csv: per-kernel averages in KB).  Kernel variants (template instantiations) are merged launch-weighted under the
+name bench.py uses for its per-kernel timing.  Usage: make_traffic_json.py gpurun_out/prof_r1f profiles/r01f"""
+import csv
+import json
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+NAMES = {"conv_igemm_kernel": "conv_igemm", "attn_fwd_kernel": "attn_fwd", "attn_smallk_kernel": "attn_fwd", "nerf_fused_kernel": "nerf_mlp_aggregate",
+         "geglu_kernel": "geglu", "volrender_kernel": "volrender", "gn_partial_kernel": "gn_silu", "gn_apply_kernel": "gn_silu", "gn_finalize_kernel": "gn_silu"}
+
+
+def load(counter):
+    out = {}
+    for r in csv.DictReader(open(f"{src}/pmc_{counter}.csv")):
+        key = next((v for k, v in NAMES.items() if k in r["kernel"]), None)
+        if key is None:
+            continue
+        d = out.setdefault(key, {"n": 0, "kb": 0.0})
+        d["n"] += int(r["dispatches"])
+        d["kb"] += float(r["total"])
+    return out
+
+
+f, w = load("FETCH_SIZE"), load("WRITE_SIZE")
+kern = {}
+for k in f:
+    n = f[k]["n"]
+    fetch, write = f[k]["kb"] / n, w.get(k, {"kb": 0.0})["kb"] / n
+    kern[k] = {"fetch_size_kb_raw": round(fetch, 1), "write_size_kb": round(write, 1), "hbm_bytes_per_launch": int((2 * fetch + write) * 1024), "dispatches": n}
+doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-profile "
+                 "--no-graph` (tools/gpu_profile.sh), " + dst + "_pmc_*.csv",
+       "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md HBM section; confirmed on geglu_kernel: "
+                     "35141 KB raw vs 71.8 MB actually read; WRITE_SIZE exact) -> bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024.  The counters sit on the "
+                     "L2 <-> fabric side, so Infinity-Cache hits are included (upper bound on HBM traffic).  gn_silu / attn_fwd sum their sub-kernels "
+                     "per launch of any of them.",
+       "kernels": kern}
+json.dump(doc, open(dst + "_pmc_traffic.json", "w"), indent=1)
+print(json.dumps({k: v["hbm_bytes_per_launch"] for k, v in kern.items()}))
