@@ -105,12 +105,19 @@ def patch_positions(r: int, device, jitter: Optional[torch.Tensor] = None) -> to
     return out
 
 
+_depth_cache = {}
+
+
 def depth_samples(num_samples: int, far: float, near: float, device, num_rays: int, jitter: Optional[torch.Tensor] = None):
     """Raymarcher buffers + stratified_sampling (nerfsd_pytorch3d.py:248-259,308-330).
     Returns (t, dists): [S] each in eval mode, [hw, S] with jitter."""
+    key = (int(num_samples), float(far), float(near), str(device))
+    if jitter is None and key in _depth_cache:  # eval mode: constants -- no host-to-device copy per call (hipGraph-capturable)
+        return _depth_cache[key]
     l = torch.linspace(near, near + (near + far), num_samples + 1)
     if jitter is None:
-        return ((l[1:] + l[:-1]) / 2.0).to(device), (l[1:] - l[:-1]).to(device)
+        _depth_cache[key] = (((l[1:] + l[:-1]) / 2.0).to(device), (l[1:] - l[:-1]).to(device))
+        return _depth_cache[key]
     center = (l[1:] + l[:-1]) / 2.0
     upper = torch.cat([center, l[-1:]], -1).to(device)
     lower = torch.cat([l[:1], center], -1).to(device)
