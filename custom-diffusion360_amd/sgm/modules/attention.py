@@ -241,7 +241,16 @@ class BasicTransformerBlock(nn.Module):
         context_ref [b, n, hw, C].  -> (xref [b,hw,C], fg [b,hw,1], prev_weights(None), alphas [b,hw,S,1], rgb [b,hw,3])"""
         if prev_weights is not None and self.use_prev_weights_imp_sample:
             raise NotImplementedError("importance sampling is dead code in the reference (SURVEY.md F3)")
-        h, dec, dists, _ = self.pose_featurenerf.render_inputs(pose, context_ref, mask_ref, tables=tables, dims=dims)
+        dup = self._duplicate_cfg_branch(pose, dims) if (tables is not None and context_ref is None and mask_ref is None) else 0
+        if dup:
+            # 3-way CFG (guiders.py:102-133): the image-conditional and the image+text-conditional thirds see the same target
+            # pose and the same references, so everything BEFORE the text cross-attention is identical for them: render the
+            # first two thirds only and reuse the second for the third (the reference computes it twice).
+            t2, d2 = self._sampling_tables(2 * dup)
+            h, dec, dists, _ = self.pose_featurenerf.render_inputs(list(pose[:2 * dup]), None, None, tables=t2, dims=d2)
+            h, dec = torch.cat([h, h[dup:]], 0), torch.cat([dec, dec[dup:]], 0)
+        else:
+            h, dec, dists, _ = self.pose_featurenerf.render_inputs(pose, context_ref, mask_ref, tables=tables, dims=dims)
         b, hw, S, C = h.shape
         tok = h.reshape(b, hw * S, C)
         if tok.dtype != x.dtype:
@@ -250,6 +259,18 @@ class BasicTransformerBlock(nn.Module):
         rendered, fg, alphas, _, rgb = ops.volrender(tok.reshape(b, hw, S, C), dec[..., 3], dists,
                                                     dec[..., :3] if self.rgb_predict else None)
         return rendered, fg, (None if not self.use_prev_weights_imp_sample else None), alphas, rgb
+
+    @staticmethod
+    def _duplicate_cfg_branch(pose, dims) -> int:
+        """bs > 0 when `pose` is a list of 3*bs camera batches whose last two thirds are the SAME objects (what the guider's
+        `[pose] * 3` / torch.cat of one conditioning produces); decided on object identity only -- no device comparison."""
+        if os.environ.get("CD360_NO_CFG_DEDUP") or not isinstance(pose, (list, tuple)) or dims is None:
+            return 0
+        b = len(pose)
+        if b != dims[0] or b % 3:
+            return 0
+        bs = b // 3
+        return bs if all(pose[bs + i] is pose[2 * bs + i] for i in range(bs)) else 0
 
     def _references_as_context(self, batch_size: int):
         """sample.py:85-96: reference features for a CFG batch from the `references` buffer; the unconditional third uses the
@@ -272,18 +293,20 @@ class BasicTransformerBlock(nn.Module):
         from cd360 import nerf as _nerf
         refs, choices = self.references, self.reference_choices
         fw = self.pose_featurenerf.model.fused_weights()
-        key = (refs.data_ptr(), refs._version, tuple(choices), batch_size, id(fw))
+        key = (refs.data_ptr(), refs._version, tuple(choices), id(fw))
+        n = len(choices)
         if self._ref_tables is None or self._ref_tables[0] != key:
-            n = len(choices)
             uniq = torch.cat([refs[-1:], refs[:-1][torch.as_tensor(choices, device=refs.device)]], 0)  # [1+n, hw, C]
             Y, lv = _nerf.reference_tables(fw, uniq[None])
+            self._ref_tables = (key, (Y, lv), {})
+        (Y, lv), maps = self._ref_tables[1], self._ref_tables[2]
+        if batch_size not in maps:  # which table image each (batch element, view) reads: per CFG layout, tiny
             groups = 3 if batch_size % 3 == 0 else 2
             bs = batch_size // groups
             cond = torch.arange(1, n + 1, dtype=torch.int32, device=refs.device)
             rows = [torch.zeros(n, dtype=torch.int32, device=refs.device)] * bs + [cond] * (bs * (groups - 1))
-            img_map = torch.stack(rows).reshape(-1).contiguous()
-            self._ref_tables = (key, (Y, lv, img_map), (batch_size, n, refs.shape[1], refs.shape[2]))
-        return self._ref_tables[1], self._ref_tables[2]
+            maps[batch_size] = torch.stack(rows).reshape(-1).contiguous()
+        return (Y, lv, maps[batch_size]), (batch_size, n, refs.shape[1], refs.shape[2])
 
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self, x, context=None, context_ref=None, pose=None, mask_ref=None, prev_weights=None, additional_tokens=None,

@@ -184,6 +184,33 @@ def test_cfgB_level1_sampling_block_cached_equals_uncached():
 
 
 @torch.no_grad()
+def test_cfg_branch_deduplication_is_bit_identical(monkeypatch):
+    """3-way CFG hands the block `[pose] * 3`: the image-conditional and image+text-conditional thirds share pose and references,
+    so the FeatureNeRF part is rendered for two thirds and reused for the third.  Must equal rendering all three, bit for bit
+    (same kernels, same inputs), and must not trigger when the thirds are different camera objects."""
+    from cd360 import sampling, synth
+    from cd360.cameras import join_cameras_as_batch
+    blk = make_block(13, C=128, heads=2, cd=32, S=6)
+    n_train, n, hw = 6, 6, 256
+    sampling.set_references(blk, {"": dev(W.tensor("references", (n_train + 1, hw, 128), seed=13))})
+    sampling.enable_reference_sampling(blk, list(range(n)))
+    one = synth.pose_batch(1, n, seed=3, n_train=n_train)
+    same = one * 3
+    distinct = [join_cameras_as_batch([one[0][i] for i in range(n + 1)]) for _ in range(3)]
+    x = dev(W.tensor("x", (3, hw, 128), seed=13))
+    ctx = dev(W.tensor("ctx", (3, 77, 32), seed=13))
+    assert blk._duplicate_cfg_branch(same, (3, n, hw, 128)) == 1 and blk._duplicate_cfg_branch(distinct, (3, n, hw, 128)) == 0
+    outs = []
+    for pose in (same, distinct):
+        sampling.clear_rendered_feat(blk)
+        o = blk(x, context=ctx, context_ref=x, pose=pose)
+        outs.append((o[0], o[1], o[3], o[4], blk.rendered_feat.clone()))
+    for a, b_ in zip(*outs):
+        assert torch.equal(a, b_)
+    assert not torch.equal(outs[0][4][1], outs[0][4][2])  # the two conditional thirds still differ after the text cross-attention
+
+
+@torch.no_grad()
 def test_references_harvest_delta_checkpoint_and_sampling_round_trip():
     """§8 f3 on the HIP path: run the reference images through the UNet WITHOUT a pose with the harvest hooks on
     (diffusion.py:151-163), build `references` (main.py:596-607), save/load the delta checkpoint into a second UNet
