@@ -337,7 +337,7 @@ def conv_igemm(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Ten
     assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.numel() == N * H * W * cin
     assert w_packed.dtype == torch.bfloat16 and w_packed.is_contiguous() and w_packed.shape[1] == taps * cin
     assert bias is None or (bias.dtype == torch.float32 and bias.is_contiguous())
-    assert emb is None or (emb.dtype == torch.bfloat16 and emb.is_contiguous() and emb.shape == (N, cout))
+    assert emb is None or (emb.dtype == torch.bfloat16 and emb.shape == (N, cout) and emb.stride(1) == 1)  # rows may be strided
     assert res is None or (res.dtype == torch.bfloat16 and res.is_contiguous() and res.numel() == N * H * W * cout)
     out = torch.empty(N, H * W, cout, dtype=torch.bfloat16, device=x.device)
     m = N * H * W
@@ -348,8 +348,8 @@ def conv_igemm(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Ten
             raise Cd360Error("conv_igemm(want_stats=True) needs H*W % 128 == 0")
         stats = torch.empty(N, (H * W) // 128 * lib.cd360_conv_stats_slabs(cout), cout, 2, dtype=torch.float32, device=x.device)
     with _timed("conv_igemm", 2.0 * m * taps * cin * cout, 2.0 * (m * cin + m * cout + taps * cin * cout)):
-        check(lib.cd360_conv_igemm_bf16(_ptr(x), _ptr(w_packed), _ptr(bias), _ptr(emb), _ptr(res), _ptr(out), N, H, W, cin, cout, taps,
-                                       _ptr(stats), _stream()), "cd360_conv_igemm_bf16")
+        check(lib.cd360_conv_igemm_bf16(_ptr(x), _ptr(w_packed), _ptr(bias), _ptr(emb), 0 if emb is None else emb.stride(0), _ptr(res), _ptr(out),
+                                       N, H, W, cin, cout, taps, _ptr(stats), _stream()), "cd360_conv_igemm_bf16")
     return (out, stats) if want_stats else out
 
 

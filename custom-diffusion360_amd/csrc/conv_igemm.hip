@@ -22,7 +22,8 @@ struct ConvParams {
   const uint16_t* x;      // [M, Cin] pixels (n, y, x) row-major, channels contiguous
   const uint16_t* w;      // [Cout, taps * Cin] packed: k = tap * Cin + ci, tap = ky * 3 + kx
   const float* bias;      // [Cout] or null
-  const uint16_t* emb;    // [N, Cout] bf16 per-image addend or null
+  const uint16_t* emb;    // [N, Cout] bf16 per-image addend (row stride emb_stride elements) or null
+  long emb_stride;
   const uint16_t* res;    // [M, Cout] bf16 residual or null
   uint16_t* out;          // [M, Cout]
   float* stats;           // optional [n_mtiles * slabs_per_tile, Cout, 2]: per-slab channel sums / sums of squares of `out`
@@ -247,8 +248,8 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_igemm_kernel(ConvParams p) {
         for (int r = 0; r < 16; ++r) v[r] += p.bias[co + r];
       }
       if (p.emb) {
-        const u32x4 e0 = *reinterpret_cast<const u32x4*>(p.emb + (long)img * p.Cout + co);
-        const u32x4 e1 = *reinterpret_cast<const u32x4*>(p.emb + (long)img * p.Cout + co + 8);
+        const u32x4 e0 = *reinterpret_cast<const u32x4*>(p.emb + (long)img * p.emb_stride + co);
+        const u32x4 e1 = *reinterpret_cast<const u32x4*>(p.emb + (long)img * p.emb_stride + co + 8);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           v[2 * e] += bf16lo_to_f32(e0[e]); v[2 * e + 1] += bf16hi_to_f32(e0[e]);
@@ -321,7 +322,8 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_igemm_kernel(ConvParams p) {
 
 // x [N*H*W, Cin] channels-last bf16; w_packed [Cout, taps*Cin] bf16 in the kernel's K order (tap = ky*3+kx, 3x3 / stride 1 / pad 1):
 // with G = cd360_conv_k_order(Cin, taps), k = ((cg * taps + tap) * G + j) * 64 + ci % 64 where ci / 64 = cg * G + j;
-// taps = 1: the plain [Cout, Cin] matrix, out = x @ w^T; bias fp32 [Cout] | NULL; emb bf16 [N, Cout] | NULL (added per image);
+// taps = 1: the plain [Cout, Cin] matrix, out = x @ w^T; bias fp32 [Cout] | NULL; emb bf16 [N, Cout] | NULL (added per image; rows
+// emb_stride elements apart, so a column slice of a wider matrix can be passed);
 // res bf16 [N*H*W, Cout] | NULL; out bf16 [N*H*W, Cout].  Cin % 64 == 0, Cout % 16 == 0.
 // K order of w_packed for a conv with `Cin` input channels: returns G, the number of 64-channel chunks per group; the K index of
 // (tap, ci) is k = ((cg * taps + tap) * G + j) * 64 + ci % 64 with chunk = ci / 64 = cg * G + j.  G = Cin / 64 is plain tap-major
@@ -342,8 +344,8 @@ extern "C" int cd360_conv_stats_slabs(int Cout) { return (Cout % 160 == 0 && Cou
 // tile_stats (optional): fp32 [N*H*W / 128 * cd360_conv_stats_slabs(Cout), Cout, 2] = per pixel slab (32 or 64 consecutive pixels)
 // and channel, the sum and the sum of squares of the bf16 outputs -- the first pass of the GroupNorm that follows the conv
 // (cd360_gn_silu_bf16's `tile_stats`).  Requires H*W % 128 == 0 (slabs must not straddle images).
-extern "C" int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const void* bias, const void* emb, const void* res, void* out,
-                                     int N, int H, int W, int Cin, int Cout, int taps, void* tile_stats, void* stream) {
+extern "C" int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const void* bias, const void* emb, int64_t emb_stride, const void* res,
+                                     void* out, int N, int H, int W, int Cin, int Cout, int taps, void* tile_stats, void* stream) {
   if (!x || !w_packed || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return CD360_ERR_ARG;
   if ((taps != 9 && taps != 1) || Cin % 64 || Cout % 16) return CD360_ERR_SHAPE;
   if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)out | (uintptr_t)emb | (uintptr_t)res) % 16) return CD360_ERR_ARG;
@@ -351,6 +353,8 @@ extern "C" int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const 
   ConvParams p;
   p.x = (const uint16_t*)x; p.w = (const uint16_t*)w_packed; p.bias = (const float*)bias; p.emb = (const uint16_t*)emb;
   p.res = (const uint16_t*)res; p.out = (uint16_t*)out; p.stats = (float*)tile_stats;
+  p.emb_stride = emb ? emb_stride : 0;
+  if (emb && (emb_stride < Cout || emb_stride % 8)) return CD360_ERR_SHAPE;  // rows of >= Cout elements, 16-byte aligned
   if (tile_stats && ((long)H * W) % BM) return CD360_ERR_SHAPE;
   p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.taps = taps;
   p.M = (long)N * H * W;

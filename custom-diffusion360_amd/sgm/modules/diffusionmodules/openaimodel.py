@@ -11,6 +11,8 @@ integer / "continuous" / "timestep" class embeddings) raise NotImplementedError.
 """
 from __future__ import annotations
 
+import os
+
 from abc import abstractmethod
 from typing import List, Optional, Tuple, Union
 
@@ -145,8 +147,11 @@ class ResBlock(TimestepBlock):
         connection fused as residual.  No elementwise kernels are left between the four launches."""
         N, _, H, W = x.shape
         t = group_norm_tokens(self.in_layers[0], x, silu=True)  # [N, HW, Cin]
-        emb_out = self.emb_layers(emb).type(t.dtype)
-        h, h_stats = conv_tokens(self.in_layers[2], t, N, H, W, emb=emb_out.contiguous(), want_stats=True)
+        pre = getattr(emb, "_cd360_emb_outs", None)  # UNetModel: every ResBlock's emb_layers(emb) from ONE GEMM (column slices)
+        emb_out = pre[id(self)] if (pre is not None and id(self) in pre) else self.emb_layers(emb).type(t.dtype)
+        if emb_out.stride(-1) != 1 or emb_out.dtype != t.dtype:
+            emb_out = emb_out.to(t.dtype).contiguous()
+        h, h_stats = conv_tokens(self.in_layers[2], t, N, H, W, emb=emb_out, want_stats=True)
         t2 = group_norm_tokens(self.out_layers[0], tokens_to_image(h, H, W), silu=True, stats=h_stats)  # statistics from the conv epilogue
         xt = x.permute(0, 2, 3, 1)
         xt = (xt if xt.is_contiguous() else xt.contiguous()).reshape(N, H * W, -1)
@@ -245,10 +250,33 @@ class UNetModel(nn.Module):
                 self.output_blocks.append(TimestepEmbedSequential(*layers))
 
         self.out = nn.Sequential(normalization(ch), nn.SiLU(), zero_module(conv_nd(dims, model_channels, out_channels, 3, padding=1)))
+        self._emb_cat = None  # (key, concatenated emb_layers weights, biases) of _tag_emb_outs
 
     @property
     def dtype(self):
         return self.out[2].weight.dtype
+
+    def _tag_emb_outs(self, emb: torch.Tensor) -> torch.Tensor:
+        """`emb_layers` of all ResBlocks (SiLU -> Linear(4*model_channels, out_channels), openaimodel.py:296-303) applied to the
+        same `emb` as ONE GEMM against the concatenated weights: 17 SiLU launches and 17 GEMMs with M = batch (3) rows -- 17 us
+        each on hipBLASLt -- become one of each.  The result rides on the `emb` tensor object as column slices keyed by block;
+        a ResBlock that does not find its slice computes its own projection as before."""
+        if not (emb.is_cuda and emb.dtype == torch.bfloat16) or torch.is_grad_enabled() or os.environ.get("CD360_NO_EMB_MERGE"):
+            return emb
+        blocks = [m for m in self.modules() if isinstance(m, ResBlock)]
+        key = tuple((b.emb_layers[1].weight.data_ptr(), b.emb_layers[1].weight._version, b.emb_layers[1].bias._version) for b in blocks)
+        if self._emb_cat is None or self._emb_cat[0] != key:
+            w = torch.cat([b.emb_layers[1].weight.detach() for b in blocks], 0).contiguous()
+            bias = torch.cat([b.emb_layers[1].bias.detach() for b in blocks], 0).contiguous()
+            self._emb_cat = (key, w, bias)
+        allp = torch.nn.functional.linear(torch.nn.functional.silu(emb), self._emb_cat[1], self._emb_cat[2])  # [b, sum(out_channels)]
+        outs, off = {}, 0
+        for blk in blocks:
+            c = blk.out_channels
+            outs[id(blk)] = allp[:, off:off + c]
+            off += c
+        emb._cd360_emb_outs = outs
+        return emb
 
     def forward(self, x, timesteps=None, context=None, y=None, timesteps2=None, **kwargs):
         """x [b,4,L,L]; context [b (+ b*n), 77, ctx]; y [b (+ b*n), adm]; kwargs: pose, mask_ref, input_ref [b,n,4,L,L], sigmas_ref.
@@ -270,7 +298,7 @@ class UNetModel(nn.Module):
         y = y[:b]
         emb = self.time_embed(timestep_embedding(timesteps, self.model_channels).to(dt))
         assert y.shape[0] == x.shape[0]
-        emb = emb + self.label_emb(y.to(dt))
+        emb = self._tag_emb_outs(emb + self.label_emb(y.to(dt)))
 
         h = x.to(dt).contiguous(memory_format=torch.channels_last)
         if reference_image:
@@ -282,7 +310,7 @@ class UNetModel(nn.Module):
                 else:
                     t_embr = timestep_embedding(torch.zeros_like(timesteps), self.model_channels)
                 embr = self.time_embed(t_embr.to(dt))[:, None].expand(-1, n, -1).reshape(b * n, -1)
-                embr = embr + self.label_emb(yr.reshape(b * n, -1).to(dt))
+                embr = self._tag_emb_outs(embr + self.label_emb(yr.reshape(b * n, -1).to(dt)))
                 contextr = contextr.to(dt)
                 hr = xr.reshape(b * n, *xr.shape[2:]).to(dt).contiguous(memory_format=torch.channels_last)
 

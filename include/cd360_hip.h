@@ -142,8 +142,10 @@ int cd360_cfg_euler_step_f32(const void* x, const void* eps, const void* sigma, 
  * bias fp32 [Cout] | NULL; emb bf16 [N, Cout] | NULL (per-image addend); res bf16 [N*H*W, Cout] | NULL; out bf16 [N*H*W, Cout].
  * Cin % 64 == 0, Cout % 16 == 0, 16-byte aligned pointers. */
 int cd360_conv_k_order(int Cin, int taps);
-int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const void* bias, const void* emb, const void* res, void* out, int N, int H,
-                          int W, int Cin, int Cout, int taps, void* tile_stats, void* stream);
+int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const void* bias, const void* emb, int64_t emb_stride, const void* res,
+                          void* out, int N, int H, int W, int Cin, int Cout, int taps, void* tile_stats, void* stream);
+/* emb_stride: elements between the rows of `emb` (>= Cout, multiple of 8): the time-embedding projections of all ResBlocks are
+ * computed as ONE GEMM and each conv reads its column slice in place. */
 /* tile_stats (optional, NULL to skip): fp32 [N*H*W/128 * cd360_conv_stats_slabs(Cout), Cout, 2] = per pixel slab and channel the
  * sum and the sum of squares of the bf16 outputs: the statistics pass of the GroupNorm that follows the conv (openaimodel.py:
  * 352-376 h = out_layers(GN -> SiLU -> conv)), handed to cd360_gn_silu_bf16.  Requires H*W % 128 == 0. */
