@@ -326,9 +326,10 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
 
 
 def conv_igemm(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], N: int, H: int, W: int, taps: int = 9,
-               emb: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, want_stats: bool = False):
+               emb: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, want_stats: bool = False, stride: int = 1):
     """x [N*H*W, Cin] (or [N, H*W, Cin]) channels-last bf16; w_packed [Cout, taps*Cin] bf16; bias fp32 [Cout]; emb bf16 [N, Cout];
-    res bf16 [N*H*W, Cout] -> [N, H*W, Cout] bf16 = conv3x3 (taps=9) or x @ w^T (taps=1) + bias + emb[n] + res.
+    res bf16 [N*Ho*Wo, Cout] -> [N, Ho*Wo, Cout] bf16 = conv3x3 (taps=9; stride 1, or 2 with Ho = H/2, Wo = W/2) or x @ w^T (taps=1)
+    + bias + emb[n] + res.
     want_stats=True (H*W % 128 == 0): returns (out, tile_stats) with tile_stats fp32 [N, slabs, Cout, 2] = per pixel slab the channel
     sums / sums of squares of `out`, for gn_silu(out, ..., tile_stats=tile_stats)."""
     _need_gpu(x, w_packed, bias, emb, res)
@@ -338,18 +339,19 @@ def conv_igemm(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Ten
     assert w_packed.dtype == torch.bfloat16 and w_packed.is_contiguous() and w_packed.shape[1] == taps * cin
     assert bias is None or (bias.dtype == torch.float32 and bias.is_contiguous())
     assert emb is None or (emb.dtype == torch.bfloat16 and emb.shape == (N, cout) and emb.stride(1) == 1)  # rows may be strided
-    assert res is None or (res.dtype == torch.bfloat16 and res.is_contiguous() and res.numel() == N * H * W * cout)
-    out = torch.empty(N, H * W, cout, dtype=torch.bfloat16, device=x.device)
-    m = N * H * W
+    ho, wo = H // stride, W // stride
+    assert res is None or (res.dtype == torch.bfloat16 and res.is_contiguous() and res.numel() == N * ho * wo * cout)
+    out = torch.empty(N, ho * wo, cout, dtype=torch.bfloat16, device=x.device)
+    m = N * ho * wo
     lib = _lib.load()
     stats = None
     if want_stats:
-        if (H * W) % 128:
-            raise Cd360Error("conv_igemm(want_stats=True) needs H*W % 128 == 0")
-        stats = torch.empty(N, (H * W) // 128 * lib.cd360_conv_stats_slabs(cout), cout, 2, dtype=torch.float32, device=x.device)
+        if (ho * wo) % 128:
+            raise Cd360Error("conv_igemm(want_stats=True) needs Ho*Wo % 128 == 0")
+        stats = torch.empty(N, (ho * wo) // 128 * lib.cd360_conv_stats_slabs(cout), cout, 2, dtype=torch.float32, device=x.device)
     with _timed("conv_igemm", 2.0 * m * taps * cin * cout, 2.0 * (m * cin + m * cout + taps * cin * cout)):
         check(lib.cd360_conv_igemm_bf16(_ptr(x), _ptr(w_packed), _ptr(bias), _ptr(emb), 0 if emb is None else emb.stride(0), _ptr(res), _ptr(out),
-                                       N, H, W, cin, cout, taps, _ptr(stats), _stream()), "cd360_conv_igemm_bf16")
+                                       N, H, W, cin, cout, taps, stride, _ptr(stats), _stream()), "cd360_conv_igemm_bf16")
     return (out, stats) if want_stats else out
 
 

@@ -28,6 +28,7 @@ struct ConvParams {
   uint16_t* out;          // [M, Cout]
   float* stats;           // optional [n_mtiles * slabs_per_tile, Cout, 2]: per-slab channel sums / sums of squares of `out`
   int N, H, W, Cin, Cout, taps;
+  int stride, Ho, Wo;     // output pixel (yo, xo) reads input (stride*yo + ky - 1, stride*xo + kx - 1); Ho = H / stride, Wo = W / stride
   long M;
   int n_mtiles, n_ntiles, w_major;
   int kgroup;  // K order: 64-channel chunks per group (cd360_conv_k_order): group outer, tap middle, chunk-in-group inner
@@ -73,7 +74,7 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_igemm_kernel(ConvParams p) {
   const int mt = p.w_major ? tile % p.n_mtiles : tile / p.n_ntiles;
   const long m0 = (long)mt * BM;
   const int co0 = nt * BNC;
-  const int HW = p.H * p.W;
+  const int HW = p.Ho * p.Wo;  // OUTPUT pixels per image
   const int chunk = tid % CPR, lrow = tid / CPR;
 
   // ---- per-thread staging geometry: NPASS weight rows and NPASS pixel rows (fixed for the whole K loop) ----
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_igemm_kernel(ConvParams p) {
   // offset beyond num_records and the hardware returns zeros -- no branches, no zero-fill moves in the K loop.
   constexpr uint32_t OOB = 0x80000000u;
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)((long)p.Cout * p.taps * p.Cin * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)(p.M * p.Cin * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)((long)p.N * p.H * p.W * p.Cin * 2), 0x00020000);
   uint32_t woff[WPASS], xbase[NPASS];
   int py[NPASS], px[NPASS];
   bool pok[NPASS];
@@ -95,10 +96,11 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_igemm_kernel(ConvParams p) {
     const long m = m0 + lrow + RPP * ps;
     pok[ps] = m < p.M;
     const long mc = pok[ps] ? m : 0;
-    const int rem = (int)(mc % HW);
-    py[ps] = rem / p.W;
-    px[ps] = rem - py[ps] * p.W;
-    xbase[ps] = (uint32_t)((mc * p.Cin + chunk * 8) * 2);
+    const int img = (int)(mc / HW), rem = (int)(mc - (long)img * HW);
+    const int yo = rem / p.Wo, xo = rem - yo * p.Wo;
+    py[ps] = yo * p.stride;  // input coordinates of the tap centre
+    px[ps] = xo * p.stride;
+    xbase[ps] = (uint32_t)(((((long)img * p.H + py[ps]) * p.W + px[ps]) * p.Cin + chunk * 8) * 2);
   }
 
   const int kchunks = p.Cin / BK;
@@ -324,7 +326,8 @@ __global__ __launch_bounds__(256 * SPLIT) void conv_igemm_kernel(ConvParams p) {
 // with G = cd360_conv_k_order(Cin, taps), k = ((cg * taps + tap) * G + j) * 64 + ci % 64 where ci / 64 = cg * G + j;
 // taps = 1: the plain [Cout, Cin] matrix, out = x @ w^T; bias fp32 [Cout] | NULL; emb bf16 [N, Cout] | NULL (added per image; rows
 // emb_stride elements apart, so a column slice of a wider matrix can be passed);
-// res bf16 [N*H*W, Cout] | NULL; out bf16 [N*H*W, Cout].  Cin % 64 == 0, Cout % 16 == 0.
+// res bf16 [N*Ho*Wo, Cout] | NULL; out bf16 [N*Ho*Wo, Cout].  Cin % 64 == 0, Cout % 16 == 0.  stride = 1, or 2 (3x3, pad 1, even H and W:
+// Downsample.op, openaimodel.py:190-213) with Ho = H / 2, Wo = W / 2.
 // K order of w_packed for a conv with `Cin` input channels: returns G, the number of 64-channel chunks per group; the K index of
 // (tap, ci) is k = ((cg * taps + tap) * G + j) * 64 + ci % 64 with chunk = ci / 64 = cg * G + j.  G = Cin / 64 is plain tap-major
 // order (k = tap * Cin + ci), G = 1 chunk-major.  Default: the largest divisor of Cin / 64 that is <= 5 (5 for every SDXL width).
@@ -345,9 +348,10 @@ extern "C" int cd360_conv_stats_slabs(int Cout) { return (Cout % 160 == 0 && Cou
 // and channel, the sum and the sum of squares of the bf16 outputs -- the first pass of the GroupNorm that follows the conv
 // (cd360_gn_silu_bf16's `tile_stats`).  Requires H*W % 128 == 0 (slabs must not straddle images).
 extern "C" int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const void* bias, const void* emb, int64_t emb_stride, const void* res,
-                                     void* out, int N, int H, int W, int Cin, int Cout, int taps, void* tile_stats, void* stream) {
+                                     void* out, int N, int H, int W, int Cin, int Cout, int taps, int stride, void* tile_stats, void* stream) {
   if (!x || !w_packed || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return CD360_ERR_ARG;
   if ((taps != 9 && taps != 1) || Cin % 64 || Cout % 16) return CD360_ERR_SHAPE;
+  if ((stride != 1 && stride != 2) || (stride == 2 && (taps != 9 || H % 2 || W % 2))) return CD360_ERR_SHAPE;
   if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)out | (uintptr_t)emb | (uintptr_t)res) % 16) return CD360_ERR_ARG;
   if ((long)N * H * W * Cin * 2 >= (1L << 31) || (long)Cout * taps * Cin * 2 >= (1L << 31)) return CD360_ERR_SHAPE;  // 32-bit buffer offsets
   ConvParams p;
@@ -355,9 +359,10 @@ extern "C" int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const 
   p.res = (const uint16_t*)res; p.out = (uint16_t*)out; p.stats = (float*)tile_stats;
   p.emb_stride = emb ? emb_stride : 0;
   if (emb && (emb_stride < Cout || emb_stride % 8)) return CD360_ERR_SHAPE;  // rows of >= Cout elements, 16-byte aligned
-  if (tile_stats && ((long)H * W) % BM) return CD360_ERR_SHAPE;
+  if (tile_stats && ((long)(H / stride) * (W / stride)) % BM) return CD360_ERR_SHAPE;
   p.N = N; p.H = H; p.W = W; p.Cin = Cin; p.Cout = Cout; p.taps = taps;
-  p.M = (long)N * H * W;
+  p.stride = stride; p.Ho = H / stride; p.Wo = W / stride;
+  p.M = (long)N * p.Ho * p.Wo;  // output pixels
   p.n_mtiles = (int)((p.M + BM - 1) / BM);
   // 160-channel tiles (4 waves of 160 x 32) when Cout is a multiple of 160 but not of 128 (Cout = 320): exact tiling
   bool wide = Cout % 160 == 0 && Cout % 128 != 0;

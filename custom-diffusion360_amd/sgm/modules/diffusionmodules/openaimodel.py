@@ -24,6 +24,7 @@ import torch.nn.functional as F
 from cd360 import ops
 from ...modules.attention import SpatialTransformer
 from ...modules.diffusionmodules.util import (
+    conv_image,
     conv_nd,
     conv_tokens,
     group_norm_tokens,
@@ -65,10 +66,11 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
             elif isinstance(layer, SpatialTransformer):
                 x, xr, fg_mask, weights, alphas, predicted_rgb = layer(x, xr, context, contextr, pose, mask_ref, prev_weights=prev_weights)
             else:
-                x = layer(x)
+                call = (lambda v: conv_image(layer, v)) if isinstance(layer, nn.Conv2d) and not torch.is_grad_enabled() else layer
+                x = call(x)
                 if xr is not None:
                     with torch.no_grad():
-                        xr = layer(xr).detach()
+                        xr = conv_image(layer, xr).detach() if isinstance(layer, nn.Conv2d) else layer(xr).detach()
         return x, xr, fg_mask, weights, alphas, predicted_rgb
 
 
@@ -106,7 +108,7 @@ class Downsample(nn.Module):
 
     def forward(self, x):
         assert x.shape[1] == self.channels
-        return self.op(x)
+        return conv_image(self.op, x) if isinstance(self.op, nn.Conv2d) else self.op(x)
 
 
 class ResBlock(TimestepBlock):
@@ -337,5 +339,5 @@ class UNetModel(nn.Module):
                 hr = _cat_channels(hr, hrp)
             h, hr, fg, _, al, rgb = module(h, emb, context, hr, embr, contextr, pose, mask_ref=mask_ref, prev_weights=None)
             collect(fg, al, rgb)
-        out = self.out[2](tokens_to_image(group_norm_tokens(self.out[0], h, silu=True), h.shape[2], h.shape[3]))
+        out = conv_image(self.out[2], tokens_to_image(group_norm_tokens(self.out[0], h, silu=True), h.shape[2], h.shape[3]))
         return out.type(x.dtype), fg_mask_list, alphas_list, predicted_rgb_list

@@ -108,40 +108,74 @@ def tokens_to_image(t: torch.Tensor, H: int, W: int) -> torch.Tensor:
 
 
 def packed_conv(conv: nn.Conv2d):
-    """(w_packed [Cout, taps*Cin] bf16 in the kernel's K order (ops.pack_conv_weight), bias fp32 | None) for cd360_conv_igemm_bf16, cached on the
-    module and rebuilt when the parameters change.  Returns None if the conv is outside the kernel's envelope."""
+    """(w_packed [Cout_p, taps*Cin_p] bf16 in the kernel's K order (ops.pack_conv_weight), bias fp32 [Cout_p] | None) for
+    cd360_conv_igemm_bf16, cached on the module and rebuilt when the parameters change.  Cin is zero-padded to a multiple of 64 and
+    Cout to a multiple of 16 when needed (the UNet's 4 -> 320 input conv and 320 -> 4 output conv, openaimodel.py:663-670,967-973):
+    conv_tokens pads the input channels / slices the output channels accordingly.  Envelope: 3x3 pad 1 (stride 1 | 2) or 1x1
+    (stride 1), no dilation, no groups; returns None outside it."""
     w = conv.weight
     k = conv.kernel_size
-    if not (w.is_cuda and k in ((3, 3), (1, 1)) and conv.stride == (1, 1) and conv.dilation == (1, 1) and conv.groups == 1
-            and conv.padding == ((1, 1) if k == (3, 3) else (0, 0)) and w.shape[1] % 64 == 0 and w.shape[0] % 16 == 0):
+    ok3 = k == (3, 3) and conv.padding == (1, 1) and conv.stride in ((1, 1), (2, 2))
+    ok1 = k == (1, 1) and conv.padding == (0, 0) and conv.stride == (1, 1)
+    if not (w.is_cuda and (ok3 or ok1) and conv.dilation == (1, 1) and conv.groups == 1 and conv.padding_mode == "zeros"):
         return None
     key = (w.data_ptr(), w._version, w.dtype, w.device, None if conv.bias is None else conv.bias._version)
     cache = getattr(conv, "_cd360_packed", None)
     if cache is None or cache[0] != key:
-        wp = ops.pack_conv_weight(w)
-        bias = None if conv.bias is None else conv.bias.detach().float().contiguous()
-        cache = (key, wp, bias)
+        cout, cin = w.shape[:2]
+        cin_p, cout_p = -(-cin // 64) * 64, -(-cout // 16) * 16
+        wd = w.detach()
+        if (cin_p, cout_p) != (cin, cout):
+            wd = torch.nn.functional.pad(wd, (0, 0, 0, 0, 0, cin_p - cin, 0, cout_p - cout))
+        bias = None
+        if conv.bias is not None:
+            bias = torch.nn.functional.pad(conv.bias.detach().float(), (0, cout_p - cout)).contiguous()
+        cache = (key, ops.pack_conv_weight(wd), bias)
         conv._cd360_packed = cache
     return cache[1], cache[2]
 
 
 def conv_tokens(conv: nn.Conv2d, tokens: torch.Tensor, N: int, H: int, W: int, emb=None, res=None, want_stats: bool = False):
-    """conv(3x3 pad 1 | 1x1) on channels-last tokens [N, H*W, Cin] -> [N, H*W, Cout], with the per-image addend `emb` [N, Cout] and the
-    residual `res` [N, H*W, Cout] fused into the epilogue (cd360_conv_igemm_bf16); falls back to MIOpen outside the envelope.
-    want_stats=True returns (tokens, stats): the GroupNorm slab statistics of the output, or None when the kernel cannot give them."""
+    """conv(3x3 pad 1, stride 1 | 2; or 1x1) on channels-last tokens [N, H*W, Cin] -> [N, Ho*Wo, Cout], with the per-image addend
+    `emb` [N, Cout] and the residual `res` [N, Ho*Wo, Cout] fused into the epilogue (cd360_conv_igemm_bf16); MIOpen only outside the
+    kernel's envelope (none of the SDXL UNet's convs).  want_stats=True returns (tokens, stats): the GroupNorm slab statistics
+    of the output, or None when the kernel cannot give them."""
     pk = packed_conv(conv) if tokens.dtype == torch.bfloat16 else None
     if pk is None:
         y = conv(tokens_to_image(tokens, H, W))
         if emb is not None:
             y = y + emb[:, :, None, None]
-        y = y.permute(0, 2, 3, 1).reshape(N, H * W, -1)
+        y = y.permute(0, 2, 3, 1).reshape(N, y.shape[2] * y.shape[3], -1)
         y = y if res is None else y + res
         return (y, None) if want_stats else y
     taps = 9 if conv.kernel_size == (3, 3) else 1
-    if want_stats and (H * W) % 128 == 0 and not os.environ.get("CD360_NO_GN_STATS"):  # (tuning knob: GroupNorm does its own pass)
-        return ops.conv_igemm(tokens, pk[0], pk[1], N, H, W, taps, emb, res, want_stats=True)
-    y = ops.conv_igemm(tokens, pk[0], pk[1], N, H, W, taps, emb, res)
-    return (y, None) if want_stats else y
+    stride = conv.stride[0]
+    cin, cout = conv.in_channels, conv.out_channels
+    cin_p = pk[0].shape[1] // taps
+    cout_p = pk[0].shape[0]
+    if cin_p != cin:
+        tokens = torch.nn.functional.pad(tokens, (0, cin_p - cin))  # zero channels against zero weights
+    padded_out = cout_p != cout
+    if padded_out and (emb is not None or res is not None):
+        raise NotImplementedError("emb / res epilogue with a padded channel count")
+    stats_ok = want_stats and not padded_out and ((H // stride) * (W // stride)) % 128 == 0 and not os.environ.get("CD360_NO_GN_STATS")
+    out = ops.conv_igemm(tokens, pk[0], pk[1], N, H, W, taps, emb, res, want_stats=stats_ok, stride=stride)
+    y, stats = out if stats_ok else (out, None)
+    if padded_out:
+        y = y[..., :cout]
+    return (y, stats) if want_stats else y
+
+
+def conv_image(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
+    """A plain nn.Conv2d call site (the UNet's input conv, Downsample.op, the output conv) on the implicit-GEMM kernel: image in,
+    image out, channels-last in between; CPU / non-bf16 tensors go through the module itself."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16) or os.environ.get("CD360_EDGE_CONVS_MIOPEN") or packed_conv(conv) is None:
+        return conv(x)  # (the environment knob keeps these four convs on MIOpen, for A/B runs)
+    N, _, H, W = x.shape
+    xt = x.permute(0, 2, 3, 1)
+    xt = (xt if xt.is_contiguous() else xt.contiguous()).reshape(N, H * W, -1)
+    s = conv.stride[0]
+    return tokens_to_image(conv_tokens(conv, xt, N, H, W), H // s, W // s)
 
 
 class GroupNorm32(nn.GroupNorm):

@@ -143,7 +143,8 @@ int cd360_cfg_euler_step_f32(const void* x, const void* eps, const void* sigma, 
  * Cin % 64 == 0, Cout % 16 == 0, 16-byte aligned pointers. */
 int cd360_conv_k_order(int Cin, int taps);
 int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const void* bias, const void* emb, int64_t emb_stride, const void* res,
-                          void* out, int N, int H, int W, int Cin, int Cout, int taps, void* tile_stats, void* stream);
+                          void* out, int N, int H, int W, int Cin, int Cout, int taps, int stride, void* tile_stats, void* stream);
+/* stride: 1, or 2 for Downsample.op (openaimodel.py:190-213: conv3x3, stride 2, pad 1; H, W even; out is [N*(H/2)*(W/2), Cout]). */
 /* emb_stride: elements between the rows of `emb` (>= Cout, multiple of 8): the time-embedding projections of all ResBlocks are
  * computed as ONE GEMM and each conv reads its column slice in place. */
 /* tile_stats (optional, NULL to skip): fp32 [N*H*W/128 * cd360_conv_stats_slabs(Cout), Cout, 2] = per pixel slab and channel the

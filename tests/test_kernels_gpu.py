@@ -265,6 +265,25 @@ def test_conv_epilogue_groupnorm_statistics(N, H, W, Cin, Cout):
         ops.conv_igemm(x[:, :100].contiguous(), wp, bias, N, 10, 10, 9, want_stats=True)  # H*W % 128 != 0
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout,stride", [(2, 16, 16, 64, 64, 2), (3, 32, 32, 320, 320, 2), (1, 8, 12, 128, 160, 2), (2, 16, 16, 4, 320, 1), (2, 16, 16, 320, 4, 1)])
+def test_conv_stride2_and_padded_channels_through_the_module_wrapper(N, H, W, Cin, Cout, stride):
+    """Downsample.op (conv3x3 stride 2 pad 1, openaimodel.py:190-213) and the UNet's 4 -> 320 / 320 -> 4 convs (:663-670,967-973)
+    on the implicit-GEMM kernel: conv_image(nn.Conv2d, x) vs torch's fp32 conv2d on the same bf16 inputs."""
+    from sgm.modules.diffusionmodules.util import conv_image, packed_conv
+    g = torch.Generator().manual_seed(Cin * 7 + Cout + stride)
+    conv = torch.nn.Conv2d(Cin, Cout, 3, stride=stride, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(bf(torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5))
+        conv.bias.copy_(bf(torch.randn(Cout, generator=g)))
+    x = bf(torch.randn(N, Cin, H, W, generator=g))
+    want = torch.nn.functional.conv2d(x, conv.weight.float(), conv.bias.float(), stride=stride, padding=1)
+    conv = conv.to(DEV, torch.bfloat16)
+    assert packed_conv(conv) is not None
+    with torch.no_grad():
+        got = conv_image(conv, x.to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last))
+    assert got.shape == want.shape and rel(got, want) < 8e-3
+
+
 # ------------------------------------------------------------------------------------------------ GroupNorm + SiLU (K7)
 @pytest.mark.parametrize("N,P,C,silu", [(2, 64, 64, True), (3, 1024, 320, True), (1, 4096, 640, False), (2, 256, 2560, True), (1, 100, 960, False)])
 def test_gn_silu(N, P, C, silu):
@@ -513,6 +532,25 @@ def test_conv_epilogue_groupnorm_statistics(N, H, W, Cin, Cout):
     assert torch.equal(a, ops.gn_silu(out, gamma, beta, 32, 1e-5, True, tile_stats=stats))  # deterministic
     with pytest.raises(Exception):
         ops.conv_igemm(x[:, :100].contiguous(), wp, bias, N, 10, 10, 9, want_stats=True)  # H*W % 128 != 0
+
+
+@pytest.mark.parametrize("N,H,W,Cin,Cout,stride", [(2, 16, 16, 64, 64, 2), (3, 32, 32, 320, 320, 2), (1, 8, 12, 128, 160, 2), (2, 16, 16, 4, 320, 1), (2, 16, 16, 320, 4, 1)])
+def test_conv_stride2_and_padded_channels_through_the_module_wrapper(N, H, W, Cin, Cout, stride):
+    """Downsample.op (conv3x3 stride 2 pad 1, openaimodel.py:190-213) and the UNet's 4 -> 320 / 320 -> 4 convs (:663-670,967-973)
+    on the implicit-GEMM kernel: conv_image(nn.Conv2d, x) vs torch's fp32 conv2d on the same bf16 inputs."""
+    from sgm.modules.diffusionmodules.util import conv_image, packed_conv
+    g = torch.Generator().manual_seed(Cin * 7 + Cout + stride)
+    conv = torch.nn.Conv2d(Cin, Cout, 3, stride=stride, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(bf(torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5))
+        conv.bias.copy_(bf(torch.randn(Cout, generator=g)))
+    x = bf(torch.randn(N, Cin, H, W, generator=g))
+    want = torch.nn.functional.conv2d(x, conv.weight.float(), conv.bias.float(), stride=stride, padding=1)
+    conv = conv.to(DEV, torch.bfloat16)
+    assert packed_conv(conv) is not None
+    with torch.no_grad():
+        got = conv_image(conv, x.to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last))
+    assert got.shape == want.shape and rel(got, want) < 8e-3
 
 
 # ------------------------------------------------------------------------------------------------ GroupNorm + SiLU (K7)
