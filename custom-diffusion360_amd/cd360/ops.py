@@ -326,7 +326,8 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
 
 
 def conv_igemm(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], N: int, H: int, W: int, taps: int = 9,
-               emb: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, want_stats: bool = False, stride: int = 1):
+               emb: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, want_stats: bool = False, stride: int = 1,
+               alg_channels: Optional[tuple] = None):
     """x [N*H*W, Cin] (or [N, H*W, Cin]) channels-last bf16; w_packed [Cout, taps*Cin] bf16; bias fp32 [Cout]; emb bf16 [N, Cout];
     res bf16 [N*Ho*Wo, Cout] -> [N, Ho*Wo, Cout] bf16 = conv3x3 (taps=9; stride 1, or 2 with Ho = H/2, Wo = W/2) or x @ w^T (taps=1)
     + bias + emb[n] + res.
@@ -349,7 +350,8 @@ def conv_igemm(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Ten
         if (ho * wo) % 128:
             raise Cd360Error("conv_igemm(want_stats=True) needs Ho*Wo % 128 == 0")
         stats = torch.empty(N, (ho * wo) // 128 * lib.cd360_conv_stats_slabs(cout), cout, 2, dtype=torch.float32, device=x.device)
-    with _timed("conv_igemm", 2.0 * m * taps * cin * cout, 2.0 * (m * cin + m * cout + taps * cin * cout)):
+    acin, acout = alg_channels or (cin, cout)  # un-padded channel counts for the algorithmic FLOP / byte accounting
+    with _timed("conv_igemm", 2.0 * m * taps * acin * acout, 2.0 * (N * H * W * acin + m * acout + taps * acin * acout)):
         check(lib.cd360_conv_igemm_bf16(_ptr(x), _ptr(w_packed), _ptr(bias), _ptr(emb), 0 if emb is None else emb.stride(0), _ptr(res), _ptr(out),
                                        N, H, W, cin, cout, taps, stride, _ptr(stats), _stream()), "cd360_conv_igemm_bf16")
     return (out, stats) if want_stats else out

@@ -159,7 +159,7 @@ def conv_tokens(conv: nn.Conv2d, tokens: torch.Tensor, N: int, H: int, W: int, e
     if padded_out and (emb is not None or res is not None):
         raise NotImplementedError("emb / res epilogue with a padded channel count")
     stats_ok = want_stats and not padded_out and ((H // stride) * (W // stride)) % 128 == 0 and not os.environ.get("CD360_NO_GN_STATS")
-    out = ops.conv_igemm(tokens, pk[0], pk[1], N, H, W, taps, emb, res, want_stats=stats_ok, stride=stride)
+    out = ops.conv_igemm(tokens, pk[0], pk[1], N, H, W, taps, emb, res, want_stats=stats_ok, stride=stride, alg_channels=(cin, cout))
     y, stats = out if stats_ok else (out, None)
     if padded_out:
         y = y[..., :cout]
