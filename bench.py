@@ -103,6 +103,14 @@ class Sampler:
             else:
                 buf.copy_(blk.rendered_feat)
             blk.rendered_feat = blk._static_rendered
+            # the reference half of pose_emb_layers (rendered_feat @ Wb^T) lives beside the render: same treatment
+            wa, wb = blk._pose_weights()
+            c = blk.rendered_feat.shape[-1]
+            if getattr(blk, "_static_proj", None) is None:
+                blk._static_proj = torch.mm(blk.rendered_feat.reshape(-1, c), wb)
+            else:
+                torch.mm(blk.rendered_feat.reshape(-1, c), wb, out=blk._static_proj)
+            blk._rendered_proj = (blk.rendered_feat, blk.rendered_feat._version, wb, blk._static_proj)
         for att in sampling._cross_attentions(self.net):  # same for the per-image context K / V^T cache
             if att._kv_cache is None:
                 continue
@@ -156,12 +164,12 @@ class Sampler:
 
     def _snapshot_pins(self):
         from cd360 import sampling
-        return ([(blk, blk.rendered_feat) for _, blk in sampling.pose_blocks(self.net)],
+        return ([(blk, blk.rendered_feat, blk._rendered_proj) for _, blk in sampling.pose_blocks(self.net)],
                 [(att, att._kv_cache) for att in sampling._cross_attentions(self.net)])
 
     def _restore_pins(self):
-        for blk, r in self._pins[0]:
-            blk.rendered_feat = r
+        for blk, r, proj in self._pins[0]:
+            blk.rendered_feat, blk._rendered_proj = r, proj
         for att, kv in self._pins[1]:
             att._kv_cache = kv
 

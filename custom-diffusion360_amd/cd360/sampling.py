@@ -67,5 +67,7 @@ def clear_rendered_feat(model: torch.nn.Module) -> None:
     context K / V^T cache."""
     for _, blk in pose_blocks(model):
         blk.rendered_feat = None
+        if hasattr(blk, "_rendered_proj"):
+            blk._rendered_proj = None  # rendered_feat @ Wb^T kept beside the cached render
     for att in _cross_attentions(model):
         att._kv_cache = None

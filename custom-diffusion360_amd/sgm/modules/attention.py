@@ -218,6 +218,7 @@ class BasicTransformerBlock(nn.Module):
         self.checkpoint = checkpoint
         self._pose_split = None
         self._ref_tables = None
+        self._rendered_proj = None  # (rendered_feat object, its version, Wb, rendered_feat @ Wb^T) of _pose_embed_cached
 
     # ------------------------------------------------------------------------------------------------ pose path
     def _pose_weights(self):
@@ -235,6 +236,20 @@ class BasicTransformerBlock(nn.Module):
         out = torch.mm(x.reshape(-1, c), wa)
         out.addmm_(xref.reshape(-1, c).to(out.dtype), wb)
         return out.reshape(b, n, c)
+
+    def _pose_embed_cached(self, x: torch.Tensor) -> torch.Tensor:
+        """pose_embed(x, rendered_feat) on the sampling path: the reference half `rendered_feat @ Wb^T` is constant while the render
+        is cached (49 of 50 steps), so it is kept beside it (`_rendered_proj`) and the step runs ONE GEMM, x Wa^T with the kept
+        half as the accumulator input, instead of two.  The kept half is tied to the (tensor object, version) it was computed
+        from and to the weight split; anything else recomputes it."""
+        wa, wb = self._pose_weights()
+        rf = self.rendered_feat
+        b, n, c = x.shape
+        tag = self._rendered_proj
+        if tag is None or tag[0] is not rf or tag[1] != rf._version or tag[2] is not wb or os.environ.get("CD360_NO_POSE_PROJ_CACHE"):
+            tag = (rf, rf._version, wb, torch.mm(rf.reshape(-1, c).to(x.dtype), wb))
+            self._rendered_proj = tag
+        return torch.addmm(tag[3], x.reshape(-1, c), wa).reshape(b, n, c)
 
     def reference_attn(self, x, context_ref, context, pose, prev_weights, mask_ref, tables=None, dims=None):
         """FeatureNeRF render of the reference features at the target pose (attention.py:571-598).
@@ -352,7 +367,7 @@ class BasicTransformerBlock(nn.Module):
                         cref = self._references_as_context(x.size(0))
                         xref, fg_mask, weights, alphas, predicted_rgb = self.reference_attn(x, cref, context, pose, prev_weights, mask_ref)
                     self.rendered_feat = xref
-                x = self.pose_embed(x, self.rendered_feat)
+                x = self._pose_embed_cached(x)
             else:
                 b = x.size(0)
                 cref = context_ref if context_ref.dim() == 4 else context_ref.reshape(b, context_ref.size(0) // b, *context_ref.shape[1:])
