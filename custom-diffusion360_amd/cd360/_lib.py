@@ -19,8 +19,7 @@ _I64P = ctypes.POINTER(c_int64)
 SIGNATURES = {
     "cd360_attn_fwd_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _I64P, _I64P, _I64P, _I64P, c_float, _P]),
     "cd360_attn_fwd_fp8mfma_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _I64P, _I64P, _I64P, _I64P, c_float, _F32P, _P]),
-    "cd360_attn_vt_workspace_bytes": (c_int64, [c_int, c_int]),
-    "cd360_attn_fwd_xformers_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
+    "cd360_attn_fwd_xformers_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "cd360_patch_rays": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "cd360_ray_project_index": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "cd360_feature_gather": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),

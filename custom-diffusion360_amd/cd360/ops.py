@@ -79,47 +79,49 @@ def _need_gpu(*ts):
 
 
 # ----------------------------------------------------------------------------------------------- attention
-def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, nk: Optional[int] = None,
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, nk: Optional[int] = None,
               out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """softmax(q k^T / 8) v per head, projection layouts consumed in place.
-    q [b, Nq, H*64], k [b, Nk, H*64] (last dim contiguous), vt [b, H*64, >=round_up(Nk,8)] (V transposed) -> [b, Nq, H*64]."""
-    _need_gpu(q, k, vt)
+    q [b, Nq, H*64], k, v [b, >=Nk, H*64] (last dim contiguous; row / batch strides free, e.g. slices of one merged q|k|v
+    projection) -> [b, Nq, H*64].  `nk` limits the keys when k / v are padded."""
+    _need_gpu(q, k, v)
     b, nq, inner = q.shape
-    assert inner == heads * 64 and q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16 and vt.dtype == torch.bfloat16
-    assert q.stride(2) == 1 and k.stride(2) == 1 and vt.stride(2) == 1
+    assert inner == heads * 64 and q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16 and v.dtype == torch.bfloat16
+    assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1 and k.shape[-1] == inner and v.shape[-1] == inner
     nk = k.shape[1] if nk is None else nk
+    assert v.shape[1] >= nk and k.shape[1] >= nk
     if out is None:
         out = torch.empty(b, nq, inner, dtype=torch.bfloat16, device=q.device)
     lib = _lib.load()
     with _timed("attn_fwd", 4.0 * b * heads * nq * nk * 64, 2.0 * (2 * b * nq * inner + 2 * b * nk * inner)):
       check(
         lib.cd360_attn_fwd_bf16(
-            _ptr(q), _ptr(k), _ptr(vt), _ptr(out), b, heads, nq, nk,
+            _ptr(q), _ptr(k), _ptr(v), _ptr(out), b, heads, nq, nk,
             _I64x3(q.stride(0), 64, q.stride(1)), _I64x3(k.stride(0), 64, k.stride(1)),
-            _I64x3(vt.stride(0), 64 * vt.stride(1), vt.stride(1)), _I64x3(out.stride(0), 64, out.stride(1)),
+            _I64x3(v.stride(0), 64, v.stride(1)), _I64x3(out.stride(0), 64, out.stride(1)),
             64 ** -0.5, _stream()),
         "cd360_attn_fwd_bf16")
     return out
 
 
-def attention_fp8mfma(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, heads: int, nk: Optional[int] = None, amax=None) -> torch.Tensor:
+def attention_fp8mfma(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, nk: Optional[int] = None, amax=None) -> torch.Tensor:
     """`attention` with both contractions on fp8 (e4m3) MFMA -- BASELINE configs[4], Nk <= 96 only.  Same bf16 tensors; the
     per-tensor scales come from `amax` = (max|q|, max|k|, max|v|), measured here (one host sync) when not given."""
-    _need_gpu(q, k, vt)
+    _need_gpu(q, k, v)
     b, nq, inner = q.shape
-    assert inner == heads * 64 and q.dtype == k.dtype == vt.dtype == torch.bfloat16
-    assert q.stride(2) == 1 and k.stride(2) == 1 and vt.stride(2) == 1
+    assert inner == heads * 64 and q.dtype == k.dtype == v.dtype == torch.bfloat16
+    assert q.stride(2) == 1 and k.stride(2) == 1 and v.stride(2) == 1
     nk = k.shape[1] if nk is None else nk
     if amax is None:
-        amax = torch.stack([q.abs().amax(), k[:, :nk].abs().amax(), vt[:, :, :nk].abs().amax()]).float().tolist()
+        amax = torch.stack([q.abs().amax(), k[:, :nk].abs().amax(), v[:, :nk].abs().amax()]).float().tolist()
     out = torch.empty(b, nq, inner, dtype=torch.bfloat16, device=q.device)
     arr = (ctypes.c_float * 3)(*[float(a) for a in amax])
     with _timed("attn_fp8mfma", 4.0 * b * heads * nq * nk * 64, 2.0 * (2 * b * nq * inner + 2 * b * nk * inner)):
       check(
         _lib.load().cd360_attn_fwd_fp8mfma_bf16(
-            _ptr(q), _ptr(k), _ptr(vt), _ptr(out), b, heads, nq, nk,
+            _ptr(q), _ptr(k), _ptr(v), _ptr(out), b, heads, nq, nk,
             _I64x3(q.stride(0), 64, q.stride(1)), _I64x3(k.stride(0), 64, k.stride(1)),
-            _I64x3(vt.stride(0), 64 * vt.stride(1), vt.stride(1)), _I64x3(out.stride(0), 64, out.stride(1)),
+            _I64x3(v.stride(0), 64, v.stride(1)), _I64x3(out.stride(0), 64, out.stride(1)),
             64 ** -0.5, arr, _stream()),
         "cd360_attn_fwd_fp8mfma_bf16")
     return out
@@ -137,10 +139,8 @@ def memory_efficient_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor
         raise Cd360Error(f"head dim {d} unsupported (SDXL uses 64)")
     dt = q.dtype
     q, k, v = (t.to(torch.bfloat16).contiguous() for t in (q, k, v))
-    lib = _lib.load()
-    ws = torch.empty(lib.cd360_attn_vt_workspace_bytes(bh, nk), dtype=torch.uint8, device=q.device)
     out = torch.empty_like(q)
-    check(lib.cd360_attn_fwd_xformers_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(ws), bh, nq, nk, 64 ** -0.5, _stream()),
+    check(_lib.load().cd360_attn_fwd_xformers_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), bh, nq, nk, 64 ** -0.5, _stream()),
           "cd360_attn_fwd_xformers_bf16")
     return out.to(dt)
 

@@ -10,9 +10,11 @@
 //     the row max / row sum of the online softmax are in-register reductions plus one exchange with lane^32.
 //   * O^T = V^T P^T: the P^T B-operand is taken straight from the lane's own S^T accumulator registers
 //     (the contraction order over keys is permuted identically on the V^T side), so P never goes through LDS.
-//   * K tile in LDS is XOR-swizzled at 16-B granularity (conflict-free ds_read_b128); V arrives already
-//     transposed ([.., d, key], produced for free by the projection GEMM) and sits in LDS with a 136-B row
-//     pitch (conflict-free ds_read_b64).
+//   * K tile in LDS is XOR-swizzled at 16-B granularity (conflict-free ds_read_b128).  V is taken ROW-MAJOR ([.., key, d], a slice
+//     of the same merged q|k|v projection GEMM as q and k), staged like K and read as the V^T A-operand with gfx950's transposing
+//     LDS read ds_read_b64_tr_b16 (lane mapping measured with tools/probe/tr_read_probe.hip): inside a group of 16 lanes, lane s
+//     supplies the address of 4 consecutive d of key s>>2 (d-chunk s&3) and lane i receives, for its d = i, the 4 keys.  A 32-B
+//     XOR swizzle ((row>>1)&3) keeps the 512 bytes of one wave-instruction at exactly two accesses per bank.
 //   * all tensors are addressed through explicit strides, so the kernel reads the projection outputs
 //     [b, N, H*64] in place and writes [b, N, H*64] directly: no head split/merge copies.
 #include "cd360_common.h"
@@ -23,23 +25,26 @@ namespace {
 struct AttnParams {
   const uint16_t* q;
   const uint16_t* k;
-  const uint16_t* vt;
+  const uint16_t* v;
   uint16_t* o;
   int B, H, Nq, Nk;
   long q_sb, q_sh, q_sn;  // element strides, d contiguous
   long k_sb, k_sh, k_sn;
-  long v_sb, v_sh, v_sd;  // vt[b][h][d][key], key contiguous
+  long v_sb, v_sh, v_sn;  // v[b][h][key][d], d contiguous (like k)
   long o_sb, o_sh, o_sn;
   float scale_log2e;
   int n_qtiles;
-  int fast;  // 1: full tiles may use 32-bit buffer offsets (K and V^T of one head span < 2 GiB)
+  int fast;  // 1: full tiles may use 32-bit buffer offsets (K and V of one head span < 2 GiB)
   float inv_sq, inv_sk, inv_sv, o_scale;  // fp8-MFMA variant: 1 / per-tensor e4m3 scales, and sv / 256 for the output
 };
 
 constexpr int BN = 64;        // keys per tile
 constexpr int K_PITCH = 128;  // bytes per K row in LDS (64 d * 2 B), XOR-swizzled
-constexpr int V_PITCH = 136;  // bytes per V^T row in LDS (64 keys * 2 B + 8 B pad)
-constexpr int TILE_BYTES = BN * K_PITCH + 64 * V_PITCH;
+constexpr int V_PITCH = 128;  // bytes per V row (key) in LDS, 32-B XOR-swizzled for the transposing read
+constexpr int TILE_BYTES = BN * K_PITCH + BN * V_PITCH;
+
+// LDS byte offset of 16-byte chunk `chunk` of V row `row` (32-B granules swapped by (row >> 1) & 3)
+__device__ __forceinline__ int v_swz(int row, int chunk) { return row * V_PITCH + ((chunk ^ (((row >> 1) & 3) << 1)) << 4); }
 
 // One K/V tile on its way from HBM to LDS: every thread carries 2 x 16 B of K and 2 x 16 B of V^T in registers, so the
 // loads of tile t+1 are in flight while tile t is being consumed (split issue / write, LDS double-buffered).
@@ -48,28 +53,16 @@ struct TileRegs {
 };
 
 __device__ __forceinline__ void tile_load(const AttnParams& p, const uint16_t* kp, const uint16_t* vp, int kt0, int tid, TileRegs& r) {
-  const bool ragged = kt0 + BN > p.Nk;
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
+  for (int pass = 0; pass < 2; ++pass) {  // rows (keys) beyond Nk are zero in both tiles: their P is exactly 0 and 0 * 0 adds nothing
     const int row = (tid >> 3) + 32 * pass, chunk = tid & 7;
-    u32x4 kv = {0u, 0u, 0u, 0u};
+    u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
     const int key = kt0 + row;
-    if (key < p.Nk) kv = *reinterpret_cast<const u32x4*>(kp + (long)key * p.k_sn + chunk * 8);
-    r.k[pass] = kv;
-    const int key0 = kt0 + chunk * 8;
-    u32x4 vv = {0u, 0u, 0u, 0u};
-    if (key0 < p.Nk) {
-      vv = *reinterpret_cast<const u32x4*>(vp + (long)row * p.v_sd + key0);
-      if (ragged) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          uint32_t w = vv[e];
-          if (key0 + 2 * e >= p.Nk) w &= 0xffff0000u;
-          if (key0 + 2 * e + 1 >= p.Nk) w &= 0x0000ffffu;
-          vv[e] = w;
-        }
-      }
+    if (key < p.Nk) {
+      kv = *reinterpret_cast<const u32x4*>(kp + (long)key * p.k_sn + chunk * 8);
+      vv = *reinterpret_cast<const u32x4*>(vp + (long)key * p.v_sn + chunk * 8);
     }
+    r.k[pass] = kv;
     r.v[pass] = vv;
   }
 }
@@ -79,9 +72,7 @@ __device__ __forceinline__ void tile_store(unsigned char* Ks, unsigned char* Vs,
   for (int pass = 0; pass < 2; ++pass) {
     const int row = (tid >> 3) + 32 * pass, chunk = tid & 7;
     *reinterpret_cast<u32x4*>(Ks + row * K_PITCH + ((chunk ^ ((row >> 1) & 7)) << 4)) = r.k[pass];
-    u32x2 lo = {r.v[pass][0], r.v[pass][1]}, hi = {r.v[pass][2], r.v[pass][3]};
-    *reinterpret_cast<u32x2*>(Vs + row * V_PITCH + chunk * 16) = lo;
-    *reinterpret_cast<u32x2*>(Vs + row * V_PITCH + chunk * 16 + 8) = hi;
+    *reinterpret_cast<u32x4*>(Vs + v_swz(row, chunk)) = r.v[pass];
   }
 }
 
@@ -101,12 +92,29 @@ __device__ __forceinline__ void tile_store_to(unsigned char* lds, int kso, int v
   unsigned char* Ks = lds + BUF * TILE_BYTES;
   unsigned char* Vs = Ks + BN * K_PITCH;
 #pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {  // rows + 32: the swizzle term ((row >> 1) & 7) is unchanged, so a constant offset
+  for (int pass = 0; pass < 2; ++pass) {  // rows + 32: both swizzle terms ((row >> 1) & 7, & 3) are unchanged, so a constant offset
     *reinterpret_cast<u32x4*>(Ks + kso + pass * 32 * K_PITCH) = r.k[pass];
-    u32x2 lo = {r.v[pass][0], r.v[pass][1]}, hi = {r.v[pass][2], r.v[pass][3]};
-    *reinterpret_cast<u32x2*>(Vs + vso + pass * 32 * V_PITCH) = lo;
-    *reinterpret_cast<u32x2*>(Vs + vso + pass * 32 * V_PITCH + 8) = hi;
+    *reinterpret_cast<u32x4*>(Vs + vso + pass * 32 * V_PITCH) = r.v[pass];
   }
+}
+
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+
+// per-lane byte offset (inside a V tile) of the transposing reads for the 32-channel block `db`; key group kk adds kk * 16 rows
+__device__ __forceinline__ int v_frag_offset(int l31, int hh, int db) {
+  const int i = l31 & 15;
+  return (4 * hh + (i >> 2)) * V_PITCH + (((2 * db + (l31 >> 4)) ^ ((2 * hh + (i >> 3)) & 3)) << 5) + 8 * (i & 3);
+}
+
+// V^T A-fragment (rows = 32 channels of block db, k = 16 keys of group kk, in the key order of the P registers) from a row-major
+// V tile: two ds_read_b64_tr_b16, keys 16kk + 4hh + {0..3} and 16kk + 8 + 4hh + {0..3}
+__device__ __forceinline__ bf16x8 v_frag(const unsigned char* Vs, int voff_db, int kk) {
+  typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(Vs + voff_db + kk * 16 * V_PITCH));
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(Vs + voff_db + kk * 16 * V_PITCH + 8 * V_PITCH));
+  typedef __attribute__((ext_vector_type(8))) short s16x8;
+  const s16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, v);
 }
 
 struct WaveState {
@@ -119,7 +127,7 @@ struct WaveState {
 // 32-key halves multiplied); the ragged last tile takes the other instantiation.  BUF is a template parameter so that every LDS
 // address is `per-lane offset computed before the loop + immediate`.
 template <int BUF, bool FULL>
-__device__ __forceinline__ void consume_tile(const AttnParams& p, const unsigned char* lds, int kt0, const int (&koff)[4], int voff,
+__device__ __forceinline__ void consume_tile(const AttnParams& p, const unsigned char* lds, int kt0, const int (&koff)[4], const int (&voff)[2],
                                              int hh, float c, WaveState& w) {
   const unsigned char* Ks = lds + BUF * TILE_BYTES;
   const unsigned char* Vs = Ks + BN * K_PITCH;
@@ -198,12 +206,8 @@ __device__ __forceinline__ void consume_tile(const AttnParams& p, const unsigned
     if (FULL || kk < 2 * nkb) {
 #pragma unroll
       for (int db = 0; db < 2; ++db) {
-        const unsigned char* vrow = Vs + db * 32 * V_PITCH + 32 * kk + voff;
-        const u32x2 v0 = *reinterpret_cast<const u32x2*>(vrow);
-        const u32x2 v1 = *reinterpret_cast<const u32x2*>(vrow + 16);
-        u32x4 vw = {v0[0], v0[1], v1[0], v1[1]};
         u32x4 pw = {pk[kk * 4 + 0], pk[kk * 4 + 1], pk[kk * 4 + 2], pk[kk * 4 + 3]};
-        w.oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vw), __builtin_bit_cast(bf16x8, pw), w.oT[db], 0, 0, 0);
+        w.oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v_frag(Vs, voff[db], kk), __builtin_bit_cast(bf16x8, pw), w.oT[db], 0, 0, 0);
       }
     }
   }
@@ -221,7 +225,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams p) {
   const int b = bh / p.H, h = bh - b * p.H;
   const uint16_t* qp = p.q + b * p.q_sb + h * p.q_sh;
   const uint16_t* kp = p.k + b * p.k_sb + h * p.k_sh;
-  const uint16_t* vp = p.vt + b * p.v_sb + h * p.v_sh;
+  const uint16_t* vp = p.v + b * p.v_sb + h * p.v_sh;
   uint16_t* op = p.o + b * p.o_sb + h * p.o_sh;
 
   WaveState w;
@@ -242,16 +246,16 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams p) {
   int koff[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) koff[ks] = l31 * K_PITCH + (((2 * ks + hh) ^ ((l31 >> 1) & 7)) << 4);
-  const int voff = l31 * V_PITCH + 8 * hh;
+  const int voff[2] = {v_frag_offset(l31, hh, 0), v_frag_offset(l31, hh, 1)};
   const int srow = tid >> 3, schunk = tid & 7;  // staging: thread -> (row, 16-byte chunk), rows + 32 on the second pass
-  const int kso = srow * K_PITCH + ((schunk ^ ((srow >> 1) & 7)) << 4), vso = srow * V_PITCH + schunk * 16;
-  const int kgo = (int)(srow * p.k_sn * 2) + schunk * 16, vgo = (int)(srow * p.v_sd * 2) + schunk * 16;
-  const int kpass = (int)(32 * p.k_sn * 2), vpass = (int)(32 * p.v_sd * 2);
+  const int kso = srow * K_PITCH + ((schunk ^ ((srow >> 1) & 7)) << 4), vso = v_swz(srow, schunk);
+  const int kgo = (int)(srow * p.k_sn * 2) + schunk * 16, vgo = (int)(srow * p.v_sn * 2) + schunk * 16;
+  const int kpass = (int)(32 * p.k_sn * 2), vpass = (int)(32 * p.v_sn * 2);
   const int n_tiles = (p.Nk + BN - 1) / BN;
   const int n_full = p.fast ? p.Nk / BN : 0;  // tiles that take the unguarded buffer-load / unmasked path
   const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, p.fast ? (int)((long)p.Nk * p.k_sn * 2) : 0, 0x00020000);
-  const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vp, 0, p.fast ? (int)(64 * p.v_sd * 2) : 0, 0x00020000);
-  const int kstep = (int)(BN * p.k_sn * 2);
+  const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vp, 0, p.fast ? (int)((long)p.Nk * p.v_sn * 2) : 0, 0x00020000);
+  const int kstep = (int)(BN * p.k_sn * 2), vstep = (int)(BN * p.v_sn * 2);
 
   TileRegs tr;
   tile_load(p, kp, vp, 0, tid, tr);
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams p) {
     const int t_ = (T), kt0 = t_ * BN;                                                                  \
     const bool more = t_ + 1 < n_tiles;                                                                 \
     if (more) {                                                                                         \
-      if (t_ + 1 < n_full) tile_load_full(krsrc, vrsrc, kgo, vgo, (t_ + 1) * kstep, (kt0 + BN) * 2, kpass, vpass, tr); \
+      if (t_ + 1 < n_full) tile_load_full(krsrc, vrsrc, kgo, vgo, (t_ + 1) * kstep, (t_ + 1) * vstep, kpass, vpass, tr); \
       else tile_load(p, kp, vp, kt0 + BN, tid, tr);                                                     \
     }                                                                                                   \
     if (t_ < n_full) consume_tile<BUF, true>(p, lds, kt0, koff, voff, hh, c, w);                        \
@@ -323,14 +327,13 @@ __device__ __forceinline__ long bf16x8_to_fp8x8(bf16x8 v, float inv_scale) {
 template <int NKB, bool FP8>
 __global__ __launch_bounds__(256, 2) void attn_smallk_kernel(AttnParams p) {
   constexpr int NKEYS = NKB * 32;
-  constexpr int VP = NKEYS * 2 + 16;  // V^T row pitch in bytes (conflict-free ds_read_b64, as V_PITCH)
-  // K / V^T staging (read once into registers) + per wave one 32 x 128 B block each for Q (in) and O (out): rows move between
+  // K / V staging (read once into registers) + per wave one 32 x 128 B block each for Q (in) and O (out): rows move between
   // HBM and LDS as FULL 128-byte lines (8 lanes x 16 B per row) and are re-read in MFMA fragment shape from LDS -- loading the
   // fragments straight from global memory touches every line four times with 32-byte pieces and capped the kernel at 2.5 TB/s.
-  __shared__ __attribute__((aligned(16))) unsigned char lds[NKEYS * K_PITCH + 64 * VP + 4 * 2 * 32 * K_PITCH];
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NKEYS * K_PITCH + NKEYS * V_PITCH + 4 * 2 * 32 * K_PITCH];
   unsigned char* Ks = lds;
   unsigned char* Vs = lds + NKEYS * K_PITCH;
-  unsigned char* Qs = lds + NKEYS * K_PITCH + 64 * VP + (threadIdx.x >> 6) * (2 * 32 * K_PITCH);  // this wave's Q block
+  unsigned char* Qs = lds + NKEYS * K_PITCH + NKEYS * V_PITCH + (threadIdx.x >> 6) * (2 * 32 * K_PITCH);  // this wave's Q block
   unsigned char* Os = Qs + 32 * K_PITCH;                                                          // ... and O block
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -338,32 +341,19 @@ __global__ __launch_bounds__(256, 2) void attn_smallk_kernel(AttnParams p) {
   const int b = bh / p.H, h = bh - b * p.H;
   const uint16_t* qp = p.q + b * p.q_sb + h * p.q_sh;
   const uint16_t* kp = p.k + b * p.k_sb + h * p.k_sh;
-  const uint16_t* vp = p.vt + b * p.v_sb + h * p.v_sh;
+  const uint16_t* vp = p.v + b * p.v_sb + h * p.v_sh;
   uint16_t* op = p.o + b * p.o_sb + h * p.o_sh;
 
-  // ---- stage K [Nk, 64] (rows >= Nk zero) and V^T [64, Nk] (keys >= Nk zero) ----
+  // ---- stage K and V [Nk, 64] (rows >= Nk zero), each in its own swizzle ----
   for (int i = tid; i < NKEYS * 8; i += 256) {
     const int row = i >> 3, chunk = i & 7;
-    u32x4 kv = {0u, 0u, 0u, 0u};
-    if (row < p.Nk) kv = *reinterpret_cast<const u32x4*>(kp + (long)row * p.k_sn + chunk * 8);
-    *reinterpret_cast<u32x4*>(Ks + row * K_PITCH + ((chunk ^ ((row >> 1) & 7)) << 4)) = kv;
-  }
-  for (int i = tid; i < 64 * (NKEYS / 8); i += 256) {
-    const int row = i / (NKEYS / 8), chunk = i - row * (NKEYS / 8), key0 = chunk * 8;
-    u32x4 vv = {0u, 0u, 0u, 0u};
-    if (key0 < p.Nk) {
-      vv = *reinterpret_cast<const u32x4*>(vp + (long)row * p.v_sd + key0);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        uint32_t w = vv[e];
-        if (key0 + 2 * e >= p.Nk) w &= 0xffff0000u;
-        if (key0 + 2 * e + 1 >= p.Nk) w &= 0x0000ffffu;
-        vv[e] = w;
-      }
+    u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+    if (row < p.Nk) {
+      kv = *reinterpret_cast<const u32x4*>(kp + (long)row * p.k_sn + chunk * 8);
+      vv = *reinterpret_cast<const u32x4*>(vp + (long)row * p.v_sn + chunk * 8);
     }
-    u32x2 lo = {vv[0], vv[1]}, hi = {vv[2], vv[3]};
-    *reinterpret_cast<u32x2*>(Vs + row * VP + chunk * 16) = lo;
-    *reinterpret_cast<u32x2*>(Vs + row * VP + chunk * 16 + 8) = hi;
+    *reinterpret_cast<u32x4*>(Ks + row * K_PITCH + ((chunk ^ ((row >> 1) & 7)) << 4)) = kv;
+    *reinterpret_cast<u32x4*>(Vs + v_swz(row, chunk)) = vv;
   }
   __syncthreads();
 
@@ -382,11 +372,7 @@ __global__ __launch_bounds__(256, 2) void attn_smallk_kernel(AttnParams p) {
   for (int db = 0; db < 2; ++db)
 #pragma unroll
     for (int kk = 0; kk < 2 * NKB; ++kk) {
-      const unsigned char* vrow = Vs + (db * 32 + l31) * VP + (16 * kk + 4 * hh) * 2;
-      const u32x2 v0 = *reinterpret_cast<const u32x2*>(vrow);
-      const u32x2 v1 = *reinterpret_cast<const u32x2*>(vrow + 16);
-      u32x4 vw = {v0[0], v0[1], v1[0], v1[1]};
-      vf[db][kk] = __builtin_bit_cast(bf16x8, vw);
+      vf[db][kk] = v_frag(Vs, v_frag_offset(l31, hh, db), kk);
       if (FP8) vf8[db][kk] = bf16x8_to_fp8x8(vf[db][kk], p.inv_sv);
     }
   f32x16 init_last;  // accumulator start of the last key block: 0 for real keys, -1e30 for padding
@@ -509,43 +495,25 @@ __global__ __launch_bounds__(256, 2) void attn_smallk_kernel(AttnParams p) {
   }
 }
 
-// [BH, N, 64] -> [BH, 64, ldk] transpose used by the xformers-layout entry point (V arrives row-major there).
-__global__ void transpose_v_kernel(const uint16_t* v, uint16_t* vt, int N, int ldk) {
-  __shared__ uint16_t t[64][66];
-  const int bh = blockIdx.y, n0 = blockIdx.x * 64;
-  const uint16_t* src = v + ((long)bh * N) * 64;
-  uint16_t* dst = vt + (long)bh * 64 * ldk;
-  for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
-    const int n = i >> 6, d = i & 63;
-    t[n][d] = (n0 + n < N) ? src[(long)(n0 + n) * 64 + d] : (uint16_t)0;
-  }
-  __syncthreads();
-  for (int i = threadIdx.x; i < 64 * 64; i += blockDim.x) {
-    const int d = i >> 6, n = i & 63;
-    if (n0 + n < ldk) dst[(long)d * ldk + n0 + n] = t[n][d];
-  }
-}
-
 }  // namespace
 
 // fp8_amax = {max|q|, max|k|, max|v|} selects the fp8-MFMA variant (Nk <= 96 only); NULL = bf16 MFMA
-static int attn_launch(const void* q, const void* k, const void* vt, void* o, int B, int H, int Nq, int Nk, const int64_t* q_strides,
-                       const int64_t* k_strides, const int64_t* vt_strides, const int64_t* o_strides, float scale, const float* fp8_amax,
+static int attn_launch(const void* q, const void* k, const void* v, void* o, int B, int H, int Nq, int Nk, const int64_t* q_strides,
+                       const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, float scale, const float* fp8_amax,
                        void* stream) {
-  if (!q || !k || !vt || !o || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return CD360_ERR_ARG;
+  if (!q || !k || !v || !o || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return CD360_ERR_ARG;
   AttnParams p;
-  p.q = (const uint16_t*)q; p.k = (const uint16_t*)k; p.vt = (const uint16_t*)vt; p.o = (uint16_t*)o;
+  p.q = (const uint16_t*)q; p.k = (const uint16_t*)k; p.v = (const uint16_t*)v; p.o = (uint16_t*)o;
   p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk;
   p.q_sb = q_strides[0]; p.q_sh = q_strides[1]; p.q_sn = q_strides[2];
   p.k_sb = k_strides[0]; p.k_sh = k_strides[1]; p.k_sn = k_strides[2];
-  p.v_sb = vt_strides[0]; p.v_sh = vt_strides[1]; p.v_sd = vt_strides[2];
+  p.v_sb = v_strides[0]; p.v_sh = v_strides[1]; p.v_sn = v_strides[2];
   p.o_sb = o_strides[0]; p.o_sh = o_strides[1]; p.o_sn = o_strides[2];
   // 16-byte vector access requirements
-  const int64_t all[] = {p.q_sb, p.q_sh, p.q_sn, p.k_sb, p.k_sh, p.k_sn, p.v_sb, p.v_sh, p.v_sd};
+  const int64_t all[] = {p.q_sb, p.q_sh, p.q_sn, p.k_sb, p.k_sh, p.k_sn, p.v_sb, p.v_sh, p.v_sn};
   for (int64_t s : all) if (s % 8) return CD360_ERR_SHAPE;
   if (p.o_sb % 4 || p.o_sh % 4 || p.o_sn % 4) return CD360_ERR_SHAPE;
-  if (p.v_sd < ((Nk + 7) / 8) * 8) return CD360_ERR_SHAPE;
-  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)vt) % 16 || (uintptr_t)o % 8) return CD360_ERR_ARG;
+  if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 || (uintptr_t)o % 8) return CD360_ERR_ARG;
   p.scale_log2e = scale * 1.4426950408889634f;
   // (its 16-byte output stores need 16-byte aligned output rows; otherwise the tiled kernel with 8-byte stores serves the call)
   bool smallk = Nk <= 96 && !(p.o_sb % 8 || p.o_sh % 8 || p.o_sn % 8 || (uintptr_t)o % 16);
@@ -583,7 +551,7 @@ static int attn_launch(const void* q, const void* k, const void* vt, void* o, in
     return CD360_OK;
   }
   p.n_qtiles = (Nq + 127) / 128;
-  p.fast = ((long)Nk * p.k_sn * 2 < (1L << 31) && 64 * p.v_sd * 2 < (1L << 31)) ? 1 : 0;
+  p.fast = ((long)Nk * p.k_sn * 2 < (1L << 31) && (long)Nk * p.v_sn * 2 < (1L << 31)) ? 1 : 0;
   if (const char* e = getenv("CD360_ATTN_FAST")) p.fast = p.fast && e[0] != '0';  // tuning/debug: 0 forces the guarded path
   const long nwg = (long)p.n_qtiles * B * H;
   if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
@@ -592,32 +560,25 @@ static int attn_launch(const void* q, const void* k, const void* vt, void* o, in
   return CD360_OK;
 }
 
-extern "C" int cd360_attn_fwd_bf16(const void* q, const void* k, const void* vt, void* o, int B, int H, int Nq, int Nk,
-                                   const int64_t* q_strides, const int64_t* k_strides, const int64_t* vt_strides,
+extern "C" int cd360_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, int B, int H, int Nq, int Nk,
+                                   const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                                    const int64_t* o_strides, float scale, void* stream) {
-  return attn_launch(q, k, vt, o, B, H, Nq, Nk, q_strides, k_strides, vt_strides, o_strides, scale, nullptr, stream);
+  return attn_launch(q, k, v, o, B, H, Nq, Nk, q_strides, k_strides, v_strides, o_strides, scale, nullptr, stream);
 }
 
 // fp8-MFMA variant for Nk <= 96 (BASELINE config 5): same bf16 tensors, Q / K / V^T / P rounded to e4m3 in registers.
 // amax = {max|q|, max|k|, max|v|} (host floats) define the per-tensor scales.  CD360_ERR_SHAPE when Nk > 96.
-extern "C" int cd360_attn_fwd_fp8mfma_bf16(const void* q, const void* k, const void* vt, void* o, int B, int H, int Nq, int Nk,
-                                           const int64_t* q_strides, const int64_t* k_strides, const int64_t* vt_strides,
+extern "C" int cd360_attn_fwd_fp8mfma_bf16(const void* q, const void* k, const void* v, void* o, int B, int H, int Nq, int Nk,
+                                           const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                                            const int64_t* o_strides, float scale, const float* amax, void* stream) {
   if (!amax) return CD360_ERR_ARG;
-  return attn_launch(q, k, vt, o, B, H, Nq, Nk, q_strides, k_strides, vt_strides, o_strides, scale, amax, stream);
+  return attn_launch(q, k, v, o, B, H, Nq, Nk, q_strides, k_strides, v_strides, o_strides, scale, amax, stream);
 }
 
-// xformers-layout convenience entry: q,k,v,o all contiguous [BH, N, 64]; `vt_ws` is caller-provided workspace
-// of cd360_attn_vt_workspace_bytes(BH, Nk) bytes.
-extern "C" int64_t cd360_attn_vt_workspace_bytes(int BH, int Nk) { return (int64_t)BH * 64 * (((int64_t)Nk + 7) / 8 * 8) * 2; }
-
-extern "C" int cd360_attn_fwd_xformers_bf16(const void* q, const void* k, const void* v, void* o, void* vt_ws, int BH, int Nq,
-                                            int Nk, float scale, void* stream) {
-  if (!v || !vt_ws || BH <= 0) return CD360_ERR_ARG;
-  const int ldk = (Nk + 7) / 8 * 8;
-  hipLaunchKernelGGL(transpose_v_kernel, dim3((ldk + 63) / 64, BH), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)v,
-                     (uint16_t*)vt_ws, Nk, ldk);
-  CD360_LAUNCH_CHECK();
-  const int64_t qs[3] = {0, (int64_t)Nq * 64, 64}, ks[3] = {0, (int64_t)Nk * 64, 64}, vs[3] = {0, (int64_t)64 * ldk, ldk};
-  return cd360_attn_fwd_bf16(q, k, vt_ws, o, 1, BH, Nq, Nk, qs, ks, vs, qs, scale, stream);
+// xformers-layout convenience entry: q, k, v, o all contiguous [BH, N, 64] (attention.py:393-408), consumed in place
+extern "C" int cd360_attn_fwd_xformers_bf16(const void* q, const void* k, const void* v, void* o, int BH, int Nq, int Nk, float scale,
+                                            void* stream) {
+  if (BH <= 0) return CD360_ERR_ARG;
+  const int64_t qs[3] = {0, (int64_t)Nq * 64, 64}, ks[3] = {0, (int64_t)Nk * 64, 64};
+  return cd360_attn_fwd_bf16(q, k, v, o, 1, BH, Nq, Nk, qs, ks, ks, qs, scale, stream);
 }

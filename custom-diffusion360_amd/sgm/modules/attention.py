@@ -90,18 +90,6 @@ def _pad_tokens(ctx: torch.Tensor, mult: int = 8) -> torch.Tensor:
     return ctx if pad == 0 else F.pad(ctx, (0, 0, 0, pad))
 
 
-def _project_transposed(w: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
-    """(x @ w^T)^T = w @ x^T for the whole batch as ONE GEMM [out, C] x [C, b*N] (x^T is consumed as a transposed BLAS operand, no
-    copy), returned as the strided view [b, out, N] of the [out, b*N] result: row d of batch i starts at column i*N.  The attention
-    kernel takes V^T through explicit (batch, head, d) strides, so the layout costs nothing (the per-batch torch.bmm form
-    measured the same step time; CD360_VT_BMM=1 selects it)."""
-    b, n, c = x.shape
-    if os.environ.get("CD360_VT_BMM"):  # tuning knob: the per-batch form
-        return torch.bmm(w.unsqueeze(0).expand(b, -1, -1), x.transpose(1, 2))
-    out = torch.mm(w, x.reshape(b * n, c).t())
-    return out.view(w.shape[0], b, n).permute(1, 0, 2)
-
-
 class MemoryEfficientCrossAttention(nn.Module):
     """to_q / to_k / to_v / to_out.0 exactly as the reference (attention.py:305-425); forward on the HIP kernel."""
 
@@ -119,20 +107,24 @@ class MemoryEfficientCrossAttention(nn.Module):
         self.to_v = nn.Linear(context_dim, inner_dim, bias=False)
         self.to_out = nn.Sequential(nn.Linear(inner_dim, query_dim), nn.Dropout(dropout))
         self.attention_op = None
-        self._merged = None
+        self._merged = {}
         self._kv_cache = None
         self.cache_context_kv = False
 
-    def _qk_weight(self):
-        """[to_q.weight; to_k.weight] for the self-attention GEMM, rebuilt when either changes."""
-        key = (self.to_q.weight.data_ptr(), self.to_q.weight._version, self.to_k.weight.data_ptr(), self.to_k.weight._version,
-               self.to_q.weight.dtype, self.to_q.weight.device)
-        if self._merged is None or self._merged[0] != key:
-            self._merged = (key, torch.cat([self.to_q.weight.detach(), self.to_k.weight.detach()], 0).contiguous())
-        return self._merged[1]
+    def _merged_weight(self, which: str):
+        """Row-concatenated projection weights, rebuilt when any of them changes: "qkv" = [to_q; to_k; to_v] for self-attention
+        (one GEMM, N = 3 inner), "kv" = [to_k; to_v] for a cross-attention context."""
+        mods = (self.to_q, self.to_k, self.to_v) if which == "qkv" else (self.to_k, self.to_v)
+        key = tuple((m.weight.data_ptr(), m.weight._version) for m in mods) + (mods[0].weight.dtype, mods[0].weight.device)
+        cache = self._merged.get(which)
+        if cache is None or cache[0] != key:
+            cache = (key, torch.cat([m.weight.detach() for m in mods], 0).contiguous())
+            self._merged[which] = cache
+        return cache[1]
 
     def project_context(self, context: torch.Tensor):
-        """K [b, Nk_pad, inner] and V^T [b, inner, Nk_pad] for a cross-attention context (reusable across query sets)."""
+        """(K, V, nk): K and V [b, Nk_pad, inner] as the two column halves of ONE [to_k; to_v] GEMM over the context (row-major V: the
+        attention kernel transposes it while reading LDS); reusable across query sets."""
         # The text context is constant over a whole sampling trajectory (and K/V do not depend on x or the timestep).  When the
         # caller opts in (cd360.sampling.enable_reference_sampling(cache_context=True): "this context buffer stays put until
         # clear_rendered_feat()"), the projections are kept resident and reused by every step and by the pose-token attention.
@@ -142,24 +134,23 @@ class MemoryEfficientCrossAttention(nn.Module):
             key = (context.data_ptr(), context._version, tuple(context.shape), context.dtype, wk.data_ptr(), wk._version, wv._version)
             if self._kv_cache is not None and self._kv_cache[0] == key:
                 return self._kv_cache[1]
-        ctx = _pad_tokens(context)
-        k = F.linear(ctx, wk)
-        vt = _project_transposed(wv, ctx)
-        out = (k, vt, context.shape[1])
+        inner = self.heads * self.dim_head
+        kv = F.linear(_pad_tokens(context), self._merged_weight("kv"))
+        out = (kv[..., :inner], kv[..., inner:], context.shape[1])
         self._kv_cache = (key, out) if use_cache else None
         return out
 
     def attend(self, x: torch.Tensor, kv) -> torch.Tensor:
-        """softmax(q k^T / sqrt(d)) v and the output projection for precomputed (k, vt, nk)."""
-        k, vt, nk = kv
+        """softmax(q k^T / sqrt(d)) v and the output projection for precomputed (k, v, nk)."""
+        k, v, nk = kv
         q = F.linear(x, self.to_q.weight)
-        return self._finish(x, q, k, vt, nk)
+        return self._finish(x, q, k, v, nk)
 
-    def _finish(self, x, q, k, vt, nk):
+    def _finish(self, x, q, k, v, nk):
         dt = x.dtype
         if dt != torch.bfloat16:
-            q, k, vt = q.to(torch.bfloat16), k.to(torch.bfloat16), vt.to(torch.bfloat16)
-        out = ops.attention(q, k, vt, self.heads, nk)
+            q, k, v = q.to(torch.bfloat16), k.to(torch.bfloat16), v.to(torch.bfloat16)
+        out = ops.attention(q, k, v, self.heads, nk)
         if dt != torch.bfloat16:
             out = out.to(dt)
         return self.to_out(out)
@@ -169,14 +160,10 @@ class MemoryEfficientCrossAttention(nn.Module):
             raise NotImplementedError("additional_tokens / cross-frame attention are not used by the shipped config")
         if exists(mask):
             raise NotImplementedError  # as the reference (attention.py:411-412)
-        if context is None:
+        if context is None:  # self-attention: q, k, v are the three column slices of one GEMM, read in place by the kernel
             inner = self.heads * self.dim_head
-            if x.shape[1] % 8 == 0:
-                qk = F.linear(x, self._qk_weight())
-                q, k = qk[..., :inner], qk[..., inner:]
-                vt = _project_transposed(self.to_v.weight, x)
-                return self._finish(x, q, k, vt, x.shape[1])
-            context = x
+            qkv = F.linear(x, self._merged_weight("qkv"))
+            return self._finish(x, qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:], x.shape[1])
         return self.attend(x, self.project_context(context))
 
 

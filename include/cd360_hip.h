@@ -31,25 +31,23 @@ extern "C" {
 /* ---- attention ---------------------------------------------------------------------------------------------
  * replaces xformers.ops.memory_efficient_attention(q, k, v, attn_bias=None, op=None)
  *          sgm/modules/attention.py:393-408 (MemoryEfficientCrossAttention.forward), head dim 64, no mask.
- * Strided form: q[b][h][n][d] at q + b*qs[0] + h*qs[1] + n*qs[2] + d (element strides, multiples of 8);
- * k likewise; vt is V TRANSPOSED, vt[b][h][d][key] at vt + b*vs[0] + h*vs[1] + d*vs[2] + key with
- * vs[2] >= round_up(Nk, 8); o like q (strides multiples of 4).  With these strides the kernel consumes the
- * to_q/to_k/to_v projection outputs [b, N, H*64] in place and writes [b, N, H*64] (attention.py:394-418 copies gone). */
-int cd360_attn_fwd_bf16(const void* q, const void* k, const void* vt, void* o, int B, int H, int Nq, int Nk,
-                        const int64_t* q_strides, const int64_t* k_strides, const int64_t* vt_strides, const int64_t* o_strides,
+ * Strided form: q[b][h][n][d] at q + b*qs[0] + h*qs[1] + n*qs[2] + d (element strides, multiples of 8); k and v likewise
+ * (v ROW-MAJOR, v[b][h][key][d]: transposed on the fly by the kernel's LDS reads); o like q (strides multiples of 4).  With
+ * these strides the kernel consumes the three slices of ONE merged q|k|v projection output [b, N, 3*H*64] in place and writes
+ * [b, N, H*64] (the permute / contiguous copies of attention.py:394-418 are gone). */
+int cd360_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, int B, int H, int Nq, int Nk,
+                        const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides,
                         float scale, void* stream);
 /* fp8-MFMA variant of cd360_attn_fwd_bf16 for Nk <= 96 -- the text / pose-token cross-attention of attention.py:578-588,620-625
- * (BASELINE.json configs[4]): same bf16 tensors and strides; Q, K, V^T and the softmax probabilities are rounded to OCP e4m3 in
+ * (BASELINE.json configs[4]): same bf16 tensors and strides; Q, K, V and the softmax probabilities are rounded to OCP e4m3 in
  * registers with per-tensor scales amax[i] / 448 (amax = {max|q|, max|k|, max|v|}, host floats) and both contractions run on
  * v_mfma_f32_32x32x16_fp8_fp8.  Returns CD360_ERR_SHAPE for Nk > 96 or output rows that are not 16-byte aligned. */
-int cd360_attn_fwd_fp8mfma_bf16(const void* q, const void* k, const void* vt, void* o, int B, int H, int Nq, int Nk,
-                                const int64_t* q_strides, const int64_t* k_strides, const int64_t* vt_strides,
+int cd360_attn_fwd_fp8mfma_bf16(const void* q, const void* k, const void* v, void* o, int B, int H, int Nq, int Nk,
+                                const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                                 const int64_t* o_strides, float scale, const float* amax, void* stream);
 
-/* xformers layout: q, k, v, o contiguous [B*H, N, 64]; vt_ws = workspace of cd360_attn_vt_workspace_bytes(BH, Nk). */
-int64_t cd360_attn_vt_workspace_bytes(int BH, int Nk);
-int cd360_attn_fwd_xformers_bf16(const void* q, const void* k, const void* v, void* o, void* vt_ws, int BH, int Nq, int Nk, float scale,
-                                 void* stream);
+/* xformers layout: q, k, v, o contiguous [B*H, N, 64], exactly the call of attention.py:406. */
+int cd360_attn_fwd_xformers_bf16(const void* q, const void* k, const void* v, void* o, int BH, int Nq, int Nk, float scale, void* stream);
 
 /* ---- rays, projection, integer bilinear indices ----------------------------------------------------------------
  * replaces get_patch_rays / get_patch_raybundle / get_directional_raybundle  (sgm/modules/utils_cameraray.py:61-196)

@@ -106,7 +106,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert isinstance(getattr(lib, name), ctypes._CFuncPtr)
     assert lib.cd360_nerf_k_padded() == 112
-    assert lib.cd360_attn_vt_workspace_bytes(2, 77) == 2 * 64 * 80 * 2
+    assert lib.cd360_conv_stats_slabs(320) == 4 and lib.cd360_conv_stats_slabs(640) == 2 and lib.cd360_conv_k_order(1280, 9) == 5
 
 
 # ------------------------------------------------------------------------------------------------ fused-render algebra

@@ -42,12 +42,13 @@ def test_attention_strided(B, H, Nq, Nk):
     k = bf(torch.randn(B, Nk, H * 64, generator=g))
     v = bf(torch.randn(B, Nk, H * 64, generator=g))
     nkp = (Nk + 7) // 8 * 8
-    vt = torch.zeros(B, H * 64, nkp)
-    vt[:, :, :Nk] = v.transpose(1, 2)
-    vt[:, :, Nk:] = float("nan")  # padding must never be read as data
-    kp = torch.full((B, nkp, H * 64), float("nan"))
-    kp[:, :Nk] = k
-    out = ops.attention(q.to(DEV, torch.bfloat16), kp.to(DEV, torch.bfloat16), vt.to(DEV, torch.bfloat16), H, nk=Nk)
+    # k and v as column slices of one wider row-major tensor (the merged projection layout), NaN rows beyond Nk: padding and the
+    # neighbouring slice must never be read as data
+    kv = torch.full((B, nkp, 2 * H * 64 + 64), float("nan"))
+    kv[:, :Nk, :H * 64] = k
+    kv[:, :Nk, H * 64 + 64:] = v
+    kvd = kv.to(DEV, torch.bfloat16)
+    out = ops.attention(q.to(DEV, torch.bfloat16), kvd[..., :H * 64], kvd[..., H * 64 + 64:], H, nk=Nk)
 
     def split(t):
         return t.reshape(B, t.shape[1], H, 64).permute(0, 2, 1, 3).reshape(B * H, t.shape[1], 64)
@@ -311,12 +312,13 @@ def test_attention_fp8_mfma_variant_tolerance(B, H, Nq, Nk):
     k = bf(torch.randn(B, Nk, H * 64, generator=g))
     v = bf(torch.randn(B, Nk, H * 64, generator=g))
     nkp = (Nk + 7) // 8 * 8
-    vt = torch.zeros(B, H * 64, nkp)
-    vt[:, :, :Nk] = v.transpose(1, 2)
-    vt[:, :, Nk:] = float("nan")  # padding must never be read as data
-    kp = torch.full((B, nkp, H * 64), float("nan"))
-    kp[:, :Nk] = k
-    out = ops.attention(q.to(DEV, torch.bfloat16), kp.to(DEV, torch.bfloat16), vt.to(DEV, torch.bfloat16), H, nk=Nk)
+    # k and v as column slices of one wider row-major tensor (the merged projection layout), NaN rows beyond Nk: padding and the
+    # neighbouring slice must never be read as data
+    kv = torch.full((B, nkp, 2 * H * 64 + 64), float("nan"))
+    kv[:, :Nk, :H * 64] = k
+    kv[:, :Nk, H * 64 + 64:] = v
+    kvd = kv.to(DEV, torch.bfloat16)
+    out = ops.attention(q.to(DEV, torch.bfloat16), kvd[..., :H * 64], kvd[..., H * 64 + 64:], H, nk=Nk)
 
     def split(t):
         return t.reshape(B, t.shape[1], H, 64).permute(0, 2, 1, 3).reshape(B * H, t.shape[1], 64)
@@ -579,11 +581,11 @@ def test_attention_fp8_mfma_variant_tolerance(B, H, Nq, Nk):
     k = bf(torch.randn(B, Nk, H * 64, generator=g))
     v = bf(torch.randn(B, Nk, H * 64, generator=g))
     nkp = (Nk + 7) // 8 * 8
-    vt = torch.full((B, H * 64, nkp), float("nan"))
-    vt[:, :, :Nk] = v.transpose(1, 2)
+    vp = torch.full((B, nkp, H * 64), float("nan"))
+    vp[:, :Nk] = v
     kp = torch.full((B, nkp, H * 64), float("nan"))
     kp[:, :Nk] = k
-    args = (q.to(DEV, torch.bfloat16), kp.to(DEV, torch.bfloat16), vt.to(DEV, torch.bfloat16), H)
+    args = (q.to(DEV, torch.bfloat16), kp.to(DEV, torch.bfloat16), vp.to(DEV, torch.bfloat16), H)
     o8 = ops.attention_fp8mfma(*args, nk=Nk)
     o16 = ops.attention(*args, nk=Nk)
 
@@ -597,4 +599,4 @@ def test_attention_fp8_mfma_variant_tolerance(B, H, Nq, Nk):
     assert rms(o8, want) > 5 * rms(o16, want)  # the variant really runs in fp8 (bf16 is ~2e-3)
     big = torch.zeros(1, 104, 64, device=DEV, dtype=torch.bfloat16)
     with pytest.raises(Exception):
-        ops.attention_fp8mfma(big, big, big.transpose(1, 2).contiguous(), 1)  # Nk = 104 > 96
+        ops.attention_fp8mfma(big, big, big, 1)  # Nk = 104 > 96

@@ -31,8 +31,8 @@ def timeit(fn, iters=20, warm=3):
 def attn(tag, b, H, nq, nk):
     q = torch.randn(b, nq, H * 64, device=dev).to(BF)
     k = torch.randn(b, (nk + 7) // 8 * 8, H * 64, device=dev).to(BF)
-    vt = torch.randn(b, H * 64, (nk + 7) // 8 * 8, device=dev).to(BF)
-    us = timeit(lambda: ops.attention(q, k, vt, H, nk))
+    v = torch.randn(b, nk, H * 64, device=dev).to(BF)
+    us = timeit(lambda: ops.attention(q, k, v, H, nk))
     fl = 4.0 * b * H * nq * nk * 64
     by = 2.0 * (2 * b * nq * H * 64 + 2 * b * nk * H * 64)
     print(f"attn {tag:12s} b{b} H{H} Nq{nq} Nk{nk}: {us:9.1f} us  {fl / us / 1e6:8.1f} TF/s  {by / us / 1e3:8.1f} GB/s", flush=True)
