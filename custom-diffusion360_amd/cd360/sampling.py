@@ -4,7 +4,7 @@ sample.py monkey-patches SpatialTransformer.forward / BasicTransformerBlock.forw
 from the per-block `references` buffer of the delta checkpoint, picked by the global `choices`, with `references[-1]` (the
 null image) for the unconditional CFG third, and (2) the FeatureNeRF render runs once per image and is cached in
 `rendered_feat`.  Those patched forwards also work on this package's modules (same attribute names).  This module offers
-the same behaviour without patching, plus per-image residency the reference does not have: the cross-attention K / V^T of
+the same behaviour without patching, plus per-image residency the reference does not have: the cross-attention K / V of
 the (constant) text context are projected once per image instead of once per block per step.
 """
 from __future__ import annotations
@@ -36,7 +36,7 @@ def set_references(model: torch.nn.Module, references: dict) -> None:
 def enable_reference_sampling(model: torch.nn.Module, choices: Iterable[int], cache_context: bool = True) -> List[str]:
     """Switch every pose block to sample.py semantics with the given reference-view `choices` (sample.py:274-278).
 
-    cache_context=True additionally keeps the cross-attention K / V^T projections of the text context resident between steps.
+    cache_context=True additionally keeps the cross-attention K / V projections of the text context resident between steps.
     Contract: the `context` buffer handed to the UNet is not rewritten in place-without-version-bump or re-allocated until
     `clear_rendered_feat(model)` is called (sample.py builds c/uc once per image and calls clear_rendered_feat between images)."""
     choices = [int(c) for c in choices]
@@ -64,7 +64,7 @@ def disable_reference_sampling(model: torch.nn.Module) -> None:
 
 def clear_rendered_feat(model: torch.nn.Module) -> None:
     """DiffusionEngine.clear_rendered_feat (sgm/models/diffusion.py:165-170): call between images.  Also drops the per-image
-    context K / V^T cache."""
+    context K / V cache."""
     for _, blk in pose_blocks(model):
         blk.rendered_feat = None
         if hasattr(blk, "_rendered_proj"):
