@@ -46,7 +46,7 @@ constexpr int TILE_BYTES = BN * K_PITCH + BN * V_PITCH;
 // LDS byte offset of 16-byte chunk `chunk` of V row `row` (32-B granules swapped by (row >> 1) & 3)
 __device__ __forceinline__ int v_swz(int row, int chunk) { return row * V_PITCH + ((chunk ^ (((row >> 1) & 3) << 1)) << 4); }
 
-// One K/V tile on its way from HBM to LDS: every thread carries 2 x 16 B of K and 2 x 16 B of V^T in registers, so the
+// One K/V tile on its way from HBM to LDS: every thread carries 2 x 16 B of K and 2 x 16 B of V in registers, so the
 // loads of tile t+1 are in flight while tile t is being consumed (split issue / write, LDS double-buffered).
 struct TileRegs {
   u32x4 k[2], v[2];
@@ -64,15 +64,6 @@ __device__ __forceinline__ void tile_load(const AttnParams& p, const uint16_t* k
     }
     r.k[pass] = kv;
     r.v[pass] = vv;
-  }
-}
-
-__device__ __forceinline__ void tile_store(unsigned char* Ks, unsigned char* Vs, int tid, const TileRegs& r) {
-#pragma unroll
-  for (int pass = 0; pass < 2; ++pass) {
-    const int row = (tid >> 3) + 32 * pass, chunk = tid & 7;
-    *reinterpret_cast<u32x4*>(Ks + row * K_PITCH + ((chunk ^ ((row >> 1) & 7)) << 4)) = r.k[pass];
-    *reinterpret_cast<u32x4*>(Vs + v_swz(row, chunk)) = r.v[pass];
   }
 }
 
