@@ -519,9 +519,11 @@ static int attn_launch(const void* q, const void* k, const void* v, void* o, int
     smallk = smallk && e[0] != '0';  // tuning override: 0 = always the tiled kernel
   }
   if (smallk) {
-    // one workgroup = one (batch, head) x one chunk of 32-query blocks; ~8 workgroups per CU in total, at least one block per wave
+    // one workgroup = one (batch, head) x one chunk of 32-query blocks; ~2 workgroups per CU in total, at least one block per wave
     const int nqb = (Nq + 31) / 32;
-    long chunks = (2048 + (long)B * H - 1) / ((long)B * H);
+    long target = 512;  // two resident workgroups per CU (swept 240 ... 8192: 480-512 best for the pose-token shapes, text shapes flat)
+    if (const char* e = getenv("CD360_SMALLK_WGS")) target = atol(e) > 0 ? atol(e) : target;  // tuning override
+    long chunks = (target + (long)B * H - 1) / ((long)B * H);
     const long max_chunks = (nqb + 3) / 4;
     if (chunks > max_chunks) chunks = max_chunks;
     if (chunks < 1) chunks = 1;
