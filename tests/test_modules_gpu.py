@@ -190,6 +190,7 @@ def test_cfg_branch_deduplication_is_bit_identical(monkeypatch):
     (same kernels, same inputs), and must not trigger when the thirds are different camera objects."""
     from cd360 import sampling, synth
     from cd360.cameras import join_cameras_as_batch
+    monkeypatch.delenv("CD360_NO_CFG_DEDUP", raising=False)  # (the A/B knob would switch the feature under test off)
     blk = make_block(13, C=128, heads=2, cd=32, S=6)
     n_train, n, hw = 6, 6, 256
     sampling.set_references(blk, {"": dev(W.tensor("references", (n_train + 1, hw, 128), seed=13))})
