@@ -312,275 +312,6 @@ def test_attention_fp8_mfma_variant_tolerance(B, H, Nq, Nk):
     k = bf(torch.randn(B, Nk, H * 64, generator=g))
     v = bf(torch.randn(B, Nk, H * 64, generator=g))
     nkp = (Nk + 7) // 8 * 8
-    # k and v as column slices of one wider row-major tensor (the merged projection layout), NaN rows beyond Nk: padding and the
-    # neighbouring slice must never be read as data
-    kv = torch.full((B, nkp, 2 * H * 64 + 64), float("nan"))
-    kv[:, :Nk, :H * 64] = k
-    kv[:, :Nk, H * 64 + 64:] = v
-    kvd = kv.to(DEV, torch.bfloat16)
-    out = ops.attention(q.to(DEV, torch.bfloat16), kvd[..., :H * 64], kvd[..., H * 64 + 64:], H, nk=Nk)
-
-    def split(t):
-        return t.reshape(B, t.shape[1], H, 64).permute(0, 2, 1, 3).reshape(B * H, t.shape[1], 64)
-
-    want = O.attention_core(split(q), split(k), split(v)).reshape(B, H, Nq, 64).permute(0, 2, 1, 3).reshape(B, Nq, H * 64)
-    assert rel(out, want) < 1e-2
-
-
-def test_attention_xformers_layout_and_online_softmax_rescale():
-    """xformers-layout entry point; a spiked key late in the sequence forces the running-max rescale branch."""
-    from cd360 import ops
-    g = torch.Generator().manual_seed(5)
-    q, k, v = (bf(torch.randn(4, 300, 64, generator=g)) for _ in range(3))
-    k[:, 257] = 6.0 * q[:, 10]  # key 257 (tile 4) dominates query 10
-    out = ops.memory_efficient_attention(q.to(DEV, torch.bfloat16), k.to(DEV, torch.bfloat16), v.to(DEV, torch.bfloat16))
-    assert rel(out, O.attention_core(q, k, v)) < 1e-2
-
-
-# ------------------------------------------------------------------------------------------------ rays / indices (A4, A5)
-@pytest.mark.parametrize("b,n,r,S,jitter", [(2, 3, 8, 4, False), (1, 4, 32, 24, False), (2, 2, 16, 24, True), (1, 8, 64, 24, False)])
-def test_rays_points_grid_and_indices_bit_exact(b, n, r, S, jitter):
-    from cd360 import nerf, ops
-    cams = cams_for(b, n, seed=r + S)
-    jx = W.uniform("jx", (r + 1,), seed=r) if jitter else None
-    jy = W.uniform("jy", (r + 1,), seed=r) if jitter else None
-    jd = W.uniform("jd", (r * r, S + 1), seed=r) if jitter else None
-    xs_o, ys_o = O.patch_positions(r, jx), O.patch_positions(r, jy)
-    rays_o = O.patch_rays(cams, xs_o, ys_o)
-    len_o, _ = O.depth_samples(S, 2.0, 0.0, jd, r * r)
-    pts_o = O.ray_points(rays_o, len_o)
-    grid_o = O.sample_grid(cams, pts_o)
-    x0_o, y0_o, _, _, m_o = O.bilinear_corners(grid_o, r)
-
-    xs, ys = nerf.patch_positions(r, DEV, jx), nerf.patch_positions(r, DEV, jy)
-    t, _ = nerf.depth_samples(S, 2.0, 0.0, DEV, r * r, jd)
-    cd = cams.to(DEV)
-    assert torch.equal(ops.patch_rays(cd, xs, ys).cpu(), rays_o)
-    res = ops.ray_project_index(cd, xs, ys, t)
-    assert torch.equal(res["points"].cpu(), pts_o)
-    assert torch.equal(res["grid"].cpu(), grid_o)
-    assert torch.equal(res["x0"].cpu(), x0_o) and torch.equal(res["y0"].cpu(), y0_o) and torch.equal(res["mask"].cpu(), m_o)
-    assert int((m_o != 15).sum()) > 0 or r <= 8  # the case set does exercise out-of-bounds corners
-
-
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_feature_gather(dtype):
-    from cd360 import ops
-    g = torch.Generator().manual_seed(3)
-    n_img, r, C, P = 5, 16, 96, 700
-    xref = torch.randn(n_img, r * r, C, generator=g)
-    grid = (torch.rand(n_img, P, 2, generator=g) * 2.6 - 1.3).clamp(-1.2, 1.2)
-    grid[0, :4] = torch.tensor([[-1.0, -1.0], [1.0, 1.0], [1.2, 0.0], [0.0, -1.2]])
-    if dtype == torch.bfloat16:
-        xref = bf(xref)
-    want = O.gather_bilinear(xref[:, None], grid[:, None, :, None, :])[:, 0, :, 0]
-    got = ops.feature_gather(xref.to(DEV, dtype), grid.to(DEV))
-    assert rel(got, want) < (1e-6 if dtype == torch.float32 else 8e-3)
-
-
-# ------------------------------------------------------------------------------------------------ fused FeatureNeRF (A5-A9)
-def nerf_weights(C, seed):
-    shapes = {"model.plane_coefs.0.weight": (C, C + 198), "model.plane_coefs.0.bias": (C,), "model.plane_coefs.2.weight": (C, C),
-              "model.plane_coefs.2.bias": (C,), "model.nviews.weight": (1, C + 198), "model.nviews.bias": (1,), "model.decoder.weight": (4, C)}
-    return {k[len("model."):]: v for k, v in W.synth_state_dict(shapes, seed).items()}
-
-
-def test_plucker_features():
-    from cd360 import nerf, ops
-    b, n, r = 2, 3, 8
-    cams = cams_for(b, n, seed=21)
-    xs = O.patch_positions(r)
-    rays = O.patch_rays(cams, xs, xs)
-    tgt = rays[:, 0]
-    cam_o = O.world_to_view(cams[:, 1:, None, :], tgt[:, None, :, :3])
-    cam_d = O.rotate_to_view(cams[:, 1:, None, :], tgt[:, None, :, 3:])
-    want = torch.cat([O.positional_encoding(O.plucker(torch.cat([cam_o, cam_d], -1)), 8), cam_d], -1)
-    got = ops.plucker_features(cams.to(DEV), nerf.patch_positions(r, DEV), nerf.patch_positions(r, DEV)).cpu()
-    assert torch.all(got[..., 99:] == 0)
-    assert (got[..., :99] - want).abs().max().item() < 2e-5
-
-
-@pytest.mark.parametrize("C,r,n,S,b", [(64, 8, 2, 4, 2), (128, 16, 5, 24, 1), (640, 8, 3, 6, 1)])
-def test_fused_feature_nerf(C, r, n, S, b):
-    from cd360 import nerf
-    w = nerf_weights(C, seed=C + n)
-    cams = cams_for(b, n, seed=C)
-    xref = bf(W.tensor("xref", (b, n, r * r, C), seed=C))
-    feats, sigma, _, attn, rgb, _ = O.nerf_module(w, cams, xref, S, 2.0)
-    fw = nerf.FusedNerfWeights(*(w[k].to(DEV) for k in ("plane_coefs.0.weight", "plane_coefs.0.bias", "plane_coefs.2.weight", "plane_coefs.2.bias",
-                                                        "nviews.weight", "nviews.bias", "decoder.weight")))
-    h, dec, dists, vw = nerf.fused_feature_nerf(fw, cams.to(DEV), xref.to(DEV, torch.bfloat16), S, 2.0, want_view_weights=True)
-    assert rel(vw, attn) < 1e-2
-    assert rel(h, feats) < 1e-2
-    assert rel(dec[..., 3:], sigma) < 1e-2 and rel(dec[..., :3], rgb) < 1e-2
-
-
-# ------------------------------------------------------------------------------------------------ volume rendering (A10)
-@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
-def test_volrender(dtype):
-    from cd360 import ops
-    g = torch.Generator().manual_seed(8)
-    b, hw, S, C = 2, 50, 24, 64
-    feats = torch.randn(b, hw, S, C, generator=g)
-    if dtype == torch.bfloat16:
-        feats = bf(feats)
-    sigma_raw = torch.randn(b, hw, S, 1, generator=g) * 2
-    sigma_raw[0, 0, 3] = 60.0  # overflowing density: exercises nan_to_num / saturation
-    rgb_raw = torch.randn(b, hw, S, 3, generator=g)
-    dists = torch.rand(hw, S, generator=g) * 0.1 + 0.04
-    want = O.vol_render(feats, torch.exp(sigma_raw), dists[None, :, :, None], torch.sigmoid(rgb_raw))
-    got = ops.volrender(feats.to(DEV, dtype), sigma_raw[..., 0].to(DEV), dists.to(DEV), rgb_raw.to(DEV), want_weights=True)
-    tol = 1e-5 if dtype == torch.float32 else 5e-3
-    for gi, wi in zip(got, want):
-        assert rel(gi, wi) < tol
-    # module-style call: densities already exponentiated, rgb already sigmoid'ed, shared [S] dists
-    got2 = ops.volrender(feats.to(DEV, dtype), torch.exp(sigma_raw[..., 0]).to(DEV), dists[0].to(DEV), torch.sigmoid(rgb_raw).to(DEV),
-                         sigma_is_raw=False, rgb_is_raw=False)
-    want2 = O.vol_render(feats, torch.exp(sigma_raw), dists[0][None, None, :, None], torch.sigmoid(rgb_raw))
-    assert rel(got2[0], want2[0]) < tol and rel(got2[4], want2[4]) < 1e-5
-
-
-def test_rowdot4():
-    from cd360 import ops
-    g = torch.Generator().manual_seed(9)
-    h, w = bf(torch.randn(3, 37, 640, generator=g)), torch.randn(4, 640, generator=g)
-    assert rel(ops.rowdot4(h.to(DEV, torch.bfloat16), w.to(DEV)), h @ w.t()) < 1e-5
-
-
-def test_geglu_and_concat():
-    from cd360 import ops
-    g = torch.Generator().manual_seed(10)
-    p = bf(torch.randn(3, 50, 2 * 320, generator=g) * 2)
-    x, gate = p.chunk(2, dim=-1)
-    assert rel(ops.geglu(p.to(DEV, torch.bfloat16)), x * torch.nn.functional.gelu(gate)) < 8e-3
-    a, b = bf(torch.randn(2, 64, 5, 7, generator=g)), bf(torch.randn(2, 24, 5, 7, generator=g))
-    cl = torch.channels_last
-    got = ops.concat_channels(a.to(DEV, torch.bfloat16).contiguous(memory_format=cl), b.to(DEV, torch.bfloat16).contiguous(memory_format=cl))
-    assert got.shape == (2, 88, 5, 7) and torch.equal(got.float().cpu(), torch.cat([a, b], 1))
-
-
-def test_cfg_euler_step_kernel_matches_sampler_chain():
-    from cd360.sampler import cfg_euler_update
-    x, eps = W.tensor("x", (2, 4, 16, 16), seed=3), W.tensor("eps", (6, 4, 16, 16), seed=3)
-    s, sn = torch.tensor([3.3]), torch.tensor([2.9])
-    want = cfg_euler_update(x, eps, s, sn, 7.5, 3.5, fused=False)
-    got = cfg_euler_update(x.to(DEV), eps.to(DEV), s.to(DEV), sn.to(DEV), 7.5, 3.5, fused=True)
-    assert rel(got, want) < 1e-6
-
-
-@pytest.mark.parametrize("rows,C", [(37, 64), (1000, 640), (513, 1280), (5, 2048)])
-def test_add_layernorm(rows, C):
-    from cd360 import ops
-    g = torch.Generator().manual_seed(rows + C)
-    a, b = bf(torch.randn(rows, C, generator=g) * 2), bf(torch.randn(rows, C, generator=g) + 0.3)
-    gamma, beta = bf(torch.randn(C, generator=g)), bf(torch.randn(C, generator=g))
-    s, ln = ops.add_layernorm(a.to(DEV, torch.bfloat16), b.to(DEV, torch.bfloat16), gamma.to(DEV, torch.bfloat16), beta.to(DEV, torch.bfloat16), 1e-5)
-    assert rel(s, a + b) < 5e-3
-    assert rel(ln, torch.nn.functional.layer_norm(a + b, (C,), gamma, beta, 1e-5)) < 8e-3
-    s2, ln2 = ops.add_layernorm(a.to(DEV, torch.bfloat16), None, gamma.to(DEV, torch.bfloat16), beta.to(DEV, torch.bfloat16), 1e-5)
-    assert s2 is None and rel(ln2, torch.nn.functional.layer_norm(a, (C,), gamma, beta, 1e-5)) < 8e-3
-
-
-@pytest.mark.parametrize("N,H,W,Cin,Cout,taps,extras", [(2, 9, 7, 64, 48, 9, False), (1, 16, 16, 128, 320, 9, True), (3, 32, 32, 320, 640, 9, True),
-                                                       (2, 5, 5, 192, 64, 1, True), (1, 1, 1, 64, 16, 9, False), (2, 9, 7, 128, 320, 9, True), (1, 12, 12, 64, 160, 9, False)])
-@pytest.mark.parametrize("split", ["auto", "1", "2"])
-def test_conv_igemm(N, H, W, Cin, Cout, taps, extras, split, monkeypatch):
-    """implicit-GEMM conv3x3 / GEMM with fused bias + per-image addend + residual vs torch's fp32 conv2d on the same bf16 inputs.
-    `split`: the in-workgroup split-K variant (512 threads, odd K-steps on the second 4 waves) forced on / off / chosen by the
-    launch heuristic; (3,32,32,320,640) has an ODD number of K-steps (45), (1,16,16,128,320) the minimum of 2 chunks per tap.
-    Cout = 320 / 160 take the 160-channel tiling (4 waves of 160 x 32), with ragged pixel tiles in (2,9,7,...)."""
-    from cd360 import ops
-    if split != "auto":
-        monkeypatch.setenv("CD360_CONV_SPLIT", split)
-    g = torch.Generator().manual_seed(N * 100 + H + Cin + Cout)
-    k = 3 if taps == 9 else 1
-    x = bf(torch.randn(N, Cin, H, W, generator=g))
-    w = bf(torch.randn(Cout, Cin, k, k, generator=g) / (Cin * k * k) ** 0.5)
-    bias = torch.randn(Cout, generator=g)
-    emb = bf(torch.randn(N, Cout, generator=g)) if extras else None
-    res = bf(torch.randn(N, Cout, H, W, generator=g)) if extras else None
-    want = torch.nn.functional.conv2d(x, w, bias, padding=k // 2)
-    if extras:
-        want = want + emb[:, :, None, None] + res
-    xt = x.permute(0, 2, 3, 1).reshape(N, H * W, Cin).contiguous().to(DEV, torch.bfloat16)
-    wp = ops.pack_conv_weight(w).to(DEV)
-    rt = None if res is None else res.permute(0, 2, 3, 1).reshape(N, H * W, Cout).contiguous().to(DEV, torch.bfloat16)
-    got = ops.conv_igemm(xt, wp, bias.to(DEV), N, H, W, taps, None if emb is None else emb.to(DEV, torch.bfloat16), rt)
-    assert rel(got.reshape(N, H, W, Cout).permute(0, 3, 1, 2), want) < 8e-3
-
-
-@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 16, 16, 128, 256), (1, 32, 32, 64, 320), (3, 32, 32, 320, 640), (2, 16, 8, 128, 160)])
-def test_conv_epilogue_groupnorm_statistics(N, H, W, Cin, Cout):
-    """conv_igemm(want_stats=True) hands the GroupNorm that follows its per-slab channel sums (openaimodel.py:352-376: conv ->
-    GN -> SiLU -> conv): GN from those statistics must equal GN with its own statistics pass, in every launch shape (default
-    128-channel tiles, 160-channel tiles for Cout = 320 / 160, in-workgroup split-K for (3,32,32,320,640)), with emb + residual."""
-    from cd360 import ops
-    g = torch.Generator().manual_seed(Cin + Cout)
-    x = bf(torch.randn(N, H * W, Cin, generator=g)).to(DEV, torch.bfloat16)
-    wp = ops.pack_conv_weight(bf(torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5)).to(DEV)
-    bias = torch.randn(Cout, generator=g).to(DEV)
-    emb = bf(torch.randn(N, Cout, generator=g)).to(DEV, torch.bfloat16)
-    res = bf(torch.randn(N, H * W, Cout, generator=g)).to(DEV, torch.bfloat16)
-    out, stats = ops.conv_igemm(x, wp, bias, N, H, W, 9, emb, res, want_stats=True)
-    assert torch.equal(out, ops.conv_igemm(x, wp, bias, N, H, W, 9, emb, res))  # same output with and without the statistics
-    slabs = stats.shape[1]
-    assert stats.shape == (N, slabs, Cout, 2) and (H * W) % slabs == 0
-    want = out.float().reshape(N, slabs, H * W // slabs, Cout)
-    assert rel(stats[..., 0], want.sum(2)) < 1e-5 and rel(stats[..., 1], (want * want).sum(2)) < 1e-5
-    gamma, beta = torch.randn(Cout, generator=g).to(DEV), torch.randn(Cout, generator=g).to(DEV)
-    a = ops.gn_silu(out, gamma, beta, 32, 1e-5, True, tile_stats=stats)
-    b = ops.gn_silu(out, gamma, beta, 32, 1e-5, True)
-    assert rel(a, b) < 4e-3  # bf16 outputs; statistics differ only in summation order
-    assert torch.equal(a, ops.gn_silu(out, gamma, beta, 32, 1e-5, True, tile_stats=stats))  # deterministic
-    with pytest.raises(Exception):
-        ops.conv_igemm(x[:, :100].contiguous(), wp, bias, N, 10, 10, 9, want_stats=True)  # H*W % 128 != 0
-
-
-@pytest.mark.parametrize("N,H,W,Cin,Cout,stride", [(2, 16, 16, 64, 64, 2), (3, 32, 32, 320, 320, 2), (1, 8, 12, 128, 160, 2), (2, 16, 16, 4, 320, 1), (2, 16, 16, 320, 4, 1)])
-def test_conv_stride2_and_padded_channels_through_the_module_wrapper(N, H, W, Cin, Cout, stride):
-    """Downsample.op (conv3x3 stride 2 pad 1, openaimodel.py:190-213) and the UNet's 4 -> 320 / 320 -> 4 convs (:663-670,967-973)
-    on the implicit-GEMM kernel: conv_image(nn.Conv2d, x) vs torch's fp32 conv2d on the same bf16 inputs."""
-    from sgm.modules.diffusionmodules.util import conv_image, packed_conv
-    g = torch.Generator().manual_seed(Cin * 7 + Cout + stride)
-    conv = torch.nn.Conv2d(Cin, Cout, 3, stride=stride, padding=1)
-    with torch.no_grad():
-        conv.weight.copy_(bf(torch.randn(Cout, Cin, 3, 3, generator=g) / (9 * Cin) ** 0.5))
-        conv.bias.copy_(bf(torch.randn(Cout, generator=g)))
-    x = bf(torch.randn(N, Cin, H, W, generator=g))
-    want = torch.nn.functional.conv2d(x, conv.weight.float(), conv.bias.float(), stride=stride, padding=1)
-    conv = conv.to(DEV, torch.bfloat16)
-    assert packed_conv(conv) is not None
-    with torch.no_grad():
-        got = conv_image(conv, x.to(DEV, torch.bfloat16).contiguous(memory_format=torch.channels_last))
-    assert got.shape == want.shape and rel(got, want) < 8e-3
-
-
-# ------------------------------------------------------------------------------------------------ GroupNorm + SiLU (K7)
-@pytest.mark.parametrize("N,P,C,silu", [(2, 64, 64, True), (3, 1024, 320, True), (1, 4096, 640, False), (2, 256, 2560, True), (1, 100, 960, False)])
-def test_gn_silu(N, P, C, silu):
-    from cd360 import ops
-    g = torch.Generator().manual_seed(C + P)
-    x = bf(torch.randn(N, P, C, generator=g) * 2 + 0.5)
-    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g)
-    want = torch.nn.functional.group_norm(x.permute(0, 2, 1), 32, gamma, beta, 1e-5).permute(0, 2, 1)
-    if silu:
-        want = torch.nn.functional.silu(want)
-    got = ops.gn_silu(x.to(DEV, torch.bfloat16), gamma.to(DEV), beta.to(DEV), 32, 1e-5, silu)
-    assert rel(got, want) < 8e-3
-
-
-# ------------------------------------------------------------------------------------------------ fp8-MFMA cross-attention (configs[4])
-@pytest.mark.parametrize("B,H,Nq,Nk", [(1, 3, 200, 77), (2, 2, 96, 40), (3, 10, 4096, 77)])
-def test_attention_fp8_mfma_variant_tolerance(B, H, Nq, Nk):
-    """BASELINE configs[4]: QK^T and PV on e4m3 MFMA, bf16 tensors in and out.  Tolerances (stated): against the fp32 oracle
-    the fp8 variant stays within 6e-2 relative (max-norm) and 2e-2 in RMS, and within the same bounds of the bf16 kernel; the bf16
-    kernel itself is within 1e-2.  NaN padding beyond Nk must never leak."""
-    from cd360 import ops
-    g = torch.Generator().manual_seed(B * 1000 + Nq + Nk)
-    q = bf(torch.randn(B, Nq, H * 64, generator=g))
-    k = bf(torch.randn(B, Nk, H * 64, generator=g))
-    v = bf(torch.randn(B, Nk, H * 64, generator=g))
-    nkp = (Nk + 7) // 8 * 8
     vp = torch.full((B, nkp, H * 64), float("nan"))
     vp[:, :Nk] = v
     kp = torch.full((B, nkp, H * 64), float("nan"))
