@@ -19,6 +19,8 @@ _I64P = ctypes.POINTER(c_int64)
 SIGNATURES = {
     "cd360_attn_fwd_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _I64P, _I64P, _I64P, _I64P, c_float, _P]),
     "cd360_attn_fwd_fp8mfma_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _I64P, _I64P, _I64P, _I64P, c_float, _F32P, _P]),
+    "cd360_attn_fwd_lse_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _I64P, _I64P, _I64P, _I64P, c_float, _P]),
+    "cd360_attn_bwd_bf16": (c_int, [_P] * 10 + [c_int] * 4 + [_I64P] * 8 + [c_float, _P]),
     "cd360_attn_fwd_xformers_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "cd360_patch_rays": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "cd360_ray_project_index": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),

@@ -75,15 +75,26 @@ def _need_gpu(*ts):
         if not t.is_cuda:
             raise Cd360Error("cd360 operators run only on the GPU (HIP extension); got a CPU tensor")
         if t.requires_grad and torch.is_grad_enabled():
-            raise NotImplementedError("the cd360 HIP operators are forward-only in this round; call them under torch.no_grad()")
+            raise NotImplementedError("this cd360 HIP operator has no backward; call it under torch.no_grad()")
+
+
+def _wants_grad(*ts) -> bool:
+    """True when the call must be recorded by autograd: the differentiable operators then go through cd360/grad.py
+    (torch.autograd.Function around the forward and backward HIP kernels)."""
+    return torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in ts)
 
 
 # ----------------------------------------------------------------------------------------------- attention
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, nk: Optional[int] = None,
-              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              out: Optional[torch.Tensor] = None, want_lse: bool = False):
     """softmax(q k^T / 8) v per head, projection layouts consumed in place.
     q [b, Nq, H*64], k, v [b, >=Nk, H*64] (last dim contiguous; row / batch strides free, e.g. slices of one merged q|k|v
-    projection) -> [b, Nq, H*64].  `nk` limits the keys when k / v are padded."""
+    projection) -> [b, Nq, H*64].  `nk` limits the keys when k / v are padded.  want_lse=True returns (out, lse [b*H, Nq] fp32),
+    the training forward (cd360_attn_fwd_lse_bf16).  Differentiable: under autograd the call is recorded (grad.AttentionFn)."""
+    if _wants_grad(q, k, v):
+        from . import grad
+        assert out is None and not want_lse
+        return grad.AttentionFn.apply(q, k, v, heads, nk)
     _need_gpu(q, k, v)
     b, nq, inner = q.shape
     assert inner == heads * 64 and q.dtype == torch.bfloat16 and k.dtype == torch.bfloat16 and v.dtype == torch.bfloat16
@@ -93,15 +104,38 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, nk:
     if out is None:
         out = torch.empty(b, nq, inner, dtype=torch.bfloat16, device=q.device)
     lib = _lib.load()
+    strides = (_I64x3(q.stride(0), 64, q.stride(1)), _I64x3(k.stride(0), 64, k.stride(1)),
+               _I64x3(v.stride(0), 64, v.stride(1)), _I64x3(out.stride(0), 64, out.stride(1)))
     with _timed("attn_fwd", 4.0 * b * heads * nq * nk * 64, 2.0 * (2 * b * nq * inner + 2 * b * nk * inner)):
-      check(
-        lib.cd360_attn_fwd_bf16(
-            _ptr(q), _ptr(k), _ptr(v), _ptr(out), b, heads, nq, nk,
-            _I64x3(q.stride(0), 64, q.stride(1)), _I64x3(k.stride(0), 64, k.stride(1)),
-            _I64x3(v.stride(0), 64, v.stride(1)), _I64x3(out.stride(0), 64, out.stride(1)),
-            64 ** -0.5, _stream()),
-        "cd360_attn_fwd_bf16")
+        if want_lse:
+            lse = torch.empty(b * heads, nq, dtype=torch.float32, device=q.device)
+            check(lib.cd360_attn_fwd_lse_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), b, heads, nq, nk, *strides, 64 ** -0.5, _stream()),
+                  "cd360_attn_fwd_lse_bf16")
+            return out, lse
+        check(lib.cd360_attn_fwd_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), b, heads, nq, nk, *strides, 64 ** -0.5, _stream()),
+              "cd360_attn_fwd_bf16")
     return out
+
+
+def attention_bwd(q, k, v, o, dout, lse, heads: int, nk: Optional[int] = None, need_dq: bool = True, need_dkv: bool = True):
+    """Backward of attention(..., want_lse=True): (dq | None, dk | None, dv | None), bf16, contiguous, rows >= nk of dk / dv zero."""
+    _need_gpu(q, k, v, o, dout, lse)
+    b, nq, inner = q.shape
+    nk = k.shape[1] if nk is None else nk
+    if dout.stride(2) != 1 or dout.stride(0) % 8 or dout.stride(1) % 8 or dout.data_ptr() % 16:
+        dout = dout.contiguous()
+    assert dout.dtype == torch.bfloat16 and dout.shape == q.shape and lse.shape == (b * heads, nq) and lse.dtype == torch.float32
+    dq = torch.empty(b, nq, inner, dtype=torch.bfloat16, device=q.device) if need_dq else None
+    dk = torch.zeros(b, k.shape[1], inner, dtype=torch.bfloat16, device=q.device) if need_dkv else None
+    dv = torch.zeros(b, v.shape[1], inner, dtype=torch.bfloat16, device=q.device) if need_dkv else None
+    ws = torch.empty(b * heads * nq, dtype=torch.float32, device=q.device)
+    s3 = lambda t: None if t is None else _I64x3(t.stride(0), 64, t.stride(1))
+    flops = 4.0 * b * heads * nq * nk * 64 * ((1.5 if need_dq else 0.0) + (2.0 if need_dkv else 0.0))
+    with _timed("attn_bwd", flops, 2.0 * (4 * b * nq * inner + 4 * b * nk * inner)):
+        check(_lib.load().cd360_attn_bwd_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(o), _ptr(dout), _ptr(lse), _ptr(dq), _ptr(dk), _ptr(dv), _ptr(ws),
+                                             b, heads, nq, nk, s3(q), s3(k), s3(v), s3(o), s3(dout), s3(dq), s3(dk), s3(dv), 64 ** -0.5, _stream()),
+              "cd360_attn_bwd_bf16")
+    return dq, dk, dv
 
 
 def attention_fp8mfma(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, nk: Optional[int] = None, amax=None) -> torch.Tensor:

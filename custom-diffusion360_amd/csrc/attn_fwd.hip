@@ -27,6 +27,7 @@ struct AttnParams {
   const uint16_t* k;
   const uint16_t* v;
   uint16_t* o;
+  float* lse;  // optional [B*H, Nq] fp32: log-sum-exp of the scaled scores (natural log), what cd360_attn_bwd_bf16 reads
   int B, H, Nq, Nk;
   long q_sb, q_sh, q_sn;  // element strides, d contiguous
   long k_sb, k_sh, k_sn;
@@ -279,6 +280,7 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams p) {
   // a percent of a 16-64 tile K-loop -- and cost a register spill)
   if (qrow < p.Nq) {
     const float inv = 1.f / w.l_run;
+    if (p.lse && hh == 0) p.lse[(long)bh * p.Nq + qrow] = (w.m_run * c + __log2f(w.l_run)) * 0.6931471805599453f;
     uint16_t* orow = op + (long)qrow * p.o_sn;
 #pragma unroll
     for (int db = 0; db < 2; ++db) {
@@ -467,6 +469,7 @@ __global__ __launch_bounds__(256, 2) void attn_smallk_kernel(AttnParams p) {
     // O^T registers (lane = query, 4 consecutive d per group) -> this wave's LDS block -> full 128-byte rows to HBM
     {
       const float inv = (FP8 ? p.o_scale : 1.f) / rs;
+      if (!FP8 && p.lse && hh == 0 && qb * 32 + l31 < p.Nq) p.lse[(long)bh * p.Nq + qb * 32 + l31] = (mx * c + __log2f(rs)) * 0.6931471805599453f;
 #pragma unroll
       for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -491,10 +494,10 @@ __global__ __launch_bounds__(256, 2) void attn_smallk_kernel(AttnParams p) {
 // fp8_amax = {max|q|, max|k|, max|v|} selects the fp8-MFMA variant (Nk <= 96 only); NULL = bf16 MFMA
 static int attn_launch(const void* q, const void* k, const void* v, void* o, int B, int H, int Nq, int Nk, const int64_t* q_strides,
                        const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, float scale, const float* fp8_amax,
-                       void* stream) {
+                       float* lse, void* stream) {
   if (!q || !k || !v || !o || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return CD360_ERR_ARG;
   AttnParams p;
-  p.q = (const uint16_t*)q; p.k = (const uint16_t*)k; p.v = (const uint16_t*)v; p.o = (uint16_t*)o;
+  p.q = (const uint16_t*)q; p.k = (const uint16_t*)k; p.v = (const uint16_t*)v; p.o = (uint16_t*)o; p.lse = lse;
   p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk;
   p.q_sb = q_strides[0]; p.q_sh = q_strides[1]; p.q_sn = q_strides[2];
   p.k_sb = k_strides[0]; p.k_sh = k_strides[1]; p.k_sn = k_strides[2];
@@ -556,7 +559,16 @@ static int attn_launch(const void* q, const void* k, const void* v, void* o, int
 extern "C" int cd360_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, int B, int H, int Nq, int Nk,
                                    const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                                    const int64_t* o_strides, float scale, void* stream) {
-  return attn_launch(q, k, v, o, B, H, Nq, Nk, q_strides, k_strides, v_strides, o_strides, scale, nullptr, stream);
+  return attn_launch(q, k, v, o, B, H, Nq, Nk, q_strides, k_strides, v_strides, o_strides, scale, nullptr, nullptr, stream);
+}
+
+// Training forward: the same kernels, additionally writing lse [B*H, Nq] fp32 (natural-log log-sum-exp of the scaled scores of every
+// query row), the only statistic cd360_attn_bwd_bf16 needs besides q, k, v, o.
+extern "C" int cd360_attn_fwd_lse_bf16(const void* q, const void* k, const void* v, void* o, void* lse, int B, int H, int Nq, int Nk,
+                                       const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                                       const int64_t* o_strides, float scale, void* stream) {
+  if (!lse) return CD360_ERR_ARG;
+  return attn_launch(q, k, v, o, B, H, Nq, Nk, q_strides, k_strides, v_strides, o_strides, scale, nullptr, (float*)lse, stream);
 }
 
 // fp8-MFMA variant for Nk <= 96 (BASELINE config 5): same bf16 tensors, Q / K / V^T / P rounded to e4m3 in registers.
@@ -565,7 +577,7 @@ extern "C" int cd360_attn_fwd_fp8mfma_bf16(const void* q, const void* k, const v
                                            const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                                            const int64_t* o_strides, float scale, const float* amax, void* stream) {
   if (!amax) return CD360_ERR_ARG;
-  return attn_launch(q, k, v, o, B, H, Nq, Nk, q_strides, k_strides, v_strides, o_strides, scale, amax, stream);
+  return attn_launch(q, k, v, o, B, H, Nq, Nk, q_strides, k_strides, v_strides, o_strides, scale, amax, nullptr, stream);
 }
 
 // xformers-layout convenience entry: q, k, v, o all contiguous [BH, N, 64] (attention.py:393-408), consumed in place

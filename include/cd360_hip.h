@@ -46,6 +46,20 @@ int cd360_attn_fwd_fp8mfma_bf16(const void* q, const void* k, const void* v, voi
                                 const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                                 const int64_t* o_strides, float scale, const float* amax, void* stream);
 
+/* Training pair (the fine-tuning loop differentiates attention.py:406 through xformers' autograd; BASELINE.json configs[3]).
+ * cd360_attn_fwd_lse_bf16 = cd360_attn_fwd_bf16 that also writes lse [B*H, Nq] fp32, the natural-log log-sum-exp of every
+ * query row's scaled scores.  cd360_attn_bwd_bf16 takes q, k, v, o, dout (bf16, forward layouts, strides multiples of 8) and
+ * that lse, and writes dq (may be NULL) and dk / dv (both or neither) in bf16 with their own strides (multiples of 4) -- e.g.
+ * the three column slices of one d(q|k|v) buffer.  delta_ws: B*H*Nq floats of caller-allocated workspace.  No atomics: the
+ * result is deterministic. */
+int cd360_attn_fwd_lse_bf16(const void* q, const void* k, const void* v, void* o, void* lse, int B, int H, int Nq, int Nk,
+                            const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides,
+                            float scale, void* stream);
+int cd360_attn_bwd_bf16(const void* q, const void* k, const void* v, const void* o, const void* dout, const void* lse, void* dq,
+                        void* dk, void* dv, void* delta_ws, int B, int H, int Nq, int Nk, const int64_t* q_strides,
+                        const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, const int64_t* do_strides,
+                        const int64_t* dq_strides, const int64_t* dk_strides, const int64_t* dv_strides, float scale, void* stream);
+
 /* xformers layout: q, k, v, o contiguous [B*H, N, 64], exactly the call of attention.py:406. */
 int cd360_attn_fwd_xformers_bf16(const void* q, const void* k, const void* v, void* o, int BH, int Nq, int Nk, float scale, void* stream);
 
