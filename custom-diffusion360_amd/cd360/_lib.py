@@ -29,10 +29,15 @@ SIGNATURES = {
     "cd360_nerf_k_padded": (c_int, []),
     "cd360_nerf_mlp_aggregate": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "cd360_volrender": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
+    "cd360_volrender_bwd": (c_int, [_P, _P, _P, _P, c_int] + [_P] * 8 + [c_int] * 6 + [_P]),
     "cd360_rowdot4_bf16": (c_int, [_P, _P, _P, c_int64, c_int, _P]),
     "cd360_geglu_bf16": (c_int, [_P, _P, c_int64, c_int, _P]),
     "cd360_concat_channels_bf16": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P]),
     "cd360_add_layernorm_bf16": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, c_float, _P]),
+    "cd360_geglu_bwd_bf16": (c_int, [_P, _P, _P, c_int64, c_int, _P]),
+    "cd360_add_layernorm_bwd_bf16": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, c_float, _P]),
+    "cd360_gn_bwd_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
+    "cd360_gn_silu_bwd_bf16": (c_int, [_P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P]),
     "cd360_cfg_euler_step_f32": (c_int, [_P, _P, _P, _P, c_float, c_float, _P, c_int64, _P]),
     "cd360_conv_k_order": (c_int, [c_int, c_int]),
     "cd360_conv_igemm_bf16": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),

@@ -36,3 +36,91 @@ class AttentionFn(torch.autograd.Function):
         need_dkv = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]
         dq, dk, dv = ops.attention_bwd(q, k, v, out, dout, lse, ctx.heads, ctx.nk, need_dq, need_dkv)
         return dq, dk, dv, None, None
+
+
+class VolRenderFn(torch.autograd.Function):
+    """ops.volrender (_TruncExp + VolRender, attention.py:192-208, nerfsd_pytorch3d.py:170-231) with cd360_volrender_bwd."""
+
+    @staticmethod
+    def forward(ctx, feats, sigma_raw, dists, rgb_raw, want_weights, sigma_is_raw, rgb_is_raw):
+        rendered, fg, alphas, weights, rgb = ops.volrender(feats, sigma_raw, dists, rgb_raw, want_weights, sigma_is_raw, rgb_is_raw)
+        ctx.save_for_backward(feats, sigma_raw, dists, rgb_raw)
+        ctx.set_materialize_grads(False)
+        ctx.flags = (sigma_is_raw, rgb_is_raw)
+        ctx.has = (weights is not None, rgb is not None)
+        return rendered, fg, alphas, weights, rgb
+
+    @staticmethod
+    def backward(ctx, d_rendered, d_fg, d_alphas, d_weights, d_rgb):
+        feats, sigma_raw, dists, rgb_raw = ctx.saved_tensors
+        d_feats, d_sigma, d_rgb_raw = ops.volrender_bwd(feats, sigma_raw, dists, rgb_raw, d_rendered, d_fg, d_alphas, d_weights, d_rgb, *ctx.flags)
+        d_sigma = d_sigma.reshape(sigma_raw.shape).to(sigma_raw.dtype)
+        if d_rgb_raw is not None:
+            d_rgb_raw = d_rgb_raw.reshape(rgb_raw.shape).to(rgb_raw.dtype)
+        return d_feats, d_sigma, None, d_rgb_raw, None, None, None
+
+
+class GroupNormSiluFn(torch.autograd.Function):
+    """ops.gn_silu (GroupNorm32 + SiLU, diffusionmodules/util.py:309-311, openaimodel.py:280-328) with cd360_gn_silu_bwd_bf16."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, groups, eps, silu, tile_stats):
+        _no_wgrad("gn_silu", gamma, beta)
+        y = ops.gn_silu(x, gamma, beta, groups, eps, silu, tile_stats=tile_stats)
+        ctx.save_for_backward(x, gamma, beta)
+        ctx.cfg = (groups, eps, silu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta = ctx.saved_tensors
+        return ops.gn_silu_bwd(x, dy, gamma, beta, *ctx.cfg), None, None, None, None, None, None
+
+
+class GegluFn(torch.autograd.Function):
+    """ops.geglu (GEGLU.forward, attention.py:89-96) with cd360_geglu_bwd_bf16."""
+
+    @staticmethod
+    def forward(ctx, proj):
+        ctx.save_for_backward(proj)
+        return ops.geglu(proj)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (proj,) = ctx.saved_tensors
+        return ops.geglu_bwd(proj, dy)
+
+
+class AddLayerNormFn(torch.autograd.Function):
+    """ops.add_layernorm (residual add + nn.LayerNorm, attention.py:609-636) with cd360_add_layernorm_bwd_bf16.  Returns
+    (sum, ln); with b None the sum IS a (returned as a view so the residual stream keeps one gradient path)."""
+
+    @staticmethod
+    def forward(ctx, a, b, gamma, beta, eps):
+        _no_wgrad("add_layernorm", gamma, beta)
+        s, ln = ops.add_layernorm(a, b, gamma, beta, eps, want_sum=True)
+        x = a if b is None else s
+        ctx.save_for_backward(x, gamma)
+        ctx.set_materialize_grads(False)
+        ctx.eps, ctx.has_b = eps, b is not None
+        if b is None:
+            return ln
+        return s, ln
+
+    @staticmethod
+    def backward(ctx, *grads):
+        x, gamma = ctx.saved_tensors
+        d_sum, d_ln = (grads if ctx.has_b else (None, grads[0]))
+        if d_ln is None:
+            dx = d_sum
+        else:
+            dx = ops.add_layernorm_bwd(x, gamma, d_ln, d_sum, ctx.eps)
+        return dx, (dx if ctx.has_b else None), None, None, None
+
+
+def add_layernorm(a, b, gamma, beta, eps, want_sum=True):
+    """ops.add_layernorm's (sum | None, ln) contract under autograd."""
+    if b is None:
+        return None, AddLayerNormFn.apply(a, None, gamma, beta, eps)
+    s, ln = AddLayerNormFn.apply(a, b, gamma, beta, eps)
+    return (s if want_sum else None), ln

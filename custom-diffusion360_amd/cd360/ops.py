@@ -263,7 +263,11 @@ def nerf_mlp_aggregate(cams, xs, ys, t, Y, zP, lv, cview, Wk, want_logits=False,
 
 # ----------------------------------------------------------------------------------------------- volume rendering
 def volrender(feats, sigma_raw, dists, rgb_raw=None, want_weights=False, sigma_is_raw=True, rgb_is_raw=True):
-    """feats [b,hw,S,C] (fp32|bf16), sigma_raw [b,hw,S] fp32, dists [S] or [hw,S] fp32, rgb_raw [b,hw,S,3] fp32|None."""
+    """feats [b,hw,S,C] (fp32|bf16), sigma_raw [b,hw,S] fp32, dists [S] or [hw,S] fp32, rgb_raw [b,hw,S,3] fp32|None.
+    Differentiable with respect to feats, sigma_raw and rgb_raw (grad.VolRenderFn)."""
+    if _wants_grad(feats, sigma_raw, rgb_raw):
+        from . import grad
+        return grad.VolRenderFn.apply(feats, sigma_raw, dists, rgb_raw, want_weights, sigma_is_raw, rgb_is_raw)
     _need_gpu(feats, sigma_raw, dists, rgb_raw)
     b, hw, S, C = feats.shape
     feats, sigma_raw, dists = feats.contiguous(), sigma_raw.contiguous().float(), dists.contiguous().float()
@@ -284,6 +288,30 @@ def volrender(feats, sigma_raw, dists, rgb_raw=None, want_weights=False, sigma_i
     return rendered, fg, alphas, weights, rgb
 
 
+def volrender_bwd(feats, sigma_raw, dists, rgb_raw, d_rendered, d_fg, d_alphas, d_weights, d_rgb, sigma_is_raw=True, rgb_is_raw=True):
+    """Backward of volrender: (d_feats [b,hw,S,C], d_sigma_raw [b,hw,S] fp32, d_rgb_raw [b,hw,S,3] fp32 | None).  Gradients that
+    did not arrive are None."""
+    _need_gpu(feats, sigma_raw, dists, rgb_raw, d_rendered, d_fg, d_alphas, d_weights, d_rgb)
+    b, hw, S, C = feats.shape
+    f32 = lambda t, shape: None if t is None else t.reshape(shape).contiguous().float()
+    feats, sigma_raw, dists = feats.contiguous(), sigma_raw.contiguous().float(), dists.contiguous().float()
+    rgb_raw = None if rgb_raw is None else rgb_raw.contiguous().float()
+    if d_rendered is None:
+        d_rendered = torch.zeros(b, hw, C, dtype=feats.dtype, device=feats.device)
+    d_rendered = d_rendered.contiguous().to(feats.dtype)
+    d_fg, d_alphas, d_weights, d_rgb = f32(d_fg, (b, hw)), f32(d_alphas, (b, hw, S)), f32(d_weights, (b, hw, S)), f32(d_rgb, (b, hw, 3))
+    d_feats = torch.empty_like(feats)
+    d_sigma = torch.empty(b, hw, S, dtype=torch.float32, device=feats.device)
+    d_rgb_raw = torch.empty(b, hw, S, 3, dtype=torch.float32, device=feats.device) if rgb_raw is not None else None
+    dt = {torch.float32: 0, torch.bfloat16: 1}[feats.dtype]
+    stride = 0 if dists.dim() == 1 else S
+    with _timed("volrender_bwd", 0.0, feats.element_size() * C * b * hw * (2.0 * S + 1.0)):
+        check(_lib.load().cd360_volrender_bwd(_ptr(feats), _ptr(sigma_raw), _ptr(rgb_raw), _ptr(dists), stride, _ptr(d_rendered), _ptr(d_fg),
+                                             _ptr(d_alphas), _ptr(d_weights), _ptr(d_rgb), _ptr(d_feats), _ptr(d_sigma), _ptr(d_rgb_raw), b, hw, S, C,
+                                             dt, (0 if sigma_is_raw else 1) | (0 if rgb_is_raw else 2), _stream()), "cd360_volrender_bwd")
+    return d_feats, d_sigma, d_rgb_raw
+
+
 def rowdot4(h: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     """h [..., C] bf16, w [4, C] fp32 -> [..., 4] fp32 (FeatureNeRF decoder)."""
     _need_gpu(h, w)
@@ -301,7 +329,11 @@ def gn_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: in
             out: Optional[torch.Tensor] = None, tile_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
     """x: channels-last bf16 viewed as [N, P, C] (contiguous).  gamma/beta fp32 [C].
     tile_stats: the fp32 [N, slabs, C, 2] per-slab channel sums conv_igemm(..., want_stats=True) returned for this very tensor
-    (the statistics read pass is skipped)."""
+    (the statistics read pass is skipped).  Differentiable with respect to x (grad.GroupNormSiluFn)."""
+    if _wants_grad(x, gamma, beta):
+        from . import grad
+        assert out is None
+        return grad.GroupNormSiluFn.apply(x, gamma, beta, groups, eps, silu, tile_stats)
     _need_gpu(x, gamma, beta, tile_stats)
     N, P, C = x.shape
     slabs = 0
@@ -319,9 +351,27 @@ def gn_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: in
     return out
 
 
+def gn_silu_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, silu: bool) -> torch.Tensor:
+    """Backward of gn_silu with respect to x: x, dy [N, P, C] bf16 -> dx."""
+    _need_gpu(x, dy, gamma, beta)
+    N, P, C = x.shape
+    dy = dy.contiguous()
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and dy.dtype == torch.bfloat16 and dy.shape == x.shape
+    lib = _lib.load()
+    ws = torch.empty(lib.cd360_gn_bwd_workspace_bytes(N, P, C), dtype=torch.uint8, device=x.device)
+    dx = torch.empty_like(x)
+    with _timed("gn_silu_bwd", 0.0, 2.0 * 6 * N * P * C):
+        check(lib.cd360_gn_silu_bwd_bf16(_ptr(x), _ptr(dy), _ptr(gamma), _ptr(beta), _ptr(dx), _ptr(ws), N, P, C, groups, float(eps), int(silu),
+                                         _stream()), "cd360_gn_silu_bwd_bf16")
+    return dx
+
+
 # ----------------------------------------------------------------------------------------------- epilogues
 def geglu(proj: torch.Tensor) -> torch.Tensor:
-    """proj [..., 2*inner] bf16 = [x | gate] -> [..., inner] = x * gelu(gate)."""
+    """proj [..., 2*inner] bf16 = [x | gate] -> [..., inner] = x * gelu(gate).  Differentiable (grad.GegluFn)."""
+    if _wants_grad(proj):
+        from . import grad
+        return grad.GegluFn.apply(proj)
     _need_gpu(proj)
     inner = proj.shape[-1] // 2
     assert proj.dtype == torch.bfloat16 and proj.is_contiguous()
@@ -330,6 +380,19 @@ def geglu(proj: torch.Tensor) -> torch.Tensor:
     with _timed("geglu", 0.0, 2.0 * 3 * rows * inner):
         check(_lib.load().cd360_geglu_bf16(_ptr(proj), _ptr(out), rows, inner, _stream()), "cd360_geglu_bf16")
     return out
+
+
+def geglu_bwd(proj: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    """Backward of geglu: d(proj) [..., 2*inner] = [dy gelu(gate) | dy x gelu'(gate)]."""
+    _need_gpu(proj, dy)
+    inner = proj.shape[-1] // 2
+    dy = dy.contiguous()
+    assert proj.dtype == torch.bfloat16 and proj.is_contiguous() and dy.dtype == torch.bfloat16 and dy.shape == (*proj.shape[:-1], inner)
+    rows = proj.numel() // (2 * inner)
+    din = torch.empty_like(proj)
+    with _timed("geglu_bwd", 0.0, 2.0 * 5 * rows * inner):
+        check(_lib.load().cd360_geglu_bwd_bf16(_ptr(proj), _ptr(dy), _ptr(din), rows, inner, _stream()), "cd360_geglu_bwd_bf16")
+    return din
 
 
 def concat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
@@ -392,7 +455,11 @@ def conv_igemm(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Ten
 
 
 def add_layernorm(a: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor, eps: float, want_sum: bool = True):
-    """(a + b, LayerNorm(a + b) * gamma + beta) in one pass; b None -> (None, LayerNorm(a)).  All bf16, last dim C."""
+    """(a + b, LayerNorm(a + b) * gamma + beta) in one pass; b None -> (None, LayerNorm(a)).  All bf16, last dim C.
+    Differentiable with respect to a and b (grad.AddLayerNormFn)."""
+    if _wants_grad(a, b, gamma, beta):
+        from . import grad
+        return grad.add_layernorm(a, b, gamma, beta, eps, want_sum)
     _need_gpu(a, b, gamma, beta)
     C = a.shape[-1]
     assert a.dtype == torch.bfloat16 and a.is_contiguous() and gamma.dtype == torch.bfloat16 and beta.dtype == torch.bfloat16
@@ -404,6 +471,22 @@ def add_layernorm(a: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tenso
         check(_lib.load().cd360_add_layernorm_bf16(_ptr(a), _ptr(b), _ptr(gamma), _ptr(beta), _ptr(s), _ptr(ln), rows, C, float(eps), _stream()),
               "cd360_add_layernorm_bf16")
     return s, ln
+
+
+def add_layernorm_bwd(x: torch.Tensor, gamma: torch.Tensor, d_ln: torch.Tensor, d_sum: Optional[torch.Tensor], eps: float) -> torch.Tensor:
+    """Backward of add_layernorm with respect to the summed input x (= a + b): LayerNorm backward of d_ln plus d_sum."""
+    _need_gpu(x, gamma, d_ln, d_sum)
+    C = x.shape[-1]
+    d_ln = d_ln.contiguous()
+    d_sum = None if d_sum is None else d_sum.contiguous()
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and gamma.dtype == torch.bfloat16 and d_ln.dtype == torch.bfloat16 and d_ln.shape == x.shape
+    assert d_sum is None or (d_sum.dtype == torch.bfloat16 and d_sum.shape == x.shape)
+    rows = x.numel() // C
+    dx = torch.empty_like(x)
+    with _timed("add_layernorm_bwd", 0.0, 2.0 * rows * C * (3 + (d_sum is not None))):
+        check(_lib.load().cd360_add_layernorm_bwd_bf16(_ptr(x), _ptr(gamma), _ptr(d_ln), _ptr(d_sum), _ptr(dx), rows, C, float(eps), _stream()),
+              "cd360_add_layernorm_bwd_bf16")
+    return dx
 
 
 def cfg_euler_step(x: torch.Tensor, eps: torch.Tensor, sigma: torch.Tensor, sigma_next: torch.Tensor, scale: float, scale_im: float):

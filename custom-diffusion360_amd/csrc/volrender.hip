@@ -104,6 +104,145 @@ extern "C" int cd360_volrender(const void* feats, const void* sigma_raw, const v
   return CD360_OK;
 }
 
+// ---- backward of cd360_volrender (the reference differentiates VolRender.forward and _TruncExp through torch autograd;
+// _TruncExp.backward = g * exp(clamp(x, -15, 15)), attention.py:203-207).  One wave per ray: lane s owns sample s of the scan
+// (S <= 64), channels are spread over the lanes for the feature pass, which reads feats once and writes d_feats once.
+//   w_s = alpha_s T_s,  alpha_s = 1 - e^{-dd_s},  T_s = e^{-sum_{j<s} dd_j},  dd = dists * sigma
+//   dw_s = <d_rendered, feat_s> + d_fg + <d_rgb, col_s> + d_weights_s          (0 where nan_to_num replaced w)
+//   d(dd)_j = dw_j T_{j+1} - sum_{s>j} dw_s w_s + d_alphas_j e^{-dd_j}
+namespace {
+template <bool BF16>
+__global__ __launch_bounds__(256) void volrender_bwd_kernel(const void* __restrict__ feats_, const float* __restrict__ sigma_raw,
+                                                            const float* __restrict__ rgb_raw, const float* __restrict__ dists, int d_ray_stride,
+                                                            const void* __restrict__ d_rendered_, const float* __restrict__ d_fg,
+                                                            const float* __restrict__ d_alphas, const float* __restrict__ d_weights,
+                                                            const float* __restrict__ d_rgb, void* __restrict__ d_feats_,
+                                                            float* __restrict__ d_sigma_raw, float* __restrict__ d_rgb_raw, long nrays, int hw,
+                                                            int S, int C, int flags) {
+  constexpr int VEC = BF16 ? 8 : 4;
+  const int lane = threadIdx.x & 63;
+  const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  for (long ray = wave0; ray < nrays; ray += nwaves) {
+    const int k = (int)(ray % hw);
+    // ---- the scan, lane s = sample s ----
+    float dd = 0.f, sig = 0.f, raw = 0.f, dist = 0.f;
+    if (lane < S) {
+      raw = sigma_raw[ray * S + lane];
+      dist = dists[(long)k * d_ray_stride + lane];
+      sig = (flags & 1) ? raw : expf(raw);
+      dd = dist * sig;
+    }
+    float incl = dd;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const float t = __shfl_up(incl, off);
+      if (lane >= off) incl += t;
+    }
+    float excl = __shfl_up(incl, 1);  // (not incl - dd: one huge dd would cancel the small prefix away)
+    if (lane == 0) excl = 0.f;
+    const float e_own = expf(-dd), alpha = 1.f - e_own, t_next = expf(-incl), t_cur = expf(-excl);
+    float w = alpha * t_cur;
+    const bool dead = (w != w) || lane >= S;  // nan_to_num replaced a NaN by the constant 0 (no gradient); +-inf clamps likewise
+    if (dead) w = 0.f;
+    const bool clamped = fabsf(w) > 3.402823466e38f;
+    w = fminf(fmaxf(w, -3.402823466e38f), 3.402823466e38f);
+
+    // ---- feature pass: d_feats = w_s d_rendered, dot_s = <d_rendered, feat_s> ----
+    float dot_own = 0.f;
+    for (int s = 0; s < S; ++s) {
+      const float ws = __shfl(w, s);
+      float part = 0.f;
+      for (int c = lane * VEC; c < C; c += 64 * VEC) {
+        const long foff = (ray * S + s) * (long)C + c, roff = ray * (long)C + c;
+        if (BF16) {
+          const u32x4 f = *reinterpret_cast<const u32x4*>((const uint16_t*)feats_ + foff);
+          const u32x4 g = *reinterpret_cast<const u32x4*>((const uint16_t*)d_rendered_ + roff);
+          u32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float g0 = bf16lo_to_f32(g[e]), g1 = bf16hi_to_f32(g[e]);
+            part += g0 * bf16lo_to_f32(f[e]) + g1 * bf16hi_to_f32(f[e]);
+            o[e] = pack_bf16x2(ws * g0, ws * g1);
+          }
+          *reinterpret_cast<u32x4*>((uint16_t*)d_feats_ + foff) = o;
+        } else {
+          const f32x4 f = *reinterpret_cast<const f32x4*>((const float*)feats_ + foff);
+          const f32x4 g = *reinterpret_cast<const f32x4*>((const float*)d_rendered_ + roff);
+          f32x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            part += g[e] * f[e];
+            o[e] = ws * g[e];
+          }
+          *reinterpret_cast<f32x4*>((float*)d_feats_ + foff) = o;
+        }
+      }
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+      if (lane == s) dot_own = part;
+    }
+
+    // ---- per-sample gradients, lane s = sample s ----
+    float dw = dot_own;
+    if (d_fg) dw += d_fg[ray];
+    if (d_weights && lane < S) dw += d_weights[ray * S + lane];
+    if (rgb_raw && d_rgb && lane < S) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) {
+        const float rr = rgb_raw[(ray * S + lane) * 3 + j], gj = d_rgb[ray * 3 + j];
+        const float col = (flags & 2) ? rr : 1.f / (1.f + expf(-rr));
+        dw += gj * col;
+        if (d_rgb_raw) d_rgb_raw[(ray * S + lane) * 3 + j] = w * gj * ((flags & 2) ? 1.f : col * (1.f - col));
+      }
+    } else if (d_rgb_raw && lane < S) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j) d_rgb_raw[(ray * S + lane) * 3 + j] = 0.f;
+    }
+    if (dead || clamped) dw = 0.f;
+    const float dww = dw * w;
+    float suf = dww;  // inclusive suffix sum of dw_s w_s (a direct reverse scan: total - prefix would cancel)
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const float t = __shfl_down(suf, off);
+      if (lane + off < 64) suf += t;
+    }
+    float after = __shfl_down(suf, 1);  // sum over s > lane
+    if (lane == 63) after = 0.f;
+    float ddd = dw * t_next - after;
+    if (d_alphas && lane < S) ddd += d_alphas[ray * S + lane] * e_own;
+    if (lane < S) {
+      float gs = ddd * dist;
+      if (!(flags & 1)) gs *= expf(fminf(fmaxf(raw, -15.f), 15.f));
+      d_sigma_raw[ray * S + lane] = gs;
+    }
+  }
+}
+}  // namespace
+
+// Backward of cd360_volrender: same feats / sigma_raw / rgb_raw / dists / flags as the forward call; incoming gradients d_rendered
+// [b, hw, C] (feats' dtype; required), d_fg [b, hw], d_alphas / d_weights [b, hw, S], d_rgb [b, hw, 3] (fp32, any may be NULL = zero).
+// out: d_feats [b, hw, S, C] (feats' dtype), d_sigma_raw [b, hw, S] fp32, d_rgb_raw [b, hw, S, 3] fp32 (may be NULL).
+extern "C" int cd360_volrender_bwd(const void* feats, const void* sigma_raw, const void* rgb_raw, const void* dists, int d_ray_stride,
+                                   const void* d_rendered, const void* d_fg, const void* d_alphas, const void* d_weights, const void* d_rgb,
+                                   void* d_feats, void* d_sigma_raw, void* d_rgb_raw, int b, int hw, int S, int C, int dtype, int flags,
+                                   void* stream) {
+  if (!feats || !sigma_raw || !dists || !d_rendered || !d_feats || !d_sigma_raw || b <= 0 || hw <= 0 || S <= 0 || C <= 0) return CD360_ERR_ARG;
+  if (S > MAX_S || (dtype != 0 && dtype != 1) || C % (dtype ? 8 : 4)) return CD360_ERR_SHAPE;
+  if (d_ray_stride != 0 && d_ray_stride != S) return CD360_ERR_SHAPE;
+  const long nrays = (long)b * hw;
+  const unsigned blocks = (unsigned)((nrays + 3) / 4 > 256 * 16 ? 256 * 16 : (nrays + 3) / 4);
+  if (dtype)
+    hipLaunchKernelGGL(volrender_bwd_kernel<true>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, feats, (const float*)sigma_raw,
+                       (const float*)rgb_raw, (const float*)dists, d_ray_stride, d_rendered, (const float*)d_fg, (const float*)d_alphas,
+                       (const float*)d_weights, (const float*)d_rgb, d_feats, (float*)d_sigma_raw, (float*)d_rgb_raw, nrays, hw, S, C, flags);
+  else
+    hipLaunchKernelGGL(volrender_bwd_kernel<false>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, feats, (const float*)sigma_raw,
+                       (const float*)rgb_raw, (const float*)dists, d_ray_stride, d_rendered, (const float*)d_fg, (const float*)d_alphas,
+                       (const float*)d_weights, (const float*)d_rgb, d_feats, (float*)d_sigma_raw, (float*)d_rgb_raw, nrays, hw, S, C, flags);
+  CD360_LAUNCH_CHECK();
+  return CD360_OK;
+}
+
 // ---- A9: decoder (zero-init Linear(C -> 4, no bias), sgm/modules/nerfsd_pytorch3d.py:49-51,160) on bf16 tokens with
 // fp32 weights, fp32 accumulation and fp32 output (sigma_raw feeds exp(): it must not be rounded to bf16).
 // One wave per row; HBM-bound (reads h once).

@@ -112,6 +112,15 @@ int cd360_nerf_mlp_aggregate(const void* cams, const void* xs, const void* ys, c
 int cd360_volrender(const void* feats, const void* sigma_raw, const void* rgb_raw, const void* dists, int d_ray_stride, void* rendered,
                     void* fg, void* alphas, void* weights, void* rgb, int b, int hw, int S, int C, int dtype, int flags, void* stream);
 
+/* Backward of cd360_volrender for the fine-tuning loop (the reference differentiates VolRender.forward (nerfsd_pytorch3d.py:170-231)
+ * and _TruncExp, whose backward is g * exp(clamp(x, -15, 15)) (attention.py:203-207), through torch autograd).  Same feats /
+ * sigma_raw / rgb_raw / dists / flags as the forward call; incoming gradients d_rendered [b, hw, C] (dtype of feats; required),
+ * d_fg [b, hw], d_alphas, d_weights [b, hw, S], d_rgb [b, hw, 3] (fp32; NULL = zero).  Outputs d_feats [b, hw, S, C] (dtype of
+ * feats), d_sigma_raw [b, hw, S] fp32, d_rgb_raw [b, hw, S, 3] fp32 (may be NULL). */
+int cd360_volrender_bwd(const void* feats, const void* sigma_raw, const void* rgb_raw, const void* dists, int d_ray_stride,
+                        const void* d_rendered, const void* d_fg, const void* d_alphas, const void* d_weights, const void* d_rgb,
+                        void* d_feats, void* d_sigma_raw, void* d_rgb_raw, int b, int hw, int S, int C, int dtype, int flags, void* stream);
+
 /* replaces FeatureNeRFEncoding.decoder, Linear(C -> 1+3, bias=False) (nerfsd_pytorch3d.py:49-51,160) and the channel split in
  * NerfSDModule.forward (:443-449): h [rows, C] bf16, w [4, C] fp32 -> out [rows, 4] fp32 = (rgb_raw 0..2, sigma_raw 3). */
 int cd360_rowdot4_bf16(const void* h, const void* w, void* out, int64_t rows, int C, void* stream);
@@ -126,6 +135,12 @@ int cd360_gn_silu_bf16(const void* x, const void* gamma, const void* beta, void*
 /* tile_stats / stats_slabs (optional, NULL / 0): per-slab channel sums [N, stats_slabs, C, 2] already produced by the conv that
  * wrote x (cd360_conv_igemm_bf16); the statistics read pass over x is then skipped. */
 
+/* Backward of cd360_gn_silu_bf16 with respect to x (GroupNorm32 / SiLU under torch autograd in the reference's training loop):
+ * x, dy, dx [N, P, C] bf16 (dx may alias dy); ws = cd360_gn_bwd_workspace_bytes(N, P, C) bytes.  No gamma / beta gradients. */
+int64_t cd360_gn_bwd_workspace_bytes(int N, int P, int C);
+int cd360_gn_silu_bwd_bf16(const void* x, const void* dy, const void* gamma, const void* beta, void* dx, void* ws, int N, int P, int C, int G,
+                           float eps, int silu, void* stream);
+
 /* ---- epilogues around the transformer blocks -------------------------------------------------------------------------
  * replaces GEGLU.forward's chunk / F.gelu / multiply (sgm/modules/attention.py:94-96): in [rows, 2*inner] bf16 = [x | gate]
  * -> out [rows, inner] = x * gelu(gate) (erf form).  inner % 8 == 0. */
@@ -138,6 +153,14 @@ int cd360_concat_channels_bf16(const void* a, const void* b, void* out, int64_t 
  * sum_out = a + b (NULL to skip; b NULL = plain LayerNorm), ln_out = LayerNorm(a + b) * gamma + beta.  All bf16, C % 8 == 0, C <= 2048. */
 int cd360_add_layernorm_bf16(const void* a, const void* b, const void* gamma, const void* beta, void* sum_out, void* ln_out, int64_t rows,
                              int C, float eps, void* stream);
+
+/* Backward of the two epilogues above (torch autograd of GEGLU.forward / nn.LayerNorm + residual add in the reference):
+ * geglu: in [rows, 2*inner] (the forward input), dy [rows, inner] -> din [rows, 2*inner] = [dx | dgate];
+ * add_layernorm: x = a + b (the forward's sum_out, or a when b was NULL), d_ln, d_sum (gradient arriving on sum_out; NULL = none)
+ * -> dx = da = db, all [rows, C] bf16 (dx may alias d_ln / d_sum).  No gamma / beta gradients. */
+int cd360_geglu_bwd_bf16(const void* in, const void* dy, void* din, int64_t rows, int inner, void* stream);
+int cd360_add_layernorm_bwd_bf16(const void* x, const void* gamma, const void* d_ln, const void* d_sum, void* dx, int64_t rows, int C, float eps,
+                                 void* stream);
 
 /* replaces the elementwise tail of one sampling step: DiscreteDenoiser's c_out/c_skip (denoiser.py:41-44), ScheduledCFGImgTextRef.__call__
  * (guiders.py:111-114), to_d and the Euler update (sampling.py:101-106).  x [n] fp32, eps [3n] fp32 (u | ic | c), sigma / sigma_next

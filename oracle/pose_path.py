@@ -337,6 +337,22 @@ def feed_forward(w: Dict[str, Tensor], x: Tensor) -> Tensor:
 # --------------------------------------------------------------------------------------
 # A3 + A10 + A11 + A12: pose-conditioned transformer block
 # --------------------------------------------------------------------------------------
+class _TruncExp(torch.autograd.Function):
+    """attention.py:192-208: exp forward; the backward multiplies by exp of the input clamped to [-15, 15]."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return torch.exp(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g * torch.exp(ctx.saved_tensors[0].clamp(-15, 15))
+
+
+trunc_exp = _TruncExp.apply
+
+
 def reference_attn(w: Dict[str, Tensor], context_ref: Tensor, context: Tensor, cams: Tensor, heads: int,
                    num_samples: int, far: float, near: float = 0.0, mask_ref=None, rgb_predict=True,
                    average=False, xy_jitter=None, depth_jitter=None):
@@ -349,7 +365,7 @@ def reference_attn(w: Dict[str, Tensor], context_ref: Tensor, context: Tensor, c
     tok = feats.reshape(b, hw * S, C)
     tok = cross_attention(sub(w, "attn2"), layer_norm(w, "norm2", tok), context, heads) + tok  # (:581-586)
     feats2 = tok.reshape(b, hw, S, C)
-    sig = torch.exp(sigma)  # _TruncExp forward (attention.py:192-199)
+    sig = trunc_exp(sigma)  # _TruncExp (attention.py:192-208)
     rendered, fg, alphas, _, rgb_out = vol_render(feats2, sig, dists, torch.sigmoid(rgb) if rgb is not None else None)
     dbg.update(feats=feats, sigma_raw=sigma, rgb_raw=rgb, view_weights=attn, tokens=feats2)
     return rendered, fg, alphas, rgb_out, dbg

@@ -62,3 +62,107 @@ def test_attention_backward(B, H, Nq, Nk, kv_grad):
         assert (kd.grad[:, Nk:] == 0).all() and (vd.grad[:, Nk:] == 0).all()
     else:
         assert kd.grad is None and vd.grad is None
+
+
+# ------------------------------------------------------------------------------------------------ volume rendering
+@pytest.mark.parametrize("b,hw,S,C,dtype,per_ray", [(2, 16, 24, 64, torch.float32, False), (1, 64, 24, 640, torch.bfloat16, True),
+                                                    (3, 9, 5, 1280, torch.bfloat16, False), (1, 4, 64, 8, torch.float32, True)])
+def test_volrender_backward(b, hw, S, C, dtype, per_ray):
+    """Gradients of (rendered, fg, alphas, rgb) with respect to (feats, sigma_raw, rgb_raw): _TruncExp + VolRender under autograd.
+    One sigma_raw of 20 exercises the clamped derivative exp(15) of _TruncExp.backward (attention.py:203-207)."""
+    from cd360 import ops
+    g = torch.Generator().manual_seed(hw * S + C)
+    feats = torch.randn(b, hw, S, C, generator=g)
+    if dtype == torch.bfloat16:
+        feats = bf(feats)
+    sigma_raw = torch.randn(b, hw, S, generator=g) * 1.5
+    sigma_raw[0, 0, S // 2] = 20.0
+    rgb_raw = torch.randn(b, hw, S, 3, generator=g)
+    dists = (torch.rand(hw, S, generator=g) if per_ray else torch.rand(S, generator=g)) * 0.2 + 0.01
+    g_r, g_fg, g_al, g_rgb = (torch.randn(b, hw, C, generator=g), torch.randn(b, hw, 1, generator=g), torch.randn(b, hw, S, 1, generator=g),
+                              torch.randn(b, hw, 3, generator=g))
+    if dtype == torch.bfloat16:
+        g_r = bf(g_r)
+
+    fo, so, ro = (t.clone().requires_grad_(True) for t in (feats, sigma_raw, rgb_raw))
+    d3 = (dists if per_ray else dists[None].expand(hw, S))[None, :, :, None]
+    rendered, fg, alphas, _, rgb = O.vol_render(fo, O.trunc_exp(so)[..., None], d3, torch.sigmoid(ro))
+    want = torch.autograd.grad([rendered, fg, alphas, rgb], (fo, so, ro), [g_r, g_fg, g_al, g_rgb])
+
+    fd = feats.to(DEV, dtype).requires_grad_(True)
+    sd = sigma_raw.to(DEV).requires_grad_(True)
+    rd = rgb_raw.to(DEV).requires_grad_(True)
+    out = ops.volrender(fd, sd, dists.to(DEV), rd)
+    assert rel(out[0], rendered) < (1e-2 if dtype == torch.bfloat16 else 1e-5)
+    torch.autograd.backward([out[0], out[1], out[2], out[4]], [g_r.to(DEV, dtype), g_fg.to(DEV), g_al.to(DEV), g_rgb.to(DEV)])
+    tol = 1e-2 if dtype == torch.bfloat16 else 2e-4
+    assert rel(fd.grad, want[0]) < tol
+    assert rel(sd.grad, want[1]) < tol
+    assert rel(rd.grad, want[2]) < tol
+
+
+# ------------------------------------------------------------------------------------------------ GroupNorm (+SiLU), LayerNorm, GEGLU
+@pytest.mark.parametrize("N,P,C,silu", [(2, 256, 320, True), (1, 1024, 640, False), (3, 64, 1280, True), (1, 100, 2560, True), (2, 16, 64, False)])
+def test_gn_silu_backward(N, P, C, silu):
+    from cd360 import ops
+    g = torch.Generator().manual_seed(P + C)
+    x = bf(torch.randn(N, P, C, generator=g) * 1.5 + 0.3)
+    gamma, beta = torch.randn(C, generator=g), torch.randn(C, generator=g) * 0.5
+    dy = bf(torch.randn(N, P, C, generator=g))
+    xo = x.clone().requires_grad_(True)
+    y = torch.nn.functional.group_norm(xo.permute(0, 2, 1), 32, gamma, beta, 1e-5).permute(0, 2, 1)
+    if silu:
+        y = torch.nn.functional.silu(y)
+    (want,) = torch.autograd.grad(y, xo, dy)
+    xd = x.to(DEV, torch.bfloat16).requires_grad_(True)
+    got = ops.gn_silu(xd, gamma.to(DEV), beta.to(DEV), 32, 1e-5, silu)
+    assert rel(got, y) < 1e-2
+    got.backward(dy.to(DEV, torch.bfloat16))
+    assert rel(xd.grad, want) < 1e-2
+
+
+@pytest.mark.parametrize("rows,C,with_b,sum_grad", [(300, 640, True, True), (77, 1280, False, False), (1000, 320, True, False), (5, 2048, True, True)])
+def test_add_layernorm_backward(rows, C, with_b, sum_grad):
+    from cd360 import ops
+    g = torch.Generator().manual_seed(rows + C)
+    a = bf(torch.randn(rows, C, generator=g))
+    b = bf(torch.randn(rows, C, generator=g)) if with_b else None
+    gamma, beta = bf(torch.randn(C, generator=g)), bf(torch.randn(C, generator=g))
+    d_ln, d_s = bf(torch.randn(rows, C, generator=g)), bf(torch.randn(rows, C, generator=g))
+    ao = a.clone().requires_grad_(True)
+    bo = b.clone().requires_grad_(True) if with_b else None
+    so = ao + bo if with_b else ao
+    ln = torch.nn.functional.layer_norm(so, (C,), gamma, beta, 1e-5)
+    outs, gr = [ln], [d_ln]
+    if sum_grad:
+        outs.append(so)
+        gr.append(d_s)
+    want = torch.autograd.grad(outs, [ao] + ([bo] if with_b else []), gr)
+    ad = a.to(DEV, torch.bfloat16).requires_grad_(True)
+    bd = b.to(DEV, torch.bfloat16).requires_grad_(True) if with_b else None
+    s, lnd = ops.add_layernorm(ad, bd, gamma.to(DEV, torch.bfloat16), beta.to(DEV, torch.bfloat16), 1e-5)
+    assert rel(lnd, ln) < 1e-2
+    outs, gr = [lnd], [d_ln.to(DEV, torch.bfloat16)]
+    if sum_grad:
+        outs.append(s)
+        gr.append(d_s.to(DEV, torch.bfloat16))
+    torch.autograd.backward(outs, gr)
+    assert rel(ad.grad, want[0]) < 1e-2
+    if with_b:
+        assert rel(bd.grad, want[1]) < 1e-2
+
+
+def test_geglu_backward():
+    from cd360 import ops
+    g = torch.Generator().manual_seed(3)
+    proj = bf(torch.randn(2, 150, 2 * 640, generator=g) * 2)
+    dy = bf(torch.randn(2, 150, 640, generator=g))
+    po = proj.clone().requires_grad_(True)
+    h, gate = po.chunk(2, dim=-1)
+    y = h * torch.nn.functional.gelu(gate)
+    (want,) = torch.autograd.grad(y, po, dy)
+    pd = proj.to(DEV, torch.bfloat16).requires_grad_(True)
+    got = ops.geglu(pd)
+    assert rel(got, y) < 1e-2
+    got.backward(dy.to(DEV, torch.bfloat16))
+    assert rel(pd.grad, want) < 1e-2
