@@ -124,3 +124,46 @@ def add_layernorm(a, b, gamma, beta, eps, want_sum=True):
         return None, AddLayerNormFn.apply(a, None, gamma, beta, eps)
     s, ln = AddLayerNormFn.apply(a, b, gamma, beta, eps)
     return (s if want_sum else None), ln
+
+
+class NerfAggregateFn(torch.autograd.Function):
+    """ops.nerf_mlp_aggregate (FeatureNeRFEncoding.forward, nerfsd_pytorch3d.py:53-158) with cd360_nerf_mlp_aggregate_bwd.
+    The kernel leaves dz = softmax_i dg SiLU'(z_i) and the generated inputs F in HBM; the parameter-side reductions are one GEMM
+    (dWk = dz^T F) and one sum over the depth samples (dzP)."""
+
+    @staticmethod
+    def forward(ctx, cams, xs, ys, t, Y, zP, lv, cview, Wk, img_map):
+        g, logits, lse = ops.nerf_mlp_aggregate(cams, xs, ys, t, Y, zP, lv, cview, Wk, want_logits=True, img_map=img_map)
+        ctx.save_for_backward(cams, xs, ys, t, Y, zP, lv, cview, Wk, g, lse)
+        ctx.img_map = img_map
+        ctx.mark_non_differentiable(logits, lse)
+        return g, logits, lse
+
+    @staticmethod
+    def backward(ctx, dg, _dlogits, _dlse):
+        cams, xs, ys, t, Y, zP, lv, cview, Wk, g, lse = ctx.saved_tensors
+        dz, F, dY, dlv, dcview = ops.nerf_mlp_aggregate_bwd(cams, xs, ys, t, Y, zP, lv, cview, Wk, ctx.img_map, g, lse, dg)
+        b, n, npts, C = dz.shape
+        S = t.shape[-1]
+        dzP = dz.reshape(b * n, npts // S, S, C).sum(2, dtype=torch.float32).to(zP.dtype)
+        dWk = torch.mm(dz.reshape(-1, C).t(), F.reshape(-1, F.shape[-1])).to(Wk.dtype)
+        return None, None, None, None, dY.to(Y.dtype), dzP, dlv, dcview, dWk, None
+
+
+class RowDot4Fn(torch.autograd.Function):
+    """ops.rowdot4 (FeatureNeRFEncoding.decoder, Linear(C -> 4, no bias), nerfsd_pytorch3d.py:49-51,160); its backward is two
+    K = 4 library GEMMs."""
+
+    @staticmethod
+    def forward(ctx, h, w):
+        ctx.save_for_backward(h, w)
+        return ops.rowdot4(h, w)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        h, w = ctx.saved_tensors
+        C = h.shape[-1]
+        d2 = d_out.reshape(-1, 4).float()
+        dh = torch.mm(d2, w).to(h.dtype).reshape(h.shape) if ctx.needs_input_grad[0] else None
+        dw = torch.mm(d2.t().to(h.dtype), h.reshape(-1, C)).float() if ctx.needs_input_grad[1] else None
+        return dh, dw

@@ -56,11 +56,15 @@ def positional_encoding(x: torch.Tensor, n_freqs: int) -> torch.Tensor:
 class FusedNerfWeights:
     """Derived, cached forms of one FeatureNeRFEncoding's parameters."""
 
-    def __init__(self, W1, b1, W2, b2, wv, bv, Wd, dtype=torch.bfloat16):
+    def __init__(self, W1, b1, W2, b2, wv, bv, Wd, dtype=torch.bfloat16, live: bool = False):
+        """live=True (training): the derived tensors stay connected to the parameters by autograd (slicing, transposes and casts
+        are recorded), so gradients of the tables and of Wk flow back into plane_coefs / nviews / decoder; nothing is cached."""
         C = W2.shape[0]
         self.C = C
         dev = W1.device
-        W1f = W1.detach().float()
+        if not live:
+            W1, b1, W2, b2, wv, bv, Wd = (p.detach() for p in (W1, b1, W2, b2, wv, bv, Wd))
+        W1f = W1.float()
         self.Wf_t = W1f[:, :C].t().contiguous().to(dtype)  # [C, C]: Y = xref @ Wf_t
         cols = xyz_k_columns(C)
         Wk = torch.zeros(C, len(cols), dtype=torch.float32, device=dev)
@@ -72,15 +76,15 @@ class FusedNerfWeights:
         Wp = torch.zeros(104, C, dtype=torch.float32, device=dev)
         Wp[:99] = W1f[:, C + 99:C + 198].t()
         self.Wp_t = Wp.contiguous()  # [104, C] fp32
-        self.b1 = b1.detach().float().contiguous()
-        self.W2_t = W2.detach().t().contiguous().to(dtype)
-        self.b2 = b2.detach().to(dtype).contiguous()
-        wvf = wv.detach().float().reshape(-1)
+        self.b1 = b1.float().contiguous()
+        self.W2_t = W2.t().contiguous().to(dtype)
+        self.b2 = b2.to(dtype).contiguous()
+        wvf = wv.float().reshape(-1)
         self.vf = wvf[:C].contiguous()
         self.v_otgt = wvf[C + 99:C + 102].contiguous()
         self.v_otgt_enc = wvf[C + 102:C + 198].contiguous()
-        self.bv = bv.detach().float().reshape(())
-        self.Wd = Wd.detach().float().contiguous()  # [4, C]
+        self.bv = bv.float().reshape(())
+        self.Wd = Wd.float().contiguous()  # [4, C]
 
 
 _grid_cache = {}

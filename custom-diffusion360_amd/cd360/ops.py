@@ -237,7 +237,11 @@ def nerf_k_padded() -> int:
 
 
 def nerf_mlp_aggregate(cams, xs, ys, t, Y, zP, lv, cview, Wk, want_logits=False, img_map=None):
-    """img_map (int32 [b*n], optional): Y / lv hold only distinct table images [n_tab, hw, ...]; (batch, view) reads image img_map[b*n_idx]."""
+    """img_map (int32 [b*n], optional): Y / lv hold only distinct table images [n_tab, hw, ...]; (batch, view) reads image img_map[b*n_idx].
+    Differentiable with respect to Y, zP, lv, cview and Wk (grad.NerfAggregateFn; logits and lse are then always returned)."""
+    if _wants_grad(Y, zP, lv, cview, Wk):
+        from . import grad
+        return grad.NerfAggregateFn.apply(cams, xs, ys, t, Y, zP, lv, cview, Wk, img_map)
     _need_gpu(cams, xs, ys, t, Y, zP, lv, cview, Wk, img_map)
     b, n1, _ = cams.shape
     n, r = n1 - 1, xs.numel()
@@ -259,6 +263,33 @@ def nerf_mlp_aggregate(cams, xs, ys, t, Y, zP, lv, cview, Wk, want_logits=False,
                                               _ptr(cview), _ptr(Wk), _ptr(img_map), _ptr(g), _ptr(logits), _ptr(lse), b, n, r, S, C, _stream()),
           "cd360_nerf_mlp_aggregate")
     return g, logits, lse
+
+
+def nerf_mlp_aggregate_bwd(cams, xs, ys, t, Y, zP, lv, cview, Wk, img_map, g, lse, dg):
+    """Backward kernel of nerf_mlp_aggregate -> (dz [b,n,hw*S,C] bf16, F [b,n,hw*S,112] bf16, dY [tables,hw,C] fp32,
+    dlv [tables,hw] fp32, dcview [b,n] fp32)."""
+    _need_gpu(cams, xs, ys, t, Y, zP, lv, cview, Wk, img_map, g, lse, dg)
+    b, n1, _ = cams.shape
+    n, r = n1 - 1, xs.numel()
+    hw, S = r * r, t.shape[-1]
+    C = Y.shape[-1]
+    dev = Y.device
+    dg = dg.contiguous()
+    assert dg.dtype == torch.bfloat16 and dg.shape == (b, hw * S, C) and g.shape == dg.shape and lse.shape == (b, hw * S, 2)
+    kp = nerf_k_padded()
+    dz = torch.empty(b, n, hw * S, C, dtype=torch.bfloat16, device=dev)
+    F = torch.empty(b, n, hw * S, kp, dtype=torch.bfloat16, device=dev)
+    dY = torch.zeros(Y.shape, dtype=torch.float32, device=dev)
+    dlogit = torch.zeros(b, n, hw * S, dtype=torch.float32, device=dev)
+    dlv = torch.zeros(lv.shape, dtype=torch.float32, device=dev)
+    dcview = torch.zeros(b, n, dtype=torch.float32, device=dev)
+    stride = 0 if t.dim() == 1 else S
+    with _timed("nerf_mlp_aggregate_bwd", 2.0 * b * n * hw * S * 99 * C, 2.0 * C * (2 * b * n * hw + (2 + n) * b * hw * S)):
+        check(_lib.load().cd360_nerf_mlp_aggregate_bwd(_ptr(cams), _ptr(xs), _ptr(ys), _ptr(t.contiguous()), stride, _ptr(Y), _ptr(zP), _ptr(lv),
+                                                      _ptr(cview), _ptr(Wk), _ptr(img_map), _ptr(g), _ptr(lse), _ptr(dg), _ptr(dz), _ptr(F), _ptr(dY),
+                                                      _ptr(dlogit), _ptr(dlv), _ptr(dcview), b, n, r, S, C, _stream()),
+              "cd360_nerf_mlp_aggregate_bwd")
+    return dz, F, dY, dlv, dcview
 
 
 # ----------------------------------------------------------------------------------------------- volume rendering
@@ -313,7 +344,10 @@ def volrender_bwd(feats, sigma_raw, dists, rgb_raw, d_rendered, d_fg, d_alphas, 
 
 
 def rowdot4(h: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
-    """h [..., C] bf16, w [4, C] fp32 -> [..., 4] fp32 (FeatureNeRF decoder)."""
+    """h [..., C] bf16, w [4, C] fp32 -> [..., 4] fp32 (FeatureNeRF decoder).  Differentiable (grad.RowDot4Fn)."""
+    if _wants_grad(h, w):
+        from . import grad
+        return grad.RowDot4Fn.apply(h, w)
     _need_gpu(h, w)
     C = h.shape[-1]
     assert h.dtype == torch.bfloat16 and h.is_contiguous() and w.shape == (4, C) and w.dtype == torch.float32 and w.is_contiguous()

@@ -41,6 +41,11 @@ class FeatureNeRFEncoding(nn.Module):
         ps = [self.plane_coefs[0].weight, self.plane_coefs[0].bias, self.plane_coefs[2].weight, self.plane_coefs[2].bias,
               self.nviews.weight, self.nviews.bias, self.decoder.weight]
         key = tuple((p.data_ptr(), p._version, p.device, p.dtype) for p in ps)
+        if torch.is_grad_enabled() and any(p.requires_grad for p in ps):  # training: derived weights stay on the autograd tape
+            wd = self.decoder.weight
+            if wd.shape[0] == 1:
+                wd = torch.cat([torch.zeros(3, wd.shape[1], device=wd.device, dtype=wd.dtype), wd], 0)
+            return _nerf.FusedNerfWeights(ps[0], ps[1], ps[2], ps[3], ps[4], ps[5], wd, live=True)
         if self._fused is None or self._fused[0] != key:
             wd = self.decoder.weight
             if wd.shape[0] == 1:  # rgb_predict False: only sigma; pad rgb rows with zeros (row 3 = sigma)

@@ -112,6 +112,17 @@ int cd360_nerf_mlp_aggregate(const void* cams, const void* xs, const void* ys, c
 int cd360_volrender(const void* feats, const void* sigma_raw, const void* rgb_raw, const void* dists, int d_ray_stride, void* rendered,
                     void* fg, void* alphas, void* weights, void* rgb, int b, int hw, int S, int C, int dtype, int flags, void* stream);
 
+/* Backward of cd360_nerf_mlp_aggregate for the fine-tuning loop (torch autograd through FeatureNeRFEncoding.forward in the
+ * reference; the trainable parameters here are plane_coefs, nviews and decoder, diffusion.py:139-144).  Inputs as the forward,
+ * plus its outputs g and lse, and dg [b, hw*S, C] bf16.  Writes dz [b, n, hw*S, C] bf16 (= softmax_i dg SiLU'(z_i)) and the
+ * generated per-sample inputs F [b, n, hw*S, cd360_nerf_k_padded()] bf16 (the host forms dWk = dz^T F and dzP = sum_s dz with
+ * library calls), and ACCUMULATES with fp32 atomics into caller-zeroed dY [tables, hw, C], dlogit [b, n, hw*S],
+ * dlv [tables, hw], dcview [b, n]. */
+int cd360_nerf_mlp_aggregate_bwd(const void* cams, const void* xs, const void* ys, const void* t, int t_ray_stride, const void* Y,
+                                 const void* zP, const void* lv, const void* cview, const void* Wk, const void* img_map, const void* g,
+                                 const void* lse, const void* dg, void* dz, void* F, void* dY, void* dlogit, void* dlv, void* dcview, int b,
+                                 int n, int r, int S, int C, void* stream);
+
 /* Backward of cd360_volrender for the fine-tuning loop (the reference differentiates VolRender.forward (nerfsd_pytorch3d.py:170-231)
  * and _TruncExp, whose backward is g * exp(clamp(x, -15, 15)) (attention.py:203-207), through torch autograd).  Same feats /
  * sigma_raw / rgb_raw / dists / flags as the forward call; incoming gradients d_rendered [b, hw, C] (dtype of feats; required),

@@ -166,3 +166,48 @@ def test_geglu_backward():
     assert rel(got, y) < 1e-2
     got.backward(dy.to(DEV, torch.bfloat16))
     assert rel(pd.grad, want) < 1e-2
+
+
+# ------------------------------------------------------------------------------------------------ fused FeatureNeRF (A5-A9)
+NERF_KEYS = ("plane_coefs.0.weight", "plane_coefs.0.bias", "plane_coefs.2.weight", "plane_coefs.2.bias", "nviews.weight", "nviews.bias",
+             "decoder.weight")
+
+
+@pytest.mark.parametrize("C,r,n,S,b,jitter", [(64, 8, 2, 4, 2, False), (128, 16, 4, 24, 1, True), (640, 8, 3, 6, 1, False)])
+def test_fused_feature_nerf_backward(C, r, n, S, b, jitter):
+    """Gradients of (features, rgb_raw, sigma_raw) with respect to ALL SEVEN FeatureNeRFEncoding parameters (the trainable set of
+    trainkeys='pose', diffusion.py:139-144) through the fused render: the tables Y / zP / lv / cview / Wk, the HIP backward kernel
+    (dz, dY scatter, view-softmax logits), the decoder.  jitter=True is the stratified training mode (xy and depth jitter)."""
+    import weights as W
+    from cd360 import nerf, synth
+    from cd360.cameras import pack_cameras
+    shapes = {"model.plane_coefs.0.weight": (C, C + 198), "model.plane_coefs.0.bias": (C,), "model.plane_coefs.2.weight": (C, C),
+              "model.plane_coefs.2.bias": (C,), "model.nviews.weight": (1, C + 198), "model.nviews.bias": (1,), "model.decoder.weight": (4, C)}
+    w = {k[len("model."):]: v for k, v in W.synth_state_dict(shapes, C + n).items()}
+    cams = pack_cameras(synth.pose_batch(b, n, seed=C))
+    xref = bf(W.tensor("xref", (b, n, r * r, C), seed=C))
+    g = torch.Generator().manual_seed(C + r)
+    xy = (torch.rand(r + 1, generator=g), torch.rand(r + 1, generator=g)) if jitter else None
+    dj = torch.rand(r * r, S + 1, generator=g) if jitter else None
+    gf, gs, gr = bf(torch.randn(b, r * r, S, C, generator=g)), torch.randn(b, r * r, S, 1, generator=g), torch.randn(b, r * r, S, 3, generator=g)
+
+    wo = {k: v.clone().requires_grad_(True) for k, v in w.items()}
+    feats, sigma, _, _, rgb, _ = O.nerf_module(wo, cams, xref, S, 2.0, xy_jitter=xy, depth_jitter=dj)
+    want = torch.autograd.grad([feats, sigma, rgb], [wo[k] for k in NERF_KEYS], [gf, gs, gr])
+
+    wd = {k: v.to(DEV).requires_grad_(True) for k, v in w.items()}
+    fw = nerf.FusedNerfWeights(*(wd[k] for k in NERF_KEYS), live=True)
+    h, dec, _, _ = nerf.fused_feature_nerf(fw, cams.to(DEV), xref.to(DEV, torch.bfloat16), S, 2.0, xy_jitter=xy,
+                                           depth_jitter=None if dj is None else dj.to(DEV))
+    assert rel(h, feats) < 1e-2
+    torch.autograd.backward([h, dec], [gf.to(DEV, torch.bfloat16), torch.cat([gr, gs], -1).to(DEV)])
+    scale_v = want[NERF_KEYS.index("nviews.weight")].abs().max().item()
+    for k, wg in zip(NERF_KEYS, want):
+        assert wd[k].grad is not None, k
+        if k == "nviews.bias":
+            # mathematically zero (the view softmax is shift invariant); what the kernel leaves is the bf16 rounding of the forward's g
+            # in sum_i a_i <dg, silu(z_i) - g>, measured against the scale of the other view-logit gradient
+            print("nviews.bias grad", wd[k].grad.item(), "oracle", wg.item(), "nviews.weight grad scale", scale_v)
+            assert abs(wd[k].grad.item() - wg.item()) < 3e-2 * scale_v, k
+        else:
+            assert rel(wd[k].grad, wg) < 3e-2, k
