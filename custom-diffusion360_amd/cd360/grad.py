@@ -167,3 +167,67 @@ class RowDot4Fn(torch.autograd.Function):
         dh = torch.mm(d2, w).to(h.dtype).reshape(h.shape) if ctx.needs_input_grad[0] else None
         dw = torch.mm(d2.t().to(h.dtype), h.reshape(-1, C)).float() if ctx.needs_input_grad[1] else None
         return dh, dw
+
+
+class ConvIgemmFn(torch.autograd.Function):
+    """ops.conv_igemm (conv3x3 / 1x1 + bias + emb + residual, openaimodel.py:280-376) differentiated with respect to its
+    activations.  The data gradient is the SAME implicit-GEMM kernel run on dy with the transposed, tap-flipped weight
+    (cd360_conv_igemm_bf16 again, no new kernel); a stride-2 convolution's data gradient is that stride-1 convolution applied to
+    dy with zeros inserted between the pixels.  d_res = dy, d_emb = sum of dy over the pixels of each image."""
+
+    @staticmethod
+    def forward(ctx, x, w_packed, bias, emb, res, N, H, W, taps, want_stats, stride, alg_channels, w_dgrad):
+        _no_wgrad("conv_igemm", w_packed, bias)
+        if w_dgrad is None:
+            raise NotImplementedError("conv_igemm under autograd needs w_dgrad (the packed data-gradient weight)")
+        out = ops.conv_igemm(x, w_packed, bias, N, H, W, taps, emb, res, want_stats, stride, alg_channels)
+        y, stats = out if want_stats else (out, None)
+        ctx.cfg = (N, H, W, taps, stride, x.shape[-1], tuple(x.shape))
+        ctx.w_dgrad = w_dgrad
+        ctx.set_materialize_grads(False)
+        if stats is not None:
+            ctx.mark_non_differentiable(stats)
+        return y, stats
+
+    @staticmethod
+    def backward(ctx, dy, _dstats):
+        N, H, W, taps, stride, cin, xshape = ctx.cfg
+        if dy is None:
+            return (None,) * 13
+        dy = dy.contiguous()
+        cout = dy.shape[-1]
+        dx = d_emb = d_res = None
+        if ctx.needs_input_grad[4]:
+            d_res = dy
+        if ctx.needs_input_grad[3]:
+            d_emb = dy.reshape(N, -1, cout).sum(1, dtype=torch.float32).to(dy.dtype)
+        if ctx.needs_input_grad[0]:
+            wd = ctx.w_dgrad() if callable(ctx.w_dgrad) else ctx.w_dgrad  # [Cin_p16, taps * Cout_p64]
+            cin_d = wd.shape[1] // taps
+            g = dy.reshape(N, (H // stride) * (W // stride), cout)
+            if stride == 2:
+                z = torch.zeros(N, H, W, cout, dtype=dy.dtype, device=dy.device)
+                z[:, ::2, ::2] = g.reshape(N, H // 2, W // 2, cout)
+                g = z.reshape(N, H * W, cout)
+            if cin_d != cout:
+                g = torch.nn.functional.pad(g, (0, cin_d - cout))
+            dx = ops.conv_igemm(g.contiguous(), wd, None, N, H, W, taps)[..., :cin].reshape(xshape)
+        return dx, None, None, d_emb, d_res, None, None, None, None, None, None, None, None
+
+
+def conv_igemm(x, w_packed, bias, N, H, W, taps, emb, res, want_stats, stride, alg_channels, w_dgrad):
+    y, stats = ConvIgemmFn.apply(x, w_packed, bias, emb, res, N, H, W, taps, want_stats, stride, alg_channels, w_dgrad)
+    return (y, stats) if want_stats else y
+
+
+class ConcatChannelsFn(torch.autograd.Function):
+    """ops.concat_channels (the skip-connection concat, openaimodel.py:1074-1076)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        ctx.ca = a.shape[1]
+        return ops.concat_channels(a, b)
+
+    @staticmethod
+    def backward(ctx, d):
+        return d[:, :ctx.ca], d[:, ctx.ca:]

@@ -430,7 +430,11 @@ def geglu_bwd(proj: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
 
 
 def concat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
-    """torch.cat([a, b], dim=1) for channels-last bf16 images [N, C, H, W]; returns a channels-last [N, Ca+Cb, H, W]."""
+    """torch.cat([a, b], dim=1) for channels-last bf16 images [N, C, H, W]; returns a channels-last [N, Ca+Cb, H, W].
+    Differentiable (grad.ConcatChannelsFn: the backward is two channel slices)."""
+    if _wants_grad(a, b):
+        from . import grad
+        return grad.ConcatChannelsFn.apply(a, b)
     _need_gpu(a, b)
     N, ca, H, W = a.shape
     cb = b.shape[1]
@@ -458,12 +462,17 @@ def pack_conv_weight(w: torch.Tensor) -> torch.Tensor:
 
 def conv_igemm(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Tensor], N: int, H: int, W: int, taps: int = 9,
                emb: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, want_stats: bool = False, stride: int = 1,
-               alg_channels: Optional[tuple] = None):
+               alg_channels: Optional[tuple] = None, w_dgrad=None):
     """x [N*H*W, Cin] (or [N, H*W, Cin]) channels-last bf16; w_packed [Cout, taps*Cin] bf16; bias fp32 [Cout]; emb bf16 [N, Cout];
     res bf16 [N*Ho*Wo, Cout] -> [N, Ho*Wo, Cout] bf16 = conv3x3 (taps=9; stride 1, or 2 with Ho = H/2, Wo = W/2) or x @ w^T (taps=1)
     + bias + emb[n] + res.
     want_stats=True (H*W % 128 == 0): returns (out, tile_stats) with tile_stats fp32 [N, slabs, Cout, 2] = per pixel slab the channel
-    sums / sums of squares of `out`, for gn_silu(out, ..., tile_stats=tile_stats)."""
+    sums / sums of squares of `out`, for gn_silu(out, ..., tile_stats=tile_stats).
+    Differentiable with respect to x, emb and res (grad.ConvIgemmFn) when `w_dgrad` is given: a callable returning the packed weight
+    of the data-gradient convolution (taps flipped, channels transposed: sgm...util.packed_conv_dgrad).  No weight gradient."""
+    if _wants_grad(x, emb, res, w_packed, bias):
+        from . import grad
+        return grad.conv_igemm(x, w_packed, bias, N, H, W, taps, emb, res, want_stats, stride, alg_channels, w_dgrad)
     _need_gpu(x, w_packed, bias, emb, res)
     cin = x.shape[-1]
     cout = w_packed.shape[0]

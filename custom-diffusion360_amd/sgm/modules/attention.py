@@ -116,6 +116,8 @@ class MemoryEfficientCrossAttention(nn.Module):
         (one GEMM, N = 3 inner), "kv" = [to_k; to_v] for a cross-attention context."""
         mods = (self.to_q, self.to_k, self.to_v) if which == "qkv" else (self.to_k, self.to_v)
         key = tuple((m.weight.data_ptr(), m.weight._version) for m in mods) + (mods[0].weight.dtype, mods[0].weight.device)
+        if torch.is_grad_enabled() and any(m.weight.requires_grad for m in mods):  # trainkeys poseattn: stay on the autograd tape
+            return torch.cat([m.weight for m in mods], 0)
         cache = self._merged.get(which)
         if cache is None or cache[0] != key:
             cache = (key, torch.cat([m.weight.detach() for m in mods], 0).contiguous())
@@ -210,6 +212,9 @@ class BasicTransformerBlock(nn.Module):
     # ------------------------------------------------------------------------------------------------ pose path
     def _pose_weights(self):
         w = self.pose_emb_layers.weight
+        if torch.is_grad_enabled() and w.requires_grad:  # training: the two halves stay views of the parameter (autograd)
+            c = w.shape[0]
+            return w[:, :c].t(), w[:, c:].t()
         key = (w.data_ptr(), w._version, w.dtype, w.device)
         if self._pose_split is None or self._pose_split[0] != key:
             c = w.shape[0]

@@ -66,7 +66,7 @@ class TimestepEmbedSequential(nn.Sequential, TimestepBlock):
             elif isinstance(layer, SpatialTransformer):
                 x, xr, fg_mask, weights, alphas, predicted_rgb = layer(x, xr, context, contextr, pose, mask_ref, prev_weights=prev_weights)
             else:
-                call = (lambda v: conv_image(layer, v)) if isinstance(layer, nn.Conv2d) and not torch.is_grad_enabled() else layer
+                call = (lambda v: conv_image(layer, v)) if isinstance(layer, nn.Conv2d) else layer  # (conv_image itself defers to MIOpen for a trainable conv)
                 x = call(x)
                 if xr is not None:
                     with torch.no_grad():

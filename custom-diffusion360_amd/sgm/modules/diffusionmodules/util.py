@@ -96,6 +96,8 @@ def group_norm_tokens(norm: nn.GroupNorm, x: torch.Tensor, silu: bool, stats=Non
     if dt != torch.bfloat16:
         xt = xt.to(torch.bfloat16)
         stats = None  # the statistics were taken of the bf16 tensor the conv wrote; x is something else
+    if torch.is_grad_enabled() and (norm.weight.requires_grad or norm.bias.requires_grad):
+        raise NotImplementedError("GroupNorm affine parameters are not trainable on the HIP path (trainkeys pose / poseattn never train them)")
     g, b = _fp32_affine(norm)
     y = ops.gn_silu(xt, g, b, norm.num_groups, norm.eps, silu, tile_stats=stats)
     return y if dt == torch.bfloat16 else y.to(dt)
@@ -135,12 +137,36 @@ def packed_conv(conv: nn.Conv2d):
     return cache[1], cache[2]
 
 
+def packed_conv_dgrad(conv: nn.Conv2d):
+    """Packed weight of the DATA-GRADIENT convolution of `conv` for cd360_conv_igemm_bf16 (cd360.grad.ConvIgemmFn): channels
+    transposed, taps flipped -- dx = conv_stride1(dy [zero-inserted for stride 2], w_d), w_d[ci, co, ky, kx] = w[co, ci, 2-ky, 2-kx].
+    As an igemm weight its input channels (= Cout, padded like packed_conv's outputs) are zero-padded to a multiple of 64 and its
+    output channels (= Cin padded to 64 by packed_conv) kept.  Cached on the module like packed_conv."""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, w.dtype, w.device)
+    cache = getattr(conv, "_cd360_packed_dgrad", None)
+    if cache is None or cache[0] != key:
+        cout, cin = w.shape[:2]
+        cin_p, cout_p = -(-cin // 64) * 64, -(-(-(-cout // 16) * 16) // 64) * 64
+        wt = w.detach().flip(2, 3).transpose(0, 1)  # [cin, cout, k, k]
+        wt = torch.nn.functional.pad(wt, (0, 0, 0, 0, 0, cout_p - cout, 0, cin_p - cin))
+        cache = (key, ops.pack_conv_weight(wt.contiguous()))
+        conv._cd360_packed_dgrad = cache
+    return cache[1]
+
+
+def _frozen(conv: nn.Conv2d) -> bool:
+    """True when the conv's own parameters need no gradient (always, for trainkeys pose / poseattn: diffusion.py:117-150); the
+    implicit-GEMM kernel has a data gradient but no weight gradient, so a trainable conv stays on torch's own convolution."""
+    return not (torch.is_grad_enabled() and (conv.weight.requires_grad or (conv.bias is not None and conv.bias.requires_grad)))
+
+
 def conv_tokens(conv: nn.Conv2d, tokens: torch.Tensor, N: int, H: int, W: int, emb=None, res=None, want_stats: bool = False):
     """conv(3x3 pad 1, stride 1 | 2; or 1x1) on channels-last tokens [N, H*W, Cin] -> [N, Ho*Wo, Cout], with the per-image addend
     `emb` [N, Cout] and the residual `res` [N, Ho*Wo, Cout] fused into the epilogue (cd360_conv_igemm_bf16); MIOpen only outside the
     kernel's envelope (none of the SDXL UNet's convs).  want_stats=True returns (tokens, stats): the GroupNorm slab statistics
     of the output, or None when the kernel cannot give them."""
-    pk = packed_conv(conv) if tokens.dtype == torch.bfloat16 else None
+    pk = packed_conv(conv) if (tokens.dtype == torch.bfloat16 and _frozen(conv)) else None
     if pk is None:
         y = conv(tokens_to_image(tokens, H, W))
         if emb is not None:
@@ -159,7 +185,8 @@ def conv_tokens(conv: nn.Conv2d, tokens: torch.Tensor, N: int, H: int, W: int, e
     if padded_out and (emb is not None or res is not None):
         raise NotImplementedError("emb / res epilogue with a padded channel count")
     stats_ok = want_stats and not padded_out and ((H // stride) * (W // stride)) % 128 == 0 and not os.environ.get("CD360_NO_GN_STATS")
-    out = ops.conv_igemm(tokens, pk[0], pk[1], N, H, W, taps, emb, res, want_stats=stats_ok, stride=stride, alg_channels=(cin, cout))
+    out = ops.conv_igemm(tokens, pk[0], pk[1], N, H, W, taps, emb, res, want_stats=stats_ok, stride=stride, alg_channels=(cin, cout),
+                         w_dgrad=lambda: packed_conv_dgrad(conv))
     y, stats = out if stats_ok else (out, None)
     if padded_out:
         y = y[..., :cout]
@@ -169,7 +196,7 @@ def conv_tokens(conv: nn.Conv2d, tokens: torch.Tensor, N: int, H: int, W: int, e
 def conv_image(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     """A plain nn.Conv2d call site (the UNet's input conv, Downsample.op, the output conv) on the implicit-GEMM kernel: image in,
     image out, channels-last in between; CPU / non-bf16 tensors go through the module itself."""
-    if not (x.is_cuda and x.dtype == torch.bfloat16) or os.environ.get("CD360_EDGE_CONVS_MIOPEN") or packed_conv(conv) is None:
+    if not (x.is_cuda and x.dtype == torch.bfloat16) or os.environ.get("CD360_EDGE_CONVS_MIOPEN") or not _frozen(conv) or packed_conv(conv) is None:
         return conv(x)  # (the environment knob keeps these four convs on MIOpen, for A/B runs)
     N, _, H, W = x.shape
     xt = x.permute(0, 2, 3, 1)

@@ -211,3 +211,47 @@ def test_fused_feature_nerf_backward(C, r, n, S, b, jitter):
             assert abs(wd[k].grad.item() - wg.item()) < 3e-2 * scale_v, k
         else:
             assert rel(wd[k].grad, wg) < 3e-2, k
+
+
+# ------------------------------------------------------------------------------------------------ convolutions (data gradient)
+@pytest.mark.parametrize("N,H,W,cin,cout,k,stride,with_emb_res", [(2, 16, 16, 64, 128, 3, 1, True), (1, 32, 32, 320, 640, 3, 1, False),
+                                                                  (2, 16, 16, 128, 128, 3, 2, False), (1, 16, 16, 640, 320, 1, 1, False),
+                                                                  (1, 16, 16, 320, 4, 3, 1, False)])
+def test_conv_data_gradient(N, H, W, cin, cout, k, stride, with_emb_res):
+    """conv_tokens under autograd: dx through the implicit-GEMM kernel run on dy with the transposed, tap-flipped weight (zero-inserted dy
+    for stride 2; channel padding for the 320 -> 4 output conv), d_emb and d_res from the fused epilogue; against F.conv2d's autograd."""
+    import torch.nn as nn
+    from sgm.modules.diffusionmodules.util import conv_tokens
+    g = torch.Generator().manual_seed(cin + cout + k)
+    conv = nn.Conv2d(cin, cout, k, stride=stride, padding=k // 2)
+    with torch.no_grad():
+        conv.weight.copy_(bf(torch.randn(conv.weight.shape, generator=g) / (cin * k * k) ** 0.5))
+        conv.bias.copy_(torch.randn(cout, generator=g) * 0.1)
+    conv.requires_grad_(False)
+    x = bf(torch.randn(N, H * W, cin, generator=g))
+    ho, wo = H // stride, W // stride
+    emb = bf(torch.randn(N, cout, generator=g)) if with_emb_res else None
+    res = bf(torch.randn(N, ho * wo, cout, generator=g)) if with_emb_res else None
+    dy = bf(torch.randn(N, ho * wo, cout, generator=g))
+
+    xo = x.clone().requires_grad_(True)
+    leaves = [xo]
+    y = conv(xo.reshape(N, H, W, cin).permute(0, 3, 1, 2)).permute(0, 2, 3, 1).reshape(N, ho * wo, cout)
+    if with_emb_res:
+        eo, ro = emb.clone().requires_grad_(True), res.clone().requires_grad_(True)
+        y = y + eo[:, None, :] + ro
+        leaves += [eo, ro]
+    want = torch.autograd.grad(y, leaves, dy)
+
+    convd = conv.to(DEV, torch.bfloat16)
+    xd = x.to(DEV, torch.bfloat16).requires_grad_(True)
+    kw = {}
+    if with_emb_res:
+        ed, rd = emb.to(DEV, torch.bfloat16).requires_grad_(True), res.to(DEV, torch.bfloat16).requires_grad_(True)
+        kw = dict(emb=ed, res=rd)
+    got = conv_tokens(convd, xd, N, H, W, **kw)
+    assert rel(got, y) < 1e-2
+    got.backward(dy.to(DEV, torch.bfloat16))
+    assert rel(xd.grad, want[0]) < 1e-2
+    if with_emb_res:
+        assert rel(ed.grad, want[1]) < 1e-2 and rel(rd.grad, want[2]) < 1e-2
