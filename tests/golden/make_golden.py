@@ -224,6 +224,39 @@ def case_unet():
     keyfile("unet_tiny", net)
 
 
+def unet_grad_loss(out, fgs, rgbs):
+    """The scalar both sides differentiate: fixed random cotangents on eps, every fg mask and every predicted rgb."""
+    loss = (out.float() * W.tensor("g_out", tuple(out.shape), seed=5).to(out.device)).sum()
+    for i, (fg, rgb) in enumerate(zip(fgs, rgbs)):
+        loss = loss + (fg.float() * W.tensor(f"g_fg{i}", tuple(fg.shape), seed=5).to(fg.device)).sum()
+        loss = loss + (rgb.float() * W.tensor(f"g_rgb{i}", tuple(rgb.shape), seed=5).to(rgb.device)).sum()
+    return loss
+
+
+def case_unet_grads():
+    """Gradients of the trainable ('pose' in the name, diffusion.py:139-144) parameters of the tiny UNet, by the reference's own
+    autograd (eval mode: no jitter; same inputs as unet_tiny.npz).  Pins the backward of the whole path: the data gradient runs
+    from eps back through every layer downstream of the first pose block."""
+    net = ns.openaimodel.UNetModel(**UNET_TINY)
+    W.load_into(net, seed=5)
+    net.eval()
+    for name, p_ in net.named_parameters():
+        p_.requires_grad = "pose" in name
+    b, n, L, T = 1, 2, 16, 77
+    pose = synth.pose_batch(b, n, seed=7)
+    x = W.tensor("x", (b, 4, L, L), seed=5)
+    xin = W.tensor("input_ref", (b, n, 4, L, L), seed=5)
+    ctx = W.tensor("ctx", (b + b * n, T, 32), seed=5)
+    y = W.tensor("y", (b + b * n, 16), seed=5)
+    with torch.enable_grad():
+        out, fgs, alphas, rgbs = net(x, timesteps=torch.tensor([500.0]), context=ctx, y=y, pose=pose, input_ref=xin,
+                                     sigmas_ref=torch.tensor([120.0]), mask_ref=None)
+        unet_grad_loss(out, fgs, rgbs).backward()
+    grads = {name: p_.grad for name, p_ in net.named_parameters() if p_.requires_grad}
+    assert all(g is not None for g in grads.values()), [k for k, g in grads.items() if g is None]
+    npz("unet_tiny_grads", **grads)
+
+
 def dummy_network(x_in, c_noise, cond, **kw):
     """Deterministic stand-in for OpenAIWrapper(UNet): depends on every input the sampler stack prepares."""
     b = x_in.shape[0]
@@ -372,6 +405,7 @@ if __name__ == "__main__":
     case_st_dual()
     case_customforward()
     case_unet()
+    case_unet_grads()
     case_sampler()
     case_sdxl_keys()
     assert not os.path.exists(os.path.join(refshim.REF_ROOT, "sgm", "__pycache__")), "bytecode leaked into the reference tree"

@@ -130,6 +130,32 @@ def test_unet_dual_stream_matches_reference():
         close(rgbs[i], g[f"rgb{i}"], atol=1e-4)
 
 
+def unet_grad_loss(out, fgs, rgbs):
+    """The scalar tests/golden/make_golden.py::case_unet_grads differentiated (fixed random cotangents)."""
+    loss = (out.float() * W.tensor("g_out", tuple(out.shape), seed=5).to(out.device)).sum()
+    for i, (fg, rgb) in enumerate(zip(fgs, rgbs)):
+        loss = loss + (fg.float() * W.tensor(f"g_fg{i}", tuple(fg.shape), seed=5).to(fg.device)).sum()
+        loss = loss + (rgb.float() * W.tensor(f"g_rgb{i}", tuple(rgb.shape), seed=5).to(rgb.device)).sum()
+    return loss
+
+
+def test_unet_pose_parameter_gradients_match_reference_autograd():
+    """Backward pin of the oracle: torch autograd through the oracle's forward reproduces the gradients the REFERENCE's autograd
+    gave for every trainable ('pose') parameter of the tiny UNet (tests/golden/unet_tiny_grads.npz)."""
+    g, gg = load("unet_tiny"), load("unet_tiny_grads")
+    sd = W.synth_state_dict(keys("unet_tiny"), seed=5)
+    for k in gg:
+        sd[k] = sd[k].clone().requires_grad_(True)
+    with torch.enable_grad():
+        out, fgs, _, rgbs = O.unet_forward(sd, g["x"], g["t"], g["ctx"], g["y"], cams=g["cams"], input_ref=g["input_ref"],
+                                           sigmas_ref=g["sigmas_ref"], model_channels=64, num_samples=4, far=2.0)
+        grads = torch.autograd.grad(unet_grad_loss(out, fgs, rgbs), [sd[k] for k in gg])
+    assert len(gg) == 24
+    for k, got in zip(gg, grads):
+        scale = max(gg[k].abs().max().item(), 1e-3)
+        assert (got - gg[k]).abs().max().item() < 2e-3 * scale, k
+
+
 # ------------------------------------------------------------------------------------------- conventions (Appendix B)
 def _cam(R=None, T=(0, 0, 1), f=(1, 1), pp=(0, 0)):
     R = torch.eye(3) if R is None else R
