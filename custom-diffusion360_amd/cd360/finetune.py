@@ -9,6 +9,9 @@ UNet module that an engine (or a test) calls.
                                                    the `references` buffer the sampling path reads (sample.py:91)
   delta_state_dict          main.py:611-624        the delta checkpoint: pose parameters (no raymarcher buffers) + references
   load_delta_state_dict     sgm/util.py:227-240    its inverse on a freshly built UNet
+  MasterAdamW / train_step  diffusion.py:226-262   one optimisation step of the fine-tuning loop: UNet forward (HIP kernels), the four
+                                                   loss terms, backward (HIP backward kernels via cd360/grad.py), AdamW on fp32 master
+                                                   copies of the trainable (bf16) parameters
 
 The all-gather in harvest_references is the one exchange step of the training side: each rank holds the features of its share
 of the reference images ([N_local, hw, C] per pose block, 12 blocks) and every rank needs all of them in dataset order
@@ -60,17 +63,17 @@ def combine_losses(loss, loss_fg, loss_bg, loss_rgb, drop_im, *, rgb: bool = Tru
     """DiffusionEngine.forward (diffusion.py:226-241).  `drop_im` [b] is 1 where the sample kept its reference images; the
     render losses only count those samples.  Defaults are configs/train_co3d_concept.yaml:9-11."""
     total = loss.mean()
-    out = {"loss": float(total)}
+    out = {"loss": float(total.detach())}
     den = drop_im.sum() + 1e-12
     if rgb and global_step > 0:
         fg = (loss_fg.mean(1) * drop_im.reshape(-1)).sum() / den
         bg = (loss_bg.mean(1) * drop_im.reshape(-1)).sum() / den
         total = total + loss_fg_lambda * fg + loss_bg_lambda * bg
-        out["loss_fg"], out["loss_bg"] = float(fg), float(bg)
+        out["loss_fg"], out["loss_bg"] = float(fg.detach()), float(bg.detach())
     if rgb_predict and loss_rgb.mean() > 0:
         lr = (loss_rgb.mean(1) * drop_im.reshape(-1)).sum() / den
         total = total + loss_rgb_lambda * lr
-        out["loss_rgb"] = float(lr)
+        out["loss_rgb"] = float(lr.detach())
     return total, out
 
 
@@ -152,3 +155,44 @@ def load_delta_state_dict(unet: torch.nn.Module, sd_delta: Dict[str, object], pr
     stripped = {k[len(prefix):] if k.startswith(prefix) else k: v for k, v in sd.items()}
     _missing, unexpected = unet.load_state_dict(stripped, strict=False)
     return list(unexpected)
+
+
+# ---------------------------------------------------------------- one optimisation step
+class MasterAdamW:
+    """AdamW (configs/train_co3d_concept.yaml: optimizer_config AdamW) on fp32 master copies of the trainable parameters: the HIP
+    path keeps the UNet in bf16, and a bf16 parameter cannot absorb updates of lr ~ 1e-5 (its spacing near 1 is 8e-3), so the
+    optimiser state and the accumulated weights live in fp32 and the bf16 parameters are refreshed from them after every step."""
+
+    def __init__(self, params, lr: float = 1e-5, **kw):
+        self.params = [p for p in params if p.requires_grad]
+        self.master = [p.detach().float().clone() for p in self.params]
+        self.opt = torch.optim.AdamW(self.master, lr=lr, **kw)
+
+    def zero_grad(self) -> None:
+        for p in self.params:
+            p.grad = None
+
+    @torch.no_grad()
+    def step(self) -> None:
+        for m, p in zip(self.master, self.params):
+            m.grad = None if p.grad is None else p.grad.float()
+        self.opt.step()
+        for m, p in zip(self.master, self.params):
+            p.copy_(m)
+
+
+def train_step(unet: torch.nn.Module, loss_fn, optimizer, *, noised, timesteps, context, y, pose, input_ref, sigmas_ref, target, target_rgb,
+               w, mask, opacity, drop_im=None, mask_ref=None, **loss_kw):
+    """One step of the fine-tuning loop on already-noised inputs (the engine's denoiser / conditioner / data loading stay outside
+    the path): forward, StandardDiffusionLossImgRef.get_loss (loss.py:177-209), the lambda-weighted total
+    (diffusion.py:226-241), backward, optimiser step.  Returns (total loss tensor, dict of logged terms)."""
+    optimizer.zero_grad()
+    out, fgs, alphas, rgbs = unet(noised, timesteps=timesteps, context=context, y=y, pose=pose, input_ref=input_ref, sigmas_ref=sigmas_ref,
+                                  mask_ref=mask_ref)
+    l2, lfg, lbg, lrgb = loss_fn.get_loss(out, fgs, rgbs, target, target_rgb, w, mask, mask_ref, opacity, alphas)
+    if drop_im is None:
+        drop_im = torch.ones(noised.shape[0], device=noised.device)
+    total, logged = combine_losses(l2, lfg, lbg, lrgb, drop_im, **loss_kw)
+    total.backward()
+    optimizer.step()
+    return total.detach(), logged

@@ -152,3 +152,40 @@ def test_reference_hooks_record_only_pose_free_calls():
     assert refs[names[0]].shape == (4, 4, C) and torch.equal(blk.references, refs[names[0]])
     finetune.remove_hooks(handles)
     assert not blk._forward_hooks
+
+
+def test_train_step_updates_fp32_masters_and_reduces_the_loss():
+    """finetune.train_step / MasterAdamW with a stand-in network (CPU): only 'pose' parameters move, the bf16 parameters follow
+    fp32 master copies (an lr of 1e-3 on bf16 weights near 1 would round away otherwise), and the total loss goes down."""
+    from make_golden_params import LOSS_CFG
+    from sgm.util import instantiate_from_config
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.pose_mix = torch.nn.Parameter(torch.ones(4, dtype=torch.bfloat16))
+            self.frozen = torch.nn.Parameter(torch.ones(4, dtype=torch.bfloat16))
+
+        def forward(self, x, timesteps=None, context=None, y=None, pose=None, input_ref=None, sigmas_ref=None, mask_ref=None):
+            out = x * (self.pose_mix * self.frozen).float().view(1, 4, 1, 1)
+            b = x.shape[0]
+            s = self.pose_mix.float().mean()
+            return out, [torch.full((b, 16, 1), 0.5) * s], [torch.full((b, 16, 4, 1), 0.5) * s], [torch.full((b, 16, 3), 0.5) * s]
+
+    net = Net()
+    assert finetune.select_trainable(net, "pose") == ["pose_mix"]
+    opt = finetune.MasterAdamW(net.parameters(), lr=1e-3)
+    assert len(opt.params) == 1 and opt.master[0].dtype == torch.float32
+    loss_fn = instantiate_from_config({"target": "sgm.modules.diffusionmodules.loss.StandardDiffusionLossImgRef", "params": LOSS_CFG})
+    g = torch.Generator().manual_seed(0)
+    b = 2
+    x = torch.randn(b, 4, 8, 8, generator=g)
+    kw = dict(noised=x, timesteps=None, context=None, y=None, pose=None, input_ref=None, sigmas_ref=None, target=0.5 * x,
+              target_rgb=torch.zeros(b, 3, 64, 64), w=torch.ones(b, 1, 1, 1), mask=torch.ones(b, 1, 8, 8), opacity=torch.full((b, 1, 64, 64), 0.5))
+    first = float(finetune.train_step(net, loss_fn, opt, **kw)[0])
+    for _ in range(30):
+        last, logged = finetune.train_step(net, loss_fn, opt, **kw)
+    assert float(last) < first and {"loss", "loss_fg", "loss_bg", "loss_rgb"} <= set(logged)
+    assert torch.equal(net.frozen.detach(), torch.ones(4, dtype=torch.bfloat16)) and net.frozen.grad is None
+    assert (opt.master[0] != 1).all() and torch.equal(net.pose_mix.detach(), opt.master[0].to(torch.bfloat16))
+    assert (opt.master[0] - 1).abs().max() < 8e-3 * 30  # 30 steps of 1e-3: individually below bf16's spacing at 1, kept by the masters
