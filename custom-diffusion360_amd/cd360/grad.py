@@ -142,12 +142,52 @@ class NerfAggregateFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dg, _dlogits, _dlse):
         cams, xs, ys, t, Y, zP, lv, cview, Wk, g, lse = ctx.saved_tensors
-        dz, F, dY, dlv, dcview = ops.nerf_mlp_aggregate_bwd(cams, xs, ys, t, Y, zP, lv, cview, Wk, ctx.img_map, g, lse, dg)
+        dz, F, dY, dlv, dcview, _ = ops.nerf_mlp_aggregate_bwd(cams, xs, ys, t, Y, zP, lv, cview, Wk, ctx.img_map, g, lse, dg)
         b, n, npts, C = dz.shape
         S = t.shape[-1]
         dzP = dz.reshape(b * n, npts // S, S, C).sum(2, dtype=torch.float32).to(zP.dtype)
         dWk = torch.mm(dz.reshape(-1, C).t(), F.reshape(-1, F.shape[-1])).to(Wk.dtype)
         return None, None, None, None, dY.to(Y.dtype), dzP, dlv, dcview, dWk, None
+
+
+class NerfRenderFn(torch.autograd.Function):
+    """The fused render from the reference FEATURES and the live weights (the training path): Y = xref Wf^T and lv = xref . vf are
+    formed here, and the backward never scatters into those tables.  With xg = bilinear_gather(xref) at the sample positions
+    (cd360_feature_gather, the same corner arithmetic as the fused kernel),
+        dWf^T = xg^T dz          dvf = xg^T dlogit          dzP = sum_s dz          dcview = sum dlogit          dWk = dz^T F
+    are four library GEMMs / reductions over tensors the backward kernel wrote once; the 4 x C atomic adds per (sample, view) of the
+    table form (NerfAggregateFn) measured 22 ms per render at the training shapes, this form a fraction of it.  xref itself gets
+    no gradient (the reference stream runs under no_grad: attention.py:845-857)."""
+
+    @staticmethod
+    def forward(ctx, cams, xs, ys, t, xref, Wf_t, vf, zP, cview, Wk):
+        if xref.requires_grad:
+            raise NotImplementedError("gradients with respect to the reference features are not provided (the reference stream is no_grad)")
+        b, n, hw, C = xref.shape
+        x2 = xref.reshape(b * n * hw, C)
+        Y = torch.mm(x2.to(Wf_t.dtype), Wf_t).reshape(b * n, hw, C).contiguous()
+        lv = torch.mv(x2.float(), vf).reshape(b * n, hw).contiguous()
+        g, logits, lse = ops.nerf_mlp_aggregate(cams, xs, ys, t, Y, zP, lv, cview, Wk, want_logits=True)
+        ctx.save_for_backward(cams, xs, ys, t, xref, Y, lv, zP, cview, Wk, g, lse)
+        ctx.mark_non_differentiable(logits, lse)
+        return g, logits, lse
+
+    @staticmethod
+    def backward(ctx, dg, _dlogits, _dlse):
+        cams, xs, ys, t, xref, Y, lv, zP, cview, Wk, g, lse = ctx.saved_tensors
+        dz, F, _, _, _, dlogit = ops.nerf_mlp_aggregate_bwd(cams, xs, ys, t, Y, zP, lv, cview, Wk, None, g, lse, dg, scatter=False)
+        b, n, npts, C = dz.shape
+        S = t.shape[-1]
+        hw = npts // S
+        grid = ops.ray_project_index(cams, xs, ys, t, want_points=False, want_index=False)["grid"].reshape(b * n, npts, 2)
+        xg = ops.feature_gather(xref.reshape(b * n, hw, C).to(dz.dtype), grid).reshape(b * n * npts, C)
+        dz2 = dz.reshape(b * n * npts, C)
+        dWf_t = torch.mm(xg.t(), dz2)                                                  # [C_in, C_out], the layout of Wf_t
+        dvf = torch.mm(dlogit.reshape(1, -1).to(xg.dtype), xg).reshape(C).float()
+        dzP = dz.reshape(b * n, hw, S, C).sum(2, dtype=torch.float32).to(zP.dtype)
+        dcview = dlogit.reshape(b, n, npts).sum(-1)
+        dWk = torch.mm(dz2.t(), F.reshape(-1, F.shape[-1])).to(Wk.dtype)
+        return None, None, None, None, None, dWf_t, dvf, dzP, dcview, dWk
 
 
 class RowDot4Fn(torch.autograd.Function):

@@ -149,14 +149,19 @@ def fused_feature_nerf(fw: FusedNerfWeights, cams: torch.Tensor, xref: Optional[
     xs = patch_positions(r, dev, None if xy_jitter is None else xy_jitter[0])
     ys = patch_positions(r, dev, None if xy_jitter is None else xy_jitter[1])
     t, dists = depth_samples(num_samples, far, near, dev, hw, depth_jitter)
-    if tables is None:
-        tables = reference_tables(fw, xref)
-    Y, lv = tables[0], tables[1]
-    img_map = tables[2] if len(tables) > 2 else None
     pf = ops.plucker_features(cams, xs, ys).reshape(b * n * hw, 104)
     zP = torch.addmm(fw.b1, pf, fw.Wp_t).to(torch.bfloat16).reshape(b * n, hw, C)
     cview = view_constants(fw, cams)
-    g, logits, lse = ops.nerf_mlp_aggregate(cams, xs, ys, t, Y, zP, lv, cview, fw.Wk, want_logits=want_view_weights, img_map=img_map)
+    if tables is None and torch.is_grad_enabled() and any(w.requires_grad for w in (fw.Wf_t, fw.vf, fw.Wk, zP, cview)):
+        # training: live weights; the render and its backward go through grad.NerfRenderFn (no table scatters)
+        from . import grad
+        g, logits, lse = grad.NerfRenderFn.apply(cams, xs, ys, t, xref, fw.Wf_t, fw.vf, zP, cview, fw.Wk)
+    else:
+        if tables is None:
+            tables = reference_tables(fw, xref)
+        Y, lv = tables[0], tables[1]
+        img_map = tables[2] if len(tables) > 2 else None
+        g, logits, lse = ops.nerf_mlp_aggregate(cams, xs, ys, t, Y, zP, lv, cview, fw.Wk, want_logits=want_view_weights, img_map=img_map)
     h = torch.addmm(fw.b2, g.reshape(-1, C), fw.W2_t).reshape(b, hw, num_samples, C)
     dec = ops.rowdot4(h, fw.Wd)
     vw = None

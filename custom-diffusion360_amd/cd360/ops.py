@@ -265,9 +265,10 @@ def nerf_mlp_aggregate(cams, xs, ys, t, Y, zP, lv, cview, Wk, want_logits=False,
     return g, logits, lse
 
 
-def nerf_mlp_aggregate_bwd(cams, xs, ys, t, Y, zP, lv, cview, Wk, img_map, g, lse, dg):
+def nerf_mlp_aggregate_bwd(cams, xs, ys, t, Y, zP, lv, cview, Wk, img_map, g, lse, dg, scatter: bool = True):
     """Backward kernel of nerf_mlp_aggregate -> (dz [b,n,hw*S,C] bf16, F [b,n,hw*S,112] bf16, dY [tables,hw,C] fp32,
-    dlv [tables,hw] fp32, dcview [b,n] fp32)."""
+    dlv [tables,hw] fp32, dcview [b,n] fp32, dlogit [b,n,hw*S] fp32).  scatter=False skips the atomic table scatters (dY, dlv and
+    dcview come back None; the caller reduces dz / dlogit itself)."""
     _need_gpu(cams, xs, ys, t, Y, zP, lv, cview, Wk, img_map, g, lse, dg)
     b, n1, _ = cams.shape
     n, r = n1 - 1, xs.numel()
@@ -279,17 +280,17 @@ def nerf_mlp_aggregate_bwd(cams, xs, ys, t, Y, zP, lv, cview, Wk, img_map, g, ls
     kp = nerf_k_padded()
     dz = torch.empty(b, n, hw * S, C, dtype=torch.bfloat16, device=dev)
     F = torch.empty(b, n, hw * S, kp, dtype=torch.bfloat16, device=dev)
-    dY = torch.zeros(Y.shape, dtype=torch.float32, device=dev)
+    dY = torch.zeros(Y.shape, dtype=torch.float32, device=dev) if scatter else None
     dlogit = torch.zeros(b, n, hw * S, dtype=torch.float32, device=dev)
-    dlv = torch.zeros(lv.shape, dtype=torch.float32, device=dev)
-    dcview = torch.zeros(b, n, dtype=torch.float32, device=dev)
+    dlv = torch.zeros(lv.shape, dtype=torch.float32, device=dev) if scatter else None
+    dcview = torch.zeros(b, n, dtype=torch.float32, device=dev) if scatter else None
     stride = 0 if t.dim() == 1 else S
     with _timed("nerf_mlp_aggregate_bwd", 2.0 * b * n * hw * S * 99 * C, 2.0 * C * (2 * b * n * hw + (2 + n) * b * hw * S)):
         check(_lib.load().cd360_nerf_mlp_aggregate_bwd(_ptr(cams), _ptr(xs), _ptr(ys), _ptr(t.contiguous()), stride, _ptr(Y), _ptr(zP), _ptr(lv),
                                                       _ptr(cview), _ptr(Wk), _ptr(img_map), _ptr(g), _ptr(lse), _ptr(dg), _ptr(dz), _ptr(F), _ptr(dY),
                                                       _ptr(dlogit), _ptr(dlv), _ptr(dcview), b, n, r, S, C, _stream()),
               "cd360_nerf_mlp_aggregate_bwd")
-    return dz, F, dY, dlv, dcview
+    return dz, F, dY, dlv, dcview, dlogit
 
 
 # ----------------------------------------------------------------------------------------------- volume rendering

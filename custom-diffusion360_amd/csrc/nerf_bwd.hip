@@ -210,10 +210,11 @@ __global__ __launch_bounds__(256) void nerf_bwd_kernel(NerfBwdParams p) {
           }
           *reinterpret_cast<u32x4*>(dzrow + mb * 32) = o0;
           *reinterpret_cast<u32x4*>(dzrow + mb * 32 + 8) = o1;
-          // ---- dY += w_corner dz at the four texels (corners with zero weight -- out of range -- are skipped) ----
+          // ---- dY += w_corner dz at the four texels (corners with zero weight -- out of range -- are skipped).  Optional: the
+          // training path forms the weight gradient it is after as ONE GEMM, dWf = gather(xref)^T dz, and passes dY = NULL ----
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            if (w[c] != 0.f) {
+            if (p.dY && w[c] != 0.f) {
               float* dst = p.dY + pix[c] * p.C + ch0 + mb * 32 + 16 * hh;
 #pragma unroll
               for (int e = 0; e < 16; ++e) atomicAdd(dst + e, w[c] * dzv[e]);
@@ -270,13 +271,14 @@ __global__ __launch_bounds__(256) void nerf_logit_bwd_kernel(const float* __rest
 
 // Inputs as cd360_nerf_mlp_aggregate, plus its outputs g and lse and the incoming gradient dg [b, hw*S, C] bf16.
 // Outputs: dz [b, n, hw*S, C] bf16 and F [b, n, hw*S, 112] bf16 (fully written); dY [tables, hw, C], dlogit [b, n, hw*S],
-// dlv [tables, hw], dcview [b, n] fp32 -- these four are ACCUMULATED atomically: the caller zero-fills them.
+// dlv [tables, hw], dcview [b, n] fp32 -- these four are ACCUMULATED atomically: the caller zero-fills them.  dY may be NULL and
+// dlv / dcview may both be NULL (no scatter: the caller reduces dz and dlogit itself, e.g. against gathered reference features).
 extern "C" int cd360_nerf_mlp_aggregate_bwd(const void* cams, const void* xs, const void* ys, const void* t, int t_ray_stride, const void* Y,
                                             const void* zP, const void* lv, const void* cview, const void* Wk, const void* img_map,
                                             const void* g, const void* lse, const void* dg, void* dz, void* F, void* dY, void* dlogit, void* dlv,
                                             void* dcview, int b, int n, int r, int S, int C, void* stream) {
-  if (!cams || !xs || !ys || !t || !Y || !zP || !lv || !cview || !Wk || !g || !lse || !dg || !dz || !F || !dY || !dlogit || !dlv || !dcview)
-    return CD360_ERR_ARG;
+  if (!cams || !xs || !ys || !t || !Y || !zP || !lv || !cview || !Wk || !g || !lse || !dg || !dz || !F || !dlogit) return CD360_ERR_ARG;
+  if ((dlv == nullptr) != (dcview == nullptr)) return CD360_ERR_ARG;
   if (b <= 0 || n <= 0 || r <= 0 || S <= 0 || C <= 0 || C % CN) return CD360_ERR_SHAPE;
   if (t_ray_stride != 0 && t_ray_stride != S) return CD360_ERR_SHAPE;
   if (((uintptr_t)Y | (uintptr_t)zP | (uintptr_t)Wk | (uintptr_t)g | (uintptr_t)dg | (uintptr_t)dz | (uintptr_t)F) % 16) return CD360_ERR_ARG;
@@ -293,6 +295,7 @@ extern "C" int cd360_nerf_mlp_aggregate_bwd(const void* cams, const void* xs, co
   if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
   hipLaunchKernelGGL(nerf_bwd_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
   CD360_LAUNCH_CHECK();
+  if (!dlv) return CD360_OK;
   const long blocks = (npts + 255) / 256;
   hipLaunchKernelGGL(nerf_logit_bwd_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks), (unsigned)(b * n)), dim3(256), 0, (hipStream_t)stream,
                      p.cams, p.xs, p.ys, p.t, t_ray_stride, p.img_map, (const float*)dlogit, (float*)dlv, (float*)dcview, n, r, S);

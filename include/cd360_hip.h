@@ -117,7 +117,8 @@ int cd360_volrender(const void* feats, const void* sigma_raw, const void* rgb_ra
  * plus its outputs g and lse, and dg [b, hw*S, C] bf16.  Writes dz [b, n, hw*S, C] bf16 (= softmax_i dg SiLU'(z_i)) and the
  * generated per-sample inputs F [b, n, hw*S, cd360_nerf_k_padded()] bf16 (the host forms dWk = dz^T F and dzP = sum_s dz with
  * library calls), and ACCUMULATES with fp32 atomics into caller-zeroed dY [tables, hw, C], dlogit [b, n, hw*S],
- * dlv [tables, hw], dcview [b, n]. */
+ * dlv [tables, hw], dcview [b, n].  dY may be NULL, and dlv / dcview both NULL: the training path skips the table scatters and
+ * forms the weight gradients it needs as GEMMs against the gathered reference features (cd360_feature_gather). */
 int cd360_nerf_mlp_aggregate_bwd(const void* cams, const void* xs, const void* ys, const void* t, int t_ray_stride, const void* Y,
                                  const void* zP, const void* lv, const void* cview, const void* Wk, const void* img_map, const void* g,
                                  const void* lse, const void* dg, void* dz, void* F, void* dY, void* dlogit, void* dlv, void* dcview, int b,

@@ -296,3 +296,34 @@ def test_unet_pose_parameter_gradients_match_reference_autograd():
     bad = {k: v for k, v in worst.items() if not v < 5e-2}
     print("worst gradient deviations:", sorted(worst.items(), key=lambda kv: -kv[1])[:5])
     assert not bad, bad
+
+
+def test_feature_nerf_table_scatter_backward_equals_gemm_form():
+    """Two routes to the same parameter gradients: grad.NerfRenderFn (training path: weight gradients as GEMMs against gathered
+    reference features, no scatter) and grad.NerfAggregateFn (precomputed tables: the backward kernel scatters into dY / dlv with fp32
+    atomics, torch differentiates the table GEMMs).  Both must agree on every FeatureNeRFEncoding parameter."""
+    import weights as W
+    from cd360 import nerf, synth
+    from cd360.cameras import pack_cameras
+    C, r, n, S, b = 128, 8, 3, 6, 2
+    shapes = {"model.plane_coefs.0.weight": (C, C + 198), "model.plane_coefs.0.bias": (C,), "model.plane_coefs.2.weight": (C, C),
+              "model.plane_coefs.2.bias": (C,), "model.nviews.weight": (1, C + 198), "model.nviews.bias": (1,), "model.decoder.weight": (4, C)}
+    w = {k[len("model."):]: v for k, v in W.synth_state_dict(shapes, 9).items()}
+    cams = pack_cameras(synth.pose_batch(b, n, seed=2)).to(DEV)
+    xref = W.tensor("xref", (b, n, r * r, C), seed=9).to(DEV, torch.bfloat16)
+    g = torch.Generator().manual_seed(4)
+    gf, gd = torch.randn(b, r * r, S, C, generator=g).to(DEV, torch.bfloat16), torch.randn(b, r * r, S, 4, generator=g).to(DEV)
+    grads = []
+    for route in ("gemm", "tables"):
+        wd = {k: v.to(DEV).requires_grad_(True) for k, v in w.items()}
+        fw = nerf.FusedNerfWeights(*(wd[k] for k in NERF_KEYS), live=True)
+        if route == "gemm":
+            h, dec, _, _ = nerf.fused_feature_nerf(fw, cams, xref, S, 2.0)
+        else:
+            h, dec, _, _ = nerf.fused_feature_nerf(fw, cams, None, S, 2.0, tables=nerf.reference_tables(fw, xref), dims=(b, n, r * r, C))
+        torch.autograd.backward([h, dec], [gf, gd])
+        grads.append({k: wd[k].grad for k in NERF_KEYS})
+    for k in NERF_KEYS:
+        if k == "nviews.bias":
+            continue  # rounding residual of a mathematically zero gradient on both routes
+        assert rel(grads[1][k], grads[0][k]) < 1e-2, k
