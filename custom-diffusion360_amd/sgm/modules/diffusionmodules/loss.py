@@ -8,8 +8,8 @@ returns the per-sample terms the engine weights (diffusion.py:226-241, see cd360
   loss_bg  [b, blocks]  |alpha - opacity| (1 - opacity) on rays with opacity < 0.1
   loss_rgb [b, blocks]  masked (rgb_target_r - rgb_pred)^2 / sum(mask)
 The arithmetic is a few small elementwise/resize ops on [b, 4, 64, 64]-sized tensors, done with torch on whatever device the
-model outputs live; the UNet forward it wraps is the HIP path.  Backward through the HIP kernels (config 4's training step) is a
-later-round row: this class evaluates the loss, it does not make the pose path differentiable.
+model outputs live; the UNet forward it wraps is the HIP path, and under autograd its backward runs on the HIP backward kernels
+(cd360/grad.py; cd360.finetune.train_step is one optimisation step of config 4).
 """
 import math
 from typing import List, Optional, Union
