@@ -173,7 +173,27 @@ class MasterAdamW:
             p.grad = None
 
     @torch.no_grad()
-    def step(self) -> None:
+    def allreduce_grads(self, group: Optional[dist.ProcessGroup] = None) -> None:
+        """Data-parallel fine-tuning (the reference trains under Lightning DDP, main.py): average the gradients of the trainable
+        parameters over the ranks as ONE flat fp32 all-reduce (66.7 M values = 267 MB at SDXL size: a single RCCL ring over xGMI,
+        per-link bound, instead of 96 small collectives).  No-op without an initialised process group."""
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return
+        grads = [p.grad for p in self.params]
+        if any(g is None for g in grads):
+            raise RuntimeError("allreduce_grads: a trainable parameter has no gradient on this rank (ranks would disagree on the buffer layout)")
+        flat = torch.cat([g.reshape(-1).float() for g in grads])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat.div_(dist.get_world_size(group))
+        off = 0
+        for p, g in zip(self.params, grads):
+            n = g.numel()
+            p.grad = flat[off:off + n].reshape(g.shape).to(g.dtype)
+            off += n
+
+    @torch.no_grad()
+    def step(self, group: Optional[dist.ProcessGroup] = None) -> None:
+        self.allreduce_grads(group)
         for m, p in zip(self.master, self.params):
             m.grad = None if p.grad is None else p.grad.float()
         self.opt.step()

@@ -38,6 +38,28 @@ class AttentionFn(torch.autograd.Function):
         return dq, dk, dv, None, None
 
 
+class SelfAttentionFn(torch.autograd.Function):
+    """ops.self_attention_qkv: q, k, v are column slices of one projection output; d(q|k|v) is written in place by the kernel."""
+
+    @staticmethod
+    def forward(ctx, qkv, heads):
+        inner = heads * 64
+        out, lse = ops.attention(qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:], heads, qkv.shape[1], want_lse=True)
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.heads = heads
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        inner = ctx.heads * 64
+        dqkv = torch.empty_like(qkv)
+        sl = lambda t: (t[..., :inner], t[..., inner:2 * inner], t[..., 2 * inner:])
+        q, k, v = sl(qkv)
+        ops.attention_bwd(q, k, v, out, dout, lse, ctx.heads, qkv.shape[1], out=sl(dqkv))
+        return dqkv, None
+
+
 class VolRenderFn(torch.autograd.Function):
     """ops.volrender (_TruncExp + VolRender, attention.py:192-208, nerfsd_pytorch3d.py:170-231) with cd360_volrender_bwd."""
 

@@ -117,17 +117,24 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, nk:
     return out
 
 
-def attention_bwd(q, k, v, o, dout, lse, heads: int, nk: Optional[int] = None, need_dq: bool = True, need_dkv: bool = True):
-    """Backward of attention(..., want_lse=True): (dq | None, dk | None, dv | None), bf16, contiguous, rows >= nk of dk / dv zero."""
+def attention_bwd(q, k, v, o, dout, lse, heads: int, nk: Optional[int] = None, need_dq: bool = True, need_dkv: bool = True, out=None):
+    """Backward of attention(..., want_lse=True): (dq | None, dk | None, dv | None), bf16, contiguous, rows >= nk of dk / dv zero.
+    out = (dq, dk, dv) writes into caller-provided (possibly strided, last dim contiguous) tensors instead, e.g. the three column
+    slices of one d(q|k|v) buffer."""
     _need_gpu(q, k, v, o, dout, lse)
     b, nq, inner = q.shape
     nk = k.shape[1] if nk is None else nk
     if dout.stride(2) != 1 or dout.stride(0) % 8 or dout.stride(1) % 8 or dout.data_ptr() % 16:
         dout = dout.contiguous()
     assert dout.dtype == torch.bfloat16 and dout.shape == q.shape and lse.shape == (b * heads, nq) and lse.dtype == torch.float32
-    dq = torch.empty(b, nq, inner, dtype=torch.bfloat16, device=q.device) if need_dq else None
-    dk = torch.zeros(b, k.shape[1], inner, dtype=torch.bfloat16, device=q.device) if need_dkv else None
-    dv = torch.zeros(b, v.shape[1], inner, dtype=torch.bfloat16, device=q.device) if need_dkv else None
+    if out is not None:
+        dq, dk, dv = out
+        assert all(t.dtype == torch.bfloat16 and t.stride(2) == 1 and t.stride(0) % 4 == 0 and t.stride(1) % 4 == 0 for t in out)
+        assert dq.shape == q.shape and dk.shape[1] >= nk and dv.shape[1] >= nk
+    else:
+        dq = torch.empty(b, nq, inner, dtype=torch.bfloat16, device=q.device) if need_dq else None
+        dk = torch.zeros(b, k.shape[1], inner, dtype=torch.bfloat16, device=q.device) if need_dkv else None
+        dv = torch.zeros(b, v.shape[1], inner, dtype=torch.bfloat16, device=q.device) if need_dkv else None
     ws = torch.empty(b * heads * nq, dtype=torch.float32, device=q.device)
     s3 = lambda t: None if t is None else _I64x3(t.stride(0), 64, t.stride(1))
     flops = 4.0 * b * heads * nq * nk * 64 * ((1.5 if need_dq else 0.0) + (2.0 if need_dkv else 0.0))
@@ -136,6 +143,18 @@ def attention_bwd(q, k, v, o, dout, lse, heads: int, nk: Optional[int] = None, n
                                              b, heads, nq, nk, s3(q), s3(k), s3(v), s3(o), s3(dout), s3(dq), s3(dk), s3(dv), 64 ** -0.5, _stream()),
               "cd360_attn_bwd_bf16")
     return dq, dk, dv
+
+
+def self_attention_qkv(qkv: torch.Tensor, heads: int) -> torch.Tensor:
+    """Self-attention on the merged projection output qkv [b, N, 3*H*64] (q | k | v column slices, read in place).  Under autograd
+    the backward kernel writes dq, dk, dv straight into the three slices of ONE d(qkv) buffer (grad.SelfAttentionFn), so the
+    projection's backward is a single GEMM and no slice-gradient fills / adds are launched."""
+    inner = heads * 64
+    assert qkv.shape[-1] == 3 * inner
+    if _wants_grad(qkv):
+        from . import grad
+        return grad.SelfAttentionFn.apply(qkv, heads)
+    return attention(qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:], heads, qkv.shape[1])
 
 
 def attention_fp8mfma(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, nk: Optional[int] = None, amax=None) -> torch.Tensor:

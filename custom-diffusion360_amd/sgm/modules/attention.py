@@ -165,6 +165,8 @@ class MemoryEfficientCrossAttention(nn.Module):
         if context is None:  # self-attention: q, k, v are the three column slices of one GEMM, read in place by the kernel
             inner = self.heads * self.dim_head
             qkv = F.linear(x, self._merged_weight("qkv"))
+            if qkv.dtype == torch.bfloat16 and qkv.requires_grad and torch.is_grad_enabled():
+                return self.to_out(ops.self_attention_qkv(qkv, self.heads))  # training: one d(q|k|v) buffer written by the backward kernel
             return self._finish(x, qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:], x.shape[1])
         return self.attend(x, self.project_context(context))
 
@@ -262,7 +264,11 @@ class BasicTransformerBlock(nn.Module):
         tok = h.reshape(b, hw * S, C)
         if tok.dtype != x.dtype:
             tok = tok.to(x.dtype)
-        tok = self.attn2(self.norm2(tok), context=context) + tok  # pose-token cross-attention (:581-586)
+        if tok.is_cuda and tok.dtype == torch.bfloat16 and self.norm2.weight.dtype == torch.bfloat16 and C <= 2048:
+            n2 = ops.add_layernorm(tok.contiguous(), None, self.norm2.weight, self.norm2.bias, self.norm2.eps)[1]  # HIP LayerNorm (fwd + bwd)
+        else:
+            n2 = self.norm2(tok)
+        tok = self.attn2(n2, context=context) + tok  # pose-token cross-attention (:581-586)
         rendered, fg, alphas, _, rgb = ops.volrender(tok.reshape(b, hw, S, C), dec[..., 3], dists,
                                                     dec[..., :3] if self.rgb_predict else None)
         return rendered, fg, (None if not self.use_prev_weights_imp_sample else None), alphas, rgb

@@ -327,3 +327,26 @@ def test_feature_nerf_table_scatter_backward_equals_gemm_form():
         if k == "nviews.bias":
             continue  # rounding residual of a mathematically zero gradient on both routes
         assert rel(grads[1][k], grads[0][k]) < 1e-2, k
+
+
+def test_self_attention_merged_qkv_backward_writes_one_buffer():
+    """ops.self_attention_qkv: forward reads q | k | v as column slices of one projection output; the backward kernel writes dq, dk, dv
+    into the three slices of one d(qkv) tensor (no slice-gradient fills).  Against autograd of the oracle."""
+    from cd360 import ops
+    B, H, N = 2, 3, 200
+    g = torch.Generator().manual_seed(11)
+    qkv = bf(torch.randn(B, N, 3 * H * 64, generator=g))
+    do = bf(torch.randn(B, N, H * 64, generator=g))
+
+    def split(t):
+        return t.reshape(B, N, H, 64).permute(0, 2, 1, 3).reshape(B * H, N, 64)
+
+    qo = qkv.clone().requires_grad_(True)
+    q, k, v = qo.chunk(3, dim=-1)
+    want = O.attention_core(split(q), split(k), split(v)).reshape(B, H, N, 64).permute(0, 2, 1, 3).reshape(B, N, H * 64)
+    (gq,) = torch.autograd.grad(want, qo, do)
+    qd = qkv.to(DEV, torch.bfloat16).requires_grad_(True)
+    out = ops.self_attention_qkv(qd, H)
+    assert rel(out, want) < 1e-2
+    out.backward(do.to(DEV, torch.bfloat16))
+    assert qd.grad.shape == qkv.shape and rel(qd.grad, gq) < 2e-2

@@ -110,3 +110,44 @@ def test_references_harvest_allgather_restores_dataset_order(world, n_images):
         p.join(60)
         assert p.exitcode == 0
     assert all(ok for _, ok in res)
+
+
+def _dp_worker(rank, world, port, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "custom-diffusion360_amd"))
+    from cd360 import finetune
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.ones(3, 5, dtype=torch.bfloat16)), torch.nn.Parameter(torch.ones(7, dtype=torch.bfloat16))]
+    opt = finetune.MasterAdamW(params, lr=1e-2, weight_decay=0.0)
+    for p in params:  # rank-dependent gradients: the average over ranks is (world + 1) / 2
+        p.grad = torch.full_like(p, float(rank + 1))
+    opt.allreduce_grads()
+    avg_ok = all(torch.all(p.grad.float() == (world + 1) / 2) for p in params)
+    opt.step()
+    gathered = [torch.empty(22) for _ in range(world)]
+    dist.all_gather(gathered, torch.cat([m.reshape(-1) for m in opt.master]))
+    same = all(torch.equal(g, gathered[0]) for g in gathered)
+    q.put((rank, bool(avg_ok), bool(same), float(opt.master[0][0, 0])))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_data_parallel_gradient_allreduce(world):
+    """finetune.MasterAdamW.allreduce_grads: ONE flat all-reduce averages the trainable gradients over the ranks (the reference trains
+    under DDP); afterwards every rank takes the identical AdamW step on its fp32 masters."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_dp_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert all(avg_ok and same for _, avg_ok, same, _ in res)
+    assert all(abs(v - (1.0 - 1e-2)) < 1e-6 for _, _, _, v in res)  # first AdamW step = -lr * sign(grad)
