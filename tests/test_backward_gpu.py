@@ -350,3 +350,52 @@ def test_self_attention_merged_qkv_backward_writes_one_buffer():
     assert rel(out, want) < 1e-2
     out.backward(do.to(DEV, torch.bfloat16))
     assert qd.grad.shape == qkv.shape and rel(qd.grad, gq) < 2e-2
+
+
+def test_pose_block_train_mode_poseattn_gradients(monkeypatch):
+    """One pose block in TRAIN mode (stratified: the xy / depth jitter the reference drew, injected) with the reference's
+    `trainkeys: poseattn` trainable set (diffusion.py:121-138: the pose parameters plus attn1 / attn2 of the pose block): forward
+    against the reference's own train-mode golden (tests/golden/block_train.npz), gradients -- including the attention weight
+    gradients through the live merged q|k|v / k|v projections and dK / dV of the text cross-attention -- against autograd of the
+    oracle (pinned on that golden)."""
+    import gzip
+    import json
+    import os
+    import numpy as np
+    import weights as W
+    from cd360.cameras import unpack_cameras
+    from sgm.modules.attention import BasicTransformerBlock
+    from sgm.modules.nerfsd_pytorch3d import Raymarcher
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(gold, "block_train.npz")).items()}
+    with gzip.open(os.path.join(gold, "block.keys.json.gz"), "rt") as f:
+        sd = W.synth_state_dict(json.load(f), seed=2)
+    train = lambda k: "pose" in k or k.startswith(("attn1.", "attn2."))
+    so = {k: (v.clone().requires_grad_(True) if train(k) else v) for k, v in sd.items()}
+    gen = torch.Generator().manual_seed(3)
+    cot = [torch.randn(g[k].shape, generator=gen) for k in ("out", "fg", "rgb")]
+    out, fg, alphas, rgb, _ = O.transformer_block(so, g["x"], g["ctx"], 1, context_ref=g["cref"], cams=g["cams"], num_samples=4, far=2.0,
+                                                  xy_jitter=(g["jit_x"], g["jit_y"]), depth_jitter=g["jit_d"])
+    names = [k for k in sd if train(k)]
+    want = dict(zip(names, torch.autograd.grad([out, fg, rgb], [so[k] for k in names], cot)))
+
+    blk = BasicTransformerBlock(64, 1, 64, context_dim=32, checkpoint=False, attn_mode="softmax-xformers", image_cross=True, far=2, num_samples=4,
+                                rgb_predict=True, mode="feature-nerf", stratified=True).train()
+    W.load_into(blk, seed=2)
+    blk = blk.to(DEV, torch.bfloat16)
+    for k, p in blk.named_parameters():
+        p.requires_grad = train(k)
+    monkeypatch.setattr(Raymarcher, "jitter", lambda self, resolution, device: ((g["jit_x"], g["jit_y"]), g["jit_d"].to(device)))
+    b16 = lambda t: t.to(DEV, torch.bfloat16)
+    o2, fg2, _, al2, rgb2 = blk(b16(g["x"]), context=b16(g["ctx"]), context_ref=b16(g["cref"]), pose=unpack_cameras(g["cams"]))
+    assert rel(o2, g["out"]) < 2.5e-2 and rel(fg2, g["fg"]) < 2.5e-2 and rel(al2, g["alphas"]) < 2.5e-2 and rel(rgb2, g["rgb"]) < 2.5e-2
+    torch.autograd.backward([o2, fg2, rgb2], [cot[0].to(DEV, torch.bfloat16), cot[1].to(DEV), cot[2].to(DEV)])
+    params = dict(blk.named_parameters())
+    worst = {}
+    for k in names:
+        assert params[k].grad is not None, k
+        if k.endswith("nviews.bias"):
+            continue
+        worst[k] = rel(params[k].grad, want[k])
+    print("worst:", sorted(worst.items(), key=lambda kv: -kv[1])[:4])
+    assert max(worst.values()) < 3e-2, {k: v for k, v in worst.items() if v >= 3e-2}
