@@ -517,6 +517,22 @@ def conv_igemm(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Ten
     return (out, stats) if want_stats else out
 
 
+def pose_embed(x: torch.Tensor, xref: torch.Tensor, wa: torch.Tensor, wb: torch.Tensor) -> torch.Tensor:
+    """pose_emb_layers(cat[x, xref]) (attention.py:634) as x wa^T + xref wb^T through the C ABI (cd360_pose_embed_bf16); wa = W[:, :C],
+    wb = W[:, C:], contiguous.  Forward-only operator-level entry (the modules run the same two products on the library GEMM, which
+    torch differentiates)."""
+    _need_gpu(x, xref, wa, wb)
+    C = x.shape[-1]
+    for t in (x, xref, wa, wb):
+        assert t.dtype == torch.bfloat16 and t.is_contiguous()
+    assert xref.shape == x.shape and wa.shape == (C, C) and wb.shape == (C, C)
+    out = torch.empty_like(x)
+    rows = x.numel() // C
+    with _timed("pose_embed", 4.0 * rows * C * C, 2.0 * (3 * rows * C + 2 * C * C)):
+        check(_lib.load().cd360_pose_embed_bf16(_ptr(x), _ptr(xref), _ptr(wa), _ptr(wb), _ptr(out), rows, C, _stream()), "cd360_pose_embed_bf16")
+    return out
+
+
 def add_layernorm(a: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor, eps: float, want_sum: bool = True):
     """(a + b, LayerNorm(a + b) * gamma + beta) in one pass; b None -> (None, LayerNorm(a)).  All bf16, last dim C.
     Differentiable with respect to a and b (grad.AddLayerNormFn)."""

@@ -407,3 +407,16 @@ extern "C" int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const 
   CD360_LAUNCH_CHECK();
   return CD360_OK;
 }
+
+// A11: pose_emb_layers(cat[x, xref]) = Linear(2C -> C, no bias) (sgm/modules/attention.py:515-516,634) without the concat:
+// out = x wa^T + xref wb^T with wa = W[:, :C], wb = W[:, C:] (each [C, C] contiguous, bf16).  Two GEMM-mode launches of the implicit
+// GEMM kernel, the second accumulating onto the first through the residual epilogue (res aliases out: every element is read and
+// written by the same lane).  x, xref, out: [rows, C] bf16; C % 64 == 0.
+extern "C" int cd360_pose_embed_bf16(const void* x, const void* xref, const void* wa, const void* wb, void* out, int64_t rows, int C,
+                                     void* stream) {
+  if (!x || !xref || !wa || !wb || !out || rows <= 0 || C <= 0) return CD360_ERR_ARG;
+  if (rows > 0x7fffffffL) return CD360_ERR_SHAPE;
+  const int rc = cd360_conv_igemm_bf16(x, wa, nullptr, nullptr, 0, nullptr, out, 1, (int)rows, 1, C, C, 1, 1, nullptr, stream);
+  if (rc != CD360_OK) return rc;
+  return cd360_conv_igemm_bf16(xref, wb, nullptr, nullptr, 0, out, out, 1, (int)rows, 1, C, C, 1, 1, nullptr, stream);
+}

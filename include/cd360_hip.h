@@ -199,6 +199,11 @@ int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const void* bias,
  * 352-376 h = out_layers(GN -> SiLU -> conv)), handed to cd360_gn_silu_bf16.  Requires H*W % 128 == 0. */
 int cd360_conv_stats_slabs(int Cout);
 
+/* replaces pose_emb_layers(torch.cat([x, xref], -1)), Linear(2C -> C, bias=False) (sgm/modules/attention.py:515-516,634) without the
+ * concat: out = x wa^T + xref wb^T, wa = W[:, :C], wb = W[:, C:] as contiguous [C, C] bf16; x, xref, out [rows, C] bf16, C % 64 == 0.
+ * (Two GEMM-mode launches of the implicit-GEMM kernel; the shipped modules use the library GEMM for the same two products.) */
+int cd360_pose_embed_bf16(const void* x, const void* xref, const void* wa, const void* wb, void* out, int64_t rows, int C, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

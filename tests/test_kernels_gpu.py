@@ -331,3 +331,16 @@ def test_attention_fp8_mfma_variant_tolerance(B, H, Nq, Nk):
     big = torch.zeros(1, 104, 64, device=DEV, dtype=torch.bfloat16)
     with pytest.raises(Exception):
         ops.attention_fp8mfma(big, big, big, 1)  # Nk = 104 > 96
+
+
+def test_pose_embed_c_abi():
+    """A11 through the C ABI: pose_emb_layers(cat[x, xref]) == x Wa^T + xref Wb^T (attention.py:515-516,634)."""
+    from cd360 import ops
+    g = torch.Generator().manual_seed(17)
+    for rows, C in ((300, 640), (1024, 1280), (77, 64)):
+        x, xr = bf(torch.randn(rows, C, generator=g)), bf(torch.randn(rows, C, generator=g))
+        w = bf(torch.cat([torch.eye(C), torch.zeros(C, C)], 1) + 0.05 * torch.randn(C, 2 * C, generator=g))
+        want = torch.cat([x, xr], -1) @ w.t()
+        d = lambda t: t.to(DEV, torch.bfloat16).contiguous()
+        got = ops.pose_embed(d(x), d(xr), d(w[:, :C]), d(w[:, C:]))
+        assert rel(got, want) < 1e-2
