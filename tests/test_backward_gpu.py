@@ -26,7 +26,8 @@ def bf(x):
 
 # ------------------------------------------------------------------------------------------------ attention
 @pytest.mark.parametrize("B,H,Nq,Nk,kv_grad", [(2, 2, 128, 128, True), (1, 3, 200, 77, True), (1, 1, 1024, 1024, True), (2, 2, 96, 40, False),
-                                               (1, 2, 333, 333, True), (1, 2, 50, 20, True), (2, 5, 2048, 77, False), (1, 2, 100, 97, True)])
+                                               (1, 2, 333, 333, True), (1, 2, 50, 20, True), (2, 5, 2048, 77, False), (1, 2, 100, 97, True),
+                                               (2, 10, 24576, 77, False)])  # last: the pose-token cross-attention of config 4 at full size (level 1)
 def test_attention_backward(B, H, Nq, Nk, kv_grad):
     """dq, dk, dv of softmax(q k^T / 8) v through ops.attention under autograd: tiled and small-Nk forward kernels (lse from both),
     ragged tiles on both sides, k / v as NaN-padded slices of a merged projection, and the dq-only launch (text context: k, v
