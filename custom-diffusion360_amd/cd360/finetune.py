@@ -9,6 +9,7 @@ UNet module that an engine (or a test) calls.
                                                    the `references` buffer the sampling path reads (sample.py:91)
   delta_state_dict          main.py:611-624        the delta checkpoint: pose parameters (no raymarcher buffers) + references
   load_delta_state_dict     sgm/util.py:227-240    its inverse on a freshly built UNet
+  optimizer_param_groups    diffusion.py:310-361   the optimiser groups (pose parameters at lr, attention / remaining weights at multiplier * lr)
   MasterAdamW / train_step  diffusion.py:226-262   one optimisation step of the fine-tuning loop: UNet forward (HIP kernels), the four
                                                    loss terms, backward (HIP backward kernels via cd360/grad.py), AdamW on fp32 master
                                                    copies of the trainable (bf16) parameters
@@ -55,6 +56,27 @@ def select_trainable(unet: torch.nn.Module, trainkeys: str = "pose") -> List[str
     else:
         raise ValueError(f"unknown trainkeys {trainkeys!r}")
     return [n for n, p in named if p.requires_grad]
+
+
+def optimizer_param_groups(unet: torch.nn.Module, trainkeys: str = "pose", lr: float = 1e-4, multiplier: float = 0.05) -> List[dict]:
+    """The optimiser groups of DiffusionEngine.configure_optimizers (diffusion.py:310-361) for the UNet: the pose parameters at
+    `lr`; for 'poseattn' the attn1 / attn2 weights of the pose blocks, and for 'all' every other parameter, at `multiplier * lr`
+    (configs/train_co3d_concept.yaml:2,7-8: lr 1e-4, multiplier 0.05).  Each group also lists its parameter `names`."""
+    named = list(unet.named_parameters())
+    main = [(n, p) for n, p in named if "pose" in n]
+    low = []
+    if trainkeys == "poseattn":
+        blocks = {n.split(".pose")[0] for n, _ in main}
+        low = [(n, p) for n, p in named if "transformer_blocks" in n and "pose" not in n and ("attn1" in n or "attn2" in n)
+               and any(b in n for b in blocks)]
+    elif trainkeys == "all":
+        low = [(n, p) for n, p in named if "pose" not in n]
+    elif trainkeys != "pose":
+        raise ValueError(f"unknown trainkeys {trainkeys!r}")
+    groups = [{"params": [p for _, p in main], "lr": lr, "names": [n for n, _ in main]}]
+    if low:
+        groups.append({"params": [p for _, p in low], "lr": multiplier * lr, "names": [n for n, _ in low]})
+    return groups
 
 
 # ---------------------------------------------------------------- loss weighting
@@ -164,9 +186,17 @@ class MasterAdamW:
     optimiser state and the accumulated weights live in fp32 and the bf16 parameters are refreshed from them after every step."""
 
     def __init__(self, params, lr: float = 1e-5, **kw):
-        self.params = [p for p in params if p.requires_grad]
+        """`params`: an iterable of parameters, or optimiser groups as returned by optimizer_param_groups (per-group `lr`)."""
+        params = list(params)
+        if params and isinstance(params[0], dict):
+            groups = [{**{k: v for k, v in g.items() if k not in ("params", "names")}, "params": [p for p in g["params"] if p.requires_grad]}
+                      for g in params]
+        else:
+            groups = [{"params": [p for p in params if p.requires_grad]}]
+        self.params = [p for g in groups for p in g["params"]]
         self.master = [p.detach().float().clone() for p in self.params]
-        self.opt = torch.optim.AdamW(self.master, lr=lr, **kw)
+        it = iter(self.master)
+        self.opt = torch.optim.AdamW([{**g, "params": [next(it) for _ in g["params"]]} for g in groups], lr=lr, **kw)
 
     def zero_grad(self) -> None:
         for p in self.params:

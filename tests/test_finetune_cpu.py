@@ -189,3 +189,22 @@ def test_train_step_updates_fp32_masters_and_reduces_the_loss():
     assert torch.equal(net.frozen.detach(), torch.ones(4, dtype=torch.bfloat16)) and net.frozen.grad is None
     assert (opt.master[0] != 1).all() and torch.equal(net.pose_mix.detach(), opt.master[0].to(torch.bfloat16))
     assert (opt.master[0] - 1).abs().max() < 8e-3 * 30  # 30 steps of 1e-3: individually below bf16's spacing at 1, kept by the masters
+
+
+def test_optimizer_param_groups_follow_configure_optimizers():
+    """diffusion.py:310-361: pose parameters at lr; poseattn adds the pose blocks' attn1 / attn2 weights at multiplier * lr."""
+    net = _tiny_unet()
+    names = [n for n, _ in net.named_parameters()]
+    g = finetune.optimizer_param_groups(net, "pose", lr=1e-4)
+    assert len(g) == 1 and g[0]["lr"] == 1e-4 and g[0]["names"] == [n for n in names if "pose" in n]
+    g = finetune.optimizer_param_groups(net, "poseattn", lr=1e-4, multiplier=0.05)
+    assert len(g) == 2 and abs(g[1]["lr"] - 5e-6) < 1e-12
+    pose_blocks = {n.split(".pose")[0] for n in names if "pose" in n}
+    assert g[1]["names"] and all(("attn1" in n or "attn2" in n) and "pose" not in n and any(b in n for b in pose_blocks) for n in g[1]["names"])
+    assert sorted(g[0]["names"] + g[1]["names"]) == sorted(finetune.select_trainable(net, "poseattn"))
+    g = finetune.optimizer_param_groups(net, "all", lr=1e-4)
+    assert sorted(g[0]["names"] + g[1]["names"]) == sorted(names)
+    finetune.select_trainable(net, "poseattn")
+    opt = finetune.MasterAdamW(finetune.optimizer_param_groups(net, "poseattn", lr=1e-4), lr=1e-4)
+    assert [pg["lr"] for pg in opt.opt.param_groups] == [1e-4, 1e-4 * 0.05]
+    assert len(opt.params) == len(finetune.select_trainable(net, "poseattn")) == sum(len(pg["params"]) for pg in opt.opt.param_groups)
