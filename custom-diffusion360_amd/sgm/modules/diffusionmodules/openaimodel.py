@@ -253,6 +253,7 @@ class UNetModel(nn.Module):
 
         self.out = nn.Sequential(normalization(ch), nn.SiLU(), zero_module(conv_nd(dims, model_channels, out_channels, 3, padding=1)))
         self._emb_cat = None  # (key, concatenated emb_layers weights, biases) of _tag_emb_outs
+        self._last_pose_out = None  # index of the last output block holding a pose block (set on first forward)
 
     @property
     def dtype(self):
@@ -332,10 +333,18 @@ class UNetModel(nn.Module):
             hrs.append(hr)
         h, hr, fg, _, al, rgb = self.middle_block(h, emb, context, hr, embr, contextr, pose, mask_ref=mask_ref, prev_weights=None)
         collect(fg, al, rgb)
-        for module in self.output_blocks:
+        # The reference stream only exists to feed the pose blocks (their `context_ref`); past the last one its activations are
+        # never read again (the reference still computes them, openaimodel.py:1071-1084).  It is dropped there: three level-0
+        # ResBlocks on b*n images in the SDXL layout.
+        if self._last_pose_out is None:
+            self._last_pose_out = max((i for i, m in enumerate(self.output_blocks)
+                                       if any(isinstance(l, SpatialTransformer) and l.image_cross for l in m)), default=-1)
+        for i, module in enumerate(self.output_blocks):
             h = _cat_channels(h, hs.pop())
             hrp = hrs.pop()
-            if reference_image:
+            if i > self._last_pose_out:
+                hr = None
+            if reference_image and hr is not None:
                 hr = _cat_channels(hr, hrp)
             h, hr, fg, _, al, rgb = module(h, emb, context, hr, embr, contextr, pose, mask_ref=mask_ref, prev_weights=None)
             collect(fg, al, rgb)

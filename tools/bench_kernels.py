@@ -67,6 +67,17 @@ def gn(tag, N, P, C):
     print(f"gn_silu {tag}: N{N} P{P} C{C}: {us:8.1f} us  {3.0 * 2 * N * P * C / us / 1e3:8.1f} GB/s", flush=True)
 
 
+def ln(tag, rows, C):
+    a, b = torch.randn(rows, C, device=dev).to(BF), torch.randn(rows, C, device=dev).to(BF)
+    g, bta = torch.ones(C, device=dev, dtype=BF), torch.zeros(C, device=dev, dtype=BF)
+    us = timeit(lambda: ops.add_layernorm(a, b, g, bta, 1e-5), iters=50)
+    us1 = timeit(lambda: ops.add_layernorm(a, None, g, bta, 1e-5), iters=50)
+    print(f"add_layernorm {tag}: rows {rows} C{C}: a+b {us:7.1f} us {4.0 * 2 * rows * C / us / 1e3:7.1f} GB/s | a only {us1:7.1f} us {2.0 * 2 * rows * C / us1 / 1e3:7.1f} GB/s", flush=True)
+    p = torch.randn(rows, 8 * C, device=dev).to(BF)
+    us2 = timeit(lambda: ops.geglu(p), iters=50)
+    print(f"geglu         {tag}: rows {rows} inner {4 * C}: {us2:7.1f} us {3.0 * 2 * rows * 4 * C / us2 / 1e3:7.1f} GB/s", flush=True)
+
+
 def conv(tag, N, H, W, cin, cout):
     x = torch.randn(N, H * W, cin, device=dev).to(BF)
     wp = (torch.randn(cout, 9 * cin, device=dev) / (9 * cin) ** 0.5).to(BF)
@@ -108,6 +119,8 @@ if __name__ == "__main__":
         conv("L0", 3, 128, 128, 320, 320); conv("L0 up", 3, 128, 128, 960, 320); conv("L0 ups", 3, 128, 128, 640, 640)
         conv("L1", 3, 64, 64, 640, 640); conv("L1 up", 3, 64, 64, 1920, 640); conv("L1 ups", 3, 64, 64, 1280, 1280)
         conv("L2", 3, 32, 32, 1280, 1280); conv("L2 up", 3, 32, 32, 2560, 1280)
+    if "ln" in which:
+        ln("L1", 12288, 640); ln("L2", 3072, 1280); ln("L2 pose tokens", 3 * 24576, 1280)
     if "conv1" in which:
         conv("L1", 3, 64, 64, 640, 640)
     if "attn1" in which:
