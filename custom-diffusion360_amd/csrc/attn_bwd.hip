@@ -18,15 +18,18 @@
 // with X^T / Y^T read from the same row-major LDS tiles by gfx950's transposing read ds_read_b64_tr_b16 (lane mapping as in
 // attn_fwd.hip: tools/probe/tr_read_probe.hip).  Neither P nor dS ever goes through LDS or HBM, and nothing is atomically
 // accumulated: dQ rows belong to one workgroup of the first launch, dK / dV rows to one workgroup of the second.
-// First version: tiles are staged synchronously (load, barrier, compute); the forward's register prefetch / double buffering and
-// conflict-free transposed swizzle are the known next step.
+// Tiles are register-prefetched and double-buffered in LDS (one barrier per tile); the stationary rows and the output rows move
+// between HBM and LDS as full 128-byte lines.  The transposed reads still use the K swizzle (some bank conflicts): next step.
 #include "cd360_common.h"
 
 namespace {
 
 struct AttnBwdParams {
-  const uint16_t *q, *k, *v, *dout;
-  const float *lse, *delta;  // [B*H, Nq]
+  const uint16_t *q, *k, *v, *dout, *o;
+  const float* lse;    // [B*H, Nq]
+  float* delta;        // [B*H, Nq] workspace: written by the dQ role (or attn_bwd_delta_kernel), read by the dK/dV role
+  long o_s[3];
+  int fused_delta;     // 1: the dQ role computes delta = rowsum(dO o O) of its own rows itself
   uint16_t *dq, *dk, *dv;
   int B, H, Nq, Nk;
   long q_s[3], k_s[3], v_s[3], do_s[3], dq_s[3], dk_s[3], dv_s[3];  // (batch, head, row) element strides, d contiguous
@@ -80,10 +83,11 @@ __global__ __launch_bounds__(256) void attn_bwd_delta_kernel(const uint16_t* o, 
 
 template <bool DKV>
 __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdParams p) {
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * 64 * PITCH + 2 * 64 * 4];
-  unsigned char* Xs = lds;
-  unsigned char* Ys = lds + 64 * PITCH;
-  float* st = reinterpret_cast<float*>(lds + 2 * 64 * PITCH);  // DKV: lse * log2(e) and delta of the tile's 64 query rows
+  // two tile buffers (X | Y, 64 rows x 128 B each) + the tile's lse / delta (DKV); before the loop the same 32 KB stage the
+  // workgroup's 128 stationary rows of both tensors, after it each wave's 4 KB slice stages its output rows
+  constexpr int BUF_BYTES = 2 * 64 * PITCH;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * BUF_BYTES + 2 * 2 * 64 * 4];
+  float* st_all = reinterpret_cast<float*>(lds + 2 * BUF_BYTES);
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -97,52 +101,110 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdParams p) {
   const uint16_t* yp = (DKV ? p.dout + b * p.do_s[0] + h * p.do_s[1] : p.v + b * p.v_s[0] + h * p.v_s[1]);
   const long x_sn = DKV ? p.q_s[2] : p.k_s[2], y_sn = DKV ? p.do_s[2] : p.v_s[2];
   const float* lsep = p.lse + (long)bh * p.Nq;
-  const float* delp = p.delta + (long)bh * p.Nq;
+  const float* delp = p.delta + (long)bh * p.Nq;  // (dK/dV role; dQ role without fused delta)
   constexpr float LOG2E = 1.4426950408889634f;
+  const int lrow = tid >> 3, lchunk = tid & 7;  // line-shaped access: 8 lanes x 16 B = one 128-byte row
 
-  // ---- stationary side: B fragments (column lane%32, k = d 16 ks + 8 hh ..) ----
+  // ---- stationary side: rows travel as full 128-byte lines into LDS and come back as B fragments (column lane%32, k = d 16 ks + 8 hh ..);
+  // loading the fragments straight from HBM touches every line four times with 32-byte pieces ----
+#pragma unroll
+  for (int pass = 0; pass < 4; ++pass) {
+    const int row = lrow + 32 * pass, grow = t * 128 + row;
+    u32x4 a = {0u, 0u, 0u, 0u}, c2 = {0u, 0u, 0u, 0u};
+    if (grow < Ns) {
+      a = *reinterpret_cast<const u32x4*>(f1p + (long)grow * f1_sn + lchunk * 8);
+      c2 = *reinterpret_cast<const u32x4*>(f2p + (long)grow * f2_sn + lchunk * 8);
+    }
+    *reinterpret_cast<u32x4*>(lds + lds_off(row, lchunk * 8)) = a;
+    *reinterpret_cast<u32x4*>(lds + 128 * PITCH + lds_off(row, lchunk * 8)) = c2;
+  }
+  __syncthreads();
   const int srow = t * 128 + wave * 32 + l31;
   bf16x8 f1[4], f2[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
-    u32x4 a = {0u, 0u, 0u, 0u}, c2 = {0u, 0u, 0u, 0u};
-    if (srow < Ns) {
-      a = *reinterpret_cast<const u32x4*>(f1p + (long)srow * f1_sn + 16 * ks + 8 * hh);
-      c2 = *reinterpret_cast<const u32x4*>(f2p + (long)srow * f2_sn + 16 * ks + 8 * hh);
-    }
-    f1[ks] = __builtin_bit_cast(bf16x8, a);
-    f2[ks] = __builtin_bit_cast(bf16x8, c2);
+    f1[ks] = *reinterpret_cast<const bf16x8*>(lds + lds_off(wave * 32 + l31, 16 * ks + 8 * hh));
+    f2[ks] = *reinterpret_cast<const bf16x8*>(lds + 128 * PITCH + lds_off(wave * 32 + l31, 16 * ks + 8 * hh));
   }
   float lse2_lane = 0.f, delta_lane = 0.f;
   if (!DKV && srow < Ns) {
     lse2_lane = lsep[srow] * LOG2E;
-    delta_lane = delp[srow];
+    if (!p.fused_delta) delta_lane = delp[srow];
   }
+  __syncthreads();  // the staging area becomes the tile buffers
+  if (!DKV && p.fused_delta) {
+    // delta = rowsum(dO o O) of this workgroup's own query rows: one more trip of 128 lines through LDS instead of a separate
+    // kernel that reads dO and O a second time; the dK/dV role (launched afterwards) finds it in the workspace
+    const uint16_t* op = p.o + b * p.o_s[0] + h * p.o_s[1];
+#pragma unroll
+    for (int pass = 0; pass < 4; ++pass) {
+      const int row = lrow + 32 * pass, grow = t * 128 + row;
+      u32x4 a = {0u, 0u, 0u, 0u};
+      if (grow < Ns) a = *reinterpret_cast<const u32x4*>(op + (long)grow * p.o_s[2] + lchunk * 8);
+      *reinterpret_cast<u32x4*>(lds + lds_off(row, lchunk * 8)) = a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const u32x4 ov = *reinterpret_cast<const u32x4*>(lds + lds_off(wave * 32 + l31, 16 * ks + 8 * hh));
+      const u32x4 gv = __builtin_bit_cast(u32x4, f2[ks]);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        delta_lane += bf16lo_to_f32(ov[e]) * bf16lo_to_f32(gv[e]) + bf16hi_to_f32(ov[e]) * bf16hi_to_f32(gv[e]);
+    }
+    delta_lane += __shfl_xor(delta_lane, 32);
+    if (hh == 0 && srow < Ns) p.delta[(long)bh * p.Nq + srow] = delta_lane;
+    __syncthreads();
+  }
+
   f32x16 acc1[2], acc2[2];
 #pragma unroll
   for (int i = 0; i < 16; ++i) { acc1[0][i] = 0.f; acc1[1][i] = 0.f; acc2[0][i] = 0.f; acc2[1][i] = 0.f; }
   const float c = p.scale_log2e;
 
-  for (int t0 = 0; t0 < Nt; t0 += 64) {
-    __syncthreads();  // the previous tile's reads are done
+  // ---- streamed tiles: the loads of tile i + 1 are in flight while tile i is consumed; two LDS buffers, one barrier per tile ----
+  u32x4 xr[2], yr[2];
+  float sr = 0.f;
+  auto tile_load = [&](int t0) {
 #pragma unroll
     for (int pass = 0; pass < 2; ++pass) {
-      const int row = (tid >> 3) + 32 * pass, chunk = tid & 7;
+      const int row = lrow + 32 * pass;
       u32x4 xv = {0u, 0u, 0u, 0u}, yv = {0u, 0u, 0u, 0u};
       if (t0 + row < Nt) {
-        xv = *reinterpret_cast<const u32x4*>(xp + (long)(t0 + row) * x_sn + chunk * 8);
-        yv = *reinterpret_cast<const u32x4*>(yp + (long)(t0 + row) * y_sn + chunk * 8);
+        xv = *reinterpret_cast<const u32x4*>(xp + (long)(t0 + row) * x_sn + lchunk * 8);
+        yv = *reinterpret_cast<const u32x4*>(yp + (long)(t0 + row) * y_sn + lchunk * 8);
       }
-      *reinterpret_cast<u32x4*>(Xs + lds_off(row, chunk * 8)) = xv;
-      *reinterpret_cast<u32x4*>(Ys + lds_off(row, chunk * 8)) = yv;
+      xr[pass] = xv;
+      yr[pass] = yv;
     }
     if (DKV && tid < 128) {
       const int row = tid & 63;
-      float val = 0.f;
-      if (t0 + row < Nt) val = tid < 64 ? lsep[t0 + row] * LOG2E : delp[t0 + row];
-      st[tid] = val;
+      sr = 0.f;
+      if (t0 + row < Nt) sr = tid < 64 ? lsep[t0 + row] * LOG2E : delp[t0 + row];
     }
-    __syncthreads();
+  };
+  auto tile_store = [&](int buf) {
+    unsigned char* Xb = lds + buf * BUF_BYTES;
+#pragma unroll
+    for (int pass = 0; pass < 2; ++pass) {
+      const int row = lrow + 32 * pass;
+      *reinterpret_cast<u32x4*>(Xb + lds_off(row, lchunk * 8)) = xr[pass];
+      *reinterpret_cast<u32x4*>(Xb + 64 * PITCH + lds_off(row, lchunk * 8)) = yr[pass];
+    }
+    if (DKV && tid < 128) st_all[buf * 128 + tid] = sr;
+  };
+  tile_load(0);
+  tile_store(0);
+  __syncthreads();
+
+  const int n_t = (Nt + 63) / 64;
+  for (int it = 0; it < n_t; ++it) {
+    const int t0 = it * 64, buf = it & 1;
+    const bool more = it + 1 < n_t;
+    if (more) tile_load(t0 + 64);
+    const unsigned char* Xs = lds + buf * BUF_BYTES;
+    const unsigned char* Ys = Xs + 64 * PITCH;
+    const float* st = st_all + buf * 128;
 
     // ---- S^T (streamed rows x stationary columns) and dP^T ----
     f32x16 sT[2], dpT[2];
@@ -189,31 +251,49 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(AttnBwdParams p) {
           acc2[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tr_frag(Ys, db, kk, l31, hh), __builtin_bit_cast(bf16x8, pw), acc2[db], 0, 0, 0);
       }
     }
+    if (more) tile_store(buf ^ 1);  // (last read of that buffer: tile it - 1, before the previous barrier)
+    __syncthreads();
   }
 
-  // ---- epilogue: lane = stationary row, register r of block db = d 32 db + (r & 3) + 8 (r >> 2) + 4 hh ----
-  if (srow < Ns) {
-    uint16_t* o1 = DKV ? p.dk + b * p.dk_s[0] + h * p.dk_s[1] + (long)srow * p.dk_s[2] : p.dq + b * p.dq_s[0] + h * p.dq_s[1] + (long)srow * p.dq_s[2];
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = db * 32 + 8 * g + 4 * hh;
-        const u32x2 wv = {pack_bf16x2(acc1[db][4 * g + 0] * p.scale, acc1[db][4 * g + 1] * p.scale),
-                          pack_bf16x2(acc1[db][4 * g + 2] * p.scale, acc1[db][4 * g + 3] * p.scale)};
-        *reinterpret_cast<u32x2*>(o1 + d) = wv;
-      }
-    if (DKV) {
-      uint16_t* o2 = p.dv + b * p.dv_s[0] + h * p.dv_s[1] + (long)srow * p.dv_s[2];
+  // ---- epilogue: lane = stationary row, register r of block db = d 32 db + (r & 3) + 8 (r >> 2) + 4 hh.  The accumulators go
+  // through this wave's 4 KB of LDS and leave as full 128-byte rows (8 lanes x 16 B) when the output rows are 16-byte aligned ----
+  unsigned char* Os = lds + wave * (32 * PITCH);
+  auto write_out = [&](const f32x16 (&acc)[2], float mul, uint16_t* obase, const long (&os)[3]) {
+    uint16_t* orows = obase + b * os[0] + h * os[1];
+    const bool lines = (os[0] % 8 == 0) && (os[1] % 8 == 0) && (os[2] % 8 == 0) && ((uintptr_t)obase % 16 == 0);
+    if (lines) {
 #pragma unroll
       for (int db = 0; db < 2; ++db)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int d = db * 32 + 8 * g + 4 * hh;
-          const u32x2 wv = {pack_bf16x2(acc2[db][4 * g + 0], acc2[db][4 * g + 1]), pack_bf16x2(acc2[db][4 * g + 2], acc2[db][4 * g + 3])};
-          *reinterpret_cast<u32x2*>(o2 + d) = wv;
+          const u32x2 wv = {pack_bf16x2(acc[db][4 * g + 0] * mul, acc[db][4 * g + 1] * mul), pack_bf16x2(acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul)};
+          *reinterpret_cast<u32x2*>(Os + lds_off(l31, d)) = wv;
+        }
+      // (wave-private region: no barrier; the LDS writes of this wave are visible to its own later reads)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = 8 * i + (lane >> 3), grow = t * 128 + wave * 32 + row;
+        const u32x4 v = *reinterpret_cast<const u32x4*>(Os + lds_off(row, (lane & 7) * 8));
+        if (grow < Ns) *reinterpret_cast<u32x4*>(orows + (long)grow * os[2] + (lane & 7) * 8) = v;
+      }
+    } else if (srow < Ns) {
+      uint16_t* o1 = orows + (long)srow * os[2];
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int d = db * 32 + 8 * g + 4 * hh;
+          const u32x2 wv = {pack_bf16x2(acc[db][4 * g + 0] * mul, acc[db][4 * g + 1] * mul), pack_bf16x2(acc[db][4 * g + 2] * mul, acc[db][4 * g + 3] * mul)};
+          *reinterpret_cast<u32x2*>(o1 + d) = wv;
         }
     }
+  };
+  if (DKV) {
+    write_out(acc1, p.scale, p.dk, p.dk_s);
+    write_out(acc2, 1.f, p.dv, p.dv_s);
+  } else {
+    write_out(acc1, p.scale, p.dq, p.dq_s);
   }
 }
 
@@ -233,12 +313,13 @@ extern "C" int cd360_attn_bwd_bf16(const void* q, const void* k, const void* v, 
   if ((dq && !dq_strides) || (dk && (!dk_strides || !dv_strides))) return CD360_ERR_ARG;
   AttnBwdParams p;
   p.q = (const uint16_t*)q; p.k = (const uint16_t*)k; p.v = (const uint16_t*)v; p.dout = (const uint16_t*)dout;
-  p.lse = (const float*)lse; p.delta = (const float*)delta_ws;
+  p.lse = (const float*)lse; p.delta = (float*)delta_ws; p.o = (const uint16_t*)o;
   p.dq = (uint16_t*)dq; p.dk = (uint16_t*)dk; p.dv = (uint16_t*)dv;
   p.B = B; p.H = H; p.Nq = Nq; p.Nk = Nk;
   for (int i = 0; i < 3; ++i) {
     p.q_s[i] = q_strides[i]; p.k_s[i] = k_strides[i]; p.v_s[i] = v_strides[i]; p.do_s[i] = do_strides[i];
     p.dq_s[i] = dq ? dq_strides[i] : 0; p.dk_s[i] = dk ? dk_strides[i] : 0; p.dv_s[i] = dv ? dv_strides[i] : 0;
+    p.o_s[i] = o_strides[i];
     if (p.q_s[i] % 8 || p.k_s[i] % 8 || p.v_s[i] % 8 || p.do_s[i] % 8 || o_strides[i] % 8) return CD360_ERR_SHAPE;
     if (p.dq_s[i] % 4 || p.dk_s[i] % 4 || p.dv_s[i] % 4) return CD360_ERR_SHAPE;
   }
@@ -248,10 +329,13 @@ extern "C" int cd360_attn_bwd_bf16(const void* q, const void* k, const void* v, 
   p.scale_log2e = scale * 1.4426950408889634f;
   const long rows = (long)B * H * Nq;
   if (rows > 0x7fffffffL * 32) return CD360_ERR_SHAPE;
-  hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)o,
-                     (const uint16_t*)dout, (float*)delta_ws, H, Nq, (long)o_strides[0], (long)o_strides[1], (long)o_strides[2], p.do_s[0],
-                     p.do_s[1], p.do_s[2], rows);
-  CD360_LAUNCH_CHECK();
+  p.fused_delta = dq ? 1 : 0;  // the dQ launch (first) leaves delta in the workspace for the dK/dV launch
+  if (!dq) {
+    hipLaunchKernelGGL(attn_bwd_delta_kernel, dim3((unsigned)((rows + 31) / 32)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)o,
+                       (const uint16_t*)dout, (float*)delta_ws, H, Nq, (long)o_strides[0], (long)o_strides[1], (long)o_strides[2], p.do_s[0],
+                       p.do_s[1], p.do_s[2], rows);
+    CD360_LAUNCH_CHECK();
+  }
   if (dq) {
     p.n_tiles = (Nq + 127) / 128;
     const long nwg = (long)p.n_tiles * B * H;

@@ -61,6 +61,11 @@ def test_attention_backward(B, H, Nq, Nk, kv_grad):
     if kv_grad:
         assert rel(kd.grad[:, :Nk], gk) < 2e-2 and rel(vd.grad[:, :Nk], gv) < 2e-2
         assert (kd.grad[:, Nk:] == 0).all() and (vd.grad[:, Nk:] == 0).all()
+        # dk / dv alone (q without gradient): the stand-alone delta kernel instead of the one fused into the dq launch
+        with torch.no_grad():
+            o2, lse = ops.attention(qd, kd, vd, H, nk=Nk, want_lse=True)
+            none, dk2, dv2 = ops.attention_bwd(qd, kd, vd, o2, do.to(DEV, torch.bfloat16), lse, H, Nk, need_dq=False)
+        assert none is None and rel(dk2[:, :Nk], gk) < 2e-2 and rel(dv2[:, :Nk], gv) < 2e-2
     else:
         assert kd.grad is None and vd.grad is None
 

@@ -67,6 +67,19 @@ def gn(tag, N, P, C):
     print(f"gn_silu {tag}: N{N} P{P} C{C}: {us:8.1f} us  {3.0 * 2 * N * P * C / us / 1e3:8.1f} GB/s", flush=True)
 
 
+def attn_bwd(tag, b, H, nq, nk, kv_grad=True):
+    q = torch.randn(b, nq, H * 64, device=dev).to(BF)
+    k = torch.randn(b, nk, H * 64, device=dev).to(BF)
+    v = torch.randn(b, nk, H * 64, device=dev).to(BF)
+    do = torch.randn(b, nq, H * 64, device=dev).to(BF)
+    o, lse = ops.attention(q, k, v, H, want_lse=True)
+    us_f = timeit(lambda: ops.attention(q, k, v, H, want_lse=True))
+    us = timeit(lambda: ops.attention_bwd(q, k, v, o, do, lse, H, need_dkv=kv_grad))
+    fl = 4.0 * b * H * nq * nk * 64 * (1.5 + (2.0 if kv_grad else 0.0))
+    by = 2.0 * b * H * 64 * (4 * nq + (4 if kv_grad else 2) * nk)
+    print(f"attn_bwd {tag}: b{b} H{H} Nq{nq} Nk{nk} dkv={kv_grad}: fwd {us_f:8.1f} us | bwd {us:8.1f} us {fl / us / 1e6:7.1f} TF/s {by / us / 1e3:7.1f} GB/s", flush=True)
+
+
 def ln(tag, rows, C):
     a, b = torch.randn(rows, C, device=dev).to(BF), torch.randn(rows, C, device=dev).to(BF)
     g, bta = torch.ones(C, device=dev, dtype=BF), torch.zeros(C, device=dev, dtype=BF)
@@ -119,6 +132,10 @@ if __name__ == "__main__":
         conv("L0", 3, 128, 128, 320, 320); conv("L0 up", 3, 128, 128, 960, 320); conv("L0 ups", 3, 128, 128, 640, 640)
         conv("L1", 3, 64, 64, 640, 640); conv("L1 up", 3, 64, 64, 1920, 640); conv("L1 ups", 3, 64, 64, 1280, 1280)
         conv("L2", 3, 32, 32, 1280, 1280); conv("L2 up", 3, 32, 32, 2560, 1280)
+    if "attn_bwd" in which:  # config 4 shapes: batch 4, latent 64^2
+        attn_bwd("L1 self", 4, 10, 1024, 1024); attn_bwd("L2 self", 4, 20, 256, 256)
+        attn_bwd("L1 text", 4, 10, 1024, 77, False); attn_bwd("L2 text", 4, 20, 256, 77, False)
+        attn_bwd("L1 pose", 4, 10, 24576, 77, False); attn_bwd("L2 pose", 4, 20, 6144, 77, False)
     if "ln" in which:
         ln("L1", 12288, 640); ln("L2", 3072, 1280); ln("L2 pose tokens", 3 * 24576, 1280)
     if "conv1" in which:
