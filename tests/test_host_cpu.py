@@ -96,6 +96,25 @@ def test_cpu_forward_fails_loudly():
         ops.memory_efficient_attention(torch.randn(2, 8, 64), torch.randn(2, 8, 64), torch.randn(2, 8, 64))
 
 
+def test_cpu_autograd_path_fails_loudly_too():
+    """The differentiable route (cd360/grad.py) has no CPU / PyTorch fallback either: a CPU tensor that requires grad reaches the same
+    C-ABI front end and raises, for every operator that records itself on the autograd tape."""
+    from cd360 import ops
+    from cd360._lib import Cd360Error
+    r = lambda *s: torch.randn(*s, dtype=torch.bfloat16, requires_grad=True)
+    calls = [lambda: ops.attention(r(1, 8, 64), r(1, 8, 64), r(1, 8, 64), 1),
+             lambda: ops.self_attention_qkv(r(1, 8, 192), 1),
+             lambda: ops.geglu(r(4, 128)),
+             lambda: ops.add_layernorm(r(4, 64), r(4, 64), torch.ones(64, dtype=torch.bfloat16), torch.zeros(64, dtype=torch.bfloat16), 1e-5),
+             lambda: ops.gn_silu(r(1, 16, 64), torch.ones(64), torch.zeros(64), 32, 1e-5, True),
+             lambda: ops.volrender(torch.randn(1, 4, 3, 8, requires_grad=True), torch.randn(1, 4, 3), torch.rand(3)),
+             lambda: ops.rowdot4(r(4, 64), torch.randn(4, 64)),
+             lambda: ops.conv_igemm(r(1, 16, 64), torch.zeros(64, 576, dtype=torch.bfloat16), None, 1, 4, 4, 9, w_dgrad=lambda: None)]
+    for call in calls:
+        with pytest.raises(Cd360Error):
+            call()
+
+
 # ------------------------------------------------------------------------------------------------ C ABI
 def test_library_exports_every_declared_symbol():
     from cd360 import _lib
