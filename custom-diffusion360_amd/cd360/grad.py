@@ -69,7 +69,6 @@ class VolRenderFn(torch.autograd.Function):
         ctx.save_for_backward(feats, sigma_raw, dists, rgb_raw)
         ctx.set_materialize_grads(False)
         ctx.flags = (sigma_is_raw, rgb_is_raw)
-        ctx.has = (weights is not None, rgb is not None)
         return rendered, fg, alphas, weights, rgb
 
     @staticmethod
@@ -115,7 +114,8 @@ class GegluFn(torch.autograd.Function):
 
 class AddLayerNormFn(torch.autograd.Function):
     """ops.add_layernorm (residual add + nn.LayerNorm, attention.py:609-636) with cd360_add_layernorm_bwd_bf16.  Returns
-    (sum, ln); with b None the sum IS a (returned as a view so the residual stream keeps one gradient path)."""
+    (sum, ln) -- only ln when b is None (the caller keeps using `a` as the residual stream).  The backward adds the gradient that
+    arrived on `sum` to the LayerNorm gradient in the same pass; a and b receive the same tensor."""
 
     @staticmethod
     def forward(ctx, a, b, gamma, beta, eps):

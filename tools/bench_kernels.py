@@ -132,6 +132,10 @@ if __name__ == "__main__":
         conv("L0", 3, 128, 128, 320, 320); conv("L0 up", 3, 128, 128, 960, 320); conv("L0 ups", 3, 128, 128, 640, 640)
         conv("L1", 3, 64, 64, 640, 640); conv("L1 up", 3, 64, 64, 1920, 640); conv("L1 ups", 3, 64, 64, 1280, 1280)
         conv("L2", 3, 32, 32, 1280, 1280); conv("L2 up", 3, 32, 32, 2560, 1280)
+    if "attn_par" in which:  # how the self-attention shapes react to more / fewer workgroups (tile quantisation, waves per SIMD)
+        attn("L2 self b3", 3, 20, 1024, 1024); attn("L2 self b6", 6, 20, 1024, 1024); attn("L2 self b12", 12, 20, 1024, 1024)
+        attn("L1 self 960wg", 3, 10, 4096, 4096); attn("L1 self 768wg", 3, 8, 4096, 4096); attn("L1 self 1536wg", 6, 8, 4096, 4096)
+        attn("L1 self 1920wg", 6, 10, 4096, 4096)
     if "attn_bwd" in which:  # config 4 shapes: batch 4, latent 64^2
         attn_bwd("L1 self", 4, 10, 1024, 1024); attn_bwd("L2 self", 4, 20, 256, 256)
         attn_bwd("L1 text", 4, 10, 1024, 77, False); attn_bwd("L2 text", 4, 20, 256, 77, False)
