@@ -97,20 +97,7 @@ class Sampler:
         """Keep every block's cached render in a fixed buffer so a captured graph keeps reading the current image's render."""
         from cd360 import sampling
         for _, blk in sampling.pose_blocks(self.net):
-            buf = getattr(blk, "_static_rendered", None)
-            if buf is None or buf.shape != blk.rendered_feat.shape:
-                blk._static_rendered = blk.rendered_feat.clone()
-            else:
-                buf.copy_(blk.rendered_feat)
-            blk.rendered_feat = blk._static_rendered
-            # the reference half of pose_emb_layers (rendered_feat @ Wb^T) lives beside the render: same treatment
-            wa, wb = blk._pose_weights()
-            c = blk.rendered_feat.shape[-1]
-            if getattr(blk, "_static_proj", None) is None:
-                blk._static_proj = torch.mm(blk.rendered_feat.reshape(-1, c), wb)
-            else:
-                torch.mm(blk.rendered_feat.reshape(-1, c), wb, out=blk._static_proj)
-            blk._rendered_proj = (blk.rendered_feat, blk.rendered_feat._version, wb, blk._static_proj)
+            blk.pin_rendered()  # render + its pose_emb_layers half (rendered_feat @ Wb^T) in buffers that stay put across images
         for att in sampling._cross_attentions(self.net):  # same for the per-image context K / V^T cache
             if att._kv_cache is None:
                 continue

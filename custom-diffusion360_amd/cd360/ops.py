@@ -517,6 +517,95 @@ def conv_igemm(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Ten
     return (out, stats) if want_stats else out
 
 
+# ----------------------------------------------------------------------------------------------- Linear layers (cd360_gemm_bf16)
+def _rows2d(t: torch.Tensor):
+    """(rows, row stride) of a bf16 tensor [..., C] whose leading dims collapse to uniformly strided rows (last dim contiguous)."""
+    assert t.dtype == torch.bfloat16 and t.stride(-1) == 1, "bf16 with a contiguous last dim"
+    rows, ld = 1, None
+    for size, stride in zip(reversed(t.shape[:-1]), reversed(t.stride()[:-1])):
+        if size == 1:
+            continue
+        if ld is None:
+            ld = stride
+        elif stride != rows * ld:
+            raise Cd360Error("cd360 gemm: the leading dims do not collapse to uniformly strided rows")
+        rows *= size
+    return rows, (t.shape[-1] if ld is None else ld)
+
+
+def gemm_tile_n(M: int, N: int) -> int:
+    return _lib.load().cd360_gemm_tile_n(M, N)
+
+
+def pack_ln_linear(weight: torch.Tensor, bias: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor):
+    """LayerNorm(gamma, beta) followed by Linear(weight, bias), folded for gemm(..., ln=...): -> (w' bf16 = weight * gamma,
+    wsum fp32 = rowsum(w') of the ROUNDED w', cb fp32 = weight @ beta + bias)."""
+    w32 = weight.detach().float()
+    wp = (w32 * gamma.detach().float()[None, :]).to(torch.bfloat16).contiguous()
+    cb = w32 @ beta.detach().float()
+    if bias is not None:
+        cb = cb + bias.detach().float()
+    return wp, wp.float().sum(1).contiguous(), cb.contiguous()
+
+
+def geglu_row_order(inner: int, device=None) -> torch.Tensor:
+    """Row permutation of a GEGLU projection [2*inner, K] (value rows | gate rows) for gemm(..., geglu=True): per 32 output columns
+    the 32 value rows then the 32 gate rows."""
+    assert inner % 32 == 0
+    g = torch.arange(inner // 32, device=device)[:, None] * 32 + torch.arange(32, device=device)[None, :]
+    return torch.cat([g, g + inner], 1).reshape(-1)
+
+
+def row_stats(x: torch.Tensor) -> torch.Tensor:
+    """x [..., C] bf16 -> fp32 [rows, 1, 2] (sum, sum of squares) per row: LayerNorm statistics input of gemm(..., ln=...)."""
+    _need_gpu(x)
+    rows, ld = _rows2d(x)
+    C = x.shape[-1]
+    st = torch.empty(rows, 1, 2, dtype=torch.float32, device=x.device)
+    with _timed("row_stats", 0.0, 2.0 * rows * C):
+        check(_lib.load().cd360_row_stats_bf16(_ptr(x), _ptr(st), rows, C, ld, _stream()), "cd360_row_stats_bf16")
+    return st
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, ln=None,
+         want_stats: bool = False, geglu: bool = False, out: Optional[torch.Tensor] = None):
+    """a [..., K] @ w[N, K]^T with the fused epilogues of cd360_gemm_bf16 -> out [..., N] (N / 2 with geglu), bf16.
+    bias fp32 [N]; res bf16 [..., N]; ln = (stats fp32 [rows, parts, 2], wsum fp32 [N], eps) with w / bias from pack_ln_linear;
+    want_stats=True returns (out, stats fp32 [rows, parts_out, 2]) for the next LayerNorm fold.  Forward only (inference path)."""
+    _need_gpu(a, w, bias, res)
+    M, lda = _rows2d(a)
+    K = a.shape[-1]
+    N = w.shape[0]
+    assert w.dtype == torch.bfloat16 and w.dim() == 2 and w.shape[1] == K and w.stride(1) == 1
+    assert bias is None or (bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == N)
+    nout = N // 2 if geglu else N
+    if out is None:
+        out = torch.empty(*a.shape[:-1], nout, dtype=torch.bfloat16, device=a.device)
+    mo, ldo = _rows2d(out)
+    assert mo == M and out.shape[-1] == nout
+    ldr = 0
+    if res is not None:
+        mr, ldr = _rows2d(res)
+        assert mr == M and res.shape[-1] == N
+    stats_in = wsum = None
+    parts = ln_dim = 0
+    eps = 0.0
+    if ln is not None:
+        stats_in, wsum, eps = ln
+        assert stats_in.dtype == torch.float32 and stats_in.is_contiguous() and stats_in.shape[0] == M and stats_in.shape[2] == 2
+        assert wsum.dtype == torch.float32 and wsum.is_contiguous() and wsum.numel() == N
+        parts, ln_dim = stats_in.shape[1], K
+    lib = _lib.load()
+    stats_out = None
+    if want_stats:
+        tn = lib.cd360_gemm_tile_n(M, N)
+        stats_out = torch.empty(M, (N + tn - 1) // tn, 2, dtype=torch.float32, device=a.device)
+    with _timed("gemm8p", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * nout + (M * N if res is not None else 0))):
+        check(lib.cd360_gemm_bf16(_ptr(a), _ptr(w), _ptr(out), M, N, K, lda, w.stride(0), ldo, _ptr(bias), _ptr(res), ldr, _ptr(stats_in), parts,
+                                  ln_dim, float(eps), _ptr(wsum), _ptr(stats_out), 1 if geglu else 0, _stream()), "cd360_gemm_bf16")
+    return (out, stats_out) if want_stats else out
+
+
 def pose_embed(x: torch.Tensor, xref: torch.Tensor, wa: torch.Tensor, wb: torch.Tensor) -> torch.Tensor:
     """pose_emb_layers(cat[x, xref]) (attention.py:634) as x wa^T + xref wb^T through the C ABI (cd360_pose_embed_bf16); wa = W[:, :C],
     wb = W[:, C:], contiguous.  Forward-only operator-level entry (the modules run the same two products on the library GEMM, which

@@ -1,0 +1,558 @@
+// out[M, N] = A[M, K] @ W[N, K]^T on bf16 MFMA with fused epilogues -- every Linear of the transformer blocks that bracket the
+// FeatureNeRF injection (sgm/modules/attention.py:89-115 GEGLU feed-forward, :323-329 / :368-372 / :422 attention projections,
+// :515-516 pose_emb_layers, :748 / :786 proj_in / proj_out) as ONE hand-scheduled kernel family instead of library GEMMs plus
+// separate LayerNorm / GEGLU / residual passes.
+//
+// Structure (CDNA4), template <WM, WN, NCB, NMB>: WM x WN waves, each wave owns NCB x NMB blocks of 32 channels x 32 tokens on
+// v_mfma_f32_32x32x16_bf16 in the "swapped" convention of the other kernels here (MFMA rows = output channels through `chan_pos`,
+// MFMA columns = tokens) so a lane ends up with 16 consecutive output channels of one token.
+//   <2, 4, 2, 4>: 256 x 256 tile, eight waves of 128 x 64 (two per SIMD: one wave's MFMAs cover the other's LDS / DMA issue);
+//   <4, 2, 3, 2>: 256 x 192, <4, 2, 2, 2>: 256 x 128 -- tile counts that fill the 256 CUs where 256^2 leaves a ragged last round;
+//   <2, 4, 1, 2>, <2, 2, 2, 2>: 128 x 128 with eight / four waves -- the 640- and 1280-wide projections (M = 3072: 240 tiles).
+//   (A four-wave 256^2 variant with 128 x 128 per wave and all 512 registers -- the library kernel's shape -- measured 5-10 % slower
+//   than the eight-wave one under hipcc's schedule and was dropped.)
+// Operands travel L2 -> LDS by LDS-DMA (`buffer_load_dwordx4 ... lds`, 1 KiB per wave instruction, no staging registers); the LDS
+// image is 128-byte rows with a 16-byte XOR swizzle applied on the per-lane SOURCE address (the DMA destination is lane-linear),
+// read back conflict-free with ds_read_b128 (SQ_LDS_BANK_CONFLICT = 0).
+// Schedule: ONE workgroup barrier per 64-deep K-tile.  Per 16-deep k-step the wave issues the fragment reads of step ks+1 and the
+// MFMAs of step ks; after step 2 it waits for its own reads (the whole buffer is then consumed) and for its DMA pieces of the next
+// tile, the workgroup meets once, and step 3 runs with the next tile's first fragments and the DMA pieces of tile t+2 (into the
+// buffer that just became free) issued between its MFMAs -- the matrix pipe never waits for LDS or for a landing tile.  The two
+// LDS buffers alternate by flipping one bit of the eight fragment offsets (the loop body is one tile).
+// (Measured and dropped: phase-per-barrier schedules with two wave groups one barrier apart -- 8 barrier events per tile -- and a
+// 3-deep ring of token buffers: all within 3 % of each other at 1130-1180 TF/s on 4096^3, the library kernel at 1400.)
+// Epilogues (all in registers, one bf16 write): + bias, LayerNorm folded in front of the GEMM
+//   LN(x) W^T = rstd (x (gamma o W)^T - mu rowsum(gamma o W)) + (beta W^T + b)    -- row statistics from the PRODUCER's epilogue
+// (per-row partial sums of the residual stream written by the GEMM that produced it: `stats_out`), + residual, GEGLU
+// (x * gelu(gate), weight rows interleaved per 64 at pack time so value and gate of a column sit in the same lane).
+#include "cd360_common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+namespace {
+
+struct GemmParams {
+  const uint16_t* a;    // [M, K] bf16, row stride lda
+  const uint16_t* w;    // [N, K] bf16, row stride ldw (nn.Linear weight layout)
+  uint16_t* out;        // [M, Nout] bf16, row stride ldo (Nout = N, or N / 2 with GEGLU)
+  const float* bias;    // [N] fp32 or null (added after the LayerNorm fold)
+  const uint16_t* res;  // [M, N] bf16 residual (row stride ldr) or null
+  const float* ln_stats;  // [M, ln_parts, 2] fp32 partial (sum, sum of squares) of the A rows, or null = no LayerNorm fold
+  const float* wsum;      // [N] fp32 row sums of w (only with ln_stats)
+  float* stats_out;       // [M, ceil(N / BN), 2] fp32: per-row (sum, sumsq) of the bf16 outputs of each N tile, or null
+  long lda, ldw, ldo, ldr;
+  int M, N, K;
+  int ln_parts, ln_dim;
+  float ln_eps;
+  int geglu;
+  int tiles_m, tiles_n, group_m;
+  int abl;  // what-if timing knob (CD360_GEMM_ABL; results are wrong when set): 8 no DMA wait, 16 no barrier, 32 no LDS wait, 4 no DMA
+};
+
+__device__ __forceinline__ int chan_pos(int i) { return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3); }
+// erf-form GELU with erf from Abramowitz-Stegun 7.1.26 (|abs error| <= 1.5e-7, far below the bf16 rounding of the result): one v_rcp,
+// one v_exp and a degree-5 polynomial instead of libm's branchy erff -- the epilogue is exposed time (one workgroup per CU)
+__device__ __forceinline__ float gelu_erf(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+  float poly = fmaf(1.061405429f, t, -1.453152027f);
+  poly = fmaf(poly, t, 1.421413741f);
+  poly = fmaf(poly, t, -0.284496736f);
+  poly = fmaf(poly, t, 0.254829592f);
+  const float e = 1.f - poly * t * __builtin_amdgcn_exp2f(-z * z * 1.4426950408889634f);  // erf(|x| / sqrt 2)
+  return 0.5f * x * (1.f + copysignf(e, x));
+}
+
+#define LDS_AS3(p) ((__attribute__((address_space(3))) void*)(p))
+#define WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#define WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define FENCE() __builtin_amdgcn_sched_barrier(0)
+#define BARRIER()                  \
+  do {                             \
+    FENCE();                       \
+    __builtin_amdgcn_s_barrier();  \
+    FENCE();                       \
+  } while (0)
+
+template <int WM, int WN, int NCB, int NMB, int NBUF, bool GEGLU>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
+  constexpr int NW = WM * WN;                      // waves
+  constexpr int BM = WM * NMB * 32, BN = WN * NCB * 32;
+  constexpr uint32_t XB = BM * 128, WB = BN * 128;  // bytes of one buffer of each operand (64-deep K-tile, 128-byte rows)
+  constexpr uint32_t XREG = 0, WREG = NBUF * XB;   // LDS map: NBUF token buffers, then NBUF channel buffers
+  constexpr int PR = 8 * NW;                       // rows one DMA piece of the whole workgroup covers (8 per wave)
+  constexpr int XP = BM / PR, WP = BN / PR;        // pieces per wave per K-tile
+  constexpr int NP = XP + WP, NMMA = NCB * NMB;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave / WN, wc = wave % WN;  // token / channel position of the wave in the tile
+
+  // ---- tile of this workgroup: XCD-contiguous ranges, group_m token tiles per group with the channel tile varying slowest ----
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int per_group = p.group_m * p.tiles_n;
+  const int grp = tile / per_group, in_grp = tile - grp * per_group;
+  const int first_m = grp * p.group_m;
+  const int gm = (p.tiles_m - first_m) < p.group_m ? (p.tiles_m - first_m) : p.group_m;
+  const int tm = first_m + in_grp % gm, tn = in_grp / gm;
+  const long m0 = (long)tm * BM;
+  const int n0 = tn * BN;
+
+  // ---- LDS-DMA geometry: piece j covers rows j*PR + wave*8 + lane/8 of the operand tile; LDS chunk lane%8 <- source chunk ^ swizzle.
+  // Rows past M / N are past the end of the buffer descriptor: the hardware returns zeros (they only feed masked outputs).
+  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)(((long)p.M - 1) * p.lda * 2 + (long)p.K * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)(((long)p.N - 1) * p.ldw * 2 + (long)p.K * 2), 0x00020000);
+  const int srow = wave * 8 + (lane >> 3);
+  const int schunk = (lane & 7) ^ ((srow >> 1) & 7);
+  const uint32_t xoff0 = (uint32_t)((m0 + srow) * p.lda * 2 + schunk * 16);
+  const uint32_t woff0 = (uint32_t)(((long)n0 + srow) * p.ldw * 2 + schunk * 16);
+  const uint32_t xstep = (uint32_t)(PR * p.lda * 2), wstep = (uint32_t)(PR * p.ldw * 2);
+  unsigned char* const dma_base = lds + wave * 1024;
+  // DMA piece i (0 .. NP-1) of K-tile kt into the buffers at byte offsets bx / bw (0 | one buffer).  The wave-uniform part of the
+  // source offset is added with an opaque v_add (otherwise the compiler keeps NP strength-reduced per-piece offsets live in VGPRs).
+  auto piece = [&](int kt, int i, uint32_t bx, uint32_t bw) {
+    uint32_t o;
+    if (i < XP) {
+      const uint32_t su = (uint32_t)(kt * 128) + (uint32_t)i * xstep;
+      asm volatile("v_add_u32 %0, %1, %2" : "=v"(o) : "s"(su), "v"(xoff0));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, LDS_AS3(dma_base + XREG + bx + i * (PR * 128)), 16, o, 0, 0, 0);
+    } else {
+      const uint32_t su = (uint32_t)(kt * 128) + (uint32_t)(i - XP) * wstep;
+      asm volatile("v_add_u32 %0, %1, %2" : "=v"(o) : "s"(su), "v"(woff0));
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_AS3(dma_base + WREG + bw + (i - XP) * (PR * 128)), 16, o, 0, 0, 0);
+    }
+  };
+
+  // ---- fragment read geometry: per lane one byte offset per k-step and operand (current buffer); blocks are immediates ----
+  const int cp = chan_pos(l31);
+  uint32_t xo[4], wo[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    xo[ks] = XREG + (uint32_t)((wr * NMB * 32 + l31) * 128 + (((2 * ks + hh) ^ ((l31 >> 1) & 7)) << 4));
+    wo[ks] = WREG + (uint32_t)((wc * NCB * 32 + cp) * 128 + (((2 * ks + hh) ^ ((cp >> 1) & 7)) << 4));
+  }
+  bf16x8 fx[2][NMB], fw[2][NCB];
+  auto read_ks = [&](int set, int ks) {
+#pragma unroll
+    for (int nb = 0; nb < NCB; ++nb) fw[set][nb] = *reinterpret_cast<const bf16x8*>(lds + wo[ks] + nb * 4096);
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) fx[set][mb] = *reinterpret_cast<const bf16x8*>(lds + xo[ks] + mb * 4096);
+  };
+
+  f32x16 acc[NCB][NMB];
+#pragma unroll
+  for (int nb = 0; nb < NCB; ++nb)
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[nb][mb][i] = 0.f;
+
+  const int nk = p.K >> 6;
+  const int abl = p.abl;
+  // a wave whose channels are all beyond N (last channel tile of N = 640 = 2.5 tiles) moves data and synchronises but does not multiply
+  const bool has_ch = n0 + wc * (NCB * 32) < p.N;
+
+  // ---- prologue: tiles 0 .. NBUF-1 in flight (one per buffer), tile 0 landed ----
+  // counted wait: everything but the `later` most recently issued tiles has landed (s_waitcnt takes an immediate)
+  auto wait_tiles_in_flight = [&](int later) {
+    if (abl & 8) return;
+    if (later <= 0) WAIT_VM0();
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
+    else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NP) : "memory");
+  };
+  static_assert(NBUF >= 2 && NBUF <= 4 && (NBUF - 1) * NP <= 63, "counted waits: up to 3 tiles, 6-bit vmcnt");
+#pragma unroll
+  for (int b = 0; b < NBUF; ++b)
+    if (b < nk) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) piece(b, i, b * XB, b * WB);
+    }
+  wait_tiles_in_flight((nk < NBUF ? nk : NBUF) - 1);
+  BARRIER();
+  read_ks(0, 0);
+
+  // the loop exists twice: waves with output channels multiply, the others only move data
+  auto k_loop = [&](auto mul_tag) {
+    constexpr bool MUL = decltype(mul_tag)::value;
+    auto mma_ks = [&](int set) {
+      if constexpr (MUL) {
+#pragma unroll
+        for (int i = 0; i < NMMA; ++i)
+          acc[i % NCB][i / NCB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[set][i % NCB], fx[set][i / NCB], acc[i % NCB][i / NCB], 0, 0, 0);
+      }
+    };
+    uint32_t bx = 0, bw = 0;  // buffers of tile t
+    int bnext = 1;            // index of the buffer of tile t+1
+    for (int t = 0; t < nk; ++t) {
+      // fences pin the order "reads of k-step ks+1, then the MFMAs of ks": the compiler otherwise sinks the reads to the end of the
+      // MFMA run (exposing the LDS latency) or hoists later k-steps' reads (spilling)
+      read_ks(1, 1);
+      FENCE();
+      mma_ks(0);
+      FENCE();
+      read_ks(0, 2);
+      FENCE();
+      mma_ks(1);
+      FENCE();
+      read_ks(1, 3);
+      FENCE();
+      mma_ks(0);
+      FENCE();
+      if (t + 1 < nk) {
+        if (!(abl & 32)) WAIT_LGKM0();  // this wave's reads of the buffer are done ...
+        // ... and its pieces of tile t+1 have landed (issued NBUF-1 tiles ago; tiles t+2 .. t+NBUF-1 may still be in flight)
+        wait_tiles_in_flight((nk - 1 < t + NBUF - 1 ? nk - 1 : t + NBUF - 1) - (t + 1));
+        FENCE();
+        if (!(abl & 16)) __builtin_amdgcn_s_barrier();
+        FENCE();
+        const uint32_t ax = bnext == 0 ? 0u - (NBUF - 1) * XB : XB, aw = bnext == 0 ? 0u - (NBUF - 1) * WB : WB;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          xo[ks] += ax;
+          wo[ks] += aw;
+        }
+        read_ks(0, 0);
+        FENCE();
+      }
+      {  // last k-step: its MFMAs with the DMA pieces of tile t+NBUF (into the buffer just released) spread between them.  The MFMAs
+         // are unconditional code: accumulators defined in two branch arms make the register allocator copy and spill them.
+        const bool more = t + NBUF < nk && !(abl & 4);
+#pragma unroll
+        for (int i = 0; i < NMMA; ++i) {
+          if constexpr (MUL)
+            acc[i % NCB][i / NCB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[1][i % NCB], fx[1][i / NCB], acc[i % NCB][i / NCB], 0, 0, 0);
+          if (more) {  // pieces [i NP / NMMA, (i+1) NP / NMMA): all NP of them, evenly spread over the MFMAs
+#pragma unroll
+            for (int q = i * NP / NMMA; q < (i + 1) * NP / NMMA; ++q) piece(t + NBUF, q, bx, bw);
+          }
+        }
+      }
+      FENCE();
+      bx = bnext * XB;
+      bw = bnext * WB;
+      bnext = bnext + 1 == NBUF ? 0 : bnext + 1;
+    }
+  };
+  // ======================================= epilogue =======================================
+  // lane: token row (l31) of each 32-token block; registers: 16 consecutive channels 16*hh + r of each 32-channel block
+  const int mrow0 = wr * (NMB * 32) + l31;  // + mb * 32 : row inside the tile
+  float rsum[NMB], rsq[NMB];
+#pragma unroll
+  for (int mb = 0; mb < NMB; ++mb) { rsum[mb] = 0.f; rsq[mb] = 0.f; }
+  // (a lambda called only by the multiplying waves: the accumulators then never merge with the idle waves' zeros)
+  // Output staging: the bf16 results go through a wave-private LDS image [token][channel] (16-byte chunks XOR-swizzled by the token)
+  // and leave as FULL 128-byte-or-longer row segments: the natural MFMA layout gives every lane 16-byte pieces of 32 different rows
+  // per store instruction (8 partial writes per cache line), which measured 13-30 % of the whole kernel on the short-K shapes.
+  constexpr int OCH = (GEGLU ? NCB * 16 : NCB * 32);     // output channels of one wave
+  constexpr int NCH = OCH / 8, RB = OCH * 2;              // 16-byte chunks / bytes per token row of the wave's image
+  constexpr int SWZ = (NCH % 8 == 0) ? 7 : 3;             // chunk index bits that may be XORed without leaving the row
+  static_assert(NCH % 4 == 0, "row of at least 4 chunks");
+  unsigned char* const stage = lds + wave * (NMB * 32 * RB);
+  auto stage_put = [&](int mb, int c, const u32x4& o) {   // chunk c (8 channels) of token mb*32 + l31
+    const int tr = mb * 32 + l31;
+    *reinterpret_cast<u32x4*>(stage + tr * RB + ((c ^ (tr & SWZ)) << 4)) = o;
+  };
+  auto store_tile = [&]() {
+  float mu[NMB], rs[NMB];
+  if (p.ln_stats) {
+    const float inv = 1.f / (float)p.ln_dim;
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) {
+      const long m = m0 + mrow0 + mb * 32;
+      float s = 0.f, ss = 0.f;
+      if (m < p.M) {
+        const f32x2* st = reinterpret_cast<const f32x2*>(p.ln_stats) + m * p.ln_parts;
+        for (int q = 0; q < p.ln_parts; ++q) {
+          const f32x2 v = st[q];
+          s += v[0];
+          ss += v[1];
+        }
+      }
+      const float mean = s * inv;
+      const float var = fmaxf(ss * inv - mean * mean, 0.f);
+      mu[mb] = mean;
+      rs[mb] = rsqrtf(var + p.ln_eps);
+    }
+  }
+  if constexpr (GEGLU) {  // its own instantiation: the erf code next to 256 live accumulators costs the plain epilogue registers
+    static_assert(NCB % 2 == 0, "value / gate block pairs");
+    {
+      // channel blocks 2q / 2q+1 = value / gate columns of the SAME 32 output columns (weight rows interleaved per 64 at pack time)
+#pragma unroll
+      for (int q = 0; q < NCB / 2; ++q)
+#pragma unroll
+        for (int c8 = 0; c8 < 2; ++c8) {  // 8 channels at a time keeps the epilogue inside the register budget
+          FENCE();
+          const int nv = n0 + wc * (NCB * 32) + q * 64 + 16 * hh + 8 * c8;  // packed row of the value block; gate block = + 32
+          const int no = ((n0 + wc * (NCB * 32)) >> 1) + q * 32 + 16 * hh + 8 * c8;
+          if (nv >= p.N) continue;
+          float bv[8], bg[8], sv[8], sg[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            bv[r] = p.bias ? p.bias[nv + r] : 0.f;
+            bg[r] = p.bias ? p.bias[nv + 32 + r] : 0.f;
+            sv[r] = p.ln_stats ? p.wsum[nv + r] : 0.f;
+            sg[r] = p.ln_stats ? p.wsum[nv + 32 + r] : 0.f;
+          }
+#pragma unroll
+          for (int mb = 0; mb < NMB; ++mb) {
+            const long m = m0 + mrow0 + mb * 32;
+            if (m >= p.M) continue;
+            float v[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) {
+              float xv = acc[2 * q][mb][8 * c8 + r], gv = acc[2 * q + 1][mb][8 * c8 + r];
+              if (p.ln_stats) {
+                xv = rs[mb] * (xv - mu[mb] * sv[r]);
+                gv = rs[mb] * (gv - mu[mb] * sg[r]);
+              }
+              v[r] = (xv + bv[r]) * gelu_erf(gv + bg[r]);
+            }
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+            stage_put(mb, q * 4 + 2 * hh + c8, o);
+          }
+        }
+    }
+    return;
+  }
+
+#pragma unroll
+  for (int nb = 0; nb < NCB; ++nb) {
+#pragma unroll
+    for (int c8 = 0; c8 < 2; ++c8) {
+      FENCE();  // bound the scheduling region: hoisting every block's loads next to 256 live accumulators spills
+      const int n = n0 + wc * (NCB * 32) + nb * 32 + 16 * hh + 8 * c8;
+      if (n >= p.N) continue;  // N % 16 == 0
+      float bv[8], sv[8];
+#pragma unroll
+      for (int r = 0; r < 8; ++r) {
+        bv[r] = p.bias ? p.bias[n + r] : 0.f;
+        sv[r] = p.ln_stats ? p.wsum[n + r] : 0.f;
+      }
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb) {
+        const long m = m0 + mrow0 + mb * 32;
+        if (m >= p.M) continue;
+        float v[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          float t = acc[nb][mb][8 * c8 + r];
+          if (p.ln_stats) t = rs[mb] * (t - mu[mb] * sv[r]);
+          v[r] = t + bv[r];
+        }
+        if (p.res) {
+          const u32x4 e0 = *reinterpret_cast<const u32x4*>(p.res + m * p.ldr + n);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            v[2 * e] += bf16lo_to_f32(e0[e]);
+            v[2 * e + 1] += bf16hi_to_f32(e0[e]);
+          }
+        }
+        u32x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+        stage_put(mb, nb * 4 + 2 * hh + c8, o);
+        if (p.stats_out) {  // statistics of the values as stored (bf16-rounded): what the consumer's LayerNorm fold sees
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float a0 = bf16lo_to_f32(o[e]), a1 = bf16hi_to_f32(o[e]);
+            rsum[mb] += a0 + a1;
+            rsq[mb] = fmaf(a0, a0, fmaf(a1, a1, rsq[mb]));
+          }
+        }
+      }
+    }
+  }
+
+  };
+  if (has_ch) k_loop(std::true_type{});
+  else k_loop(std::false_type{});
+  __syncthreads();  // every wave is past its last fragment read: the K-loop buffers become the output staging area
+  if (has_ch) {
+    store_tile();
+    // (wave-private image: the compiler's lgkmcnt wait orders the ds_writes before the ds_reads, no barrier)
+    const int ocol0 = (GEGLU ? (n0 >> 1) : n0) + wc * OCH;
+    const int nout = GEGLU ? (p.N >> 1) : p.N;
+#pragma unroll
+    for (int it = 0; it < (NMB * 32 * NCH + 63) / 64; ++it) {
+      const int g = it * 64 + lane, r = g / NCH, j = g - r * NCH;
+      const long m = m0 + wr * (NMB * 32) + r;
+      if (r < NMB * 32 && m < p.M && ocol0 + j * 8 < nout && !(abl & 64)) {
+        const u32x4 o = *reinterpret_cast<const u32x4*>(stage + r * RB + ((j ^ (r & SWZ)) << 4));
+        *reinterpret_cast<u32x4*>(p.out + m * p.ldo + ocol0 + j * 8) = o;
+      }
+    }
+  }
+
+  if (p.stats_out) {  // kernel-uniform: per-row sums over this N tile = both lane halves, all channel blocks, the WN waves of the row
+    float* red = reinterpret_cast<float*>(lds);  // [wc][BM][2]; the K-loop buffers are idle once every wave is past its last read
+    __syncthreads();
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) {
+      const float s = rsum[mb] + __shfl_xor(rsum[mb], 32);
+      const float q = rsq[mb] + __shfl_xor(rsq[mb], 32);
+      if (hh == 0) {
+        float* d = red + ((wc * BM) + mrow0 + mb * 32) * 2;
+        d[0] = s;
+        d[1] = q;
+      }
+    }
+    __syncthreads();
+    if (tid < BM) {
+      const long m = m0 + tid;
+      if (m < p.M) {
+        float s = 0.f, q = 0.f;
+#pragma unroll
+        for (int c = 0; c < WN; ++c) {
+          s += red[(c * BM + tid) * 2];
+          q += red[(c * BM + tid) * 2 + 1];
+        }
+        float* d = p.stats_out + (m * p.tiles_n + tn) * 2;
+        d[0] = s;
+        d[1] = q;
+      }
+    }
+  }
+}
+
+template <int WM, int WN, int NCB, int NMB, int NBUF, bool GEGLU>
+int launch_epi(const GemmParams& p0, hipStream_t stream) {
+  GemmParams p = p0;
+  constexpr int BM = WM * NMB * 32, BN = WN * NCB * 32;
+  constexpr int LDS_BYTES = NBUF * (BM + BN) * 128;
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.N + BN - 1) / BN;
+  int gm = 4;
+  if (const char* e = getenv("CD360_GEMM_GROUP_M")) gm = atoi(e) > 0 ? atoi(e) : gm;
+  p.group_m = gm;
+  p.abl = 0;
+  if (const char* e = getenv("CD360_GEMM_ABL")) p.abl = atoi(e);
+  const long nwg = (long)p.tiles_m * p.tiles_n;
+  if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_kernel<WM, WN, NCB, NMB, NBUF, GEGLU>),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  if (attr != hipSuccess) return CD360_ERR_LAUNCH;
+  hipLaunchKernelGGL((gemm_mfma_kernel<WM, WN, NCB, NMB, NBUF, GEGLU>), dim3((unsigned)nwg), dim3(64 * WM * WN), LDS_BYTES, stream, p);
+  CD360_LAUNCH_CHECK();
+  return CD360_OK;
+}
+
+template <int WM, int WN, int NCB, int NMB, int NBUF>
+int launch(const GemmParams& p, hipStream_t stream) {
+  return p.geglu ? launch_epi<WM, WN, NCB, NMB, NBUF, true>(p, stream) : launch_epi<WM, WN, NCB, NMB, NBUF, false>(p, stream);
+}
+
+// Tilings (tokens x channels, waves, LDS buffers): 1 = 128 x 128, 4 waves of 64 x 64, 2 buffers (two workgroups per CU);
+// 2 = 128 x 128, 8 waves of 64 x 32, 2 buffers; 3 = 256 x 256, 8 waves of 128 x 64, 2 buffers; 4 = as 2 with 4 buffers (3 tiles in
+// flight: long K loops of launches with one workgroup per CU); 5 = 256 x 128, 8 waves of 64 x 64, 3 buffers; 6 = 256 x 192, 8 waves of
+// 64 x 96, 2 buffers
+constexpr int NCFG = 6;
+constexpr int CFG_BM[NCFG + 1] = {0, 128, 128, 256, 128, 256, 256}, CFG_BN[NCFG + 1] = {0, 128, 128, 256, 128, 128, 192};
+int pick_cfg(int64_t M, int N, bool geglu) {
+  int cfg = 0;
+  if (const char* e = getenv("CD360_GEMM_CFG")) cfg = atoi(e);  // tuning / A-B override
+  if (cfg >= 1 && cfg <= NCFG && !(geglu && (cfg == 2 || cfg == 4 || cfg == 6))) return cfg;
+  if (geglu) return 3;
+  // Measured on the SDXL shapes (tools/bench_gemm.py, profiles/r02_gemm_shapes.txt).  Narrow outputs (the C -> C projections and the
+  // feed-forward's second Linear): 128 x 128 tiles -- with four LDS buffers when the launch has at most one workgroup per CU (the
+  // 1280-wide level: 240 tiles), two otherwise (two workgroups per CU overlap each other's prologue / epilogue) -- except for very
+  // tall problems (the FeatureNeRF pose tokens) where 256 x 256 tiles amortise the weights better.
+  if (N <= 1536) {
+    if (M >= 65536) return 3;
+    const long nwg = ((M + 127) / 128) * ((N + 127) / 128);
+    return nwg <= 256 ? 4 : 2;
+  }
+  // Wide outputs: 256 x 256 tiles unless 256 x 192 fills the 256 CUs better (q|k|v: 12 x 15 = 180 tiles against 12 x 20 = 240)
+  auto eff = [&](int bm, int bn) {
+    const long tm = (M + bm - 1) / bm, tn = (N + bn - 1) / bn, nwg = tm * tn, rounds = (nwg + 255) / 256;
+    return (double)nwg / (double)(rounds * 256) * (double)N / (double)(tn * bn);
+  };
+  return eff(256, 192) * 0.95 > eff(256, 256) ? 6 : 3;
+}
+
+}  // namespace
+
+// Number of output columns per (sum, sumsq) partial that cd360_gemm_bf16(..., stats_out) writes for an [M, N] output: the consumer
+// passes ceil(N / that) back as `ln_parts`.  Depends on the tiling the launch will choose -- ask with the same M, N.
+extern "C" int cd360_gemm_tile_n(int64_t M, int N) { return CFG_BN[pick_cfg(M, N, false)]; }
+
+// out[M, N] (bf16, row stride ldo) = epilogue(A[M, K] @ W[N, K]^T); A, W bf16 with row strides lda, ldw (elements, multiples of 8),
+// K % 64 == 0, N % 16 == 0, all base pointers 16-byte aligned.
+//   bias     fp32 [N] | NULL
+//   res      bf16 [M, N] row stride ldr | NULL : added last
+//   ln_stats fp32 [M, ln_parts, 2] | NULL : LayerNorm over the ln_dim (= K) channels of each A row folded in front of the GEMM --
+//            W must be the gamma-scaled weight, `wsum` fp32 [N] its row sums, `bias` must already contain beta W^T
+//   stats_out fp32 [M, ceil(N / cd360_gemm_tile_n(M, N)), 2] | NULL : per-row partial (sum, sumsq) of the stored bf16 outputs
+//   flags bit 0: GEGLU -- W rows are packed per 64-row group as [32 value rows | 32 gate rows] of the same 32 output columns
+//            (cd360.ops.geglu_row_order); out is [M, N / 2]
+extern "C" int cd360_gemm_bf16(const void* a, const void* w, void* out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldo,
+                               const void* bias, const void* res, int64_t ldr, const void* ln_stats, int ln_parts, int ln_dim, float ln_eps,
+                               const void* wsum, void* stats_out, int flags, void* stream) {
+  if (!a || !w || !out || M <= 0 || N <= 0 || K <= 0) return CD360_ERR_ARG;
+  if (K % 64 || N % 16 || lda % 8 || ldw % 8 || ldo % 8 || (res && ldr % 8) || lda < K || ldw < K) return CD360_ERR_SHAPE;
+  if (((uintptr_t)a | (uintptr_t)w | (uintptr_t)out | (uintptr_t)res) % 16) return CD360_ERR_ARG;
+  if (((uintptr_t)bias | (uintptr_t)ln_stats | (uintptr_t)wsum | (uintptr_t)stats_out) % 8) return CD360_ERR_ARG;
+  if (M > 0x7fffffffL || (M + 256) * lda * 2 >= (1L << 32) || ((long)N + 256) * ldw * 2 >= (1L << 32)) return CD360_ERR_SHAPE;  // 32-bit buffer offsets
+  if (ln_stats && (!wsum || ln_parts <= 0 || ln_dim <= 0)) return CD360_ERR_ARG;
+  const bool geglu = flags & 1;
+  if (geglu && (N % 64 || stats_out || res)) return CD360_ERR_SHAPE;
+  GemmParams p;
+  p.a = (const uint16_t*)a; p.w = (const uint16_t*)w; p.out = (uint16_t*)out; p.bias = (const float*)bias; p.res = (const uint16_t*)res;
+  p.ln_stats = (const float*)ln_stats; p.wsum = (const float*)wsum; p.stats_out = (float*)stats_out;
+  p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.ldr = res ? ldr : 0;
+  p.M = (int)M; p.N = N; p.K = K; p.ln_parts = ln_parts; p.ln_dim = ln_dim; p.ln_eps = ln_eps; p.geglu = geglu ? 1 : 0;
+  p.tiles_m = p.tiles_n = p.group_m = 0;
+  switch (pick_cfg(M, N, geglu)) {
+    case 1: return launch<2, 2, 2, 2, 2>(p, (hipStream_t)stream);
+    case 2: return geglu ? CD360_ERR_SHAPE : launch_epi<2, 4, 1, 2, 2, false>(p, (hipStream_t)stream);
+    case 4: return geglu ? CD360_ERR_SHAPE : launch_epi<2, 4, 1, 2, 4, false>(p, (hipStream_t)stream);
+    case 5: return launch<4, 2, 2, 2, 3>(p, (hipStream_t)stream);
+    case 6: return geglu ? CD360_ERR_SHAPE : launch_epi<4, 2, 3, 2, 2, false>(p, (hipStream_t)stream);
+    default: return launch<2, 4, 2, 4, 2>(p, (hipStream_t)stream);
+  }
+}
+
+// Per-row (sum, sumsq) of a bf16 [rows, C] matrix (row stride ld) as ONE partial per row: the `ln_stats` input of cd360_gemm_bf16 for a
+// tensor that did not come out of a stats-writing GEMM (the first block of a SpatialTransformer, the FeatureNeRF pose tokens).
+namespace {
+__global__ __launch_bounds__(256) void row_stats_kernel(const uint16_t* __restrict__ x, float* __restrict__ st, long rows, int C, long ld) {
+  const int lane = threadIdx.x & 63;
+  const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+  for (long row = wave0; row < rows; row += nwaves) {
+    const uint16_t* src = x + row * ld;
+    float s = 0.f, q = 0.f;
+    for (int c = lane * 8; c < C; c += 512) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(src + c);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float a0 = bf16lo_to_f32(v[e]), a1 = bf16hi_to_f32(v[e]);
+        s += a0 + a1;
+        q = fmaf(a0, a0, fmaf(a1, a1, q));
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      s += __shfl_xor(s, o);
+      q += __shfl_xor(q, o);
+    }
+    if (lane == 0) {
+      st[row * 2] = s;
+      st[row * 2 + 1] = q;
+    }
+  }
+}
+}  // namespace
+
+extern "C" int cd360_row_stats_bf16(const void* x, void* stats, int64_t rows, int C, int64_t ld, void* stream) {
+  if (!x || !stats || rows <= 0 || C <= 0) return CD360_ERR_ARG;
+  if (C % 8 || ld % 8 || ld < C || (uintptr_t)x % 16) return CD360_ERR_SHAPE;
+  const long blocks = (rows + 3) / 4;
+  hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)x,
+                     (float*)stats, (long)rows, C, (long)ld);
+  CD360_LAUNCH_CHECK();
+  return CD360_OK;
+}

@@ -137,7 +137,13 @@ class MemoryEfficientCrossAttention(nn.Module):
             if self._kv_cache is not None and self._kv_cache[0] == key:
                 return self._kv_cache[1]
         inner = self.heads * self.dim_head
-        kv = F.linear(_pad_tokens(context), self._merged_weight("kv"))
+        ctx = _pad_tokens(context)
+        wkv = self._merged_weight("kv")
+        if (ctx.is_cuda and ctx.dtype == torch.bfloat16 and wkv.dtype == torch.bfloat16 and not torch.is_grad_enabled() and ctx.shape[-1] % 64 == 0
+                and not os.environ.get("CD360_LIBRARY_LINEAR")):
+            kv = ops.gemm(ctx.contiguous(), wkv)  # the same hand-written GEMM as the rest of the block
+        else:
+            kv = F.linear(ctx, wkv)
         out = (kv[..., :inner], kv[..., inner:], context.shape[1])
         self._kv_cache = (key, out) if use_cache else None
         return out
@@ -210,6 +216,8 @@ class BasicTransformerBlock(nn.Module):
         self._pose_split = None
         self._ref_tables = None
         self._rendered_proj = None  # (rendered_feat object, its version, Wb, rendered_feat @ Wb^T) of _pose_embed_cached
+        self._pack = None  # (parameter versions, packed weights) of the fused inference path
+        self._static_rendered = self._static_proj = None  # pin_rendered()
 
     # ------------------------------------------------------------------------------------------------ pose path
     def _pose_weights(self):
@@ -245,6 +253,32 @@ class BasicTransformerBlock(nn.Module):
             self._rendered_proj = tag
         return torch.addmm(tag[3], x.reshape(-1, c), wa).reshape(b, n, c)
 
+    def pin_rendered(self):
+        """Move the cached render and its pose_emb_layers half (`rendered_feat @ Wb^T`) into buffers that stay put across images, so a
+        captured hipGraph of the steady-state step keeps reading the current image's render in place (bench.py; any serving loop that
+        replays graphs).  Call after every render step."""
+        rf = self.rendered_feat
+        buf = self._static_rendered
+        if buf is None or buf.shape != rf.shape or buf.dtype != rf.dtype:
+            self._static_rendered = rf.clone()
+        elif buf is not rf:
+            buf.copy_(rf)
+        rf = self.rendered_feat = self._static_rendered
+        c = rf.shape[-1]
+        if self.fused_ready(rf):
+            wb = self._packed()["pose"][1]
+            if self._static_proj is None or self._static_proj.shape != rf.shape:
+                self._static_proj = torch.empty_like(rf)
+            ops.gemm(rf, wb, out=self._static_proj)
+        else:
+            wb = self._pose_weights()[1]
+            flat = rf.reshape(-1, c)
+            if self._static_proj is None or self._static_proj.shape != flat.shape or self._static_proj.dtype != flat.dtype:
+                self._static_proj = torch.mm(flat, wb)
+            else:
+                torch.mm(flat, wb, out=self._static_proj)
+        self._rendered_proj = (rf, rf._version, wb, self._static_proj)
+
     def reference_attn(self, x, context_ref, context, pose, prev_weights, mask_ref, tables=None, dims=None):
         """FeatureNeRF render of the reference features at the target pose (attention.py:571-598).
         context_ref [b, n, hw, C].  -> (xref [b,hw,C], fg [b,hw,1], prev_weights(None), alphas [b,hw,S,1], rgb [b,hw,3])"""
@@ -264,11 +298,14 @@ class BasicTransformerBlock(nn.Module):
         tok = h.reshape(b, hw * S, C)
         if tok.dtype != x.dtype:
             tok = tok.to(x.dtype)
-        if tok.is_cuda and tok.dtype == torch.bfloat16 and self.norm2.weight.dtype == torch.bfloat16 and C <= 2048:
-            n2 = ops.add_layernorm(tok.contiguous(), None, self.norm2.weight, self.norm2.bias, self.norm2.eps)[1]  # HIP LayerNorm (fwd + bwd)
+        if self.fused_ready(tok):
+            tok = self._pose_tokens_attn(tok.contiguous(), context)  # norm2 folded into the q GEMM, residual into the out GEMM
         else:
-            n2 = self.norm2(tok)
-        tok = self.attn2(n2, context=context) + tok  # pose-token cross-attention (:581-586)
+            if tok.is_cuda and tok.dtype == torch.bfloat16 and self.norm2.weight.dtype == torch.bfloat16 and C <= 2048:
+                n2 = ops.add_layernorm(tok.contiguous(), None, self.norm2.weight, self.norm2.bias, self.norm2.eps)[1]  # HIP LayerNorm (fwd + bwd)
+            else:
+                n2 = self.norm2(tok)
+            tok = self.attn2(n2, context=context) + tok  # pose-token cross-attention (:581-586)
         rendered, fg, alphas, _, rgb = ops.volrender(tok.reshape(b, hw, S, C), dec[..., 3], dists,
                                                     dec[..., :3] if self.rgb_predict else None)
         return rendered, fg, (None if not self.use_prev_weights_imp_sample else None), alphas, rgb
@@ -321,11 +358,111 @@ class BasicTransformerBlock(nn.Module):
             maps[batch_size] = torch.stack(rows).reshape(-1).contiguous()
         return (Y, lv, maps[batch_size]), (batch_size, n, refs.shape[1], refs.shape[2])
 
+    # ------------------------------------------------------------------------------------------------ fused inference path
+    def fused_ready(self, x: torch.Tensor) -> bool:
+        """The no-grad bf16 path on cd360_gemm_bf16: every Linear of the block is the hand-written MFMA GEMM with the LayerNorm in
+        front of it folded into its epilogue, GEGLU / bias / residual fused, and the LayerNorm row statistics carried from one GEMM's
+        epilogue to the next GEMM (no LayerNorm, GEGLU or residual-add launch is left).  Training keeps the autograd path."""
+        return (x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled() and self.norm1.weight.dtype == torch.bfloat16
+                and x.shape[-1] % 64 == 0 and isinstance(self.ff.net[0], GEGLU) and not os.environ.get("CD360_LIBRARY_LINEAR"))
+
+    def _packed(self):
+        """Weights in the form the fused GEMM epilogues want, rebuilt when any source parameter changes:
+        LayerNorm-folded (gamma o W, its row sums, beta W^T + b) for the three projections that follow a LayerNorm (merged q|k|v of
+        attn1, to_q of attn2, the GEGLU projection -- the latter also row-interleaved value / gate), plain bf16 + fp32 bias for the rest."""
+        a1, a2, ff = self.attn1, self.attn2, self.ff
+        src = [self.norm1.weight, self.norm1.bias, self.norm2.weight, self.norm2.bias, self.norm3.weight, self.norm3.bias,
+               a1.to_q.weight, a1.to_k.weight, a1.to_v.weight, a1.to_out[0].weight, a1.to_out[0].bias,
+               a2.to_q.weight, a2.to_out[0].weight, a2.to_out[0].bias,
+               ff.net[0].proj.weight, ff.net[0].proj.bias, ff.net[2].weight, ff.net[2].bias]
+        if self.image_cross:
+            src.append(self.pose_emb_layers.weight)
+        key = tuple((t.data_ptr(), t._version) for t in src)
+        if self._pack is not None and self._pack[0] == key:
+            return self._pack[1]
+        P = {}
+        P["qkv"] = ops.pack_ln_linear(torch.cat([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], 0), None, self.norm1.weight, self.norm1.bias)
+        P["o1"] = (a1.to_out[0].weight.detach().to(torch.bfloat16).contiguous(), a1.to_out[0].bias.detach().float().contiguous())
+        P["q2"] = ops.pack_ln_linear(a2.to_q.weight, None, self.norm2.weight, self.norm2.bias)
+        P["o2"] = (a2.to_out[0].weight.detach().to(torch.bfloat16).contiguous(), a2.to_out[0].bias.detach().float().contiguous())
+        w, ws, cb = ops.pack_ln_linear(ff.net[0].proj.weight, ff.net[0].proj.bias, self.norm3.weight, self.norm3.bias)
+        perm = ops.geglu_row_order(w.shape[0] // 2, w.device)
+        P["ff1"] = (w[perm].contiguous(), ws[perm].contiguous(), cb[perm].contiguous())
+        P["ff2"] = (ff.net[2].weight.detach().to(torch.bfloat16).contiguous(), ff.net[2].bias.detach().float().contiguous())
+        if self.image_cross:
+            c = self.pose_emb_layers.weight.shape[0]
+            wp = self.pose_emb_layers.weight.detach().to(torch.bfloat16)
+            P["pose"] = (wp[:, :c].contiguous(), wp[:, c:].contiguous())  # Linear layout [out, in] of the x half and the xref half
+        self._pack = (key, P)
+        return P
+
+    def _pose_tokens_attn(self, tok: torch.Tensor, context) -> torch.Tensor:
+        """attn2(norm2(tok), context) + tok on the FeatureNeRF samples (attention.py:578-588) through the fused GEMMs."""
+        P = self._packed()
+        a2 = self.attn2
+        k, v, nk = a2.project_context(context)
+        w, ws, cb = P["q2"]
+        q = ops.gemm(tok, w, bias=cb, ln=(ops.row_stats(tok), ws, self.norm2.eps))
+        o = ops.attention(q, k, v, a2.heads, nk)
+        return ops.gemm(o, P["o2"][0], bias=P["o2"][1], res=tok)
+
+    def _forward_fused(self, x, stats, context=None, context_ref=None, pose=None, mask_ref=None, prev_weights=None):
+        """_forward for fused_ready() inputs.  x [b, n, C] bf16 contiguous, stats = its LayerNorm row partials (or None: computed here)
+        -> (x, fg_mask, weights, alphas, rgb, stats of the returned x)."""
+        fg_mask = weights = alphas = predicted_rgb = None
+        P = self._packed()
+        a1, a2 = self.attn1, self.attn2
+        x = x.contiguous()
+        if stats is None:
+            stats = ops.row_stats(x)
+        inner = a1.heads * a1.dim_head
+        w, ws, cb = P["qkv"]
+        qkv = ops.gemm(x, w, bias=cb, ln=(stats, ws, self.norm1.eps))
+        o = ops.attention(qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:], a1.heads, x.shape[1])
+        x, stats = ops.gemm(o, P["o1"][0], bias=P["o1"][1], res=x, want_stats=True)
+        w, ws, cb = P["q2"]
+        q = ops.gemm(x, w, bias=cb, ln=(stats, ws, self.norm2.eps))
+        k, v, nk = a2.project_context(context)
+        o = ops.attention(q, k, v, a2.heads, nk)
+        if context_ref is None:
+            x, stats = ops.gemm(o, P["o2"][0], bias=P["o2"][1], res=x, want_stats=True)
+        else:
+            x = ops.gemm(o, P["o2"][0], bias=P["o2"][1], res=x)
+            wa, wb = P["pose"]
+            if self.reference_choices is not None:  # native equivalent of sample.py's _customforward (sample.py:82-136)
+                if self.rendered_feat is None:
+                    if mask_ref is None:  # tables of the DISTINCT reference images, kept across images / poses
+                        tables, dims = self._sampling_tables(x.size(0))
+                        xref, fg_mask, weights, alphas, predicted_rgb = self.reference_attn(x, None, context, pose, prev_weights, None,
+                                                                                            tables=tables, dims=dims)
+                    else:
+                        cref = self._references_as_context(x.size(0))
+                        xref, fg_mask, weights, alphas, predicted_rgb = self.reference_attn(x, cref, context, pose, prev_weights, mask_ref)
+                    self.rendered_feat = xref
+                rf = self.rendered_feat
+                tag = self._rendered_proj  # rendered_feat @ Wb^T stays constant while the render is cached (49 of 50 steps)
+                if tag is None or tag[0] is not rf or tag[1] != rf._version or tag[2] is not wb or os.environ.get("CD360_NO_POSE_PROJ_CACHE"):
+                    tag = (rf, rf._version, wb, ops.gemm(rf.to(torch.bfloat16).contiguous(), wb))
+                    self._rendered_proj = tag
+                half = tag[3]
+            else:
+                b = x.size(0)
+                cref = context_ref if context_ref.dim() == 4 else context_ref.reshape(b, context_ref.size(0) // b, *context_ref.shape[1:])
+                xref, fg_mask, weights, alphas, predicted_rgb = self.reference_attn(x, cref, context, pose, prev_weights, mask_ref)
+                half = ops.gemm(xref.to(torch.bfloat16).contiguous(), wb)
+            x, stats = ops.gemm(x, wa, res=half.reshape(x.shape), want_stats=True)  # pose_emb_layers(cat[x, xref]) (attention.py:634)
+        w, ws, cb = P["ff1"]
+        h = ops.gemm(x, w, bias=cb, ln=(stats, ws, self.norm3.eps), geglu=True)
+        x, stats = ops.gemm(h, P["ff2"][0], bias=P["ff2"][1], res=x, want_stats=True)
+        return x, fg_mask, weights, alphas, predicted_rgb, stats
+
     # ------------------------------------------------------------------------------------------------ forward
     def forward(self, x, context=None, context_ref=None, pose=None, mask_ref=None, prev_weights=None, additional_tokens=None,
                 n_times_crossframe_attn_in_self=0):
         if additional_tokens is not None or n_times_crossframe_attn_in_self:
             raise NotImplementedError("additional_tokens / cross-frame attention are not used by the shipped config")
+        if self.fused_ready(x):
+            return self._forward_fused(x, None, context, context_ref, pose, mask_ref, prev_weights)[:5]
         return self._forward(x, context, context_ref, pose, mask_ref, prev_weights)
 
     def _forward(self, x, context=None, context_ref=None, pose=None, mask_ref=None, prev_weights=None, additional_tokens=None,
@@ -418,6 +555,7 @@ class SpatialTransformer(nn.Module):
             for d in range(depth)])
         self.proj_out = zero_module(nn.Linear(inner_dim, in_channels))
         self.use_linear = use_linear
+        self._ppack = None
 
     def _tokens(self, x):
         return self.proj_in(group_norm_tokens(self.norm, x, silu=False))
@@ -443,9 +581,72 @@ class SpatialTransformer(nn.Module):
     def _settle(t, pend):
         return t if pend is None else pend + t
 
+    def _fused_route(self, x) -> bool:
+        """True when every block can take the fused inference path and nobody watches the blocks' public forward (hooks such as the
+        references harvest, diffusion.py:151-163, or sample.py's patched forwards, sample.py:247-262, see exactly the reference's
+        call sequence through the other route)."""
+        for blk in self.transformer_blocks:
+            plain = type(blk).forward is BasicTransformerBlock.forward and "forward" not in blk.__dict__
+            if not plain or blk._forward_hooks or blk._forward_pre_hooks:
+                return False
+        return (x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled() and self.proj_in.weight.dtype == torch.bfloat16
+                and self.transformer_blocks[0].fused_ready(x.new_empty(1, 1, self.proj_in.out_features)))
+
+    def _proj_pack(self):
+        ps = (self.proj_in.weight, self.proj_in.bias, self.proj_out.weight, self.proj_out.bias)
+        key = tuple((t.data_ptr(), t._version) for t in ps)
+        if self._ppack is None or self._ppack[0] != key:
+            self._ppack = (key, tuple(t.detach().to(torch.bfloat16 if t.dim() == 2 else torch.float32).contiguous() for t in ps))
+        return self._ppack[1]
+
+    def _forward_fused(self, x, xr, context, contextr, pose, mask_ref):
+        """forward() on the fused GEMM path: proj_in writes the first block's LayerNorm statistics, every block hands its output's
+        statistics to the next, proj_out adds the SpatialTransformer's residual in its epilogue."""
+        wi, bi, wo, bo = self._proj_pack()
+        H, W = x.shape[2], x.shape[3]
+
+        def tokens_of(img):
+            t = img.permute(0, 2, 3, 1)
+            return (t if t.is_contiguous() else t.contiguous()).reshape(img.shape[0], H * W, img.shape[1])
+
+        def enter(img):
+            return ops.gemm(group_norm_tokens(self.norm, img, silu=False), wi, bias=bi, want_stats=True)
+
+        def leave(t, img):
+            return tokens_to_image(ops.gemm(t, wo, bias=bo, res=tokens_of(img)), H, W)
+
+        sampling = xr is None and pose is not None and any(getattr(b, "reference_choices", None) is not None for b in self.transformer_blocks)
+        t, st = enter(x)
+        tr = str_ = None
+        if xr is not None:
+            tr, str_ = enter(xr)
+        fg_masks, alphas, rgbs = [], [], []
+        for i, block in enumerate(self.transformer_blocks):
+            ci = i if len(context) > 1 else 0
+            pose_block = (xr is not None or sampling) and self.image_cross and (i % self.poscontrol_interval == 0)
+            if tr is not None:
+                tr, _, _, _, _, str_ = block._forward_fused(tr, str_, contextr[ci])
+            if pose_block:
+                cref = tr if tr is not None else t  # sample.py passes context_ref=x as a non-None marker (sample.py:57)
+                t, fg, _, al, rgb, st = block._forward_fused(t, st, context[ci], context_ref=cref, pose=pose, mask_ref=mask_ref)
+                fg_masks.append(fg)
+                if al is not None:
+                    alphas.append(al)
+                if rgb is not None:
+                    rgbs.append(rgb)
+            else:
+                t, _, _, _, _, st = block._forward_fused(t, st, context[ci])
+        out = leave(t, x)
+        outr = leave(tr, xr) if tr is not None else None
+        if len(fg_masks) > 0:
+            return out, outr, fg_masks, None, (alphas if alphas else None), (rgbs if rgbs else None)
+        return out, outr, None, None, None, None
+
     def forward(self, x, xr, context=None, contextr=None, pose=None, mask_ref=None, prev_weights=None):
         if not isinstance(context, list):
             context, contextr = [context], [contextr]
+        if self._fused_route(x):
+            return self._forward_fused(x, xr, context, contextr, pose, mask_ref)
         x_in, xr_in = x, xr
         sampling = xr is None and pose is not None and any(getattr(b, "reference_choices", None) is not None for b in self.transformer_blocks)
         if xr is None and not sampling:  # plain path (attention.py:800-820)

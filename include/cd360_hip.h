@@ -204,6 +204,32 @@ int cd360_conv_stats_slabs(int Cout);
  * (Two GEMM-mode launches of the implicit-GEMM kernel; the shipped modules use the library GEMM for the same two products.) */
 int cd360_pose_embed_bf16(const void* x, const void* xref, const void* wa, const void* wb, void* out, int64_t rows, int C, void* stream);
 
+/* ---- Linear layers of the transformer blocks with fused epilogues -----------------------------------------------------------
+ * replaces nn.Linear.forward / F.linear at sgm/modules/attention.py:323-329,368-372,422 (to_q / to_k / to_v / to_out of
+ *          MemoryEfficientCrossAttention), :89-96,107-115 (GEGLU.proj, FeedForward.net[2]), :515-516,634 (pose_emb_layers),
+ *          :748,786,824-826,882-884 (SpatialTransformer.proj_in / proj_out) -- and the elementwise work between them:
+ *          nn.LayerNorm (:516-518 norm1-3, applied :609-636), `x * F.gelu(gate)` (:94-96) and the residual adds (:609-636,826,884).
+ * out[M, N] (bf16, row stride ldo) = epilogue(A[M, K] @ W[N, K]^T): A, W bf16 with row strides lda / ldw (elements, multiples of 8),
+ * K % 64 == 0, N % 16 == 0, base pointers 16-byte aligned.  Hand-scheduled MFMA kernel (LDS-DMA staging, two wave groups one
+ * barrier apart), 256 x 256 or 128 x 128 tiles chosen from (M, N).
+ *   bias      fp32 [N] | NULL
+ *   res       bf16 [M, N], row stride ldr | NULL -- added last (the residual stream)
+ *   ln_stats  fp32 [M, ln_parts, 2] | NULL -- LayerNorm over the ln_dim (= K) channels of every A row folded in FRONT of the GEMM:
+ *             LN(x) W^T + b = rstd (x (gamma o W)^T - mu rowsum(gamma o W)) + (beta W^T + b); the caller passes W := gamma o W (bf16),
+ *             wsum := its fp32 row sums, bias := beta W^T + b; the row statistics are the per-row partial (sum, sum of squares) another
+ *             cd360_gemm_bf16 call wrote through `stats_out` (or cd360_row_stats_bf16)
+ *   stats_out fp32 [M, ceil(N / cd360_gemm_tile_n(M, N)), 2] | NULL -- those partials for THIS call's bf16 output rows
+ *   flags     bit 0: GEGLU -- W rows (and bias / wsum) packed per 64 rows as [32 value rows | 32 gate rows] of the same 32 output
+ *             columns; out is [M, N / 2] = value * gelu(gate) (exact erf form) */
+int cd360_gemm_bf16(const void* a, const void* w, void* out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldo, const void* bias,
+                    const void* res, int64_t ldr, const void* ln_stats, int ln_parts, int ln_dim, float ln_eps, const void* wsum,
+                    void* stats_out, int flags, void* stream);
+/* N-tile width (256 | 128) cd360_gemm_bf16 uses for an [M, N] output: stats_out holds ceil(N / that) partials per row. */
+int cd360_gemm_tile_n(int64_t M, int N);
+/* (sum, sum of squares) of every row of a bf16 [rows, C] matrix (row stride ld) as one fp32 partial per row: the `ln_stats` input for a
+ * tensor that did not come out of cd360_gemm_bf16 (C % 8 == 0). */
+int cd360_row_stats_bf16(const void* x, void* stats, int64_t rows, int C, int64_t ld, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,198 @@
+"""cd360_gemm_bf16 on the GPU: parity against an fp32 torch reference (every epilogue, ragged shapes, repeat-run race screen) and
+timing against the library GEMM (F.linear -> hipBLASLt) on the transformer shapes of the SDXL UNet at cfg-B.
+    python tools/bench_gemm.py [check] [time] [CFG=1|2]"""
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "custom-diffusion360_amd"))
+import torch
+import torch.nn.functional as F
+
+from cd360 import ops
+
+dev = torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(dev)
+
+
+def relerr(got, want):
+    return ((got.float() - want).abs().max() / want.abs().max().clamp_min(1e-6)).item()
+
+
+def check_case(M, N, K, bias=False, res=False, ln=False, geglu=False, stats=False, cfg=None, lda=None):
+    if cfg:
+        os.environ["CD360_GEMM_CFG"] = str(cfg)
+    else:
+        os.environ.pop("CD360_GEMM_CFG", None)
+    a_full = rnd(M, lda or K, seed=1).to(torch.bfloat16)
+    a = a_full[:, :K]
+    if ln:  # rows with a mean and a scale, like a residual stream
+        a = (a.float() * (0.5 + rnd(M, 1, seed=7).abs()) + 0.7 * rnd(M, 1, seed=8)).to(torch.bfloat16)
+    w = rnd(N, K, seed=2, scale=K ** -0.5)
+    b = rnd(N, seed=3) if bias else None
+    r = rnd(M, N, seed=4).to(torch.bfloat16) if res else None
+    a32 = a.float()
+    if ln:
+        gamma, beta = 1 + 0.2 * rnd(K, seed=5), 0.1 * rnd(K, seed=6)
+        wp, wsum, cb = ops.pack_ln_linear(w, b, gamma, beta)
+        want = F.linear(F.layer_norm(a32, (K,), gamma, beta, 1e-5), w, b)
+        st = ops.row_stats(a)
+        kw = dict(bias=cb, ln=(st, wsum, 1e-5))
+        wk = wp
+    else:
+        want = F.linear(a32, w.to(torch.bfloat16).float(), b)
+        kw = dict(bias=b)
+        wk = w.to(torch.bfloat16)
+    if geglu:
+        inner = N // 2
+        perm = ops.geglu_row_order(inner, dev)
+        wk = wk[perm].contiguous()
+        kw = {k: ((v[0], v[1][perm].contiguous(), v[2]) if k == "ln" else (None if v is None else v[perm].contiguous())) for k, v in kw.items()}
+        want = want[:, :inner] * F.gelu(want[:, inner:])
+    if res:
+        want = want + r.float()
+    outs = []
+    for _ in range(4):  # race screen: identical launches must agree bit for bit
+        got = ops.gemm(a, wk, res=r, want_stats=stats, geglu=geglu, **kw)
+        outs.append(got)
+    torch.cuda.synchronize()
+    st_out = None
+    if stats:
+        st_out = [o[1] for o in outs]
+        outs = [o[0] for o in outs]
+    same = all(torch.equal(outs[0], o) for o in outs[1:])
+    e = relerr(outs[0], want)
+    msg = f"M={M} N={N} K={K} cfg={cfg or 'auto'} bias={int(bias)} res={int(res)} ln={int(ln)} geglu={int(geglu)} stats={int(stats)}: err {e:.2e} repeat-equal {same}"
+    ok = same and e < (1.2e-2 if ln else 8e-3) and bool(torch.isfinite(outs[0]).all())
+    if stats:
+        o32 = outs[0].float()
+        tn = ops.gemm_tile_n(M, N)
+        parts = st_out[0].shape[1]
+        ws = torch.stack([torch.stack([o32[:, i * tn:(i + 1) * tn].sum(1), (o32[:, i * tn:(i + 1) * tn] ** 2).sum(1)], -1) for i in range(parts)], 1)
+        es = relerr(st_out[0], ws)
+        msg += f" stats err {es:.2e}"
+        ok = ok and es < 1e-4 and all(torch.equal(st_out[0], s) for s in st_out[1:])
+    print(("ok   " if ok else "FAIL ") + msg, flush=True)
+    return ok
+
+
+def check():
+    ok = True
+    for cfg in (1, 2, 3, 4, 5, 6):
+        for (M, N, K) in [(256, 256, 64), (256, 256, 128), (512, 512, 192), (300, 272, 320), (128, 128, 64), (1000, 640, 640), (3072, 1280, 1280)]:
+            ok &= check_case(M, N, K, cfg=cfg)
+        ok &= check_case(520, 640, 320, bias=True, res=True, stats=True, cfg=cfg)
+        ok &= check_case(777, 1280, 640, bias=True, ln=True, cfg=cfg)
+        ok &= check_case(1024, 384, 256, bias=True, ln=True, res=True, stats=True, cfg=cfg, lda=512)
+    ok &= check_case(515, 1280, 320, bias=True, ln=True, geglu=True)
+    ok &= check_case(3072, 10240, 1280, bias=True, ln=True, geglu=True)
+    ok &= check_case(12288, 1920, 640, bias=True, ln=True)
+    ok &= check_case(12288, 640, 2560, bias=True, res=True, stats=True)
+    ok &= check_case(3072, 1280, 5120, bias=True, res=True, stats=True)
+    print("CHECK", "PASSED" if ok else "FAILED", flush=True)
+    return ok
+
+
+def timeit(fn, iters=40, warm=8):
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 1e9
+    for _ in range(3):
+        e0.record()
+        for _ in range(iters):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / iters)
+    return best * 1e3  # us
+
+
+SHAPES = [  # (name, M, N, K, epilogue) at cfg-B: b = 3; level 1: 4096 tokens x 640, level 2: 1024 tokens x 1280
+    ("L1 qkv", 12288, 1920, 640, "ln"), ("L1 out", 12288, 640, 640, "res"), ("L1 ff1", 12288, 5120, 640, "geglu"), ("L1 ff2", 12288, 640, 2560, "res"),
+    ("L2 qkv", 3072, 3840, 1280, "ln"), ("L2 out", 3072, 1280, 1280, "res"), ("L2 ff1", 3072, 10240, 1280, "geglu"), ("L2 ff2", 3072, 1280, 5120, "res"),
+    ("A3 q L1", 98304 * 3, 640, 640, "ln"), ("A3 q L2", 24576 * 3, 1280, 1280, "ln"), ("4k cube", 4096, 4096, 4096, ""),
+]
+
+
+VARIANTS = [(3, 0), (6, 0), (5, 0), (1, 0), (2, 0), (4, 0)]
+
+
+def time_all():
+    for name, M, N, K, epi in SHAPES:
+        a = rnd(M, K, seed=1).to(torch.bfloat16)
+        w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
+        b32 = rnd(N, seed=3)
+        b16 = b32.to(torch.bfloat16)
+        r = rnd(M, N, seed=4).to(torch.bfloat16) if epi == "res" else None
+        flops = 2.0 * M * N * K
+        t_lib = timeit(lambda: F.linear(a, w, b16))
+        line = f"{name:8s} M={M:6d} N={N:5d} K={K:4d} | hipBLASLt {t_lib:7.1f} us {flops / t_lib * 1e-6:6.0f} TF"
+        for cfg, sched in VARIANTS:
+            if epi == "geglu" and cfg in (2, 4, 6):
+                continue
+            os.environ["CD360_GEMM_CFG"] = str(cfg)
+            os.environ["CD360_GEMM_SCHED"] = str(sched)
+            t_plain = timeit(lambda: ops.gemm(a, w, bias=b32))
+            line += f" | cfg{cfg} plain {t_plain:7.1f} us {flops / t_plain * 1e-6:6.0f} TF"
+            if epi == "ln":
+                st = ops.row_stats(a)
+                ws = w.float().sum(1).contiguous()
+                t = timeit(lambda: ops.gemm(a, w, bias=b32, ln=(st, ws, 1e-5)))
+                line += f" ln {t:7.1f}"
+            elif epi == "res":
+                t = timeit(lambda: ops.gemm(a, w, bias=b32, res=r, want_stats=True))
+                line += f" res+stats {t:7.1f}"
+            elif epi == "geglu":
+                st = ops.row_stats(a)
+                ws = w.float().sum(1).contiguous()
+                t = timeit(lambda: ops.gemm(a, w, bias=b32, ln=(st, ws, 1e-5), geglu=True))
+                line += f" ln+geglu {t:7.1f}"
+        if epi == "geglu":  # what the fused call replaces: library GEMM + geglu pass (+ the LayerNorm pass in front, not timed here)
+            t2 = timeit(lambda: ops.geglu(F.linear(a, w, b16)))
+            line += f" | lib+geglu {t2:7.1f}"
+        print(line, flush=True)
+    os.environ.pop("CD360_GEMM_CFG", None)
+    os.environ.pop("CD360_GEMM_SCHED", None)
+
+
+def ablate():
+    """What-if timings (CD360_GEMM_ABL; results are garbage by construction): what the waits, the DMA and the stores cost."""
+    for (M, N, K) in ((4096, 4096, 4096), (3072, 10240, 1280), (3072, 3840, 1280), (12288, 5120, 640)):
+        a = rnd(M, K, seed=1).to(torch.bfloat16)
+        w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
+        print(f"M={M} N={N} K={K}")
+        for cfg in (3, 6, 1):
+            os.environ["CD360_GEMM_CFG"] = str(cfg)
+            line = f"cfg{cfg}:"
+            for abl, name in ((0, "full"), (64, "no stores"), (16, "no barrier"), (56, "no waits at all"), (4, "no DMA"), (60, "no DMA no waits"), (124, "no DMA/waits/stores")):
+                os.environ["CD360_GEMM_ABL"] = str(abl)
+                t = timeit(lambda: ops.gemm(a, w), iters=20, warm=3)
+                line += f" | {name} {t:6.1f}"
+            print(line, flush=True)
+    for k in ("CD360_GEMM_ABL", "CD360_GEMM_CFG"):
+        os.environ.pop(k, None)
+
+
+if __name__ == "__main__":
+    what = sys.argv[1:] or ["check", "time"]
+    good = True
+    if "check" in what:
+        good = check()
+    if "time" in what:
+        time_all()
+    if "ablate" in what:
+        ablate()
+    if "one" in what:  # a few launches of one shape for rocprofv3 --pmc passes: one M N K (env CD360_GEMM_* select the variant)
+        M, N, K = (int(v) for v in what[what.index("one") + 1:what.index("one") + 4])
+        a = rnd(M, K, seed=1).to(torch.bfloat16)
+        w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
+        for _ in range(6):
+            ops.gemm(a, w)
+        torch.cuda.synchronize()
+    sys.exit(0 if good else 1)
