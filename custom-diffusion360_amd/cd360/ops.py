@@ -606,6 +606,42 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return (out, stats_out) if want_stats else out
 
 
+def qproj_attention_ok(a: torch.Tensor, nk: int) -> bool:
+    """Shape envelope of qproj_attention: [b, Nq, K] queries with Nq % 256 == 0 (a 256-token tile stays inside one batch element),
+    K % 64 == 0, at most 96 keys."""
+    return a.dim() == 3 and a.shape[1] % 256 == 0 and a.shape[2] % 64 == 0 and nk <= 96
+
+
+def qproj_attention(a: torch.Tensor, w: torch.Tensor, k: torch.Tensor, v: torch.Tensor, nk: int, heads: int,
+                    bias: Optional[torch.Tensor] = None, ln=None) -> torch.Tensor:
+    """softmax((a w^T [+ LayerNorm fold, + bias]) k^T / 8) v per head with the query projection and the attention in ONE kernel
+    (cd360_qproj_attn_bf16): a [b, Nq, K] bf16, w [heads*64, K] bf16, k / v [b, >= nk, heads*64] (last dim contiguous, e.g. the two
+    halves of the merged k|v projection), nk <= 96 -> [b, Nq, heads*64].  bias / ln as gemm().  Forward only."""
+    _need_gpu(a, w, k, v, bias)
+    b, nq, K = a.shape
+    N = heads * 64
+    M, lda = _rows2d(a)
+    assert w.dtype == torch.bfloat16 and w.shape == (N, K) and w.stride(1) == 1
+    assert k.dtype == torch.bfloat16 and v.dtype == torch.bfloat16 and k.shape[0] == b and v.shape[0] == b and k.shape[-1] == N and v.shape[-1] == N
+    assert k.stride(2) == 1 and v.stride(2) == 1 and k.shape[1] >= nk and v.shape[1] >= nk and qproj_attention_ok(a, nk)
+    assert bias is None or (bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == N)
+    stats_in = wsum = None
+    parts = ln_dim = 0
+    eps = 0.0
+    if ln is not None:
+        stats_in, wsum, eps = ln
+        assert stats_in.dtype == torch.float32 and stats_in.is_contiguous() and stats_in.shape[0] == M and stats_in.shape[2] == 2
+        assert wsum.dtype == torch.float32 and wsum.is_contiguous() and wsum.numel() == N
+        parts, ln_dim = stats_in.shape[1], K
+    out = torch.empty(b, nq, N, dtype=torch.bfloat16, device=a.device)
+    flops = 2.0 * M * N * K + 4.0 * M * nk * N
+    with _timed("qproj_attn", flops, 2.0 * (M * K + N * K + M * N + 2 * b * nk * N)):
+        check(_lib.load().cd360_qproj_attn_bf16(_ptr(a), _ptr(w), _ptr(out), M, N, K, lda, w.stride(0), N, _ptr(bias), _ptr(stats_in), parts, ln_dim,
+                                               float(eps), _ptr(wsum), _ptr(k), _ptr(v), k.stride(0), k.stride(1), v.stride(0), v.stride(1), nq, nk,
+                                               64 ** -0.5, _stream()), "cd360_qproj_attn_bf16")
+    return out
+
+
 def pose_embed(x: torch.Tensor, xref: torch.Tensor, wa: torch.Tensor, wb: torch.Tensor) -> torch.Tensor:
     """pose_emb_layers(cat[x, xref]) (attention.py:634) as x wa^T + xref wb^T through the C ABI (cd360_pose_embed_bf16); wa = W[:, :C],
     wb = W[:, C:], contiguous.  Forward-only operator-level entry (the modules run the same two products on the library GEMM, which

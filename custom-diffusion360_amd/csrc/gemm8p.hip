@@ -46,6 +46,12 @@ struct GemmParams {
   float ln_eps;
   int geglu;
   int tiles_m, tiles_n, group_m;
+  // EPI 2: the projection output is the QUERY of a cross-attention over Nk <= 96 keys; it never leaves the registers
+  const uint16_t* ak;  // K [B, >= Nk, heads*64] (element strides ak_sb, ak_sn; head h at columns 64 h)
+  const uint16_t* av;  // V likewise (row-major: transposed by the LDS reads)
+  long ak_sb, ak_sn, av_sb, av_sn;
+  int a_nq, a_nk;      // queries per batch element (M = B * a_nq, a_nq % 256 == 0), keys
+  float a_scale_log2e;
   int abl;  // what-if timing knob (CD360_GEMM_ABL; results are wrong when set): 8 no DMA wait, 16 no barrier, 32 no LDS wait, 4 no DMA
 };
 
@@ -74,7 +80,7 @@ __device__ __forceinline__ float gelu_erf(float x) {
     FENCE();                       \
   } while (0)
 
-template <int WM, int WN, int NCB, int NMB, int NBUF, bool GEGLU>
+template <int WM, int WN, int NCB, int NMB, int NBUF, int EPI>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
   constexpr int NW = WM * WN;                      // waves
   constexpr int BM = WM * NMB * 32, BN = WN * NCB * 32;
@@ -83,6 +89,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
   constexpr int PR = 8 * NW;                       // rows one DMA piece of the whole workgroup covers (8 per wave)
   constexpr int XP = BM / PR, WP = BN / PR;        // pieces per wave per K-tile
   constexpr int NP = XP + WP, NMMA = NCB * NMB;
+  // epilogue: 0 linear, 1 GEGLU, 2 / 3 / 4 small-Nk attention on the projected tile with 1 / 2 / 3 blocks of 32 keys
+  constexpr bool GEGLU = EPI == 1, ATTN = EPI >= 2;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
 
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -369,9 +377,181 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
   }
 
   };
+
+  // ---- EPI 2: softmax(q k^T * scale) v per head on the projected tile (sgm/modules/attention.py:368-372,406-408 for a 77-token
+  // context: the text cross-attention attn2 of every block and the pose-token attention :578-588) -------------------------------------
+  // A wave's 128 x 64 accumulator IS the query block of one head (WN = 4 waves = 4 heads per 256-column tile).  The LayerNorm fold and
+  // the bias are applied in registers and the rows are packed to bf16 MFMA B fragments without moving: the contraction over the 64
+  // channels runs in the order the accumulator holds them (k-step j <-> channels 32 (j >> 1) + 16 hh + 8 (j & 1) + 0..7), which the K
+  // fragments follow by reading chunk 4 (j >> 1) + 2 hh + (j & 1) of their rows.  S^T for all keys at once (keys >= Nk masked through
+  // the accumulator's initial value), one max / exp2 / sum per token, P from the accumulator registers straight into the P V MFMAs with
+  // V^T taken from the row-major V rows by ds_read_b64_tr_b16 (attn_fwd.hip's small-Nk kernel, minus its Q round trip through HBM).
+  constexpr int NKB = ATTN ? EPI - 1 : 1, NKEYS = NKB * 32, HEAD_LDS = 2 * NKEYS * 128;  // per head: K rows then V rows, 128 B each
+  auto attn_tile = [&]() {
+    if constexpr (ATTN) {
+      static_assert(!ATTN || (NCB == 2 && NMB == 4 && WN == 4), "one head per wave");
+      unsigned char* const Ks = lds + wc * HEAD_LDS;
+      unsigned char* const Vs = Ks + NKEYS * 128;
+      unsigned char* const Os = lds + WN * HEAD_LDS + wave * (32 * 128);  // this wave's 32-token output block
+      // LayerNorm fold + bias, pack to B fragments (has_ch waves only; the others hold zeros and are skipped below)
+      bf16x8 qf[NMB][4];
+      if (has_ch) {
+        float mu[NMB], rs[NMB];
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb) {
+          mu[mb] = 0.f;
+          rs[mb] = 1.f;
+        }
+        if (p.ln_stats) {
+          const float inv = 1.f / (float)p.ln_dim;
+#pragma unroll
+          for (int mb = 0; mb < NMB; ++mb) {
+            const long m = m0 + mrow0 + mb * 32;
+            float s = 0.f, ss = 0.f;
+            if (m < p.M) {
+              const f32x2* st = reinterpret_cast<const f32x2*>(p.ln_stats) + m * p.ln_parts;
+              for (int q = 0; q < p.ln_parts; ++q) {
+                const f32x2 v = st[q];
+                s += v[0];
+                ss += v[1];
+              }
+            }
+            const float mean = s * inv;
+            mu[mb] = mean;
+            rs[mb] = rsqrtf(fmaxf(ss * inv - mean * mean, 0.f) + p.ln_eps);
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          FENCE();
+          const int nb = j >> 1, c8 = j & 1;
+          const int n = n0 + wc * 64 + nb * 32 + 16 * hh + 8 * c8;
+          float bv[8], sv[8];
+#pragma unroll
+          for (int r = 0; r < 8; ++r) {
+            bv[r] = p.bias ? p.bias[n + r] : 0.f;
+            sv[r] = p.ln_stats ? p.wsum[n + r] : 0.f;
+          }
+#pragma unroll
+          for (int mb = 0; mb < NMB; ++mb) {
+            u32x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float t0 = acc[nb][mb][8 * c8 + 2 * e], t1 = acc[nb][mb][8 * c8 + 2 * e + 1];
+              if (p.ln_stats) {
+                t0 = rs[mb] * (t0 - mu[mb] * sv[2 * e]);
+                t1 = rs[mb] * (t1 - mu[mb] * sv[2 * e + 1]);
+              }
+              o[e] = pack_bf16x2(t0 + bv[2 * e], t1 + bv[2 * e + 1]);
+            }
+            qf[mb][j] = __builtin_bit_cast(bf16x8, o);
+          }
+        }
+      }
+      // K and V rows of the tile's four heads -> LDS (rows >= Nk zero), all waves
+      const int bidx = (int)(m0 / p.a_nq);
+      for (int i = tid; i < WN * NKEYS * 8; i += 64 * NW) {
+        const int hl = i / (NKEYS * 8), rem = i - hl * (NKEYS * 8), row = rem >> 3, chunk = rem & 7;
+        const int col = n0 + hl * 64 + chunk * 8;
+        u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+        if (row < p.a_nk && col < p.N) {
+          kv = *reinterpret_cast<const u32x4*>(p.ak + bidx * p.ak_sb + (long)row * p.ak_sn + col);
+          vv = *reinterpret_cast<const u32x4*>(p.av + bidx * p.av_sb + (long)row * p.av_sn + col);
+        }
+        unsigned char* hb = lds + hl * HEAD_LDS;
+        *reinterpret_cast<u32x4*>(hb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = kv;
+        *reinterpret_cast<u32x4*>(hb + NKEYS * 128 + row * 128 + ((chunk ^ (((row >> 1) & 3) << 1)) << 4)) = vv;
+      }
+      __syncthreads();
+      if (!has_ch) return;
+      f32x16 init_last;  // accumulator start of the last key block: 0 for real keys, -1e30 for padding
+#pragma unroll
+      for (int r = 0; r < 16; ++r) init_last[r] = ((NKB - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh < p.a_nk) ? 0.f : -1e30f;
+      const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      const float c = p.a_scale_log2e;
+      // per-lane offsets: K fragment of k-step j = chunk 4 (j >> 1) + 2 hh + (j & 1) of row kb * 32 + l31 (16-B XOR swizzle);
+      // V^T fragments as attn_fwd.hip's v_frag_offset / v_frag (32-B swizzle, transposing reads)
+      int koff[4], voff[2];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) koff[j] = l31 * 128 + (((4 * (j >> 1) + 2 * hh + (j & 1)) ^ ((l31 >> 1) & 7)) << 4);
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const int i = l31 & 15;
+        voff[db] = (4 * hh + (i >> 2)) * 128 + (((2 * db + (l31 >> 4)) ^ ((2 * hh + (i >> 3)) & 3)) << 5) + 8 * (i & 3);
+      }
+      typedef __attribute__((ext_vector_type(4))) short s16x4;
+      typedef __attribute__((ext_vector_type(8))) short s16x8;
+      typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+      const int lrow = lane >> 3, lchunk = lane & 7;
+      const int ocol = n0 + wc * 64 + lchunk * 8;
+#pragma unroll  // (a runtime mb would index qf[] dynamically: scratch)
+      for (int mb = 0; mb < NMB; ++mb) {
+        FENCE();
+        f32x16 sT[NKB];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bf16x8 kfr = *reinterpret_cast<const bf16x8*>(Ks + kb * 32 * 128 + koff[j]);
+            sT[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kfr, qf[mb][j], j == 0 ? (kb == NKB - 1 ? init_last : zero) : sT[kb], 0, 0, 0);
+          }
+        float mx = sT[0][0];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sT[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mc = -mx * c;
+        float rsum_p = 0.f;
+        uint32_t pk[NKB * 8];
+#pragma unroll
+        for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+          for (int r = 0; r < 16; r += 2) {
+            const float p0 = __builtin_amdgcn_exp2f(fmaf(sT[kb][r], c, mc)), p1 = __builtin_amdgcn_exp2f(fmaf(sT[kb][r + 1], c, mc));
+            rsum_p += p0 + p1;
+            pk[kb * 8 + (r >> 1)] = pack_bf16x2(p0, p1);
+          }
+        rsum_p += __shfl_xor(rsum_p, 32);
+        f32x16 oT[2];
+#pragma unroll
+        for (int kk = 0; kk < 2 * NKB; ++kk) {
+          const u32x4 pw = {pk[kk * 4 + 0], pk[kk * 4 + 1], pk[kk * 4 + 2], pk[kk * 4 + 3]};
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(Vs + voff[db] + kk * 16 * 128));
+            const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(Vs + voff[db] + kk * 16 * 128 + 8 * 128));
+            const s16x8 vfr = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vfr), __builtin_bit_cast(bf16x8, pw), kk == 0 ? zero : oT[db], 0, 0, 0);
+          }
+        }
+        // O^T registers (lane = token, 4 consecutive channels per group) -> this wave's LDS block -> full 128-byte rows
+        const float inv = 1.f / rsum_p;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            const int dbyte = (db * 32 + 8 * g + 4 * hh) * 2;
+            const u32x2 wv = {pack_bf16x2(oT[db][4 * g + 0] * inv, oT[db][4 * g + 1] * inv), pack_bf16x2(oT[db][4 * g + 2] * inv, oT[db][4 * g + 3] * inv)};
+            *reinterpret_cast<u32x2*>(Os + l31 * 128 + (((dbyte >> 4) ^ ((l31 >> 1) & 7)) << 4) + (dbyte & 8)) = wv;
+          }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = 8 * i + lrow;
+          const long m = m0 + wr * (NMB * 32) + mb * 32 + row;
+          const u32x4 v = *reinterpret_cast<const u32x4*>(Os + row * 128 + ((lchunk ^ ((row >> 1) & 7)) << 4));
+          if (m < p.M) *reinterpret_cast<u32x4*>(p.out + m * p.ldo + ocol) = v;
+        }
+      }
+    }
+  };
   if (has_ch) k_loop(std::true_type{});
   else k_loop(std::false_type{});
   __syncthreads();  // every wave is past its last fragment read: the K-loop buffers become the output staging area
+  if constexpr (ATTN) {
+    attn_tile();
+    return;
+  }
   if (has_ch) {
     store_tile();
     // (wave-private image: the compiler's lgkmcnt wait orders the ds_writes before the ds_reads, no barrier)
@@ -419,7 +599,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
   }
 }
 
-template <int WM, int WN, int NCB, int NMB, int NBUF, bool GEGLU>
+template <int WM, int WN, int NCB, int NMB, int NBUF, int EPI>
 int launch_epi(const GemmParams& p0, hipStream_t stream) {
   GemmParams p = p0;
   constexpr int BM = WM * NMB * 32, BN = WN * NCB * 32;
@@ -433,17 +613,17 @@ int launch_epi(const GemmParams& p0, hipStream_t stream) {
   if (const char* e = getenv("CD360_GEMM_ABL")) p.abl = atoi(e);
   const long nwg = (long)p.tiles_m * p.tiles_n;
   if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_kernel<WM, WN, NCB, NMB, NBUF, GEGLU>),
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_kernel<WM, WN, NCB, NMB, NBUF, EPI>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   if (attr != hipSuccess) return CD360_ERR_LAUNCH;
-  hipLaunchKernelGGL((gemm_mfma_kernel<WM, WN, NCB, NMB, NBUF, GEGLU>), dim3((unsigned)nwg), dim3(64 * WM * WN), LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((gemm_mfma_kernel<WM, WN, NCB, NMB, NBUF, EPI>), dim3((unsigned)nwg), dim3(64 * WM * WN), LDS_BYTES, stream, p);
   CD360_LAUNCH_CHECK();
   return CD360_OK;
 }
 
 template <int WM, int WN, int NCB, int NMB, int NBUF>
 int launch(const GemmParams& p, hipStream_t stream) {
-  return p.geglu ? launch_epi<WM, WN, NCB, NMB, NBUF, true>(p, stream) : launch_epi<WM, WN, NCB, NMB, NBUF, false>(p, stream);
+  return p.geglu ? launch_epi<WM, WN, NCB, NMB, NBUF, 1>(p, stream) : launch_epi<WM, WN, NCB, NMB, NBUF, 0>(p, stream);
 }
 
 // Tilings (tokens x channels, waves, LDS buffers): 1 = 128 x 128, 4 waves of 64 x 64, 2 buffers (two workgroups per CU);
@@ -506,14 +686,43 @@ extern "C" int cd360_gemm_bf16(const void* a, const void* w, void* out, int64_t 
   p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.ldr = res ? ldr : 0;
   p.M = (int)M; p.N = N; p.K = K; p.ln_parts = ln_parts; p.ln_dim = ln_dim; p.ln_eps = ln_eps; p.geglu = geglu ? 1 : 0;
   p.tiles_m = p.tiles_n = p.group_m = 0;
+  p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f;
   switch (pick_cfg(M, N, geglu)) {
     case 1: return launch<2, 2, 2, 2, 2>(p, (hipStream_t)stream);
-    case 2: return geglu ? CD360_ERR_SHAPE : launch_epi<2, 4, 1, 2, 2, false>(p, (hipStream_t)stream);
-    case 4: return geglu ? CD360_ERR_SHAPE : launch_epi<2, 4, 1, 2, 4, false>(p, (hipStream_t)stream);
+    case 2: return geglu ? CD360_ERR_SHAPE : launch_epi<2, 4, 1, 2, 2, 0>(p, (hipStream_t)stream);
+    case 4: return geglu ? CD360_ERR_SHAPE : launch_epi<2, 4, 1, 2, 4, 0>(p, (hipStream_t)stream);
     case 5: return launch<4, 2, 2, 2, 3>(p, (hipStream_t)stream);
-    case 6: return geglu ? CD360_ERR_SHAPE : launch_epi<4, 2, 3, 2, 2, false>(p, (hipStream_t)stream);
+    case 6: return geglu ? CD360_ERR_SHAPE : launch_epi<4, 2, 3, 2, 2, 0>(p, (hipStream_t)stream);
     default: return launch<2, 4, 2, 4, 2>(p, (hipStream_t)stream);
   }
+}
+
+// out[M, N] = softmax_keys((A W^T [LayerNorm-folded] + bias) K_h^T * scale) V_h per head h (N = heads * 64): the query projection of a
+// cross-attention over Nk <= 96 keys fused with the attention itself -- Q never exists in memory.  A, W, bias, ln_stats, wsum as in
+// cd360_gemm_bf16; k, v bf16 [B, >= Nk, N] (element strides k_sb / k_sn, v_sb / v_sn: batch, key; head h at columns 64 h .. 64 h + 63),
+// M = B * Nq with Nq % 256 == 0 (a 256-token tile never straddles two batch elements).
+extern "C" int cd360_qproj_attn_bf16(const void* a, const void* w, void* out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldo,
+                                     const void* bias, const void* ln_stats, int ln_parts, int ln_dim, float ln_eps, const void* wsum,
+                                     const void* k, const void* v, int64_t k_sb, int64_t k_sn, int64_t v_sb, int64_t v_sn, int Nq, int Nk,
+                                     float scale, void* stream) {
+  if (!a || !w || !out || !k || !v || M <= 0 || N <= 0 || K <= 0 || Nq <= 0 || Nk <= 0) return CD360_ERR_ARG;
+  if (K % 64 || N % 64 || lda % 8 || ldw % 8 || ldo % 8 || lda < K || ldw < K || Nk > 96 || Nq % 256 || M % Nq) return CD360_ERR_SHAPE;
+  if (k_sb % 8 || k_sn % 8 || v_sb % 8 || v_sn % 8) return CD360_ERR_SHAPE;
+  if (((uintptr_t)a | (uintptr_t)w | (uintptr_t)out | (uintptr_t)k | (uintptr_t)v) % 16) return CD360_ERR_ARG;
+  if (((uintptr_t)bias | (uintptr_t)ln_stats | (uintptr_t)wsum) % 8) return CD360_ERR_ARG;
+  if (M > 0x7fffffffL || (M + 256) * lda * 2 >= (1L << 32) || ((long)N + 256) * ldw * 2 >= (1L << 32)) return CD360_ERR_SHAPE;
+  if (ln_stats && (!wsum || ln_parts <= 0 || ln_dim <= 0)) return CD360_ERR_ARG;
+  GemmParams p;
+  p.a = (const uint16_t*)a; p.w = (const uint16_t*)w; p.out = (uint16_t*)out; p.bias = (const float*)bias; p.res = nullptr;
+  p.ln_stats = (const float*)ln_stats; p.wsum = (const float*)wsum; p.stats_out = nullptr;
+  p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.ldr = 0;
+  p.M = (int)M; p.N = N; p.K = K; p.ln_parts = ln_parts; p.ln_dim = ln_dim; p.ln_eps = ln_eps; p.geglu = 0;
+  p.tiles_m = p.tiles_n = p.group_m = 0;
+  p.ak = (const uint16_t*)k; p.av = (const uint16_t*)v; p.ak_sb = k_sb; p.ak_sn = k_sn; p.av_sb = v_sb; p.av_sn = v_sn;
+  p.a_nq = Nq; p.a_nk = Nk; p.a_scale_log2e = scale * 1.4426950408889634f;
+  if (Nk <= 32) return launch_epi<2, 4, 2, 4, 2, 2>(p, (hipStream_t)stream);
+  if (Nk <= 64) return launch_epi<2, 4, 2, 4, 2, 3>(p, (hipStream_t)stream);
+  return launch_epi<2, 4, 2, 4, 2, 4>(p, (hipStream_t)stream);
 }
 
 // Per-row (sum, sumsq) of a bf16 [rows, C] matrix (row stride ld) as ONE partial per row: the `ln_stats` input of cd360_gemm_bf16 for a

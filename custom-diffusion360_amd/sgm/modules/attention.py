@@ -402,8 +402,11 @@ class BasicTransformerBlock(nn.Module):
         a2 = self.attn2
         k, v, nk = a2.project_context(context)
         w, ws, cb = P["q2"]
-        q = ops.gemm(tok, w, bias=cb, ln=(ops.row_stats(tok), ws, self.norm2.eps))
-        o = ops.attention(q, k, v, a2.heads, nk)
+        ln = (ops.row_stats(tok), ws, self.norm2.eps)
+        if ops.qproj_attention_ok(tok, nk) and not os.environ.get("CD360_NO_QPROJ_ATTN"):
+            o = ops.qproj_attention(tok, w, k, v, nk, a2.heads, bias=cb, ln=ln)  # q never leaves the registers (cd360_qproj_attn_bf16)
+        else:
+            o = ops.attention(ops.gemm(tok, w, bias=cb, ln=ln), k, v, a2.heads, nk)
         return ops.gemm(o, P["o2"][0], bias=P["o2"][1], res=tok)
 
     def _forward_fused(self, x, stats, context=None, context_ref=None, pose=None, mask_ref=None, prev_weights=None):

@@ -224,7 +224,16 @@ int cd360_pose_embed_bf16(const void* x, const void* xref, const void* wa, const
 int cd360_gemm_bf16(const void* a, const void* w, void* out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldo, const void* bias,
                     const void* res, int64_t ldr, const void* ln_stats, int ln_parts, int ln_dim, float ln_eps, const void* wsum,
                     void* stats_out, int flags, void* stream);
-/* N-tile width (256 | 128) cd360_gemm_bf16 uses for an [M, N] output: stats_out holds ceil(N / that) partials per row. */
+/* replaces to_q (nn.Linear, attention.py:323,368) + xformers.ops.memory_efficient_attention (attention.py:406) of a cross-attention whose
+ * context has Nk <= 96 tokens -- attn2 over the 77 text tokens, in every transformer block (attention.py:620-625) and on the FeatureNeRF
+ * pose tokens (attention.py:578-588, the north-star kernel: 98 304 queries per batch element at 1024^2): the query projection and
+ * softmax(q k^T * scale) v run in ONE kernel, Q never exists in memory.  a / w / bias / ln_stats / wsum as in cd360_gemm_bf16 (optional
+ * LayerNorm fold of norm2 in front of to_q); N = heads * 64; k, v bf16 [B, >= Nk, N] with element strides (batch, key), head h at
+ * columns 64 h; out bf16 [M, N] (row stride ldo), M = B * Nq, Nq % 256 == 0. */
+int cd360_qproj_attn_bf16(const void* a, const void* w, void* out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldo,
+                          const void* bias, const void* ln_stats, int ln_parts, int ln_dim, float ln_eps, const void* wsum, const void* k,
+                          const void* v, int64_t k_sb, int64_t k_sn, int64_t v_sb, int64_t v_sn, int Nq, int Nk, float scale, void* stream);
+/* N-tile width (256 | 192 | 128) cd360_gemm_bf16 uses for an [M, N] output: stats_out holds ceil(N / that) partials per row. */
 int cd360_gemm_tile_n(int64_t M, int N);
 /* (sum, sum of squares) of every row of a bf16 [rows, C] matrix (row stride ld) as one fp32 partial per row: the `ln_stats` input for a
  * tensor that did not come out of cd360_gemm_bf16 (C % 8 == 0). */

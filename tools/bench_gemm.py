@@ -80,8 +80,43 @@ def check_case(M, N, K, bias=False, res=False, ln=False, geglu=False, stats=Fals
     return ok
 
 
+def check_qattn(b, nq, C, K, nk, ln=True):
+    """qproj_attention against fp32 torch: LayerNorm -> Linear -> softmax(q k^T / 8) v per head."""
+    heads = C // 64
+    a = (rnd(b, nq, K, seed=11) * (0.5 + rnd(b, nq, 1, seed=12).abs()) + 0.5 * rnd(b, nq, 1, seed=13)).to(torch.bfloat16)
+    w = rnd(C, K, seed=14, scale=K ** -0.5)
+    kv = rnd(b, max(80, nk), 2 * C, seed=15).to(torch.bfloat16)
+    k, v = kv[..., :C], kv[..., C:]
+    a32 = a.float()
+    if ln:
+        gamma, beta = 1 + 0.2 * rnd(K, seed=5), 0.1 * rnd(K, seed=6)
+        wp, wsum, cb = ops.pack_ln_linear(w, None, gamma, beta)
+        q = F.linear(F.layer_norm(a32, (K,), gamma, beta, 1e-5), w)
+        got = [ops.qproj_attention(a, wp, k, v, nk, heads, bias=cb, ln=(ops.row_stats(a), wsum, 1e-5)) for _ in range(3)]
+    else:
+        wb = w.to(torch.bfloat16)
+        q = F.linear(a32, wb.float())
+        got = [ops.qproj_attention(a, wb, k, v, nk, heads) for _ in range(3)]
+    qh = q.reshape(b, nq, heads, 64).transpose(1, 2)
+    kh = k[:, :nk].float().reshape(b, nk, heads, 64).transpose(1, 2)
+    vh = v[:, :nk].float().reshape(b, nk, heads, 64).transpose(1, 2)
+    want = (torch.softmax(qh @ kh.transpose(-1, -2) / 8.0, -1) @ vh).transpose(1, 2).reshape(b, nq, C)
+    torch.cuda.synchronize()
+    e = relerr(got[0], want)
+    same = all(torch.equal(got[0], g) for g in got[1:])
+    ok = same and e < 1e-2 and bool(torch.isfinite(got[0]).all())
+    print(("ok   " if ok else "FAIL ") + f"qproj_attention b={b} nq={nq} C={C} K={K} nk={nk} ln={int(ln)}: err {e:.2e} repeat-equal {same}", flush=True)
+    return ok
+
+
 def check():
     ok = True
+    ok &= check_qattn(2, 256, 128, 128, 77)
+    ok &= check_qattn(1, 512, 64, 64, 77, ln=False)
+    ok &= check_qattn(3, 1024, 640, 640, 77)
+    ok &= check_qattn(2, 256, 1280, 1280, 50)
+    ok &= check_qattn(1, 768, 256, 320, 96)
+    ok &= check_qattn(2, 256, 128, 192, 20)
     for cfg in (1, 2, 3, 4, 5, 6):
         for (M, N, K) in [(256, 256, 64), (256, 256, 128), (512, 512, 192), (300, 272, 320), (128, 128, 64), (1000, 640, 640), (3072, 1280, 1280)]:
             ok &= check_case(M, N, K, cfg=cfg)
@@ -121,6 +156,26 @@ SHAPES = [  # (name, M, N, K, epilogue) at cfg-B: b = 3; level 1: 4096 tokens x 
 
 
 VARIANTS = [(3, 0), (6, 0), (5, 0), (1, 0), (2, 0), (4, 0)]
+
+
+def time_qattn():
+    """The pose-token attention (A3) and the text cross-attention (A2) at cfg-B: fused kernel against q GEMM + small-Nk attention."""
+    for name, b, nq, C in (("A3 L1", 3, 98304, 640), ("A3 L2", 3, 24576, 1280), ("A2 L1", 3, 4096, 640), ("A2 L2", 3, 1024, 1280)):
+        heads = C // 64
+        a = rnd(b, nq, C, seed=1).to(torch.bfloat16)
+        w = rnd(C, C, seed=2, scale=C ** -0.5).to(torch.bfloat16)
+        ws = w.float().sum(1).contiguous()
+        cb = rnd(C, seed=3)
+        kv = rnd(b, 80, 2 * C, seed=4).to(torch.bfloat16)
+        k, v = kv[..., :C], kv[..., C:]
+        st = ops.row_stats(a)
+        t_f = timeit(lambda: ops.qproj_attention(a, w, k, v, 77, heads, bias=cb, ln=(st, ws, 1e-5)), iters=20, warm=3)
+        t_g = timeit(lambda: ops.gemm(a, w, bias=cb, ln=(st, ws, 1e-5)), iters=20, warm=3)
+        q = ops.gemm(a, w, bias=cb, ln=(st, ws, 1e-5))
+        t_a = timeit(lambda: ops.attention(q, k, v, heads, 77), iters=20, warm=3)
+        t_l = timeit(lambda: F.linear(a, w), iters=20, warm=3)
+        flops = b * nq * (2.0 * C * C + 4.0 * 77 * C)
+        print(f"{name}: fused q-proj+attention {t_f:7.1f} us ({flops / t_f * 1e-6:5.0f} TF/s) | q GEMM {t_g:7.1f} + attention {t_a:7.1f} = {t_g + t_a:7.1f} | library q GEMM {t_l:7.1f}", flush=True)
 
 
 def time_all():
@@ -186,6 +241,8 @@ if __name__ == "__main__":
         good = check()
     if "time" in what:
         time_all()
+    if "qattn" in what:
+        time_qattn()
     if "ablate" in what:
         ablate()
     if "one" in what:  # a few launches of one shape for rocprofv3 --pmc passes: one M N K (env CD360_GEMM_* select the variant)
