@@ -101,14 +101,14 @@ class Sampler:
         for att in sampling._cross_attentions(self.net):  # same for the per-image context K / V^T cache
             if att._kv_cache is None:
                 continue
-            key, (k, vt, nk) = att._kv_cache
+            key, (k, vt, nk) = att._kv_cache[:2]
             st = getattr(att, "_static_kv", None)
             if st is None or st[0].shape != k.shape:
                 att._static_kv = (k.clone(), vt.clone())
             else:
                 st[0].copy_(k)
                 st[1].copy_(vt)
-            att._kv_cache = (key, (att._static_kv[0], att._static_kv[1], nk))
+            att._kv_cache = (key, (att._static_kv[0], att._static_kv[1], nk)) + tuple(att._kv_cache[2:])
 
     def _capture(self, fn):
         """Warm `fn` on a side stream (allocator / library workspaces), then capture it into a hipGraph."""

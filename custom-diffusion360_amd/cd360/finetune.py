@@ -32,7 +32,9 @@ from .sampling import pose_blocks
 
 # ---------------------------------------------------------------- which parameters train
 def select_trainable(unet: torch.nn.Module, trainkeys: str = "pose") -> List[str]:
-    """Sets requires_grad exactly as diffusion.py:117-150 and returns the names left trainable."""
+    """Sets requires_grad exactly as diffusion.py:117-150 and returns the names left trainable.  Call it BEFORE any grad-enabled forward:
+    freshly constructed modules have every parameter trainable, and the HIP path refuses (NotImplementedError) to run a trainable
+    convolution / norm affine it cannot differentiate."""
     named = list(unet.named_parameters())
     if trainkeys == "poseattn":
         blocks = []
@@ -51,6 +53,12 @@ def select_trainable(unet: torch.nn.Module, trainkeys: str = "pose") -> List[str
         for name, p in named:
             p.requires_grad = "pose" in name
     elif trainkeys == "all":
+        # the reference accepts it (diffusion.py:117-150) and so does this function, but the HIP path has no weight gradients for
+        # convolutions and for the GroupNorm / LayerNorm affines: say so HERE, not only at the first forward
+        import warnings
+        warnings.warn("trainkeys='all': convolution weights and GroupNorm / LayerNorm affine parameters have no backward kernel on the HIP "
+                      "path -- a grad-enabled forward will raise NotImplementedError for them; the shipped configs train 'pose' / 'poseattn'",
+                      stacklevel=2)
         for _, p in named:
             p.requires_grad = True
     else:

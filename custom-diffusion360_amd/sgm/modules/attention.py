@@ -145,7 +145,8 @@ class MemoryEfficientCrossAttention(nn.Module):
         else:
             kv = F.linear(ctx, wkv)
         out = (kv[..., :inner], kv[..., inner:], context.shape[1])
-        self._kv_cache = (key, out) if use_cache else None
+        # the keyed tensors are held by the entry: their addresses cannot be recycled for other content while the entry is alive
+        self._kv_cache = (key, out, (context, wk, wv)) if use_cache else None
         return out
 
     def attend(self, x: torch.Tensor, kv) -> torch.Tensor:
@@ -289,7 +290,7 @@ class BasicTransformerBlock(nn.Module):
             # 3-way CFG (guiders.py:102-133): the image-conditional and the image+text-conditional thirds see the same target
             # pose and the same references, so everything BEFORE the text cross-attention is identical for them: render the
             # first two thirds only and reuse the second for the third (the reference computes it twice).
-            t2, d2 = self._sampling_tables(2 * dup)
+            t2, d2 = self._sampling_tables(dup, dup)  # the layout is stated, never re-inferred from the de-duplicated batch size
             h, dec, dists, _ = self.pose_featurenerf.render_inputs(list(pose[:2 * dup]), None, None, tables=t2, dims=d2)
             h, dec = torch.cat([h, h[dup:]], 0), torch.cat([dec, dec[dup:]], 0)
         else:
@@ -336,10 +337,18 @@ class BasicTransformerBlock(nn.Module):
         cond = sel[None].expand(bs, -1, -1, -1)
         return torch.cat([refs[-1:][None].expand(bs, n, -1, -1), cond], 0)
 
-    def _sampling_tables(self, batch_size: int):
-        """(Y, lv, img_map), dims for the CFG batch of sample.py:89-96 built from the DISTINCT images only: table image 0 = the null
-        image `references[-1]`, images 1..n = `references[choices]`.  They depend on (references, choices, weights) alone, so they are
-        computed once and reused for every target pose and image (the reference recomputes the equivalent work in every render)."""
+    @staticmethod
+    def _cfg_layout(batch_size: int):
+        """(n_null, n_cond) of sample.py's CFG batch (sample.py:89-96): the first third (3-way) or half (2-way) is unconditional."""
+        if batch_size % 3 == 0:
+            return batch_size // 3, 2 * (batch_size // 3)
+        return batch_size // 2, batch_size - batch_size // 2
+
+    def _sampling_tables(self, n_null: int, n_cond: int):
+        """(Y, lv, img_map), dims for a batch of n_null unconditional + n_cond image-conditional elements (sample.py:89-96) built from the
+        DISTINCT images only: table image 0 = the null image `references[-1]`, images 1..n = `references[choices]`.  They depend on
+        (references, choices, weights) alone, so they are computed once and reused for every target pose and image (the reference
+        recomputes the equivalent work in every render)."""
         from cd360 import nerf as _nerf
         refs, choices = self.references, self.reference_choices
         fw = self.pose_featurenerf.model.fused_weights()
@@ -348,15 +357,13 @@ class BasicTransformerBlock(nn.Module):
         if self._ref_tables is None or self._ref_tables[0] != key:
             uniq = torch.cat([refs[-1:], refs[:-1][torch.as_tensor(choices, device=refs.device)]], 0)  # [1+n, hw, C]
             Y, lv = _nerf.reference_tables(fw, uniq[None])
-            self._ref_tables = (key, (Y, lv), {})
+            self._ref_tables = (key, (Y, lv), {}, fw)  # fw kept alive: its id is part of the key
         (Y, lv), maps = self._ref_tables[1], self._ref_tables[2]
-        if batch_size not in maps:  # which table image each (batch element, view) reads: per CFG layout, tiny
-            groups = 3 if batch_size % 3 == 0 else 2
-            bs = batch_size // groups
+        if (n_null, n_cond) not in maps:  # which table image each (batch element, view) reads: per CFG layout, tiny
             cond = torch.arange(1, n + 1, dtype=torch.int32, device=refs.device)
-            rows = [torch.zeros(n, dtype=torch.int32, device=refs.device)] * bs + [cond] * (bs * (groups - 1))
-            maps[batch_size] = torch.stack(rows).reshape(-1).contiguous()
-        return (Y, lv, maps[batch_size]), (batch_size, n, refs.shape[1], refs.shape[2])
+            rows = [torch.zeros(n, dtype=torch.int32, device=refs.device)] * n_null + [cond] * n_cond
+            maps[(n_null, n_cond)] = torch.stack(rows).reshape(-1).contiguous()
+        return (Y, lv, maps[(n_null, n_cond)]), (n_null + n_cond, n, refs.shape[1], refs.shape[2])
 
     # ------------------------------------------------------------------------------------------------ fused inference path
     def fused_ready(self, x: torch.Tensor) -> bool:
@@ -435,7 +442,7 @@ class BasicTransformerBlock(nn.Module):
             if self.reference_choices is not None:  # native equivalent of sample.py's _customforward (sample.py:82-136)
                 if self.rendered_feat is None:
                     if mask_ref is None:  # tables of the DISTINCT reference images, kept across images / poses
-                        tables, dims = self._sampling_tables(x.size(0))
+                        tables, dims = self._sampling_tables(*self._cfg_layout(x.size(0)))
                         xref, fg_mask, weights, alphas, predicted_rgb = self.reference_attn(x, None, context, pose, prev_weights, None,
                                                                                             tables=tables, dims=dims)
                     else:
@@ -498,7 +505,7 @@ class BasicTransformerBlock(nn.Module):
             if self.reference_choices is not None:  # native equivalent of sample.py's _customforward (sample.py:82-136)
                 if self.rendered_feat is None:
                     if mask_ref is None:  # tables of the DISTINCT reference images, kept across images / poses
-                        tables, dims = self._sampling_tables(x.size(0))
+                        tables, dims = self._sampling_tables(*self._cfg_layout(x.size(0)))
                         xref, fg_mask, weights, alphas, predicted_rgb = self.reference_attn(x, None, context, pose, prev_weights, None,
                                                                                             tables=tables, dims=dims)
                     else:

@@ -16,7 +16,16 @@ def packed_pose(pose, device) -> torch.Tensor:
     """Pack (and memoise on the list object's elements) the cameras of one forward call."""
     if isinstance(pose, torch.Tensor):
         return pack_cameras(pose, device)
-    key = tuple(id(c) for c in pose)
+    # keyed on the camera objects AND on the storage / version of their fields: an in-place edit (cam.T = ..., the crop / scale adjusters
+    # of data_co3d.py, a replaced list element) must not be served the stale packing
+    def _fp(c):
+        out = [id(c)]
+        for name in ("R", "T", "focal_length", "principal_point"):
+            t = getattr(c, name, None)
+            out.append((t.data_ptr(), t._version) if isinstance(t, torch.Tensor) else None)
+        return tuple(out)
+
+    key = tuple(_fp(c) for c in pose)
     cache = _PACK_CACHE.get(key)
     if cache is not None and cache[0] == str(device):
         return cache[1]

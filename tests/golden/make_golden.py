@@ -138,6 +138,64 @@ def case_block(train: bool):
         keyfile("block", blk)
 
 
+# ---------------------------------------------------------------- 2b. mask_ref (nerfsd_pytorch3d.py:61-70; live in config 4: data_co3d.py:485, loss.py:154)
+def case_mask_ref():
+    """The reference-view masks: NerfSDModule, the pose block (eval, and train mode with the jitter draws recorded plus the reference's
+    own autograd gradients of the 'pose' parameters) and the tiny UNet, all with a [b, n, 1, Hm, Wm] 0/1 mask that the module
+    nearest-resizes to the feature-map side and multiplies onto the reference features."""
+    out = {}
+    # NerfSDModule (same weights / inputs as case_nerf)
+    C, r, n, S, b = 64, 8, 2, 4, 2
+    m = ns.nerf.NerfSDModule(mode="feature-nerf", out_channels=C, far_plane=2.0, num_samples=S, rgb_predict=True, stratified=True)
+    W.load_into(m, seed=1)
+    m.eval()
+    pose = synth.pose_batch(b, n, seed=3)
+    xref = W.tensor("xref", (b, n, r * r, C), seed=1)
+    mask = (W.tensor("mask_ref", (b, n, 1, 4 * r, 4 * r), seed=1) > -0.3).float()  # ~60 % ones, 4x the feature-map side
+    feats, sigma, dists, attn, rgb, _, _ = m(pose, xref, mask_ref=mask)
+    out.update(nerf_cams=pack_cameras(pose), nerf_xref=xref, nerf_mask=mask, nerf_feats=feats, nerf_sigma=sigma, nerf_view_weights=attn, nerf_rgb=rgb)
+    # pose block, eval and train (same weights / inputs as case_block)
+    C, heads, r, n, S, b, T, cd = 64, 1, 8, 2, 4, 2, 77, 32
+    pose = synth.pose_batch(b, n, seed=4)
+    x = W.tensor("x", (b, r * r, C), seed=2)
+    ctx = W.tensor("ctx", (b, T, cd), seed=2)
+    cref = W.tensor("cref", (b * n, r * r, C), seed=2)
+    mask = (W.tensor("mask_ref", (b, n, 1, 2 * r, 2 * r), seed=2) > -0.3).float()
+    out.update(blk_cams=pack_cameras(pose), blk_x=x, blk_ctx=ctx, blk_cref=cref, blk_mask=mask)
+    for train in (False, True):
+        blk = make_block(C, heads, cd, S)
+        W.load_into(blk, seed=2)
+        blk.train(train)
+        tag = "train" if train else "eval"
+        torch.manual_seed(12)
+        for name, p_ in blk.named_parameters():
+            p_.requires_grad = train and "pose" in name
+        with Recorder() as rec, torch.set_grad_enabled(train):
+            o, fg, wts, alphas, rgb = blk(x, context=ctx, context_ref=cref, pose=pose, mask_ref=mask)
+            if train:
+                cot = W.tensor("cot", tuple(o.shape), seed=2)
+                ((o * cot).sum() + fg.sum() + rgb.sum()).backward()
+        out.update({f"blk_{tag}_out": o.detach(), f"blk_{tag}_fg": fg.detach(), f"blk_{tag}_alphas": alphas.detach(), f"blk_{tag}_rgb": rgb.detach()})
+        if train:
+            out.update({f"blk_train_{k}": v for k, v in jitter_kw(rec).items()})
+            out.update({f"blk_grad.{name}": p_.grad for name, p_ in blk.named_parameters() if p_.requires_grad and p_.grad is not None})
+    # tiny UNet (same weights / inputs as case_unet)
+    net = ns.openaimodel.UNetModel(**UNET_TINY)
+    W.load_into(net, seed=5)
+    net.eval()
+    b, n, L, T = 1, 2, 16, 77
+    pose = synth.pose_batch(b, n, seed=7)
+    x = W.tensor("x", (b, 4, L, L), seed=5)
+    xin = W.tensor("input_ref", (b, n, 4, L, L), seed=5)
+    ctx = W.tensor("ctx", (b + b * n, T, 32), seed=5)
+    y = W.tensor("y", (b + b * n, 16), seed=5)
+    mask = (W.tensor("mask_ref", (b, n, 1, 8 * L, 8 * L), seed=5) > -0.3).float()  # image-resolution mask (data_co3d.py:485)
+    eps, fgs, alphas, rgbs = net(x, timesteps=torch.tensor([500.0]), context=ctx, y=y, pose=pose, input_ref=xin, sigmas_ref=torch.tensor([120.0]),
+                                 mask_ref=mask)
+    out.update(unet_mask=mask, unet_out=eps, **{f"unet_fg{i}": v for i, v in enumerate(fgs)}, **{f"unet_rgb{i}": v for i, v in enumerate(rgbs)})
+    npz("mask_ref", **out)
+
+
 # ---------------------------------------------------------------- 3. SpatialTransformer dual stream
 def make_st(C, heads, depth, cd, S):
     return ns.attention.SpatialTransformer(C, heads, 64, depth=depth, context_dim=cd, use_linear=True, attn_type="softmax-xformers",
@@ -402,6 +460,7 @@ if __name__ == "__main__":
     case_nerf(True)
     case_block(False)
     case_block(True)
+    case_mask_ref()
     case_st_dual()
     case_customforward()
     case_unet()

@@ -405,3 +405,42 @@ def test_pose_block_train_mode_poseattn_gradients(monkeypatch):
         worst[k] = rel(params[k].grad, want[k])
     print("worst:", sorted(worst.items(), key=lambda kv: -kv[1])[:4])
     assert max(worst.values()) < 3e-2, {k: v for k, v in worst.items() if v >= 3e-2}
+
+
+def test_pose_block_mask_ref_train_mode_gradients(monkeypatch):
+    """The pose block in TRAIN mode WITH reference-view masks (nerfsd_pytorch3d.py:61-70, config 4's live branch): forward against the
+    reference's train-mode golden and the gradients of the 'pose' parameters against the reference's OWN autograd
+    (tests/golden/mask_ref.npz: blk_train_*, blk_grad.*)."""
+    import os
+    import numpy as np
+    import weights as W
+    from cd360.cameras import unpack_cameras
+    from sgm.modules.attention import BasicTransformerBlock
+    from sgm.modules.nerfsd_pytorch3d import Raymarcher
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(gold, "mask_ref.npz")).items()}
+    blk = BasicTransformerBlock(64, 1, 64, context_dim=32, checkpoint=False, attn_mode="softmax-xformers", image_cross=True, far=2, num_samples=4,
+                                rgb_predict=True, mode="feature-nerf", stratified=True).train()
+    W.load_into(blk, seed=2)
+    blk = blk.to(DEV, torch.bfloat16)
+    for k, p in blk.named_parameters():
+        p.requires_grad = "pose" in k
+    monkeypatch.setattr(Raymarcher, "jitter", lambda self, resolution, device: ((g["blk_train_jit_x"], g["blk_train_jit_y"]), g["blk_train_jit_d"].to(device)))
+    b16 = lambda t: t.to(DEV, torch.bfloat16)
+    out, fg, _, alphas, rgb = blk(b16(g["blk_x"]), context=b16(g["blk_ctx"]), context_ref=b16(g["blk_cref"]), pose=unpack_cameras(g["blk_cams"]),
+                                  mask_ref=g["blk_mask"].to(DEV))
+    assert rel(out, g["blk_train_out"]) < 2.5e-2 and rel(fg, g["blk_train_fg"]) < 2.5e-2 and rel(alphas, g["blk_train_alphas"]) < 2.5e-2
+    assert rel(rgb, g["blk_train_rgb"]) < 2.5e-2
+    cot = W.tensor("cot", tuple(out.shape), seed=2).to(DEV)
+    ((out.float() * cot).sum() + fg.float().sum() + rgb.float().sum()).backward()
+    params = dict(blk.named_parameters())
+    names = [k[len("blk_grad."):] for k in g if k.startswith("blk_grad.")]
+    assert len(names) >= 7
+    worst = {}
+    for k in names:
+        assert params[k].grad is not None, k
+        if k.endswith("nviews.bias"):  # mathematically zero (softmax shift invariance); the kernel leaves bf16 rounding there
+            continue
+        worst[k] = rel(params[k].grad, g["blk_grad." + k])
+    print("worst:", sorted(worst.items(), key=lambda kv: -kv[1])[:4])
+    assert max(worst.values()) < 5e-2, worst

@@ -100,6 +100,39 @@ def test_nerf_module_matches_reference_golden():
 
 
 @torch.no_grad()
+def test_mask_ref_forward_matches_reference_golden():
+    """mask_ref (nerfsd_pytorch3d.py:61-70): NerfSDModule, the pose block and the tiny UNet with reference-view masks against the vectors
+    the imported reference produced (tests/golden/mask_ref.npz)."""
+    from make_golden_params import UNET_TINY
+    from sgm.modules.diffusionmodules.openaimodel import UNetModel
+    from sgm.modules.nerfsd_pytorch3d import NerfSDModule
+    g = load("mask_ref")
+    m = NerfSDModule(mode="feature-nerf", out_channels=64, far_plane=2.0, num_samples=4, rgb_predict=True, stratified=True).eval()
+    W.load_into(m, seed=1)
+    m = m.to(DEV, BF)
+    m.return_view_weights = True
+    feats, sigma, dists, attn, rgb, _, _ = m(unpack_cameras(g["nerf_cams"]), dev(g["nerf_xref"]), mask_ref=g["nerf_mask"].to(DEV))
+    assert rel(feats, g["nerf_feats"]) < TOL and rel(sigma, g["nerf_sigma"]) < TOL and rel(rgb, g["nerf_rgb"]) < TOL
+    assert rel(attn, g["nerf_view_weights"]) < TOL
+    blk = make_block(2)
+    out, fg, wts, alphas, rgb = blk(dev(g["blk_x"]), context=dev(g["blk_ctx"]), context_ref=dev(g["blk_cref"]), pose=unpack_cameras(g["blk_cams"]),
+                                    mask_ref=g["blk_mask"].to(DEV))
+    assert rel(out, g["blk_eval_out"]) < TOL and rel(fg, g["blk_eval_fg"]) < TOL and rel(alphas, g["blk_eval_alphas"]) < TOL
+    assert rel(rgb, g["blk_eval_rgb"]) < TOL
+    plain_golden = load("block_eval")  # same weights / inputs without the mask: the masked run must be the closer one by far
+    assert rel(fg, plain_golden["fg"]) > 4 * rel(fg, g["blk_eval_fg"]) and rel(rgb, plain_golden["rgb"]) > 4 * rel(rgb, g["blk_eval_rgb"])
+    u = load("unet_tiny")
+    net = UNetModel(**UNET_TINY).eval()
+    W.load_into(net, seed=5)
+    net = net.to(DEV, BF)
+    eps, fgs, _, rgbs = net(u["x"].to(DEV), timesteps=u["t"].to(DEV), context=u["ctx"].to(DEV), y=u["y"].to(DEV), pose=unpack_cameras(u["cams"]),
+                            input_ref=u["input_ref"].to(DEV), sigmas_ref=u["sigmas_ref"].to(DEV), mask_ref=g["unet_mask"].to(DEV))
+    assert rel(eps, g["unet_out"]) < 4e-2
+    for i in range(3):
+        assert rel(fgs[i], g[f"unet_fg{i}"]) < 4e-2 and rel(rgbs[i], g[f"unet_rgb{i}"]) < 4e-2
+
+
+@torch.no_grad()
 def test_spatial_transformer_dual_stream_matches_reference_golden():
     g = load("st_dual")
     st = make_st(3)
@@ -235,6 +268,35 @@ def test_cfg_branch_deduplication_is_bit_identical(monkeypatch):
 
 
 @torch.no_grad()
+def test_cfg_deduplication_with_three_samples_per_step(monkeypatch):
+    """Three diffusion samples per step (x batch 9 = [3 null | 3 image | 3 image+text]): the de-duplicated render batch has 6 elements,
+    which must be read as 3 null + 3 conditional, not as a 3-way batch of 2 (the layout is passed explicitly, never inferred from the
+    de-duplicated size).  Bit-identical to the path with the de-duplication switched off."""
+    from cd360 import sampling, synth
+    blk = make_block(14, C=128, heads=2, cd=32, S=6)
+    n_train, n, hw, bs = 6, 6, 256, 3
+    sampling.set_references(blk, {"": dev(W.tensor("references", (n_train + 1, hw, 128), seed=14))})
+    sampling.enable_reference_sampling(blk, list(range(n)))
+    poses = synth.pose_batch(bs, n, seed=5, n_train=n_train)
+    pose9 = poses * 3
+    x = dev(W.tensor("x", (3 * bs, hw, 128), seed=14))
+    ctx = dev(W.tensor("ctx", (3 * bs, 77, 32), seed=14))
+    assert blk._duplicate_cfg_branch(pose9, (3 * bs, n, hw, 128)) == bs
+    outs = []
+    for off in (False, True):
+        if off:
+            monkeypatch.setenv("CD360_NO_CFG_DEDUP", "1")
+        else:
+            monkeypatch.delenv("CD360_NO_CFG_DEDUP", raising=False)
+        sampling.clear_rendered_feat(blk)
+        o = blk(x, context=ctx, context_ref=x, pose=pose9)
+        outs.append((o[0], o[1], o[3], o[4], blk.rendered_feat.clone()))
+    for a, b_ in zip(*outs):
+        assert torch.equal(a, b_)
+    assert not torch.equal(outs[0][4][0], outs[0][4][bs])  # unconditional (null image) and conditional renders differ
+
+
+@torch.no_grad()
 def test_references_harvest_delta_checkpoint_and_sampling_round_trip():
     """§8 f3 on the HIP path: run the reference images through the UNet WITHOUT a pose with the harvest hooks on
     (diffusion.py:151-163), build `references` (main.py:596-607), save/load the delta checkpoint into a second UNet
@@ -331,7 +393,21 @@ def test_full_sdxl_unet_configA_matches_cpu_oracle():
     y = W.tensor("A.y", (b + b * n, 2816), seed=21)
     t, tr = torch.tensor([500.0]), torch.tensor([3.0])
     torch.set_num_threads(min(os.cpu_count() or 8, 32))
-    want, wfg, wal, wrgb = O.unet_forward(sd, x, t, ctx, y, cams=cams, input_ref=xr, sigmas_ref=tr, model_channels=320, num_samples=24, far=2.0)
+    # teacher forcing: record what every pose block of the ORACLE run was given and what its render produced, so that the HIP render
+    # can be judged on identical inputs -- separately from the drift the bf16 residual stream accumulates over 70 blocks
+    taught, orig_block = [], O.transformer_block
+
+    def recording_block(w, xin, context, heads, context_ref=None, cams=None, rendered_feat=None, **kw):
+        res = orig_block(w, xin, context, heads, context_ref=context_ref, cams=cams, rendered_feat=rendered_feat, **kw)
+        if context_ref is not None and rendered_feat is None:
+            taught.append(dict(x=xin, ctx=context, cref=context_ref, fg=res[1], alphas=res[2], rgb=res[3], xref=res[4]))
+        return res
+
+    O.transformer_block = recording_block
+    try:
+        want, wfg, wal, wrgb = O.unet_forward(sd, x, t, ctx, y, cams=cams, input_ref=xr, sigmas_ref=tr, model_channels=320, num_samples=24, far=2.0)
+    finally:
+        O.transformer_block = orig_block
     del sd
     got, fgs, als, rgbs = net(x.to(DEV), timesteps=t.to(DEV), context=ctx.to(DEV), y=y.to(DEV), pose=unpack_cameras(cams), input_ref=xr.to(DEV),
                               sigmas_ref=tr.to(DEV), mask_ref=None)
@@ -340,5 +416,23 @@ def test_full_sdxl_unet_configA_matches_cpu_oracle():
     for i in range(12):
         errs[f"fg{i}"], errs[f"rgb{i}"], errs[f"alpha{i}"] = rel(fgs[i], wfg[i]), rel(rgbs[i], wrgb[i]), rel(als[i], wal[i])
     print("full-SDXL cfg-A rel errors:", {k: round(v, 4) for k, v in errs.items()})
-    assert errs["eps"] < 6e-2, errs
-    assert max(v for k, v in errs.items() if k != "eps") < 8e-2, errs
+    # End to end the bf16 residual stream drifts over 70 transformer blocks and the renders inherit it through their inputs (alphas most:
+    # alpha = 1 - exp(-delta exp(sigma_raw)) amplifies a relative error of sigma_raw); measured eps 2.4e-2, worst alpha 4.2e-2.  The
+    # render ITSELF is within 6e-3 on identical inputs -- the teacher-forced check below, which is where the 1e-2 bar is asserted.
+    assert errs["eps"] < 4e-2, errs
+    assert max(v for k, v in errs.items() if k != "eps") < 6e-2, errs
+    # ---- the same 12 renders, teacher-forced: each HIP pose block gets the oracle's own block inputs (rounded to bf16) ----
+    from cd360 import sampling
+    blocks = [blk for _, blk in sampling.pose_blocks(net)]
+    assert len(blocks) == len(taught) == 12
+    pose = unpack_cameras(cams)
+    tf = {}
+    for i, (blk, rec) in enumerate(zip(blocks, taught)):
+        cref = rec["cref"]
+        if cref.dim() == 3:
+            cref = cref.reshape(b, cref.shape[0] // b, *cref.shape[1:])
+        xref, fg, _, al, rgb = blk.reference_attn(dev(rec["x"]), dev(cref), dev(rec["ctx"]), pose, None, None)
+        tf[i] = (rel(xref, rec["xref"]), rel(fg, rec["fg"]), rel(al, rec["alphas"]), rel(rgb, rec["rgb"]))
+    print("teacher-forced render errors (xref, fg, alphas, rgb) per pose block:", {k: tuple(round(e, 4) for e in v) for k, v in tf.items()})
+    # north_star tolerance: bf16 render outputs within 1e-2 of the reference's path on identical inputs
+    assert max(max(v) for v in tf.values()) < 1e-2, tf

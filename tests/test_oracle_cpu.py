@@ -156,6 +156,44 @@ def test_unet_pose_parameter_gradients_match_reference_autograd():
         assert (got - gg[k]).abs().max().item() < 2e-3 * scale, k
 
 
+# ------------------------------------------------------------------------------------------- mask_ref (nerfsd_pytorch3d.py:61-70)
+def test_mask_ref_matches_reference():
+    """Reference-view masks (live in config 4: data_co3d.py:485 -> loss.py:154): NerfSDModule, the pose block (eval / train), the
+    reference's own autograd gradients of the block's 'pose' parameters, and the tiny UNet -- all from the imported reference."""
+    g = load("mask_ref")
+    feats, sigma, _, attn, rgb, _ = O.nerf_module(nerf_weights(64, 1), g["nerf_cams"], g["nerf_xref"], 4, 2.0, mask_ref=g["nerf_mask"])
+    close(feats, g["nerf_feats"]); close(sigma, g["nerf_sigma"]); close(rgb, g["nerf_rgb"]); close(attn, g["nerf_view_weights"])
+    plain = O.nerf_module(nerf_weights(64, 1), g["nerf_cams"], g["nerf_xref"], 4, 2.0)[0]
+    assert not torch.allclose(plain, g["nerf_feats"], atol=1e-3), "the mask must change the render"
+    sd = W.synth_state_dict(keys("block"), seed=2)
+    for mode in ("eval", "train"):
+        jit = {} if mode == "eval" else dict(xy_jitter=(g["blk_train_jit_x"], g["blk_train_jit_y"]), depth_jitter=g["blk_train_jit_d"])
+        out, fg, alphas, rgb, _ = O.transformer_block(sd, g["blk_x"], g["blk_ctx"], 1, context_ref=g["blk_cref"], cams=g["blk_cams"],
+                                                      num_samples=4, far=2.0, mask_ref=g["blk_mask"], **jit)
+        close(out, g[f"blk_{mode}_out"], atol=1e-4); close(fg, g[f"blk_{mode}_fg"]); close(alphas, g[f"blk_{mode}_alphas"]); close(rgb, g[f"blk_{mode}_rgb"])
+    # gradients (train mode, same jitter): autograd through the oracle against the reference's autograd
+    names = [k[len("blk_grad."):] for k in g if k.startswith("blk_grad.")]
+    assert len(names) >= 7
+    sg = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    with torch.enable_grad():
+        out, fg, _, rgb, _ = O.transformer_block(sg, g["blk_x"], g["blk_ctx"], 1, context_ref=g["blk_cref"], cams=g["blk_cams"], num_samples=4,
+                                                 far=2.0, mask_ref=g["blk_mask"], xy_jitter=(g["blk_train_jit_x"], g["blk_train_jit_y"]),
+                                                 depth_jitter=g["blk_train_jit_d"])
+        cot = W.tensor("cot", tuple(out.shape), seed=2)
+        grads = torch.autograd.grad((out * cot).sum() + fg.sum() + rgb.sum(), [sg[k] for k in names], allow_unused=True)
+    for k, got in zip(names, grads):
+        want = g["blk_grad." + k]
+        got = torch.zeros_like(want) if got is None else got
+        assert (got - want).abs().max().item() < 2e-3 * max(want.abs().max().item(), 1e-3), k
+    u = load("unet_tiny")
+    sdu = W.synth_state_dict(keys("unet_tiny"), seed=5)
+    out, fgs, _, rgbs = O.unet_forward(sdu, u["x"], u["t"], u["ctx"], u["y"], cams=u["cams"], input_ref=u["input_ref"], sigmas_ref=u["sigmas_ref"],
+                                       model_channels=64, num_samples=4, far=2.0, mask_ref=g["unet_mask"])
+    close(out, g["unet_out"], atol=5e-4, rtol=1e-3)
+    for i in range(3):
+        close(fgs[i], g[f"unet_fg{i}"], atol=1e-4); close(rgbs[i], g[f"unet_rgb{i}"], atol=1e-4)
+
+
 # ------------------------------------------------------------------------------------------- conventions (Appendix B)
 def _cam(R=None, T=(0, 0, 1), f=(1, 1), pp=(0, 0)):
     R = torch.eye(3) if R is None else R
