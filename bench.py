@@ -21,7 +21,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-for p in (ROOT, os.path.join(ROOT, "custom-diffusion360_amd"), os.path.join(ROOT, "tests", "golden")):
+for p in (ROOT, os.path.join(ROOT, "custom-diffusion360_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
@@ -33,7 +33,7 @@ MFMA_BF16_PEAK_TF = 2500.0  # dense bf16 MFMA peak
 
 
 def build_model(latent: int, n_ref: int, n_train: int, device, seed: int = 0):
-    from make_golden_params import SDXL_NETWORK_CONFIG
+    from cd360.configs import SDXL_NETWORK_CONFIG
     from sgm.util import instantiate_from_config
     from cd360 import sampling
 
@@ -83,6 +83,22 @@ class Sampler:
         self.ctx, self.y = cond3["crossattn"].contiguous(), cond3["vector"].contiguous()
         self.use_graph, self.graph = use_graph, None
         self.graph_render, self.rgraph = use_graph and not os.environ.get("CD360_BENCH_EAGER_RENDER"), None
+
+    def retarget(self, pose, ctx, y):
+        """Point the sampler at another target pose / conditioning (the next pose of this rank's share).  The captured graphs read both
+        through fixed device buffers, so the new values are copied INTO them: the CFG conditioning batch, and the packed
+        [3, n+1, 16] camera tensor the render path memoises for `self.pose` (sgm/modules/utils_cameraray.py::packed_pose)."""
+        c = {"crossattn": ctx[2:3], "vector": y[2:3]}
+        uc = {"crossattn": ctx[0:1], "vector": y[0:1]}
+        _, _, cond3 = self.guider.prepare_inputs(ctx.new_zeros(1, 1), ctx.new_zeros(1), c, uc)
+        self.ctx.copy_(cond3["crossattn"])
+        self.y.copy_(cond3["vector"])
+        if self.use_graph:
+            from cd360.cameras import pack_cameras
+            from sgm.modules.utils_cameraray import packed_pose
+            packed_pose(self.pose, self.ctx.device).copy_(pack_cameras(pose, self.ctx.device))
+        else:
+            self.pose = pose
 
     def _math(self, x, s, s_next, t_unused=None):
         """One sampler step = guider.prepare_inputs -> DiscreteDenoiser (sigma -> table index, c_in) -> UNet -> fused
@@ -220,6 +236,8 @@ def main():
     ap.add_argument("--latent", type=int, default=128, help="latent side (128 = 1024^2 image)")
     ap.add_argument("--refs", type=int, default=50)
     ap.add_argument("--traj", type=int, default=50, help="sampler steps per image (render on step 0 of each)")
+    ap.add_argument("--poses", type=int, default=0, help="target poses of the whole job (default: one per GPU); P > GPUs gives every rank "
+                    "its cd360.shard.assign_poses share and runs them one after the other (BASELINE configs[2] on fewer than 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying the steady-state step from a hipGraph")
@@ -236,13 +254,19 @@ def main():
 
     from cd360 import ops, synth
 
+    from cd360 import shard
+    n_poses = args.poses or world
+    mine = shard.assign_poses(n_poses, world, rank)  # indices of the target poses this rank samples (independent trajectories)
+    assert len(mine) >= 1, "--poses must be >= --gpus"
     net = build_model(args.latent, args.refs, 50, dev)
-    pose1 = synth.pose_batch(1, args.refs, seed=100 + rank, n_train=50)  # one target pose per rank, 50 shared reference cameras
-    pose = pose1 * 3
-    g = torch.Generator(device=dev).manual_seed(7 + rank)
-    ctx = torch.randn(3, 77, 2048, generator=g, device=dev).to(torch.bfloat16)
-    y = torch.randn(3, 2816, generator=g, device=dev).to(torch.bfloat16)
-    x = torch.randn(1, 4, args.latent, args.latent, generator=g, device=dev)
+    jobs = []
+    for pi in mine:  # one target pose = one CFG-3 batch with its own latent; the 50 reference cameras are shared
+        pose = synth.pose_batch(1, args.refs, seed=100 + pi, n_train=50) * 3
+        g = torch.Generator(device=dev).manual_seed(7 + pi)
+        ctx = torch.randn(3, 77, 2048, generator=g, device=dev).to(torch.bfloat16)
+        y = torch.randn(3, 2816, generator=g, device=dev).to(torch.bfloat16)
+        jobs.append((pose, ctx, y, torch.randn(1, 4, args.latent, args.latent, generator=g, device=dev)))
+    pose, ctx, y, x = jobs[0]
     smp = Sampler(net, pose, ctx, y, args.traj, use_graph=not args.no_graph)
 
     def sync():
@@ -258,13 +282,23 @@ def main():
     sync(); t0 = time.perf_counter(); xw = smp.step(x.clone(), 0); sync(); render_ms = (time.perf_counter() - t0) * 1e3
     t0 = time.perf_counter(); xw = smp.step(xw, 1); sync(); steady_ms = (time.perf_counter() - t0) * 1e3
 
-    xs = x.clone()
+    # timed region: K steps of EVERY pose of this rank, one pose after the other (the graphs read the pose / conditioning of the job
+    # through the sampler's static buffers: switching pose = pointing the sampler at the next job and re-rendering on its step 0)
+    finals = []
     sync()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        xs = smp.step(xs, i)
+    for j, (pose_j, ctx_j, y_j, x_j) in enumerate(jobs):
+        if j > 0:
+            smp.retarget(pose_j, ctx_j, y_j)
+        xs = x_j.clone()
+        for i in range(args.steps):
+            xs = smp.step(xs, i)
+        finals.append(xs)
     sync()
     elapsed = time.perf_counter() - t0
+    steps_done = args.steps * len(jobs)
+    if len(jobs) > 1:
+        smp.retarget(*jobs[0][:3])
 
     # Per-kernel HIP-event timing: the SAME K steps replayed eagerly right after the timed region (events cannot bracket kernels
     # inside a hipGraph replay, and ~800 event records per step would otherwise sit inside the headline number).
@@ -281,47 +315,78 @@ def main():
     tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        from cd360 import shard
-        gathered = shard.gather_latents(xs, world)  # the job's one exchange: final latents of every pose
-        assert gathered.shape[0] == world and torch.isfinite(gathered).all()
+        gathered = shard.gather_latents(torch.cat(finals, 0), n_poses)  # the job's one exchange: final latents of every pose
+        assert gathered.shape[0] == n_poses and torch.isfinite(gathered).all()
     elapsed = float(tmax.item())
-    assert torch.isfinite(xs).all()
+    assert all(torch.isfinite(f).all() for f in finals)
 
+    sum_steps = args.steps * n_poses
     if rank == 0:
-        roof = None
-        if prof:
-            name = max(prof, key=lambda k: prof[k]["ms"])
+        # ---- rooflines.  `achieved` = ALGORITHMIC flops (MFMA-bound kernels) or bytes (HBM-bound) of the launches / their HIP-event time on
+        # the launch stream (ops._timed: SURVEY.md section 8d formulas, stated per kernel in DESIGN.md section 7b) ----
+        MFMA_KERNELS = {"gemm8p", "qproj_attn", "attn_self", "conv_igemm", "nerf_mlp_aggregate"}
+
+        def roofline_of(name):
             e = prof[name]
-            if e["flops"] > 0 and name in ("attn_fwd", "nerf_mlp_aggregate", "conv_igemm"):
+            if name in MFMA_KERNELS and e["flops"] > 0:
                 ach = e["flops"] / (e["ms"] * 1e-3) / 1e12
-                roof = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s",
-                        "frac": round(ach / MFMA_BF16_PEAK_TF, 4), "traffic": None, "launches": e["n"], "avg_us": round(e["ms"] * 1e3 / e["n"], 2)}
+                r = {"kernel": name, "bound": "mfma", "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TF, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TF, 4)}
             else:
                 ach = e["bytes"] / (e["ms"] * 1e-3) / 1e9
-                roof = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "launches": e["n"], "avg_us": round(e["ms"] * 1e3 / e["n"], 2)}
-            # HBM traffic per launch of that kernel comes from the committed rocprofv3 PMC passes over this same command
-            # (profiles/*_pmc_traffic.json: FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 1/2-FETCH correction applied).
-            roof["alg_bytes_per_launch"] = round(e["bytes"] / e["n"])
-            roof["alg_flops_per_launch"] = round(e["flops"] / e["n"])
+                r = {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4)}
+            r.update(traffic=None, launches=e["n"], avg_us=round(e["ms"] * 1e3 / e["n"], 2), alg_bytes_per_launch=round(e["bytes"] / e["n"]),
+                     alg_flops_per_launch=round(e["flops"] / e["n"]))
+            # HBM traffic per launch comes from the committed rocprofv3 PMC passes over this same command (profiles/*_pmc_traffic.json:
+            # FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 1/2-FETCH correction applied)
             try:
                 import glob
                 pm_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]
                 with open(pm_file) as f:
-                    roof["traffic"] = json.load(f)["kernels"][name]["hbm_bytes_per_launch"]
-                roof["traffic_source"] = os.path.relpath(pm_file, ROOT)
+                    r["traffic"] = json.load(f)["kernels"][name]["hbm_bytes_per_launch"]
+                r["traffic_source"] = os.path.relpath(pm_file, ROOT)
             except Exception:  # noqa: BLE001
-                roof["traffic"] = None
+                r["traffic"] = None
+            return r
+
+        roof, roofs = None, {}
+        if prof:
+            roof = roofline_of(max(prof, key=lambda k: prof[k]["ms"]))  # the dominant kernel of the timed steps
+            # the kernels north_star names: attention on MFMA, the FeatureNeRF render on HBM / VALU, and the whole step
+            notes = {"gemm8p": "every Linear of the transformer blocks (cd360_gemm_bf16: LayerNorm fold / GEGLU / residual epilogues)",
+                     "qproj_attn": "pose-token cross-attention A3, FUSED form: q projection + softmax(q k^T) v over 77 keys in one kernel; flops = 2 M C^2 + 4 M 77 C "
+                                   "(the out projection runs as a gemm8p launch with the residual fused); render step only",
+                     "attn_self": "self-attention attn1 (tiled flash kernel), core form 4 B H N^2 64, projections in gemm8p",
+                     "attn_smallk": "text cross-attention attn2 core over 77 keys (register-resident K / V): HBM-bound streaming of q and o",
+                     "nerf_mlp_aggregate": "FeatureNeRF gather + per-sample MLP + view softmax (A5-A8) after the algebraic restructuring: VALU-bound "
+                                           "(projection, sin / cos, bilinear blend, SiLU); flops = 2 M 99 C MFMA part only; render step only",
+                     "volrender": "volume render scan (A10), HBM-bound; render step only",
+                     "conv_igemm": "all 51 convolutions (implicit GEMM)"}
+            for k in notes:
+                if k in prof:
+                    roofs[k] = roofline_of(k)
+                    roofs[k]["what"] = notes[k]
+            # whole steady-state step: 2.03e13 FLOP per CFG-3 step at 1024^2 (FlopCounterMode on the plain UNet)
+            if args.latent == 128:
+                roofs["steady_step"] = {"bound": "mfma", "achieved": round(2.03e13 / (steady_ms * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TF,
+                                        "unit": "TFLOP/s", "frac": round(2.03e13 / (steady_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4),
+                                        "what": "2.03e13 algorithmic FLOP of one CFG-3 UNet step / steady_step_ms (hipGraph replay wall time)"}
         out = {
-            "metric": "UNet denoise steps/sec @ SDXL 1024^2, 50 ref views", "value": round(args.steps * world / elapsed, 4), "unit": "steps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "metric": "UNet denoise steps/sec @ SDXL 1024^2, 50 ref views", "value": round(sum_steps / elapsed, 4), "unit": "steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / steps_done * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "sample.py 50-step sampling, SDXL UNet (random init), latent %d^2, CFG x3, %d ref views (synthetic ring cameras), "
-                                   "1 target pose per GPU; render on step 0 of each %d-step trajectory, cached afterwards" % (args.latent, args.refs, args.traj),
+                                   "%d target pose(s) over %d GPU(s); render on step 0 of each %d-step trajectory, cached afterwards.  Untimed, once per "
+                                   "job in Sampler.prepare(): the FeatureNeRF reference tables Y = xref W1[:, :C]^T and lv (they depend on the "
+                                   "`references` buffers and weights only; the reference recomputes the equivalent inside every render) and hipGraph "
+                                   "capture.  Inside the timed render step, once per image: the text K / V projections (reused by the 49 cached steps)"
+                                   % (args.latent, args.refs, n_poses, world, args.traj),
                        "render_step_ms": round(render_ms, 2), "steady_step_ms": round(steady_ms, 2), "cfg_batch": 3, "latent": args.latent,
-                       "n_ref": args.refs, "poses_per_gpu": 1, "hipgraph": not args.no_graph, "hipgraph_render_step": smp.rgraph is not None,
+                       "n_ref": args.refs, "poses": n_poses, "poses_per_gpu": len(mine), "world_size": world,
+                       "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1, "parallelism": "pose-dp%d" % world,
+                       "hipgraph": not args.no_graph, "hipgraph_render_step": smp.rgraph is not None,
                        "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}},
             "roofline": roof,
+            "rooflines": roofs,
         }
         if world == 1 and not args.no_cpu_baseline:
             try:

@@ -106,7 +106,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, nk:
     lib = _lib.load()
     strides = (_I64x3(q.stride(0), 64, q.stride(1)), _I64x3(k.stride(0), 64, k.stride(1)),
                _I64x3(v.stride(0), 64, v.stride(1)), _I64x3(out.stride(0), 64, out.stride(1)))
-    with _timed("attn_fwd", 4.0 * b * heads * nq * nk * 64, 2.0 * (2 * b * nq * inner + 2 * b * nk * inner)):
+    # self-attention (tiled kernel) and the <= 96-key cross-attention (register-resident kernel) are different kernels: timed apart
+    with _timed("attn_self" if nk > 96 else "attn_smallk", 4.0 * b * heads * nq * nk * 64, 2.0 * (2 * b * nq * inner + 2 * b * nk * inner)):
         if want_lse:
             lse = torch.empty(b * heads, nq, dtype=torch.float32, device=q.device)
             check(lib.cd360_attn_fwd_lse_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), b, heads, nq, nk, *strides, 64 ** -0.5, _stream()),

@@ -436,3 +436,116 @@ def test_full_sdxl_unet_configA_matches_cpu_oracle():
     print("teacher-forced render errors (xref, fg, alphas, rgb) per pose block:", {k: tuple(round(e, 4) for e in v) for k, v in tf.items()})
     # north_star tolerance: bf16 render outputs within 1e-2 of the reference's path on identical inputs
     assert max(max(v) for v in tf.values()) < 1e-2, tf
+
+
+# ------------------------------------------------------------------------------------------- BASELINE configs[1] / [3] at full size
+def _sdxl_net(seed=31):
+    """Random-init SDXL UNet (the reference's network_config) with the pose path switched on (the stock init makes it a no-op, F7)."""
+    from cd360 import sampling
+    from cd360.configs import SDXL_NETWORK_CONFIG
+    from sgm.util import instantiate_from_config
+    torch.manual_seed(seed)
+    with torch.device(DEV):
+        net = instantiate_from_config(SDXL_NETWORK_CONFIG)
+    net = net.to(BF)
+    g = torch.Generator(device=DEV).manual_seed(seed + 1)
+    with torch.no_grad():
+        for _, blk in sampling.pose_blocks(net):
+            c = blk.pose_emb_layers.weight.shape[0]
+            blk.pose_emb_layers.weight.add_(torch.randn(c, 2 * c, generator=g, device=DEV).mul_(0.02).to(BF))
+            blk.pose_featurenerf.model.decoder.weight.copy_(torch.randn(4, c, generator=g, device=DEV).mul_(0.02))
+        for m in net.modules():
+            if m.__class__.__name__ == "SpatialTransformer":
+                m.proj_out.weight.copy_(torch.randn(m.proj_out.weight.shape, generator=g, device=DEV).mul_(0.02))
+        net.out[-1].weight.copy_(torch.randn(net.out[-1].weight.shape, generator=g, device=DEV).mul_(0.02))  # zero_module: eps would be 0
+    return net, g
+
+
+@torch.no_grad()
+def test_cfgB_level2_sampling_block_n50_cached_equals_uncached():
+    """BASELINE configs[1] shape for one LEVEL-2 pose block: C=1280, r=32 (hw=1024), S=24, n=50 references, CFG batch 3 -- the same
+    size-independent properties as the level-1 test (cached == re-rendered, render independent of x, conditional thirds agree,
+    unconditional differs, outputs finite and in range)."""
+    from cd360 import sampling, synth
+    blk = make_block(15, C=1280, heads=20, cd=2048, S=24)
+    n_train, n, hw = 50, 50, 1024
+    sampling.set_references(blk, {"": dev(W.tensor("references", (n_train + 1, hw, 1280), seed=15))})
+    sampling.enable_reference_sampling(blk, list(range(n)))
+    pose = synth.pose_batch(1, n, seed=10, n_train=n_train) * 3
+    ctx = dev(W.tensor("ctx", (1, 77, 2048), seed=15)).expand(3, -1, -1).contiguous()
+    x = dev(W.tensor("x", (1, hw, 1280), seed=15)).expand(3, -1, -1).contiguous()
+    out_a, fg, _, alphas, rgb = blk(x, context=ctx, context_ref=x, pose=pose)
+    rend = blk.rendered_feat.clone()
+    assert torch.equal(out_a, blk(x, context=ctx, context_ref=x, pose=pose)[0])  # cached step
+    sampling.clear_rendered_feat(blk)
+    out_c = blk(x * 0.5, context=ctx, context_ref=x, pose=pose)[0]
+    assert torch.equal(blk.rendered_feat, rend) and torch.isfinite(out_c.float()).all()
+    assert float(fg.min()) >= -1e-5 and float(fg.max()) <= 1 + 1e-4 and float(alphas.min()) >= 0 and float(alphas.max()) <= 1
+    assert float(rgb.min()) >= 0 and float(rgb.max()) <= 1 + 1e-4
+    assert rel(rend[1], rend[2]) < 2e-2 and rel(rend[0], rend[1]) > 5e-2 and rel(out_a[1], out_a[2]) < 2e-2
+
+
+@torch.no_grad()
+def test_cfgB_full_unet_sampling_step_properties():
+    """BASELINE configs[1]: ONE full UNet denoise step of sample.py's path at 1024^2 -- latent 128^2, CFG batch 3, 50 reference views from
+    synthetic `references`, all 12 FeatureNeRF renders -- then a cached step.  No oracle at this size, so properties: a cached step on
+    the same input reproduces the render step bit for bit; the two image-conditional thirds (identical inputs) agree to bf16 round-off
+    while the unconditional third differs; every output is finite; 12 renders were produced and stayed cached."""
+    from cd360 import sampling, synth
+    net, g = _sdxl_net()
+    net.eval()
+    L, n = 128, 50
+    refs = {}
+    for name, blk in sampling.pose_blocks(net):
+        c = blk.pose_emb_layers.weight.shape[0]
+        r = L // 2 if c == 640 else L // 4
+        refs[name] = torch.randn(n + 1, r * r, c, generator=g, device=DEV).to(BF)
+    sampling.set_references(net, refs)
+    sampling.enable_reference_sampling(net, list(range(n)))
+    pose = synth.pose_batch(1, n, seed=12, n_train=n) * 3
+    x = torch.randn(1, 4, L, L, generator=g, device=DEV).expand(3, -1, -1, -1).contiguous()
+    ctx1 = torch.randn(2, 77, 2048, generator=g, device=DEV).to(BF)
+    y1 = torch.randn(2, 2816, generator=g, device=DEV).to(BF)
+    ctx, y = torch.cat([ctx1[:1], ctx1[:1], ctx1[1:]], 0), torch.cat([y1[:1], y1[:1], y1[1:]], 0)  # (uc, uc, c) of the 3-way guider
+    t = torch.full((3,), 500.0, device=DEV)
+    eps_a, fgs, alphas, rgbs = net(x, timesteps=t, context=ctx, y=y, pose=pose)
+    assert len(fgs) == 12 and len(alphas) == 12 and len(rgbs) == 12
+    blocks = [blk for _, blk in sampling.pose_blocks(net)]
+    assert all(blk.rendered_feat is not None for blk in blocks)
+    eps_b = net(x, timesteps=t, context=ctx, y=y, pose=pose)[0]  # cached render
+    assert torch.equal(eps_a, eps_b)
+    assert torch.isfinite(eps_a).all() and all(torch.isfinite(f.float()).all() for f in fgs + rgbs)
+    assert all(float(f.min()) >= -1e-5 and float(f.max()) <= 1 + 1e-4 for f in fgs)
+    # thirds 0 and 1 share the text conditioning and differ in the image conditioning (null image vs references); thirds 1 and 2 share
+    # the references and differ in the text: all three must be distinct, and the renders of thirds 1 and 2 must coincide before the text
+    for blk in blocks:
+        rf = blk.rendered_feat
+        assert rel(rf[0], rf[1]) > 1e-2
+    assert rel(eps_a[0], eps_a[1]) > 1e-3 and rel(eps_a[1], eps_a[2]) > 1e-3
+
+
+def test_config4_sdxl_size_train_step_reduces_the_loss():
+    """BASELINE configs[3] at SDXL width and depth (tools/bench_train.py's shapes, batch 2 to keep the test short): train mode
+    (stratified jitter), trainkeys = pose, forward + the four-term loss + backward through the HIP kernels + AdamW on fp32 masters.
+    The loss of the fixed synthetic batch must fall over four steps, every trainable gradient must be finite and non-zero."""
+    from cd360 import finetune, synth
+    from make_golden_params import LOSS_CFG
+    from sgm.util import instantiate_from_config
+    net, g = _sdxl_net(seed=41)
+    net.train()
+    names = finetune.select_trainable(net, "pose")
+    assert len(names) == 96
+    opt = finetune.MasterAdamW(finetune.optimizer_param_groups(net, "pose", lr=1e-4), lr=1e-4)
+    loss_fn = instantiate_from_config({"target": "sgm.modules.diffusionmodules.loss.StandardDiffusionLossImgRef", "params": LOSS_CFG})
+    b, n, L = 2, 4, 64
+    rn = lambda *s: torch.randn(*s, generator=g, device=DEV)
+    batch = dict(noised=rn(b, 4, L, L), timesteps=torch.full((b,), 500.0, device=DEV), context=rn(b + b * n, 77, 2048), y=rn(b + b * n, 2816),
+                 pose=synth.pose_batch(b, n, seed=3), input_ref=rn(b, n, 4, L, L), sigmas_ref=torch.full((b,), 3.0, device=DEV),
+                 target=rn(b, 4, L, L), target_rgb=rn(b, 3, 8 * L, 8 * L).clamp(-1, 1), w=torch.full((b, 1, 1, 1), 0.7, device=DEV),
+                 mask=torch.ones(b, 1, L, L, device=DEV), opacity=torch.sigmoid(3 * rn(b, 1, 8 * L, 8 * L)))
+    losses = [float(finetune.train_step(net, loss_fn, opt, **batch)[0]) for _ in range(4)]
+    print("config-4 losses:", [round(v, 4) for v in losses])
+    assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0]
+    params = dict(net.named_parameters())
+    assert all(params[k].grad is not None and torch.isfinite(params[k].grad.float()).all() for k in names)
+    assert sum(float(params[k].grad.float().abs().sum()) > 0 for k in names) >= len(names) - 12  # nviews.bias has a zero gradient
