@@ -232,3 +232,32 @@ def test_product_package_never_touches_the_oracle():
                 if re.search(r"^\s*(from|import)\s+oracle\b", src, re.M) or "oracle." in src.replace("oracle/pose_path.py", ""):
                     offenders.append(os.path.join(d, f))
     assert not offenders, offenders
+
+
+def test_layernorm_fold_and_geglu_packing_algebra():
+    """Host side of cd360_gemm_bf16's fused epilogues (CPU math only): ops.pack_ln_linear gives (W', rowsum(W'), c) with
+    LN(x) W^T + b == rstd (x W'^T - mu rowsum(W')) + c, and ops.geglu_row_order interleaves value / gate rows per 32 output columns."""
+    import torch.nn.functional as F
+    from cd360 import ops
+    g = torch.Generator().manual_seed(0)
+    K, N, M = 64, 128, 40
+    x = torch.randn(M, K, generator=g) * 1.7 + 0.3
+    w, b = torch.randn(N, K, generator=g) / 8, torch.randn(N, generator=g)
+    gamma, beta = 1 + 0.2 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    wp, wsum, cb = ops.pack_ln_linear(w, b, gamma, beta)
+    assert wp.dtype == torch.bfloat16 and wsum.dtype == torch.float32 and cb.dtype == torch.float32
+    mu, var = x.mean(1, keepdim=True), x.var(1, unbiased=False, keepdim=True)
+    rstd = torch.rsqrt(var + 1e-5)
+    folded = rstd * (x @ wp.float().t() - mu * wsum[None]) + cb[None]
+    want = F.linear(F.layer_norm(x, (K,), gamma, beta, 1e-5), w, b)
+    assert (folded - want).abs().max() < 2e-2 * want.abs().max()  # only the bf16 rounding of gamma o W separates them
+    exact = rstd * (x @ (w * gamma[None]).t() - mu * (w * gamma[None]).sum(1)[None]) + cb[None]
+    assert torch.allclose(exact, want, atol=1e-4, rtol=1e-4)       # the identity itself, without that rounding
+    # row statistics as the kernel's epilogue forms them: sum and sum of squares per row
+    assert torch.allclose(mu[:, 0], x.sum(1) / K) and torch.allclose(var[:, 0], (x * x).sum(1) / K - mu[:, 0] ** 2, atol=1e-5)
+    inner = 96
+    perm = ops.geglu_row_order(inner)
+    assert sorted(perm.tolist()) == list(range(2 * inner))
+    for grp in range(inner // 32):
+        blk = perm[grp * 64:(grp + 1) * 64]
+        assert blk[:32].tolist() == list(range(grp * 32, grp * 32 + 32)) and blk[32:].tolist() == list(range(inner + grp * 32, inner + grp * 32 + 32))
