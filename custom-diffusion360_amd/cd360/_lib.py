@@ -26,6 +26,7 @@ SIGNATURES = {
     "cd360_ray_project_index": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "cd360_feature_gather": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "cd360_plucker_features": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "cd360_plucker_features_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "cd360_nerf_k_padded": (c_int, []),
     "cd360_nerf_mlp_aggregate": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "cd360_nerf_mlp_aggregate_bwd": (c_int, [_P, _P, _P, _P, c_int] + [_P] * 15 + [c_int] * 5 + [_P]),

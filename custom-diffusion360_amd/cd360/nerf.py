@@ -15,6 +15,7 @@ reference's per-sample Linear) and the rest happens inside one HIP kernel (csrc/
 from __future__ import annotations
 
 import math
+import os
 from typing import Optional
 
 import numpy as np
@@ -85,6 +86,14 @@ class FusedNerfWeights:
         self.v_otgt_enc = wvf[C + 102:C + 198].contiguous()
         self.bv = bv.float().reshape(())
         self.Wd = Wd.float().contiguous()  # [4, C]
+        if not live:  # Linear-layout bf16 copies for the table GEMMs on cd360_gemm_bf16 (inference)
+            self.Wf = W1f[:, :C].contiguous().to(torch.bfloat16)                      # [C, C]:   Y = xref Wf^T
+            wp = torch.zeros(C, 128, dtype=torch.float32, device=dev)
+            wp[:, :99] = W1f[:, C + 99:C + 198]
+            self.Wp = wp.to(torch.bfloat16).contiguous()                               # [C, 128]: zP = plucker Wp^T + b1
+            self.W2 = W2.detach().to(torch.bfloat16).contiguous()                      # [C, C]:   h = g W2^T + b2
+            self.b2_f32 = b2.detach().float().contiguous()
+        self.live = live
 
 
 _grid_cache = {}
@@ -149,8 +158,14 @@ def fused_feature_nerf(fw: FusedNerfWeights, cams: torch.Tensor, xref: Optional[
     xs = patch_positions(r, dev, None if xy_jitter is None else xy_jitter[0])
     ys = patch_positions(r, dev, None if xy_jitter is None else xy_jitter[1])
     t, dists = depth_samples(num_samples, far, near, dev, hw, depth_jitter)
-    pf = ops.plucker_features(cams, xs, ys).reshape(b * n * hw, 104)
-    zP = torch.addmm(fw.b1, pf, fw.Wp_t).to(torch.bfloat16).reshape(b * n, hw, C)
+    # no gradient recorded (sampling, eval): the three table GEMMs run on cd360_gemm_bf16 -- Plucker features written as bf16 rows of
+    # 128 by their kernel (no fp32 intermediate, no cast pass), bias fused; under autograd they stay on torch (fp32 features)
+    fused = not torch.is_grad_enabled() and not fw.live and C % 64 == 0 and not os.environ.get("CD360_LIBRARY_LINEAR")
+    if fused:
+        zP = ops.gemm(ops.plucker_features_bf16(cams, xs, ys).reshape(b * n * hw, 128), fw.Wp, bias=fw.b1).reshape(b * n, hw, C)
+    else:
+        pf = ops.plucker_features(cams, xs, ys).reshape(b * n * hw, 104)
+        zP = torch.addmm(fw.b1, pf, fw.Wp_t).to(torch.bfloat16).reshape(b * n, hw, C)
     cview = view_constants(fw, cams)
     if tables is None and torch.is_grad_enabled() and any(w.requires_grad for w in (fw.Wf_t, fw.vf, fw.Wk, zP, cview)):
         # training: live weights; the render and its backward go through grad.NerfRenderFn (no table scatters)
@@ -162,7 +177,10 @@ def fused_feature_nerf(fw: FusedNerfWeights, cams: torch.Tensor, xref: Optional[
         Y, lv = tables[0], tables[1]
         img_map = tables[2] if len(tables) > 2 else None
         g, logits, lse = ops.nerf_mlp_aggregate(cams, xs, ys, t, Y, zP, lv, cview, fw.Wk, want_logits=want_view_weights, img_map=img_map)
-    h = torch.addmm(fw.b2, g.reshape(-1, C), fw.W2_t).reshape(b, hw, num_samples, C)
+    if fused:
+        h = ops.gemm(g.reshape(-1, C), fw.W2, bias=fw.b2_f32).reshape(b, hw, num_samples, C)
+    else:
+        h = torch.addmm(fw.b2, g.reshape(-1, C), fw.W2_t).reshape(b, hw, num_samples, C)
     dec = ops.rowdot4(h, fw.Wd)
     vw = None
     if want_view_weights:
@@ -175,6 +193,9 @@ def reference_tables(fw: FusedNerfWeights, xref: torch.Tensor):
     Y = xref @ Wf^T (bf16) and lv = xref @ vf (fp32)."""
     b, n, hw, C = xref.shape
     x2 = xref.reshape(b * n * hw, C)
-    Y = torch.mm(x2.to(fw.Wf_t.dtype), fw.Wf_t).reshape(b * n, hw, C)
+    if x2.is_cuda and x2.dtype == torch.bfloat16 and not torch.is_grad_enabled() and not fw.live and C % 64 == 0 and not os.environ.get("CD360_LIBRARY_LINEAR"):
+        Y = ops.gemm(x2.contiguous(), fw.Wf).reshape(b * n, hw, C)
+    else:
+        Y = torch.mm(x2.to(fw.Wf_t.dtype), fw.Wf_t).reshape(b * n, hw, C)
     lv = torch.mv(x2.float(), fw.vf).reshape(b * n, hw)
     return Y.contiguous(), lv.contiguous()

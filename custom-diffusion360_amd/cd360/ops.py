@@ -252,6 +252,17 @@ def plucker_features(cams, xs, ys) -> torch.Tensor:
     return out
 
 
+def plucker_features_bf16(cams, xs, ys) -> torch.Tensor:
+    """plucker_features as bf16 rows of 128 (99 values + zero pad): the A operand of the zP table GEMM on gemm()."""
+    _need_gpu(cams, xs, ys)
+    b, n1, _ = cams.shape
+    r = xs.numel()
+    out = torch.empty(b, n1 - 1, r * r, 128, dtype=torch.bfloat16, device=cams.device)
+    with _timed("plucker_features", 0.0, 2.0 * 128 * b * (n1 - 1) * r * r):
+        check(_lib.load().cd360_plucker_features_bf16(_ptr(cams), _ptr(xs), _ptr(ys), _ptr(out), b, n1 - 1, r, _stream()), "cd360_plucker_features_bf16")
+    return out
+
+
 def nerf_k_padded() -> int:
     return _lib.load().cd360_nerf_k_padded()
 

@@ -215,8 +215,11 @@ __global__ __launch_bounds__(256, 2) void nerf_fused_kernel(NerfParams p) {
 
 // (view, ray)-only inputs of plane_coefs.0: [enc8(plucker(target ray in ref-i frame)) 96 | dir 3]
 // (nerfsd_pytorch3d.py:104-112,130-131; utils_cameraray.py:201-242,270-292).  out [b, n, hw, 104] fp32 (99 + 5 zero pad)
+// BF = false: out [b, n, hw, 104] fp32 (99 + 5 zero pad); BF = true: out [b, n, hw, 128] bf16 (99 + 29 zero pad) -- the A operand of
+// the zP = [enc8(plucker), dir] Wp^T + b1 table GEMM on cd360_gemm_bf16 (K % 64 == 0), written once instead of fp32 + a cast pass
+template <bool BF>
 __global__ void plucker_features_kernel(const float* __restrict__ cams, const float* __restrict__ xs, const float* __restrict__ ys,
-                                        float* __restrict__ out, int b, int n, int r) {
+                                        void* __restrict__ out_, int b, int n, int r) {
   const int hw = r * r;
   const long gid = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (long)b * n * hw) return;
@@ -232,31 +235,54 @@ __global__ void plucker_features_kernel(const float* __restrict__ cams, const fl
   v[3] = co[1] * v[2] - co[2] * v[1];
   v[4] = co[2] * v[0] - co[0] * v[2];
   v[5] = co[0] * v[1] - co[1] * v[0];
-  float* dst = out + gid * 104;
+  float f[104];
 #pragma unroll
   for (int kf = 0; kf < 8; ++kf) {
     const float freq = __builtin_bit_cast(float, (uint32_t)((127 + kf - 4) << 23)) * 3.14159274101257324f;
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       const float arg = v[c] * freq;
-      dst[kf * 6 + c] = sinf(arg);
-      dst[48 + kf * 6 + c] = cosf(arg);
+      f[kf * 6 + c] = sinf(arg);
+      f[48 + kf * 6 + c] = cosf(arg);
     }
   }
-  dst[96] = cd[0]; dst[97] = cd[1]; dst[98] = cd[2];
+  f[96] = cd[0]; f[97] = cd[1]; f[98] = cd[2];
 #pragma unroll
-  for (int j = 99; j < 104; ++j) dst[j] = 0.f;
+  for (int j = 99; j < 104; ++j) f[j] = 0.f;
+  if (BF) {
+    uint32_t* dst = reinterpret_cast<uint32_t*>(out_) + gid * 64;
+#pragma unroll
+    for (int j = 0; j < 52; ++j) dst[j] = pack_bf16x2(f[2 * j], f[2 * j + 1]);
+#pragma unroll
+    for (int j = 52; j < 64; ++j) dst[j] = 0u;
+  } else {
+    float* dst = reinterpret_cast<float*>(out_) + gid * 104;
+#pragma unroll
+    for (int j = 0; j < 104; ++j) dst[j] = f[j];
+  }
 }
 
 }  // namespace
 
-extern "C" int cd360_plucker_features(const void* cams, const void* xs, const void* ys, void* out, int b, int n, int r, void* stream) {
+static int plucker_launch(bool bf, const void* cams, const void* xs, const void* ys, void* out, int b, int n, int r, void* stream) {
   if (!cams || !xs || !ys || !out || b <= 0 || n <= 0 || r <= 0) return CD360_ERR_ARG;
   const long total = (long)b * n * r * r;
-  hipLaunchKernelGGL(plucker_features_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const float*)cams, (const float*)xs, (const float*)ys, (float*)out, b, n, r);
+  if (bf) hipLaunchKernelGGL(plucker_features_kernel<true>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                             (const float*)cams, (const float*)xs, (const float*)ys, out, b, n, r);
+  else hipLaunchKernelGGL(plucker_features_kernel<false>, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                          (const float*)cams, (const float*)xs, (const float*)ys, out, b, n, r);
   CD360_LAUNCH_CHECK();
   return CD360_OK;
+}
+
+extern "C" int cd360_plucker_features(const void* cams, const void* xs, const void* ys, void* out, int b, int n, int r, void* stream) {
+  return plucker_launch(false, cams, xs, ys, out, b, n, r, stream);
+}
+
+// The same features as bf16 rows of 128 (99 values + zero pad): the A operand of the zP table GEMM on cd360_gemm_bf16
+extern "C" int cd360_plucker_features_bf16(const void* cams, const void* xs, const void* ys, void* out, int b, int n, int r, void* stream) {
+  if ((uintptr_t)out % 16) return CD360_ERR_ARG;
+  return plucker_launch(true, cams, xs, ys, out, b, n, r, stream);
 }
 
 extern "C" int cd360_nerf_k_padded(void) { return KP; }

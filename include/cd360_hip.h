@@ -97,6 +97,9 @@ int cd360_feature_gather(const void* xref, const void* grid, void* out, int n_im
  *   logits [b, n, hw*S] fp32 and lse [b, hw*S, 2] = (max, sum) are optional (NULL to skip).  C % 64 == 0. */
 int cd360_plucker_features(const void* cams, const void* xs, const void* ys, void* out /* [b, n, hw, 104] fp32 */, int b, int n, int r,
                            void* stream);
+/* the same features written as bf16 rows of 128 (99 values + zero pad), 16-byte aligned: the A operand of the table GEMM
+ * zP = [enc8(plucker), dir] Wp^T + b1 on cd360_gemm_bf16 (no fp32 intermediate, no cast pass) */
+int cd360_plucker_features_bf16(const void* cams, const void* xs, const void* ys, void* out, int b, int n, int r, void* stream);
 int cd360_nerf_k_padded(void);
 int cd360_nerf_mlp_aggregate(const void* cams, const void* xs, const void* ys, const void* t, int t_ray_stride, const void* Y,
                              const void* zP, const void* lv, const void* cview, const void* Wk, const void* img_map, void* g, void* logits,
