@@ -18,6 +18,7 @@ _I64P = ctypes.POINTER(c_int64)
 # name -> (restype, argtypes); must list every symbol of include/cd360_hip.h
 SIGNATURES = {
     "cd360_attn_fwd_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _I64P, _I64P, _I64P, _I64P, c_float, _P]),
+    "cd360_attn_fwd_prescaled_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _I64P, _I64P, _I64P, _I64P, _P]),
     "cd360_attn_fwd_fp8mfma_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _I64P, _I64P, _I64P, _I64P, c_float, _F32P, _P]),
     "cd360_attn_fwd_lse_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, _I64P, _I64P, _I64P, _I64P, c_float, _P]),
     "cd360_attn_bwd_bf16": (c_int, [_P] * 10 + [c_int] * 4 + [_I64P] * 8 + [c_float, _P]),

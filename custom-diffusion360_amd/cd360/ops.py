@@ -85,15 +85,20 @@ def _wants_grad(*ts) -> bool:
 
 
 # ----------------------------------------------------------------------------------------------- attention
+ATTN_PRESCALE = 64 ** -0.5 * 1.4426950408889634  # softmax scale x log2(e): what attention(..., prescaled=True) expects folded into q
+
+
 def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, nk: Optional[int] = None,
-              out: Optional[torch.Tensor] = None, want_lse: bool = False):
+              out: Optional[torch.Tensor] = None, want_lse: bool = False, prescaled: bool = False):
     """softmax(q k^T / 8) v per head, projection layouts consumed in place.
     q [b, Nq, H*64], k, v [b, >=Nk, H*64] (last dim contiguous; row / batch strides free, e.g. slices of one merged q|k|v
     projection) -> [b, Nq, H*64].  `nk` limits the keys when k / v are padded.  want_lse=True returns (out, lse [b*H, Nq] fp32),
-    the training forward (cd360_attn_fwd_lse_bf16).  Differentiable: under autograd the call is recorded (grad.AttentionFn)."""
+    the training forward (cd360_attn_fwd_lse_bf16).  Differentiable: under autograd the call is recorded (grad.AttentionFn).
+    prescaled=True: q already carries ATTN_PRESCALE (folded into the q projection by the caller; cd360_attn_fwd_prescaled_bf16) --
+    forward only."""
     if _wants_grad(q, k, v):
         from . import grad
-        assert out is None and not want_lse
+        assert out is None and not want_lse and not prescaled
         return grad.AttentionFn.apply(q, k, v, heads, nk)
     _need_gpu(q, k, v)
     b, nq, inner = q.shape
@@ -108,6 +113,11 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, heads: int, nk:
                _I64x3(v.stride(0), 64, v.stride(1)), _I64x3(out.stride(0), 64, out.stride(1)))
     # self-attention (tiled kernel) and the <= 96-key cross-attention (register-resident kernel) are different kernels: timed apart
     with _timed("attn_self" if nk > 96 else "attn_smallk", 4.0 * b * heads * nq * nk * 64, 2.0 * (2 * b * nq * inner + 2 * b * nk * inner)):
+        if prescaled:
+            assert not want_lse
+            check(lib.cd360_attn_fwd_prescaled_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), b, heads, nq, nk, *strides, _stream()),
+                  "cd360_attn_fwd_prescaled_bf16")
+            return out
         if want_lse:
             lse = torch.empty(b * heads, nq, dtype=torch.float32, device=q.device)
             check(lib.cd360_attn_fwd_lse_bf16(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(lse), b, heads, nq, nk, *strides, 64 ** -0.5, _stream()),

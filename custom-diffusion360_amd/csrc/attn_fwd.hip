@@ -20,6 +20,8 @@
 #include "cd360_common.h"
 #include <stdlib.h>
 
+#define LDS_AS3(p) ((__attribute__((address_space(3))) void*)(p))
+
 namespace {
 
 struct AttnParams {
@@ -295,6 +297,242 @@ __global__ __launch_bounds__(256, 3) void attn_fwd_kernel(AttnParams p) {
   }
 }
 
+// ---- self-attention, second generation (Nq % (128 QB) == 0, Nk % 64 == 0) -----------------------------------------------------------
+// At head dim 64 the softmax, not the MFMA, is the long pole of the tile above: per 32 x 32 block of scores 8 MFMAs (256 cycles of the
+// matrix pipe) stand against max + scale + exp + sum + pack + rescale-O = ~6 VALU instructions per score (~350 issue cycles).  This
+// kernel removes three of them and takes the staging work off the VALU:
+//   * q is scaled by (scale log2 e) once, when its fragments are built: the scores leave the MFMA in exp2 units;
+//   * the running maximum is LAZY: the accumulator of S^T = K Q^T starts at -m_ref (a 16-register tuple per query block that is
+//     only rewritten when m_ref moves), so p = exp2(S') needs no subtract; m_ref moves -- and O, l and the scores at hand are rescaled,
+//     in a wave-uniform rarely taken branch -- only when a tile's maximum exceeds it by more than 2^8 (p <= 256: harmless in bf16 /
+//     fp32, the final O / l is independent of m_ref).  The per-tile O *= alpha is gone;
+//   * max by v_max3_f32, the row sum stays per lane until the end (no per-tile exchange with lane ^ 32);
+//   * K / V tiles travel L2 -> LDS by LDS-DMA into a 4-deep ring (two tiles in flight, no staging registers, no LDS-write pass);
+//     the XOR swizzles of the two tiles are applied on the per-lane SOURCE address (the DMA destination is lane-linear);
+//   * software pipeline inside the wave: the S^T MFMAs of tile t+1 are issued before the softmax of tile t, whose VALU work
+//     runs under them, then P V of tile t.  One workgroup barrier per tile.
+// QB = query blocks (32 rows) per wave: 2 halves the LDS fragment traffic per MFMA (K and V^T fragments serve both blocks) and is
+// used when the launch still fills the chip (the 64^2 level), 1 otherwise.
+// NW = waves per workgroup (4 | 8): the K / V tile and its DMA pieces are shared by NW * 32 * QB queries.
+template <int QB, int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attn_self_kernel(AttnParams p) {
+  constexpr int NB = 4;           // ring slots: tiles t, t+1 in use, t+2 landing, t+3 being issued
+  constexpr bool PIPE = QB == 1;  // two query blocks leave no registers for the look-ahead scores: the second wave of the SIMD covers
+  constexpr int PPT = 8 / NW;     // DMA pieces per thread, tile and operand (a piece of the workgroup = NW * 8 rows)
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[NB * TILE_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int bh = tile / p.n_qtiles, qt = tile - bh * p.n_qtiles;
+  const int b = bh / p.H, h = bh - b * p.H;
+  const uint16_t* qp = p.q + b * p.q_sb + h * p.q_sh;
+  const uint16_t* kp = p.k + b * p.k_sb + h * p.k_sh;
+  const uint16_t* vp = p.v + b * p.v_sb + h * p.v_sh;
+  uint16_t* op = p.o + b * p.o_sb + h * p.o_sh;
+  const float c = p.scale_log2e;
+
+  // ---- Q fragments, pre-scaled ----
+  bf16x8 qf[QB][4];
+  const int qrow0 = qt * (NW * 32 * QB) + wave * (32 * QB) + l31;
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(qp + (long)(qrow0 + 32 * qb) * p.q_sn + 16 * ks + 8 * hh);
+      u32x4 o;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) o[i] = pack_bf16x2(bf16lo_to_f32(v[i]) * c, bf16hi_to_f32(v[i]) * c);
+      qf[qb][ks] = __builtin_bit_cast(bf16x8, o);
+    }
+
+  // ---- LDS-DMA geometry: piece j of a tile covers rows 32 j + tid / 8; LDS chunk tid % 8 <- source chunk ^ swizzle(row) ----
+  const __amdgpu_buffer_rsrc_t krsrc = __builtin_amdgcn_make_buffer_rsrc((void*)kp, 0, (int)((long)p.Nk * p.k_sn * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t vrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)vp, 0, (int)((long)p.Nk * p.v_sn * 2), 0x00020000);
+  const int srow = tid >> 3, sch = tid & 7;
+  const uint32_t kgo = (uint32_t)(srow * p.k_sn * 2) + (uint32_t)((sch ^ ((srow >> 1) & 7)) << 4);
+  const uint32_t vgo = (uint32_t)(srow * p.v_sn * 2) + (uint32_t)((sch ^ (((srow >> 1) & 3) << 1)) << 4);
+  const uint32_t kpass = (uint32_t)(NW * 8 * p.k_sn * 2), vpass = (uint32_t)(NW * 8 * p.v_sn * 2);
+  const uint32_t kstep = (uint32_t)(BN * p.k_sn * 2), vstep = (uint32_t)(BN * p.v_sn * 2);
+  unsigned char* const dma_base = lds + wave * 1024;
+  auto issue = [&](int t) {  // K rows then V rows of tile t into ring slot t % NB, PPT pieces each
+    unsigned char* slot = dma_base + (t % NB) * TILE_BYTES;
+#pragma unroll
+    for (int j = 0; j < PPT; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(krsrc, LDS_AS3(slot + j * (NW * 1024)), 16, kgo, t * kstep + j * kpass, 0, 0);
+#pragma unroll
+    for (int j = 0; j < PPT; ++j)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(vrsrc, LDS_AS3(slot + BN * K_PITCH + j * (NW * 1024)), 16, vgo, t * vstep + j * vpass, 0, 0);
+  };
+  auto wait_tiles_in_flight = [&](int later) {  // all but the `later` most recent tiles have landed
+    if (later <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PPT) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * PPT) : "memory");
+  };
+
+  // per-lane fragment offsets inside a tile
+  int koff[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) koff[ks] = l31 * K_PITCH + (((2 * ks + hh) ^ ((l31 >> 1) & 7)) << 4);
+  const int voff[2] = {BN * K_PITCH + v_frag_offset(l31, hh, 0), BN * K_PITCH + v_frag_offset(l31, hh, 1)};
+
+  f32x16 negm[QB], oT[QB][2], sc[QB][2], sn[PIPE ? QB : 1][2];
+  float l_run[QB];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    l_run[qb] = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { negm[qb][i] = 0.f; oT[qb][0][i] = 0.f; oT[qb][1][i] = 0.f; }
+  }
+
+  auto qk = [&](const unsigned char* T, auto& s) {  // S'^T = K Q^T - m_ref for one tile
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(T + kb * 32 * K_PITCH + koff[ks]);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) s[qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, qf[qb][ks], ks == 0 ? negm[qb] : s[qb][kb], 0, 0, 0);
+      }
+  };
+
+  const int n_tiles = p.Nk / BN;
+  // tile maximum of one query block (this lane's column; both key halves through lane ^ 32)
+  auto tile_max = [&](const f32x16 (&s)[2]) {
+    float m[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[j] = fmaxf(fmaxf(s[j >> 1][8 * (j & 1)], s[j >> 1][8 * (j & 1) + 1]), s[j >> 1][8 * (j & 1) + 2]);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      m[j] = fmaxf(fmaxf(m[j], s[j >> 1][8 * (j & 1) + 3]), s[j >> 1][8 * (j & 1) + 4]);
+      m[j] = fmaxf(fmaxf(m[j], s[j >> 1][8 * (j & 1) + 5]), s[j >> 1][8 * (j & 1) + 6]);
+    }
+    const float ma = fmaxf(fmaxf(m[0], m[1]), s[0][7]), mb = fmaxf(fmaxf(m[2], m[3]), s[0][15]);
+    const float mx = fmaxf(fmaxf(ma, mb), fmaxf(s[1][7], s[1][15]));
+    return fmaxf(mx, __shfl_xor(mx, 32));
+  };
+  // the rare path: move m_ref of query block qb by d (>= 0 except on the first tile) and rescale what hangs on it
+  auto move_ref = [&](int qb, float d, f32x16 (&s)[2]) {
+    const float alpha = __builtin_amdgcn_exp2f(-d);
+    l_run[qb] *= alpha;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+      negm[qb][i] -= d;
+      s[0][i] -= d; s[1][i] -= d;
+      oT[qb][0][i] *= alpha; oT[qb][1][i] *= alpha;
+    }
+  };
+  // p = exp2(S') of tile scores s -> packed bf16 P (MFMA B operand order), row sum into l_run
+  auto softmax_p = [&](int qb, const f32x16 (&s)[2], uint32_t (&pk)[16]) {
+    float r0 = 0.f, r1 = 0.f;
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int r = 0; r < 16; r += 2) {
+        const float p0 = __builtin_amdgcn_exp2f(s[kb][r]);
+        const float p1 = __builtin_amdgcn_exp2f(s[kb][r + 1]);
+        r0 += p0; r1 += p1;
+        pk[kb * 8 + (r >> 1)] = pack_bf16x2(p0, p1);
+      }
+    l_run[qb] += r0 + r1;
+  };
+  auto pv = [&](const unsigned char* T, const uint32_t (&pk)[QB][16]) {  // O^T += V^T P^T
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const bf16x8 vfr = v_frag(T, voff[db], kk);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) {
+          const u32x4 pw = {pk[qb][kk * 4 + 0], pk[qb][kk * 4 + 1], pk[qb][kk * 4 + 2], pk[qb][kk * 4 + 3]};
+          oT[qb][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr, __builtin_bit_cast(bf16x8, pw), oT[qb][db], 0, 0, 0);
+        }
+      }
+  };
+  auto rendezvous = [&](int t, int need) {  // tile `need` landed and visible; ring slot (t + NB - 1) % NB = (t - 1) % NB consumed by all waves
+    if (need < n_tiles) {
+      const int last = n_tiles - 1 < t + NB - 2 ? n_tiles - 1 : t + NB - 2;  // newest tile issued so far
+      wait_tiles_in_flight(last - need);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    if (t + NB - 1 < n_tiles) issue(t + NB - 1);
+  };
+
+#pragma unroll
+  for (int t = 0; t < NB - 1; ++t)
+    if (t < n_tiles) issue(t);
+  if (PIPE) {
+    // prologue: scores of tile 0, m_ref = their maximum
+    wait_tiles_in_flight((n_tiles < NB - 1 ? n_tiles : NB - 1) - 1);
+    __syncthreads();
+    qk(lds, sc);
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) move_ref(qb, tile_max(sc[qb]), sc[qb]);
+    // steady state, ONE basic block per tile: S' MFMAs of tile t+1 | exp / sum / pack of tile t | P V MFMAs of tile t | max of t+1
+    for (int t = 0; t + 1 < n_tiles; ++t) {
+      rendezvous(t, t + 1);
+      uint32_t pk[QB][16];
+      float mx[QB];
+      qk(lds + ((t + 1) % NB) * TILE_BYTES, sn);
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) softmax_p(qb, sc[qb], pk[qb]);
+      pv(lds + (t % NB) * TILE_BYTES, pk);
+      bool any = false;
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        mx[qb] = tile_max(sn[qb]);
+        any = any || mx[qb] > 8.f;
+      }
+      if (__builtin_amdgcn_ballot_w64(any) != 0) {
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) move_ref(qb, mx[qb] > 8.f ? mx[qb] : 0.f, sn[qb]);
+      }
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) { sc[qb][0] = sn[qb][0]; sc[qb][1] = sn[qb][1]; }
+    }
+    {  // last tile: no look-ahead
+      const int t = n_tiles - 1;
+      rendezvous(t, n_tiles);
+      uint32_t pk[QB][16];
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) softmax_p(qb, sc[qb], pk[qb]);
+      pv(lds + (t % NB) * TILE_BYTES, pk);
+    }
+  } else {
+    for (int t = 0; t < n_tiles; ++t) {
+      rendezvous(t, t);
+      const unsigned char* Tc = lds + (t % NB) * TILE_BYTES;
+      uint32_t pk[QB][16];
+      qk(Tc, sc);
+#pragma unroll
+      for (int qb = 0; qb < QB; ++qb) {
+        const float mx = tile_max(sc[qb]);
+        if (__builtin_amdgcn_ballot_w64(t == 0 || mx > 8.f) != 0) move_ref(qb, (t == 0 || mx > 8.f) ? mx : 0.f, sc[qb]);
+        softmax_p(qb, sc[qb], pk[qb]);
+      }
+      pv(Tc, pk);
+    }
+  }
+
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const float l = l_run[qb] + __shfl_xor(l_run[qb], 32);
+    const float inv = 1.f / l;
+    const int qrow = qrow0 + 32 * qb;
+    if (p.lse && hh == 0) p.lse[(long)bh * p.Nq + qrow] = (__log2f(l) - negm[qb][0]) * 0.6931471805599453f;
+    uint16_t* orow = op + (long)qrow * p.o_sn;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = db * 32 + 8 * g + 4 * hh;
+        u32x2 wv = {pack_bf16x2(oT[qb][db][4 * g + 0] * inv, oT[qb][db][4 * g + 1] * inv),
+                    pack_bf16x2(oT[qb][db][4 * g + 2] * inv, oT[qb][db][4 * g + 3] * inv)};
+        *reinterpret_cast<u32x2*>(orow + d) = wv;
+      }
+  }
+}
+
 // ---- Nk <= 96 (the text context: 77 keys) -------------------------------------------------------------------------------------
 // Cross-attention over the text tokens (A2) and over the pose tokens (A3, up to 98 304 queries per head against the same 77 keys)
 // is a streaming problem: 256 B of Q/O traffic per (query, head) against 2 x 12 MFMAs.  The whole K and V^T of a head fit in
@@ -494,7 +732,7 @@ __global__ __launch_bounds__(256, 2) void attn_smallk_kernel(AttnParams p) {
 // fp8_amax = {max|q|, max|k|, max|v|} selects the fp8-MFMA variant (Nk <= 96 only); NULL = bf16 MFMA
 static int attn_launch(const void* q, const void* k, const void* v, void* o, int B, int H, int Nq, int Nk, const int64_t* q_strides,
                        const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides, float scale, const float* fp8_amax,
-                       float* lse, void* stream) {
+                       float* lse, void* stream, bool prescaled = false) {
   if (!q || !k || !v || !o || B <= 0 || H <= 0 || Nq <= 0 || Nk <= 0) return CD360_ERR_ARG;
   AttnParams p;
   p.q = (const uint16_t*)q; p.k = (const uint16_t*)k; p.v = (const uint16_t*)v; p.o = (uint16_t*)o; p.lse = lse;
@@ -508,7 +746,7 @@ static int attn_launch(const void* q, const void* k, const void* v, void* o, int
   for (int64_t s : all) if (s % 8) return CD360_ERR_SHAPE;
   if (p.o_sb % 4 || p.o_sh % 4 || p.o_sn % 4) return CD360_ERR_SHAPE;
   if (((uintptr_t)q | (uintptr_t)k | (uintptr_t)v) % 16 || (uintptr_t)o % 8) return CD360_ERR_ARG;
-  p.scale_log2e = scale * 1.4426950408889634f;
+  p.scale_log2e = prescaled ? 1.f : scale * 1.4426950408889634f;  // prescaled: q already carries scale * log2(e)
   // (its 16-byte output stores need 16-byte aligned output rows; otherwise the tiled kernel with 8-byte stores serves the call)
   bool smallk = Nk <= 96 && !(p.o_sb % 8 || p.o_sh % 8 || p.o_sn % 8 || (uintptr_t)o % 16);
   if (fp8_amax) {
@@ -546,6 +784,23 @@ static int attn_launch(const void* q, const void* k, const void* v, void* o, int
     CD360_LAUNCH_CHECK();
     return CD360_OK;
   }
+  // Second-generation self-attention kernel (whole tiles).  Its q pre-scaling costs one more bf16 rounding of q unless the caller
+  // folded the scale into the projection (cd360_attn_fwd_prescaled_bf16: exact), so plain calls keep the first generation unless
+  // CD360_ATTN_SELF says otherwise: 0 = first generation, 1 = 4 waves x 32 queries, 2 = 8 waves x 64 queries, unset = by shape.
+  int gen2 = (Nk % 64 == 0 && Nq % 128 == 0 && (long)Nk * p.k_sn * 2 < (1L << 31) && (long)Nk * p.v_sn * 2 < (1L << 31)) ? 1 : 0;
+  int pick = prescaled ? -1 : 0;
+  if (const char* e = getenv("CD360_ATTN_SELF")) pick = atoi(e);
+  if (gen2 && pick) {
+    bool wide = Nq % 512 == 0 && (long)B * H * (Nq / 512) >= 240;  // enough 512-query workgroups for every CU
+    if (pick > 0) wide = pick == 2 && Nq % 512 == 0;
+    p.n_qtiles = Nq / (wide ? 512 : 128);
+    const long nwg2 = (long)p.n_qtiles * B * H;
+    if (nwg2 > 0x7fffffffL) return CD360_ERR_SHAPE;
+    if (wide) hipLaunchKernelGGL((attn_self_kernel<2, 8>), dim3((unsigned)nwg2), dim3(512), 0, (hipStream_t)stream, p);
+    else hipLaunchKernelGGL((attn_self_kernel<1, 4>), dim3((unsigned)nwg2), dim3(256), 0, (hipStream_t)stream, p);
+    CD360_LAUNCH_CHECK();
+    return CD360_OK;
+  }
   p.n_qtiles = (Nq + 127) / 128;
   p.fast = ((long)Nk * p.k_sn * 2 < (1L << 31) && (long)Nk * p.v_sn * 2 < (1L << 31)) ? 1 : 0;
   if (const char* e = getenv("CD360_ATTN_FAST")) p.fast = p.fast && e[0] != '0';  // tuning/debug: 0 forces the guarded path
@@ -560,6 +815,16 @@ extern "C" int cd360_attn_fwd_bf16(const void* q, const void* k, const void* v, 
                                    const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                                    const int64_t* o_strides, float scale, void* stream) {
   return attn_launch(q, k, v, o, B, H, Nq, Nk, q_strides, k_strides, v_strides, o_strides, scale, nullptr, nullptr, stream);
+}
+
+// The same operator for a q that already carries the softmax scale AND the base change: q' = q * (scale * log2 e), o = softmax_2(q' k^T) v
+// with softmax_2 the base-2 softmax (identical to softmax(scale q k^T) v).  The transformer blocks multiply the q rows of the merged
+// q|k|v projection (weights, bias, LayerNorm-fold terms) by that factor when they pack it, so q' is rounded to bf16 once -- exactly
+// like the reference's q -- and the whole-tile self-attention kernel (attn_self_kernel) needs no per-score multiply.
+extern "C" int cd360_attn_fwd_prescaled_bf16(const void* q, const void* k, const void* v, void* o, int B, int H, int Nq, int Nk,
+                                             const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                                             const int64_t* o_strides, void* stream) {
+  return attn_launch(q, k, v, o, B, H, Nq, Nk, q_strides, k_strides, v_strides, o_strides, 1.f, nullptr, nullptr, stream, true);
 }
 
 // Training forward: the same kernels, additionally writing lse [B*H, Nq] fp32 (natural-log log-sum-exp of the scaled scores of every

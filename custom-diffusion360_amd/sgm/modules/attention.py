@@ -388,7 +388,9 @@ class BasicTransformerBlock(nn.Module):
         if self._pack is not None and self._pack[0] == key:
             return self._pack[1]
         P = {}
-        P["qkv"] = ops.pack_ln_linear(torch.cat([a1.to_q.weight, a1.to_k.weight, a1.to_v.weight], 0), None, self.norm1.weight, self.norm1.bias)
+        # the q rows carry the softmax scale and log2(e) (ops.attention(prescaled=True)): q is rounded to bf16 once, as in the reference
+        P["qkv"] = ops.pack_ln_linear(torch.cat([a1.to_q.weight.detach().float() * ops.ATTN_PRESCALE, a1.to_k.weight.detach().float(),
+                                                 a1.to_v.weight.detach().float()], 0), None, self.norm1.weight, self.norm1.bias)
         P["o1"] = (a1.to_out[0].weight.detach().to(torch.bfloat16).contiguous(), a1.to_out[0].bias.detach().float().contiguous())
         P["q2"] = ops.pack_ln_linear(a2.to_q.weight, None, self.norm2.weight, self.norm2.bias)
         P["o2"] = (a2.to_out[0].weight.detach().to(torch.bfloat16).contiguous(), a2.to_out[0].bias.detach().float().contiguous())
@@ -428,7 +430,7 @@ class BasicTransformerBlock(nn.Module):
         inner = a1.heads * a1.dim_head
         w, ws, cb = P["qkv"]
         qkv = ops.gemm(x, w, bias=cb, ln=(stats, ws, self.norm1.eps))
-        o = ops.attention(qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:], a1.heads, x.shape[1])
+        o = ops.attention(qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:], a1.heads, x.shape[1], prescaled=True)
         x, stats = ops.gemm(o, P["o1"][0], bias=P["o1"][1], res=x, want_stats=True)
         w, ws, cb = P["q2"]
         q = ops.gemm(x, w, bias=cb, ln=(stats, ws, self.norm2.eps))

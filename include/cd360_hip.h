@@ -46,6 +46,15 @@ int cd360_attn_fwd_fp8mfma_bf16(const void* q, const void* k, const void* v, voi
                                 const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                                 const int64_t* o_strides, float scale, const float* amax, void* stream);
 
+/* cd360_attn_fwd_bf16 for a q that already carries the softmax scale and the base change: q' = q * (scale * log2 e),
+ * o = softmax_2(q' k^T) v (base-2 softmax; identical to softmax(scale q k^T) v).  The transformer blocks fold the factor into the q rows
+ * of the merged q|k|v projection when they pack it (attention.py:393-408 computes q with nn.Linear, then xformers scales inside), so q'
+ * is rounded to bf16 once, like the reference's q, and self-attention runs on the whole-tile kernel (lazy running maximum, LDS-DMA
+ * K / V ring) whenever Nq % 128 == 0 and Nk % 64 == 0; other shapes take the kernels of cd360_attn_fwd_bf16. */
+int cd360_attn_fwd_prescaled_bf16(const void* q, const void* k, const void* v, void* o, int B, int H, int Nq, int Nk,
+                                  const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                                  const int64_t* o_strides, void* stream);
+
 /* Training pair (the fine-tuning loop differentiates attention.py:406 through xformers' autograd; BASELINE.json configs[3]).
  * cd360_attn_fwd_lse_bf16 = cd360_attn_fwd_bf16 that also writes lse [B*H, Nq] fp32, the natural-log log-sum-exp of every
  * query row's scaled scores.  cd360_attn_bwd_bf16 takes q, k, v, o, dout (bf16, forward layouts, strides multiples of 8) and

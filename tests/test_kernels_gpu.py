@@ -67,6 +67,59 @@ def test_attention_xformers_layout_and_online_softmax_rescale():
     assert rel(out, O.attention_core(q, k, v)) < 1e-2
 
 
+@pytest.mark.parametrize("gen", ["0", "1", "2"])
+@pytest.mark.parametrize("B,H,N", [(1, 2, 256), (2, 3, 1024), (1, 1, 4096)])
+def test_self_attention_generations_agree_with_oracle(gen, B, H, N, monkeypatch):
+    """The whole-tile self-attention kernel (attn_self_kernel: lazy running maximum, pre-scaled q, LDS-DMA ring; CD360_ATTN_SELF =
+    1: 4 waves x 32 queries, 2: 8 waves x 64 queries) and the first-generation tiled kernel (0) against the fp32 oracle, on the merged
+    q|k|v layout.
+    Query 10 meets a dominating key late in the sequence (m_ref must move mid-stream), query 20 starts on a tile of strongly
+    negative scores (m_ref must move UP by far more than the 2^8 slack right after the first tile); lse as the training forward
+    returns it."""
+    from cd360 import ops
+    if gen == "2" and N % 512:
+        pytest.skip("the 8-wave x 64-query variant needs 512 queries per workgroup")
+    monkeypatch.setenv("CD360_ATTN_SELF", gen)
+    g = torch.Generator().manual_seed(N + H)
+    qkv = bf(torch.randn(B, N, 3 * H * 64, generator=g))
+    q, k, v = qkv[..., :H * 64], qkv[..., H * 64:2 * H * 64], qkv[..., 2 * H * 64:]
+    k[:, N - 70] = 8.0 * q[:, 10]
+    k[:, :64] = -3.0 * q[:, 20:21]
+    qkv = bf(qkv)
+    d = qkv.to(DEV, torch.bfloat16)
+    out, lse = ops.attention(d[..., :H * 64], d[..., H * 64:2 * H * 64], d[..., 2 * H * 64:], H, want_lse=True)
+
+    def split(t):
+        return t.reshape(B, N, H, 64).permute(0, 2, 1, 3).reshape(B * H, N, 64)
+
+    qs, ks, vs = split(qkv[..., :H * 64]), split(qkv[..., H * 64:2 * H * 64]), split(qkv[..., 2 * H * 64:])
+    want = O.attention_core(qs, ks, vs).reshape(B, H, N, 64).permute(0, 2, 1, 3).reshape(B, N, H * 64)
+    assert rel(out, want) < (1e-2 if gen == "0" else 1.5e-2)  # in-kernel q pre-scaling costs one more bf16 rounding (the modules fold it into Wq)
+    want_lse = torch.logsumexp(torch.einsum("bqd,bkd->bqk", qs.double(), ks.double()) / 8.0, dim=-1).float()
+    assert (lse.cpu() - want_lse).abs().max().item() < 2e-2 * max(1.0, want_lse.abs().max().item() / 10)
+
+
+@pytest.mark.parametrize("B,H,N", [(2, 3, 1024), (1, 2, 4096), (1, 2, 200), (3, 2, 512)])
+def test_self_attention_prescaled_q_is_exact_to_the_bf16_bar(B, H, N):
+    """cd360_attn_fwd_prescaled_bf16 (what the transformer blocks call: the softmax scale and log2 e live in the q projection):
+    softmax_2(q' k^T) v against the oracle's softmax(q k^T / 8) v with q = q' / (log2 e / 8) -- no extra rounding, the plain 1e-2 bar;
+    whole-tile shapes take attn_self_kernel (both tilings), the ragged one the first-generation kernel."""
+    from cd360 import ops
+    g = torch.Generator().manual_seed(7 * N + H)
+    qkv = bf(torch.randn(B, N, 3 * H * 64, generator=g))
+    qkv[..., :H * 64] *= 0.5  # q' = q * 0.18: keep the logits in the usual range
+    qkv[:, N - 70, H * 64:2 * H * 64] = 30.0 * qkv[:, 10, :H * 64]
+    qkv = bf(qkv)
+    d = qkv.to(DEV, torch.bfloat16)
+    out = ops.attention(d[..., :H * 64], d[..., H * 64:2 * H * 64], d[..., 2 * H * 64:], H, prescaled=True)
+
+    def split(t):
+        return t.reshape(B, N, H, 64).permute(0, 2, 1, 3).reshape(B * H, N, 64)
+
+    want = O.attention_core(split(qkv[..., :H * 64]) / ops.ATTN_PRESCALE, split(qkv[..., H * 64:2 * H * 64]), split(qkv[..., 2 * H * 64:]))
+    assert rel(out, want.reshape(B, H, N, 64).permute(0, 2, 1, 3).reshape(B, N, H * 64)) < 1e-2
+
+
 # ------------------------------------------------------------------------------------------------ rays / indices (A4, A5)
 @pytest.mark.parametrize("b,n,r,S,jitter", [(2, 3, 8, 4, False), (1, 4, 32, 24, False), (2, 2, 16, 24, True), (1, 8, 64, 24, False)])
 def test_rays_points_grid_and_indices_bit_exact(b, n, r, S, jitter):

@@ -146,6 +146,10 @@ if __name__ == "__main__":
         conv("L1", 3, 64, 64, 640, 640)
     if "attn1" in which:
         attn("L1 self", 3, 10, 4096, 4096)
+    if "attn2" in which:
+        attn("L2 self", 3, 20, 1024, 1024)
+    if "attn_self" in which:
+        attn("L1 self", 3, 10, 4096, 4096); attn("L2 self", 3, 20, 1024, 1024)
     if "nerf1" in which:
         nerf_block("L2", 1280, 32)
     if "gemm" in which:
