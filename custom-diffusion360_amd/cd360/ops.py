@@ -531,7 +531,8 @@ def conv_igemm(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Ten
     if want_stats:
         if (ho * wo) % 128:
             raise Cd360Error("conv_igemm(want_stats=True) needs Ho*Wo % 128 == 0")
-        stats = torch.empty(N, (ho * wo) // 128 * lib.cd360_conv_stats_slabs(cout), cout, 2, dtype=torch.float32, device=x.device)
+        rows = lib.cd360_conv_stats_rows(N, H, W, cin, cout, taps, stride)  # pixels per slab: the kernel serving this shape decides
+        stats = torch.empty(N, (ho * wo) // rows, cout, 2, dtype=torch.float32, device=x.device)
     acin, acout = alg_channels or (cin, cout)  # un-padded channel counts for the algorithmic FLOP / byte accounting
     with _timed("conv_igemm", 2.0 * m * taps * acin * acout, 2.0 * (N * H * W * acin + m * acout + taps * acin * acout)):
         check(lib.cd360_conv_igemm_bf16(_ptr(x), _ptr(w_packed), _ptr(bias), _ptr(emb), 0 if emb is None else emb.stride(0), _ptr(res), _ptr(out),

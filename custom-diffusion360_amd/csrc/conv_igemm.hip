@@ -347,9 +347,22 @@ extern "C" int cd360_conv_stats_slabs(int Cout) { return (Cout % 160 == 0 && Cou
 // tile_stats (optional): fp32 [N*H*W / 128 * cd360_conv_stats_slabs(Cout), Cout, 2] = per pixel slab (32 or 64 consecutive pixels)
 // and channel, the sum and the sum of squares of the bf16 outputs -- the first pass of the GroupNorm that follows the conv
 // (cd360_gn_silu_bf16's `tile_stats`).  Requires H*W % 128 == 0 (slabs must not straddle images).
+extern "C" int cd360_conv_dma_slab_rows(int N, int H, int W, int Cin, int Cout, int taps, int stride);
+extern "C" int cd360_conv3x3_dma_bf16(const void* x, const void* w_packed, const void* bias, const void* emb, int64_t emb_stride, const void* res,
+                                      void* out, int N, int H, int W, int Cin, int Cout, void* tile_stats, void* stream);
+
+// Pixels per slab of the `tile_stats` output for this convolution: decided by the kernel that will serve the call (the 3 x 3 / stride 1
+// convolutions run on the LDS-DMA GEMM core of gemm8p.hip, everything else on conv_igemm_kernel)
+extern "C" int cd360_conv_stats_rows(int N, int H, int W, int Cin, int Cout, int taps, int stride) {
+  const int rows = cd360_conv_dma_slab_rows(N, H, W, Cin, Cout, taps, stride);
+  return rows > 0 ? rows : 128 / cd360_conv_stats_slabs(Cout);
+}
+
 extern "C" int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const void* bias, const void* emb, int64_t emb_stride, const void* res,
                                      void* out, int N, int H, int W, int Cin, int Cout, int taps, int stride, void* tile_stats, void* stream) {
   if (!x || !w_packed || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return CD360_ERR_ARG;
+  if (cd360_conv_dma_slab_rows(N, H, W, Cin, Cout, taps, stride) > 0)  // 3 x 3 / stride 1: the LDS-DMA core (gemm8p.hip, EPI 5)
+    return cd360_conv3x3_dma_bf16(x, w_packed, bias, emb, emb_stride, res, out, N, H, W, Cin, Cout, tile_stats, stream);
   if ((taps != 9 && taps != 1) || Cin % 64 || Cout % 16) return CD360_ERR_SHAPE;
   if ((stride != 1 && stride != 2) || (stride == 2 && (taps != 9 || H % 2 || W % 2))) return CD360_ERR_SHAPE;
   if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)out | (uintptr_t)emb | (uintptr_t)res) % 16) return CD360_ERR_ARG;

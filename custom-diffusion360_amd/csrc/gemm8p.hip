@@ -53,6 +53,13 @@ struct GemmParams {
   int a_nq, a_nk;      // queries per batch element (M = B * a_nq, a_nq % 256 == 0), keys
   float a_scale_log2e;
   int abl;  // what-if timing knob (CD360_GEMM_ABL; results are wrong when set): 8 no DMA wait, 16 no barrier, 32 no LDS wait, 4 no DMA
+  // EPI 5: A is the implicit im2col matrix of a 3x3 / stride 1 / pad 1 convolution over a channels-last [images, H, W, Cin] tensor
+  // (lda = Cin, K = 9 Cin in cd360_conv_k_order order: K-tile kt = (group * 9 + tap) * cv_kg + j reads channel chunk group * cv_kg + j
+  // of the pixel shifted by the tap); out [M = images H W, N = Cout]
+  int cv_H, cv_W, cv_kg;
+  const uint16_t* emb;  // [images, Cout] bf16 per-image addend (row stride emb_stride elements) or null
+  long emb_stride;
+  float* cstats;        // [M / (NMB 32), Cout, 2] fp32: per slab of NMB * 32 pixels and channel, (sum, sumsq) of the stored outputs, or null
 };
 
 __device__ __forceinline__ int chan_pos(int i) { return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3); }
@@ -90,7 +97,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
   constexpr int XP = BM / PR, WP = BN / PR;        // pieces per wave per K-tile
   constexpr int NP = XP + WP, NMMA = NCB * NMB;
   // epilogue: 0 linear, 1 GEGLU, 2 / 3 / 4 small-Nk attention on the projected tile with 1 / 2 / 3 blocks of 32 keys
-  constexpr bool GEGLU = EPI == 1, ATTN = EPI >= 2;
+  constexpr bool GEGLU = EPI == 1, ATTN = EPI >= 2 && EPI <= 4, CONV = EPI == 5;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
 
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -109,7 +116,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
 
   // ---- LDS-DMA geometry: piece j covers rows j*PR + wave*8 + lane/8 of the operand tile; LDS chunk lane%8 <- source chunk ^ swizzle.
   // Rows past M / N are past the end of the buffer descriptor: the hardware returns zeros (they only feed masked outputs).
-  const __amdgpu_buffer_rsrc_t xrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)(((long)p.M - 1) * p.lda * 2 + (long)p.K * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t xrsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)(CONV ? (long)p.M * p.lda * 2 : ((long)p.M - 1) * p.lda * 2 + (long)p.K * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)(((long)p.N - 1) * p.ldw * 2 + (long)p.K * 2), 0x00020000);
   const int srow = wave * 8 + (lane >> 3);
   const int schunk = (lane & 7) ^ ((srow >> 1) & 7);
@@ -117,13 +125,50 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
   const uint32_t woff0 = (uint32_t)(((long)n0 + srow) * p.ldw * 2 + schunk * 16);
   const uint32_t xstep = (uint32_t)(PR * p.lda * 2), wstep = (uint32_t)(PR * p.ldw * 2);
   unsigned char* const dma_base = lds + wave * 1024;
+  // Convolution: bit `tap` of xmask[i] = the pixel of this lane's row of piece i has an in-image neighbour under that tap (rows past M:
+  // none).  The shifted pixel is the same row offset plus a wave-uniform tap offset; a padding neighbour reads from an offset past the
+  // end of the buffer descriptor, i.e. zeros.
+  uint32_t xmask[CONV ? XP : 1];
+  if constexpr (CONV) {
+    const int hw = p.cv_H * p.cv_W;
+#pragma unroll
+    for (int i = 0; i < XP; ++i) {
+      const long m = m0 + i * PR + srow;
+      uint32_t mk = 0;
+      if (m < p.M) {
+        const int rem = (int)(m % hw), y = rem / p.cv_W, x = rem - y * p.cv_W;
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
+          if (yy >= 0 && yy < p.cv_H && xx >= 0 && xx < p.cv_W) mk |= 1u << tap;
+        }
+      }
+      xmask[i] = mk;
+    }
+  }
+  int cv_j = 0, cv_tap = 0, cv_cg = 0;  // K-tile about to be issued (tiles are issued in order)
+  int is_tap = 0;
+  uint32_t is_tapoff = 0;
+  auto conv_next = [&]() {  // wave-uniform: byte offset of the next K-tile's (tap shift, channel chunk) relative to the output pixel's row
+    is_tap = cv_tap;
+    const int dy = cv_tap / 3, dx = cv_tap - 3 * dy;
+    is_tapoff = (uint32_t)((((dy - 1) * p.cv_W + (dx - 1)) * (int)p.lda + (cv_cg * p.cv_kg + cv_j) * 64) * 2);
+    if (++cv_j == p.cv_kg) {
+      cv_j = 0;
+      if (++cv_tap == 9) {
+        cv_tap = 0;
+        ++cv_cg;
+      }
+    }
+  };
   // DMA piece i (0 .. NP-1) of K-tile kt into the buffers at byte offsets bx / bw (0 | one buffer).  The wave-uniform part of the
   // source offset is added with an opaque v_add (otherwise the compiler keeps NP strength-reduced per-piece offsets live in VGPRs).
   auto piece = [&](int kt, int i, uint32_t bx, uint32_t bw) {
     uint32_t o;
     if (i < XP) {
-      const uint32_t su = (uint32_t)(kt * 128) + (uint32_t)i * xstep;
+      const uint32_t su = (CONV ? is_tapoff : (uint32_t)(kt * 128)) + (uint32_t)i * xstep;
       asm volatile("v_add_u32 %0, %1, %2" : "=v"(o) : "s"(su), "v"(xoff0));
+      if constexpr (CONV) o = ((xmask[i < XP ? i : 0] >> is_tap) & 1u) ? o : 0x80000000u;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, LDS_AS3(dma_base + XREG + bx + i * (PR * 128)), 16, o, 0, 0, 0);
     } else {
       const uint32_t su = (uint32_t)(kt * 128) + (uint32_t)(i - XP) * wstep;
@@ -174,6 +219,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
 #pragma unroll
   for (int b = 0; b < NBUF; ++b)
     if (b < nk) {
+      if constexpr (CONV) conv_next();
 #pragma unroll
       for (int i = 0; i < NP; ++i) piece(b, i, b * XB, b * WB);
     }
@@ -227,6 +273,9 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
       {  // last k-step: its MFMAs with the DMA pieces of tile t+NBUF (into the buffer just released) spread between them.  The MFMAs
          // are unconditional code: accumulators defined in two branch arms make the register allocator copy and spill them.
         const bool more = t + NBUF < nk && !(abl & 4);
+        if constexpr (CONV) {
+          if (more) conv_next();
+        }
 #pragma unroll
         for (int i = 0; i < NMMA; ++i) {
           if constexpr (MUL)
@@ -328,6 +377,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
     return;
   }
 
+  long embrow[CONV ? NMB : 1];  // convolution: element offset of the row's image in the per-image addend
+  if constexpr (CONV) {
+    const int hw = p.cv_H * p.cv_W;
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) embrow[mb] = ((m0 + mrow0 + mb * 32) / hw) * p.emb_stride;
+  }
 #pragma unroll
   for (int nb = 0; nb < NCB; ++nb) {
 #pragma unroll
@@ -352,6 +407,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
           if (p.ln_stats) t = rs[mb] * (t - mu[mb] * sv[r]);
           v[r] = t + bv[r];
         }
+        if constexpr (CONV) {
+          if (p.emb) {
+            const u32x4 e0 = *reinterpret_cast<const u32x4*>(p.emb + embrow[mb] + n);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              v[2 * e] += bf16lo_to_f32(e0[e]);
+              v[2 * e + 1] += bf16hi_to_f32(e0[e]);
+            }
+          }
+        }
         if (p.res) {
           const u32x4 e0 = *reinterpret_cast<const u32x4*>(p.res + m * p.ldr + n);
 #pragma unroll
@@ -364,7 +429,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
         stage_put(mb, nb * 4 + 2 * hh + c8, o);
-        if (p.stats_out) {  // statistics of the values as stored (bf16-rounded): what the consumer's LayerNorm fold sees
+        if (!CONV && p.stats_out) {  // statistics of the values as stored (bf16-rounded): what the consumer's LayerNorm fold sees
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float a0 = bf16lo_to_f32(o[e]), a1 = bf16hi_to_f32(o[e]);
@@ -557,18 +622,68 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
     // (wave-private image: the compiler's lgkmcnt wait orders the ds_writes before the ds_reads, no barrier)
     const int ocol0 = (GEGLU ? (n0 >> 1) : n0) + wc * OCH;
     const int nout = GEGLU ? (p.N >> 1) : p.N;
+    // lane -> (row it * RPI + lane / NCH, chunk lane % NCH): a lane keeps its 8 channels over all rows (the per-channel sums of the
+    // convolution epilogue accumulate in registers); chunk counts that do not divide 64 leave the last lanes idle
+    constexpr int RPI = 64 / NCH;
+    const int j = lane % NCH, rl = lane / NCH;
+    float cs[CONV ? 8 : 1], cq[CONV ? 8 : 1];
+    if constexpr (CONV) {
 #pragma unroll
-    for (int it = 0; it < (NMB * 32 * NCH + 63) / 64; ++it) {
-      const int g = it * 64 + lane, r = g / NCH, j = g - r * NCH;
+      for (int e = 0; e < 8; ++e) { cs[e] = 0.f; cq[e] = 0.f; }
+    }
+#pragma unroll
+    for (int it = 0; it < (NMB * 32 + RPI - 1) / RPI; ++it) {
+      const int r = it * RPI + rl;
       const long m = m0 + wr * (NMB * 32) + r;
-      if (r < NMB * 32 && m < p.M && ocol0 + j * 8 < nout && !(abl & 64)) {
+      if (rl < RPI && r < NMB * 32 && m < p.M && ocol0 + j * 8 < nout && !(abl & 64)) {
         const u32x4 o = *reinterpret_cast<const u32x4*>(stage + r * RB + ((j ^ (r & SWZ)) << 4));
         *reinterpret_cast<u32x4*>(p.out + m * p.ldo + ocol0 + j * 8) = o;
+        if constexpr (CONV) {
+          if (p.cstats) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float a0 = bf16lo_to_f32(o[e]), a1 = bf16hi_to_f32(o[e]);
+              cs[2 * e] += a0;
+              cs[2 * e + 1] += a1;
+              cq[2 * e] = fmaf(a0, a0, cq[2 * e]);
+              cq[2 * e + 1] = fmaf(a1, a1, cq[2 * e + 1]);
+            }
+          }
+        }
+      }
+    }
+    if constexpr (CONV) {
+      if (p.cstats) {  // fold the RPI row groups (lanes j, j + NCH, ...) in a fixed order, lane j writes its 8 channels
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          if constexpr ((RPI & (RPI - 1)) == 0) {  // NCH divides 64: xor tree over the lane bits above the chunk index
+#pragma unroll
+            for (int o = 32; o >= NCH; o >>= 1) {
+              cs[e] += __shfl_xor(cs[e], o);
+              cq[e] += __shfl_xor(cq[e], o);
+            }
+          } else {
+            float s_ = cs[e], q_ = cq[e];
+#pragma unroll
+            for (int k = 1; k < RPI; ++k) {
+              s_ += __shfl(cs[e], lane + k * NCH);
+              q_ += __shfl(cq[e], lane + k * NCH);
+            }
+            cs[e] = s_;
+            cq[e] = q_;
+          }
+        }
+        if (lane < NCH && ocol0 + j * 8 < nout) {
+          const long slab = (m0 + wr * (NMB * 32)) / (NMB * 32);
+          float* d = p.cstats + (slab * p.N + ocol0 + j * 8) * 2;
+#pragma unroll
+          for (int e = 0; e < 8; e += 2) *reinterpret_cast<f32x4*>(d + 2 * e) = f32x4{cs[e], cq[e], cs[e + 1], cq[e + 1]};
+        }
       }
     }
   }
 
-  if (p.stats_out) {  // kernel-uniform: per-row sums over this N tile = both lane halves, all channel blocks, the WN waves of the row
+  if (!CONV && p.stats_out) {  // kernel-uniform: per-row sums over this N tile = both lane halves, all channel blocks, the WN waves of the row
     float* red = reinterpret_cast<float*>(lds);  // [wc][BM][2]; the K-loop buffers are idle once every wave is past its last read
     __syncthreads();
 #pragma unroll
@@ -603,7 +718,9 @@ template <int WM, int WN, int NCB, int NMB, int NBUF, int EPI>
 int launch_epi(const GemmParams& p0, hipStream_t stream) {
   GemmParams p = p0;
   constexpr int BM = WM * NMB * 32, BN = WN * NCB * 32;
-  constexpr int LDS_BYTES = NBUF * (BM + BN) * 128;
+  constexpr int RING_BYTES = NBUF * (BM + BN) * 128, STAGE_BYTES = BM * BN * 2;  // K-loop buffers, reused as the output staging image
+  constexpr int LDS_BYTES = RING_BYTES > STAGE_BYTES ? RING_BYTES : STAGE_BYTES;
+  static_assert(LDS_BYTES <= 160 * 1024, "LDS of one CU");
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   int gm = 4;
@@ -687,6 +804,7 @@ extern "C" int cd360_gemm_bf16(const void* a, const void* w, void* out, int64_t 
   p.M = (int)M; p.N = N; p.K = K; p.ln_parts = ln_parts; p.ln_dim = ln_dim; p.ln_eps = ln_eps; p.geglu = geglu ? 1 : 0;
   p.tiles_m = p.tiles_n = p.group_m = 0;
   p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f;
+  p.cv_H = p.cv_W = p.cv_kg = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = nullptr;
   switch (pick_cfg(M, N, geglu)) {
     case 1: return launch<2, 2, 2, 2, 2>(p, (hipStream_t)stream);
     case 2: return geglu ? CD360_ERR_SHAPE : launch_epi<2, 4, 1, 2, 2, 0>(p, (hipStream_t)stream);
@@ -720,9 +838,80 @@ extern "C" int cd360_qproj_attn_bf16(const void* a, const void* w, void* out, in
   p.tiles_m = p.tiles_n = p.group_m = 0;
   p.ak = (const uint16_t*)k; p.av = (const uint16_t*)v; p.ak_sb = k_sb; p.ak_sn = k_sn; p.av_sb = v_sb; p.av_sn = v_sn;
   p.a_nq = Nq; p.a_nk = Nk; p.a_scale_log2e = scale * 1.4426950408889634f;
+  p.cv_H = p.cv_W = p.cv_kg = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = nullptr;
   if (Nk <= 32) return launch_epi<2, 4, 2, 4, 2, 2>(p, (hipStream_t)stream);
   if (Nk <= 64) return launch_epi<2, 4, 2, 4, 2, 3>(p, (hipStream_t)stream);
   return launch_epi<2, 4, 2, 4, 2, 4>(p, (hipStream_t)stream);
+}
+
+// ---- 3 x 3 / stride 1 / pad 1 convolution on the same core (EPI 5): the im2col matrix is never built -- K-tile kt of the A operand is
+// the 64-channel chunk of the input pixel shifted by the tile's tap, fetched by the same LDS-DMA pieces with a wave-uniform offset added
+// and padding neighbours redirected past the end of the buffer descriptor (zeros).  Replaces conv_igemm_kernel (register-staged
+// 128 x 128 tiles) for the ResBlock / Upsample convolutions (openaimodel.py:161-164, 352-376).
+namespace {
+// tilings (pixels x channels): 1 = 256 x 320 (Cout % 320 == 0: the 128^2 level, one channel tile), 2 = 256 x 128 / 3 buffers,
+// 3 = 256 x 256, 4 = 128 x 128 / 4 buffers (the 32^2 level: 240 tiles)
+constexpr int CONV_BM[5] = {0, 256, 256, 256, 128}, CONV_BN[5] = {0, 320, 128, 256, 128}, CONV_SLAB[5] = {0, 64, 64, 128, 64};
+int pick_conv_cfg(long M, int Cout) {
+  if (const char* e = getenv("CD360_CONV_CFG")) {
+    const int c = atoi(e);
+    if (c >= 1 && c <= 4 && !(c == 1 && Cout % 320)) return c;
+  }
+  static const double weight[5] = {0, 1.0, 0.93, 1.0, 0.85};  // relative speed of the tilings on full tiles (tools/bench_kernels.py conv)
+  int best = 4;
+  double best_eff = -1.0;
+  for (int c = 1; c <= 4; ++c) {
+    if (c == 1 && Cout % 320) continue;
+    const long tm = (M + CONV_BM[c] - 1) / CONV_BM[c], tn = (Cout + CONV_BN[c] - 1) / CONV_BN[c], nwg = tm * tn, rounds = (nwg + 255) / 256;
+    const double eff = (double)nwg / (double)(rounds * 256) * (double)Cout / (double)(tn * CONV_BN[c]) * weight[c];
+    if (eff > best_eff) { best_eff = eff; best = c; }
+  }
+  return best;
+}
+bool conv_dma_ok(int N, int H, int W, int Cin, int Cout, int taps, int stride) {
+  if (const char* e = getenv("CD360_CONV_DMA")) if (e[0] == '0') return false;
+  if (taps != 9 || stride != 1 || Cin % 64 || Cout % 16 || N <= 0 || H <= 0 || W <= 0) return false;
+  const long M = (long)N * H * W;
+  return M * Cin * 2 < (1L << 31) && ((long)Cout + 320) * 9 * Cin * 2 < (1L << 32);
+}
+}  // namespace
+
+extern "C" int cd360_conv_k_order(int Cin, int taps);
+
+// Pixels per slab of the `tile_stats` output of cd360_conv_igemm_bf16 for this convolution (the launch's wave tiling decides), or 0
+// when the call is served by the register-staged kernel (then 128 / cd360_conv_stats_slabs(Cout)).
+extern "C" int cd360_conv_dma_slab_rows(int N, int H, int W, int Cin, int Cout, int taps, int stride) {
+  if (!conv_dma_ok(N, H, W, Cin, Cout, taps, stride)) return 0;
+  const int rows = CONV_SLAB[pick_conv_cfg((long)N * H * W, Cout)];
+  return ((long)H * W) % rows ? 0 : rows;
+}
+
+// Same contract as cd360_conv_igemm_bf16 for taps = 9, stride = 1; tile_stats fp32 [N H W / cd360_conv_dma_slab_rows(...), Cout, 2].
+// CD360_ERR_SHAPE when the shape is outside the envelope (the caller then uses the register-staged kernel).
+extern "C" int cd360_conv3x3_dma_bf16(const void* x, const void* w_packed, const void* bias, const void* emb, int64_t emb_stride, const void* res,
+                                      void* out, int N, int H, int W, int Cin, int Cout, void* tile_stats, void* stream) {
+  if (!x || !w_packed || !out) return CD360_ERR_ARG;
+  if (!conv_dma_ok(N, H, W, Cin, Cout, 9, 1)) return CD360_ERR_SHAPE;
+  if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)out | (uintptr_t)emb | (uintptr_t)res | (uintptr_t)tile_stats) % 16) return CD360_ERR_ARG;
+  if (emb && (emb_stride < Cout || emb_stride % 8)) return CD360_ERR_SHAPE;
+  const long M = (long)N * H * W;
+  const int cfg = pick_conv_cfg(M, Cout);
+  if (tile_stats && ((long)H * W) % CONV_SLAB[cfg]) return CD360_ERR_SHAPE;
+  GemmParams p;
+  p.a = (const uint16_t*)x; p.w = (const uint16_t*)w_packed; p.out = (uint16_t*)out; p.bias = (const float*)bias; p.res = (const uint16_t*)res;
+  p.ln_stats = nullptr; p.wsum = nullptr; p.stats_out = nullptr;
+  p.lda = Cin; p.ldw = 9L * Cin; p.ldo = Cout; p.ldr = res ? Cout : 0;
+  p.M = (int)M; p.N = Cout; p.K = 9 * Cin; p.ln_parts = 0; p.ln_dim = 0; p.ln_eps = 0.f; p.geglu = 0;
+  p.tiles_m = p.tiles_n = p.group_m = 0;
+  p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f;
+  p.cv_H = H; p.cv_W = W; p.cv_kg = cd360_conv_k_order(Cin, 9);
+  p.emb = (const uint16_t*)emb; p.emb_stride = emb ? emb_stride : 0; p.cstats = (float*)tile_stats;
+  switch (cfg) {
+    case 1: return launch_epi<4, 2, 5, 2, 2, 5>(p, (hipStream_t)stream);
+    case 2: return launch_epi<4, 2, 2, 2, 3, 5>(p, (hipStream_t)stream);
+    case 3: return launch_epi<2, 4, 2, 4, 2, 5>(p, (hipStream_t)stream);
+    default: return launch_epi<2, 4, 1, 2, 4, 5>(p, (hipStream_t)stream);
+  }
 }
 
 // Per-row (sum, sumsq) of a bf16 [rows, C] matrix (row stride ld) as ONE partial per row: the `ln_stats` input of cd360_gemm_bf16 for a

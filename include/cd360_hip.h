@@ -210,6 +210,16 @@ int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const void* bias,
  * sum and the sum of squares of the bf16 outputs: the statistics pass of the GroupNorm that follows the conv (openaimodel.py:
  * 352-376 h = out_layers(GN -> SiLU -> conv)), handed to cd360_gn_silu_bf16.  Requires H*W % 128 == 0. */
 int cd360_conv_stats_slabs(int Cout);
+/* Pixels per slab of `tile_stats` for this very call (the kernel that serves it decides: 64 or 128 on the LDS-DMA core that runs the
+ * 3 x 3 / stride 1 convolutions, 128 / cd360_conv_stats_slabs(Cout) otherwise): tile_stats is fp32 [N*Ho*Wo / rows, Cout, 2]. */
+int cd360_conv_stats_rows(int N, int H, int W, int Cin, int Cout, int taps, int stride);
+/* The 3 x 3 / stride 1 / pad 1 case of cd360_conv_igemm_bf16 on the GEMM core of cd360_gemm_bf16 (operands L2 -> LDS by LDS-DMA, the
+ * im2col matrix implicit: a K tile is the 64-channel chunk of the pixel shifted by the tile's tap, padding read as zeros through the
+ * buffer descriptor's range check); cd360_conv_igemm_bf16 forwards to it whenever cd360_conv_dma_slab_rows(...) > 0.
+ * tile_stats fp32 [N*H*W / cd360_conv_dma_slab_rows(...), Cout, 2]. */
+int cd360_conv_dma_slab_rows(int N, int H, int W, int Cin, int Cout, int taps, int stride);
+int cd360_conv3x3_dma_bf16(const void* x, const void* w_packed, const void* bias, const void* emb, int64_t emb_stride, const void* res,
+                           void* out, int N, int H, int W, int Cin, int Cout, void* tile_stats, void* stream);
 
 /* replaces pose_emb_layers(torch.cat([x, xref], -1)), Linear(2C -> C, bias=False) (sgm/modules/attention.py:515-516,634) without the
  * concat: out = x wa^T + xref wb^T, wa = W[:, :C], wb = W[:, C:] as contiguous [C, C] bf16; x, xref, out [rows, C] bf16, C % 64 == 0.

@@ -273,8 +273,9 @@ def test_conv_igemm(N, H, W, Cin, Cout, taps, extras, split, monkeypatch):
     launch heuristic; (3,32,32,320,640) has an ODD number of K-steps (45), (1,16,16,128,320) the minimum of 2 chunks per tap.
     Cout = 320 / 160 take the 160-channel tiling (4 waves of 160 x 32), with ragged pixel tiles in (2,9,7,...)."""
     from cd360 import ops
-    if split != "auto":
+    if split != "auto":  # the register-staged kernel and its split-K variant (3 x 3 / stride 1 otherwise runs on the LDS-DMA core)
         monkeypatch.setenv("CD360_CONV_SPLIT", split)
+        monkeypatch.setenv("CD360_CONV_DMA", "0")
     g = torch.Generator().manual_seed(N * 100 + H + Cin + Cout)
     k = 3 if taps == 9 else 1
     x = bf(torch.randn(N, Cin, H, W, generator=g))
@@ -317,6 +318,40 @@ def test_conv_epilogue_groupnorm_statistics(N, H, W, Cin, Cout):
     assert torch.equal(a, ops.gn_silu(out, gamma, beta, 32, 1e-5, True, tile_stats=stats))  # deterministic
     with pytest.raises(Exception):
         ops.conv_igemm(x[:, :100].contiguous(), wp, bias, N, 10, 10, 9, want_stats=True)  # H*W % 128 != 0
+
+
+@pytest.mark.parametrize("cfg", ["1", "2", "3", "4"])
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 9, 7, 128, 320), (3, 32, 32, 320, 640), (1, 16, 16, 64, 48), (2, 16, 24, 192, 1280)])
+def test_conv3x3_on_the_dma_gemm_core_all_tilings(cfg, N, H, W, Cin, Cout, monkeypatch):
+    """cd360_conv3x3_dma_bf16 (gemm8p.hip EPI 5: implicit im2col through LDS-DMA, padding through the buffer range check) in each of its
+    four tilings (CD360_CONV_CFG: 256 x 320, 256 x 128, 256 x 256, 128 x 128) against torch's fp32 conv2d and against the register-
+    staged kernel: bias + per-image addend + residual, ragged pixel / channel tiles, tiles straddling images, the per-slab channel
+    statistics for the GroupNorm that follows."""
+    from cd360 import ops
+    if cfg == "1" and Cout % 320:
+        pytest.skip("the 320-channel tiling needs Cout % 320 == 0")
+    monkeypatch.setenv("CD360_CONV_CFG", cfg)
+    g = torch.Generator().manual_seed(N * 100 + H + Cin + Cout)
+    x = bf(torch.randn(N, Cin, H, W, generator=g))
+    w = bf(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
+    bias = torch.randn(Cout, generator=g)
+    emb = bf(torch.randn(N, Cout, generator=g))
+    res = bf(torch.randn(N, Cout, H, W, generator=g))
+    want = torch.nn.functional.conv2d(x, w, bias, padding=1) + emb[:, :, None, None] + res
+    xt = x.permute(0, 2, 3, 1).reshape(N, H * W, Cin).contiguous().to(DEV, torch.bfloat16)
+    wp = ops.pack_conv_weight(w).to(DEV)
+    rt = res.permute(0, 2, 3, 1).reshape(N, H * W, Cout).contiguous().to(DEV, torch.bfloat16)
+    args = (xt, wp, bias.to(DEV), N, H, W, 9, emb.to(DEV, torch.bfloat16), rt)
+    got = ops.conv_igemm(*args)
+    assert rel(got.reshape(N, H, W, Cout).permute(0, 3, 1, 2), want) < 8e-3
+    if (H * W) % 128 == 0:
+        out, stats = ops.conv_igemm(*args, want_stats=True)
+        assert torch.equal(out, got)
+        slabs = stats.shape[1]
+        ref = out.float().reshape(N, slabs, H * W // slabs, Cout)
+        assert rel(stats[..., 0], ref.sum(2)) < 1e-5 and rel(stats[..., 1], (ref * ref).sum(2)) < 1e-5
+    monkeypatch.setenv("CD360_CONV_DMA", "0")
+    assert rel(got, ops.conv_igemm(*args)) < 4e-3  # same sums in another order, both rounded to bf16
 
 
 @pytest.mark.parametrize("N,H,W,Cin,Cout,stride", [(2, 16, 16, 64, 64, 2), (3, 32, 32, 320, 320, 2), (1, 8, 12, 128, 160, 2), (2, 16, 16, 4, 320, 1), (2, 16, 16, 320, 4, 1)])
