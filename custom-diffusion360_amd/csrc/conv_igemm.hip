@@ -347,6 +347,9 @@ extern "C" int cd360_conv_stats_slabs(int Cout) { return (Cout % 160 == 0 && Cou
 // tile_stats (optional): fp32 [N*H*W / 128 * cd360_conv_stats_slabs(Cout), Cout, 2] = per pixel slab (32 or 64 consecutive pixels)
 // and channel, the sum and the sum of squares of the bf16 outputs -- the first pass of the GroupNorm that follows the conv
 // (cd360_gn_silu_bf16's `tile_stats`).  Requires H*W % 128 == 0 (slabs must not straddle images).
+extern "C" int cd360_gemm_bf16(const void* a, const void* w, void* out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldo,
+                               const void* bias, const void* res, int64_t ldr, const void* ln_stats, int ln_parts, int ln_dim, float ln_eps,
+                               const void* wsum, void* stats_out, int flags, void* stream);
 extern "C" int cd360_conv_dma_slab_rows(int N, int H, int W, int Cin, int Cout, int taps, int stride);
 extern "C" int cd360_conv3x3_dma_bf16(const void* x, const void* w_packed, const void* bias, const void* emb, int64_t emb_stride, const void* res,
                                       void* out, int N, int H, int W, int Cin, int Cout, void* tile_stats, void* stream);
@@ -363,6 +366,11 @@ extern "C" int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const 
   if (!x || !w_packed || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return CD360_ERR_ARG;
   if (cd360_conv_dma_slab_rows(N, H, W, Cin, Cout, taps, stride) > 0)  // 3 x 3 / stride 1: the LDS-DMA core (gemm8p.hip, EPI 5)
     return cd360_conv3x3_dma_bf16(x, w_packed, bias, emb, emb_stride, res, out, N, H, W, Cin, Cout, tile_stats, stream);
+  // 1 x 1 (the ResBlock skip_connection convs, openaimodel.py:335-343): a plain Linear over the pixels -- the same core through its GEMM entry
+  if (taps == 1 && stride == 1 && !emb && !tile_stats && Cin % 64 == 0 && Cout % 16 == 0 && !(getenv("CD360_CONV_DMA") && getenv("CD360_CONV_DMA")[0] == '0')) {
+    const int rc = cd360_gemm_bf16(x, w_packed, out, (int64_t)N * H * W, Cout, Cin, Cin, Cin, Cout, bias, res, Cout, nullptr, 0, 0, 0.f, nullptr, nullptr, 0, stream);
+    if (rc != CD360_ERR_SHAPE) return rc;
+  }
   if ((taps != 9 && taps != 1) || Cin % 64 || Cout % 16) return CD360_ERR_SHAPE;
   if ((stride != 1 && stride != 2) || (stride == 2 && (taps != 9 || H % 2 || W % 2))) return CD360_ERR_SHAPE;
   if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)out | (uintptr_t)emb | (uintptr_t)res) % 16) return CD360_ERR_ARG;

@@ -234,6 +234,29 @@ def ablate():
         os.environ.pop(k, None)
 
 
+def ablate_small():
+    """The same what-if timings for the narrow-output shapes of the 1280 level (128 x 128 tilings, one workgroup per CU)."""
+    for (M, N, K) in ((3072, 1280, 1280), (3072, 1280, 5120), (12288, 640, 2560)):
+        a = rnd(M, K, seed=1).to(torch.bfloat16)
+        w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
+        z = torch.zeros_like(a), torch.zeros_like(w)
+        print(f"M={M} N={N} K={K}")
+        for cfg in (4, 2, 1, 5):
+            os.environ["CD360_GEMM_CFG"] = str(cfg)
+            line = f"cfg{cfg}:"
+            for abl, name in ((0, "full"), (64, "no stores"), (16, "no barrier"), (8, "no DMA wait"), (32, "no LDS wait"), (56, "no waits"), (4, "no DMA"),
+                              (60, "no DMA no waits"), (124, "no DMA/waits/stores")):
+                os.environ["CD360_GEMM_ABL"] = str(abl)
+                t = timeit(lambda: ops.gemm(a, w), iters=20, warm=3)
+                line += f" | {name} {t:6.1f}"
+            os.environ["CD360_GEMM_ABL"] = "0"
+            t = timeit(lambda: ops.gemm(z[0], z[1]), iters=20, warm=3)
+            line += f" | zeros {t:6.1f}"
+            print(line, flush=True)
+    for k in ("CD360_GEMM_ABL", "CD360_GEMM_CFG"):
+        os.environ.pop(k, None)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["check", "time"]
     good = True
@@ -245,6 +268,8 @@ if __name__ == "__main__":
         time_qattn()
     if "ablate" in what:
         ablate()
+    if "ablate_small" in what:
+        ablate_small()
     if "one" in what:  # a few launches of one shape for rocprofv3 --pmc passes: one M N K (env CD360_GEMM_* select the variant)
         M, N, K = (int(v) for v in what[what.index("one") + 1:what.index("one") + 4])
         a = rnd(M, K, seed=1).to(torch.bfloat16)

@@ -17,7 +17,7 @@ head -42 $OUT/kernel_by_shape.csv | cut -c1-200
 for C in FETCH_SIZE WRITE_SIZE; do
   timeout 900 rocprofv3 --pmc $C --output-format csv -d /tmp/prof_$TAG/$C -o bench -- $BENCH > $OUT/bench_$C.log 2>&1; echo "$C exit $?"
   CC=$(find /tmp/prof_$TAG/$C -name "*counter_collection.csv" | head -1)
-  python $GRAFT_REPO_ROOT/tools/pmc_summary.py $CC $C conv_igemm attn_fwd attn_smallk nerf_fused gn_ geglu volrender gemm_mfma row_stats > $OUT/pmc_$C.csv
+  python $GRAFT_REPO_ROOT/tools/pmc_summary.py $CC $C conv_igemm attn_fwd attn_self attn_smallk nerf_fused gn_ geglu volrender gemm_mfma row_stats > $OUT/pmc_$C.csv
   cat $OUT/pmc_$C.csv
 done
 cd $GRAFT_REPO_ROOT

@@ -6,7 +6,7 @@ import json
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
-NAMES = {"conv_igemm_kernel": "conv_igemm", "attn_fwd_kernel": "attn_self", "attn_smallk_kernel": "attn_smallk", "nerf_fused_kernel": "nerf_mlp_aggregate",
+NAMES = {"conv_igemm_kernel": "conv_igemm", "attn_fwd_kernel": "attn_self", "attn_self_kernel": "attn_self", "attn_smallk_kernel": "attn_smallk", "nerf_fused_kernel": "nerf_mlp_aggregate",
          "gemm_mfma_kernel": "gemm8p", "row_stats_kernel": "row_stats",
          "geglu_kernel": "geglu", "volrender_kernel": "volrender", "gn_partial_kernel": "gn_silu", "gn_apply_kernel": "gn_silu", "gn_finalize_kernel": "gn_silu"}
 
@@ -17,10 +17,12 @@ def load(counter):
         key = next((v for k, v in NAMES.items() if k in r["kernel"]), None)
         if key is None:
             continue
-        if key == "gemm8p":  # gemm_mfma_kernel<WM, WN, NCB, NMB, NBUF, EPI>: EPI >= 2 is the fused q-projection + attention
+        if key == "gemm8p":  # gemm_mfma_kernel<WM, WN, NCB, NMB, NBUF, EPI>: EPI 2-4 = fused q-projection + attention, 5 = 3x3 convolution
             import re
             m = re.search(r"gemm_mfma_kernel<[^>]*?(\d+)>", r["kernel"])
-            if m and int(m.group(1)) >= 2:
+            if m and int(m.group(1)) == 5:
+                key = "conv_igemm"
+            elif m and int(m.group(1)) >= 2:
                 key = "qproj_attn"
         d = out.setdefault(key, {"n": 0, "kb": 0.0})
         d["n"] += int(r["dispatches"])
