@@ -636,16 +636,19 @@ def qproj_attention_ok(a: torch.Tensor, nk: int) -> bool:
 
 
 def qproj_attention(a: torch.Tensor, w: torch.Tensor, k: torch.Tensor, v: torch.Tensor, nk: int, heads: int,
-                    bias: Optional[torch.Tensor] = None, ln=None) -> torch.Tensor:
+                    bias: Optional[torch.Tensor] = None, ln=None, dup: int = 0) -> torch.Tensor:
     """softmax((a w^T [+ LayerNorm fold, + bias]) k^T / 8) v per head with the query projection and the attention in ONE kernel
     (cd360_qproj_attn_bf16): a [b, Nq, K] bf16, w [heads*64, K] bf16, k / v [b, >= nk, heads*64] (last dim contiguous, e.g. the two
-    halves of the merged k|v projection), nk <= 96 -> [b, Nq, heads*64].  bias / ln as gemm().  Forward only."""
+    halves of the merged k|v projection), nk <= 96 -> [b, Nq, heads*64].  bias / ln as gemm().  Forward only.
+    dup > 0 (cd360_qproj_attn_dedup_bf16): k / v hold b + dup batch elements; the last `dup` query elements attend to the keys of their own
+    batch index AND of index + dup -> [b + dup, Nq, heads*64] (the de-duplicated third of a 3-way CFG batch: q projected once)."""
     _need_gpu(a, w, k, v, bias)
     b, nq, K = a.shape
     N = heads * 64
     M, lda = _rows2d(a)
     assert w.dtype == torch.bfloat16 and w.shape == (N, K) and w.stride(1) == 1
-    assert k.dtype == torch.bfloat16 and v.dtype == torch.bfloat16 and k.shape[0] == b and v.shape[0] == b and k.shape[-1] == N and v.shape[-1] == N
+    assert 0 <= dup <= b
+    assert k.dtype == torch.bfloat16 and v.dtype == torch.bfloat16 and k.shape[0] == b + dup and v.shape[0] == b + dup and k.shape[-1] == N and v.shape[-1] == N
     assert k.stride(2) == 1 and v.stride(2) == 1 and k.shape[1] >= nk and v.shape[1] >= nk and qproj_attention_ok(a, nk)
     assert bias is None or (bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == N)
     stats_in = wsum = None
@@ -656,12 +659,12 @@ def qproj_attention(a: torch.Tensor, w: torch.Tensor, k: torch.Tensor, v: torch.
         assert stats_in.dtype == torch.float32 and stats_in.is_contiguous() and stats_in.shape[0] == M and stats_in.shape[2] == 2
         assert wsum.dtype == torch.float32 and wsum.is_contiguous() and wsum.numel() == N
         parts, ln_dim = stats_in.shape[1], K
-    out = torch.empty(b, nq, N, dtype=torch.bfloat16, device=a.device)
-    flops = 2.0 * M * N * K + 4.0 * M * nk * N
+    out = torch.empty(b + dup, nq, N, dtype=torch.bfloat16, device=a.device)
+    flops = 2.0 * M * N * K + 4.0 * (M + dup * nq) * nk * N
     with _timed("qproj_attn", flops, 2.0 * (M * K + N * K + M * N + 2 * b * nk * N)):
-        check(_lib.load().cd360_qproj_attn_bf16(_ptr(a), _ptr(w), _ptr(out), M, N, K, lda, w.stride(0), N, _ptr(bias), _ptr(stats_in), parts, ln_dim,
-                                               float(eps), _ptr(wsum), _ptr(k), _ptr(v), k.stride(0), k.stride(1), v.stride(0), v.stride(1), nq, nk,
-                                               64 ** -0.5, _stream()), "cd360_qproj_attn_bf16")
+        check(_lib.load().cd360_qproj_attn_dedup_bf16(_ptr(a), _ptr(w), _ptr(out), M, N, K, lda, w.stride(0), N, _ptr(bias), _ptr(stats_in), parts,
+                                                     ln_dim, float(eps), _ptr(wsum), _ptr(k), _ptr(v), k.stride(0), k.stride(1), v.stride(0),
+                                                     v.stride(1), nq, nk, 64 ** -0.5, dup, _stream()), "cd360_qproj_attn_dedup_bf16")
     return out
 
 

@@ -52,6 +52,8 @@ struct GemmParams {
   long ak_sb, ak_sn, av_sb, av_sn;
   int a_nq, a_nk;      // queries per batch element (M = B * a_nq, a_nq % 256 == 0), keys
   float a_scale_log2e;
+  int a_dup_from, a_dup;  // query batch elements >= a_dup_from attend to TWO key / value sets (batch i and i + a_dup; output rows of
+                          // batch i and i + a_dup): the de-duplicated CFG branch, whose q is projected once
   int abl;  // what-if timing knob (CD360_GEMM_ABL; results are wrong when set): 8 no DMA wait, 16 no barrier, 32 no LDS wait, 4 no DMA
   // EPI 5: A is the implicit im2col matrix of a 3x3 / stride 1 / pad 1 convolution over a channels-last [images, H, W, Cin] tensor
   // (lda = Cin, K = 9 Cin in cd360_conv_k_order order: K-tile kt = (group * 9 + tap) * cv_kg + j reads channel chunk group * cv_kg + j
@@ -513,22 +515,27 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
           }
         }
       }
-      // K and V rows of the tile's four heads -> LDS (rows >= Nk zero), all waves
       const int bidx = (int)(m0 / p.a_nq);
+      const int nrep = (p.a_dup > 0 && bidx >= p.a_dup_from) ? 2 : 1;
+      for (int rep = 0; rep < nrep; ++rep) {
+      if (rep) __syncthreads();  // the first pass has consumed its K / V
+      const int kvb = bidx + rep * p.a_dup;
+      const long orow = (long)rep * p.a_dup * p.a_nq;
+      // K and V rows of the tile's four heads -> LDS (rows >= Nk zero), all waves
       for (int i = tid; i < WN * NKEYS * 8; i += 64 * NW) {
         const int hl = i / (NKEYS * 8), rem = i - hl * (NKEYS * 8), row = rem >> 3, chunk = rem & 7;
         const int col = n0 + hl * 64 + chunk * 8;
         u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
         if (row < p.a_nk && col < p.N) {
-          kv = *reinterpret_cast<const u32x4*>(p.ak + bidx * p.ak_sb + (long)row * p.ak_sn + col);
-          vv = *reinterpret_cast<const u32x4*>(p.av + bidx * p.av_sb + (long)row * p.av_sn + col);
+          kv = *reinterpret_cast<const u32x4*>(p.ak + kvb * p.ak_sb + (long)row * p.ak_sn + col);
+          vv = *reinterpret_cast<const u32x4*>(p.av + kvb * p.av_sb + (long)row * p.av_sn + col);
         }
         unsigned char* hb = lds + hl * HEAD_LDS;
         *reinterpret_cast<u32x4*>(hb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = kv;
         *reinterpret_cast<u32x4*>(hb + NKEYS * 128 + row * 128 + ((chunk ^ (((row >> 1) & 3) << 1)) << 4)) = vv;
       }
       __syncthreads();
-      if (!has_ch) return;
+      if (!has_ch) continue;
       f32x16 init_last;  // accumulator start of the last key block: 0 for real keys, -1e30 for padding
 #pragma unroll
       for (int r = 0; r < 16; ++r) init_last[r] = ((NKB - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh < p.a_nk) ? 0.f : -1e30f;
@@ -605,9 +612,10 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
           const int row = 8 * i + lrow;
           const long m = m0 + wr * (NMB * 32) + mb * 32 + row;
           const u32x4 v = *reinterpret_cast<const u32x4*>(Os + row * 128 + ((lchunk ^ ((row >> 1) & 7)) << 4));
-          if (m < p.M) *reinterpret_cast<u32x4*>(p.out + m * p.ldo + ocol) = v;
+          if (m < p.M) *reinterpret_cast<u32x4*>(p.out + (m + orow) * p.ldo + ocol) = v;
         }
       }
+      }  // rep
     }
   };
   if (has_ch) k_loop(std::true_type{});
@@ -803,7 +811,7 @@ extern "C" int cd360_gemm_bf16(const void* a, const void* w, void* out, int64_t 
   p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.ldr = res ? ldr : 0;
   p.M = (int)M; p.N = N; p.K = K; p.ln_parts = ln_parts; p.ln_dim = ln_dim; p.ln_eps = ln_eps; p.geglu = geglu ? 1 : 0;
   p.tiles_m = p.tiles_n = p.group_m = 0;
-  p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f;
+  p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f; p.a_dup = p.a_dup_from = 0;
   p.cv_H = p.cv_W = p.cv_kg = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = nullptr;
   switch (pick_cfg(M, N, geglu)) {
     case 1: return launch<2, 2, 2, 2, 2>(p, (hipStream_t)stream);
@@ -819,11 +827,14 @@ extern "C" int cd360_gemm_bf16(const void* a, const void* w, void* out, int64_t 
 // cross-attention over Nk <= 96 keys fused with the attention itself -- Q never exists in memory.  A, W, bias, ln_stats, wsum as in
 // cd360_gemm_bf16; k, v bf16 [B, >= Nk, N] (element strides k_sb / k_sn, v_sb / v_sn: batch, key; head h at columns 64 h .. 64 h + 63),
 // M = B * Nq with Nq % 256 == 0 (a 256-token tile never straddles two batch elements).
-extern "C" int cd360_qproj_attn_bf16(const void* a, const void* w, void* out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldo,
-                                     const void* bias, const void* ln_stats, int ln_parts, int ln_dim, float ln_eps, const void* wsum,
-                                     const void* k, const void* v, int64_t k_sb, int64_t k_sn, int64_t v_sb, int64_t v_sn, int Nq, int Nk,
-                                     float scale, void* stream) {
-  if (!a || !w || !out || !k || !v || M <= 0 || N <= 0 || K <= 0 || Nq <= 0 || Nk <= 0) return CD360_ERR_ARG;
+// `dup` > 0: the last `dup` of the B = M / Nq query batch elements each attend to TWO key / value sets -- k, v then hold B + dup batch
+// elements and out (B + dup) Nq rows: query element i >= B - dup writes batch i (keys of batch i) and batch i + dup (keys of batch
+// i + dup).  The 3-way CFG batch of sample.py has identical pose tokens in its two image-conditional thirds: q is projected once.
+extern "C" int cd360_qproj_attn_dedup_bf16(const void* a, const void* w, void* out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldo,
+                                           const void* bias, const void* ln_stats, int ln_parts, int ln_dim, float ln_eps, const void* wsum,
+                                           const void* k, const void* v, int64_t k_sb, int64_t k_sn, int64_t v_sb, int64_t v_sn, int Nq, int Nk,
+                                           float scale, int dup, void* stream) {
+  if (!a || !w || !out || !k || !v || M <= 0 || N <= 0 || K <= 0 || Nq <= 0 || Nk <= 0 || dup < 0 || (int64_t)dup * Nq > M) return CD360_ERR_ARG;
   if (K % 64 || N % 64 || lda % 8 || ldw % 8 || ldo % 8 || lda < K || ldw < K || Nk > 96 || Nq % 256 || M % Nq) return CD360_ERR_SHAPE;
   if (k_sb % 8 || k_sn % 8 || v_sb % 8 || v_sn % 8) return CD360_ERR_SHAPE;
   if (((uintptr_t)a | (uintptr_t)w | (uintptr_t)out | (uintptr_t)k | (uintptr_t)v) % 16) return CD360_ERR_ARG;
@@ -838,10 +849,19 @@ extern "C" int cd360_qproj_attn_bf16(const void* a, const void* w, void* out, in
   p.tiles_m = p.tiles_n = p.group_m = 0;
   p.ak = (const uint16_t*)k; p.av = (const uint16_t*)v; p.ak_sb = k_sb; p.ak_sn = k_sn; p.av_sb = v_sb; p.av_sn = v_sn;
   p.a_nq = Nq; p.a_nk = Nk; p.a_scale_log2e = scale * 1.4426950408889634f;
+  p.a_dup = dup; p.a_dup_from = (int)(M / Nq) - dup;
   p.cv_H = p.cv_W = p.cv_kg = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = nullptr;
   if (Nk <= 32) return launch_epi<2, 4, 2, 4, 2, 2>(p, (hipStream_t)stream);
   if (Nk <= 64) return launch_epi<2, 4, 2, 4, 2, 3>(p, (hipStream_t)stream);
   return launch_epi<2, 4, 2, 4, 2, 4>(p, (hipStream_t)stream);
+}
+
+extern "C" int cd360_qproj_attn_bf16(const void* a, const void* w, void* out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldo,
+                                     const void* bias, const void* ln_stats, int ln_parts, int ln_dim, float ln_eps, const void* wsum,
+                                     const void* k, const void* v, int64_t k_sb, int64_t k_sn, int64_t v_sb, int64_t v_sn, int Nq, int Nk,
+                                     float scale, void* stream) {
+  return cd360_qproj_attn_dedup_bf16(a, w, out, M, N, K, lda, ldw, ldo, bias, ln_stats, ln_parts, ln_dim, ln_eps, wsum, k, v, k_sb, k_sn, v_sb, v_sn,
+                                     Nq, Nk, scale, 0, stream);
 }
 
 // ---- 3 x 3 / stride 1 / pad 1 convolution on the same core (EPI 5): the im2col matrix is never built -- K-tile kt of the A operand is
@@ -903,7 +923,7 @@ extern "C" int cd360_conv3x3_dma_bf16(const void* x, const void* w_packed, const
   p.lda = Cin; p.ldw = 9L * Cin; p.ldo = Cout; p.ldr = res ? Cout : 0;
   p.M = (int)M; p.N = Cout; p.K = 9 * Cin; p.ln_parts = 0; p.ln_dim = 0; p.ln_eps = 0.f; p.geglu = 0;
   p.tiles_m = p.tiles_n = p.group_m = 0;
-  p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f;
+  p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f; p.a_dup = p.a_dup_from = 0;
   p.cv_H = H; p.cv_W = W; p.cv_kg = cd360_conv_k_order(Cin, 9);
   p.emb = (const uint16_t*)emb; p.emb_stride = emb ? emb_stride : 0; p.cstats = (float*)tile_stats;
   switch (cfg) {

@@ -292,6 +292,23 @@ class BasicTransformerBlock(nn.Module):
             # first two thirds only and reuse the second for the third (the reference computes it twice).
             t2, d2 = self._sampling_tables(dup, dup)  # the layout is stated, never re-inferred from the de-duplicated batch size
             h, dec, dists, _ = self.pose_featurenerf.render_inputs(list(pose[:2 * dup]), None, None, tables=t2, dims=d2)
+            b2, hw, S, C = h.shape
+            tok = h.reshape(b2, hw * S, C)
+            if (tok.dtype == x.dtype and self.fused_ready(tok) and not os.environ.get("CD360_NO_RENDER_COMMUTE") and not os.environ.get("CD360_NO_QPROJ_ATTN")
+                    and ops.qproj_attention_ok(tok, 96)):
+                # ... and keep the pose tokens de-duplicated through their cross-attention: the shared third's queries are projected
+                # once and meet both text contexts inside cd360_qproj_attn_dedup_bf16; the render commutes with the out projection
+                o = self._pose_tokens_attn(tok.contiguous(), context, project=False, dup=dup)  # [3 dup, hw S, C]
+                if o is not None:
+                    def expand(t):
+                        return torch.cat([t, t[dup:]], 0)
+                    rgb_raw = dec[..., :3] if self.rgb_predict else None
+                    r_tok, fg, alphas, _, rgb = ops.volrender(h, dec[..., 3], dists, rgb_raw)
+                    r_o = ops.volrender(o.reshape(3 * dup, hw, S, C), expand(dec[..., 3]), dists, None)[0]
+                    fg, alphas = expand(fg), expand(alphas)
+                    wo, bo = self._packed()["o2"]
+                    rendered = ops.gemm(r_o, wo, res=(expand(r_tok).float() + fg * bo).to(torch.bfloat16))
+                    return rendered, fg, None, alphas, (None if rgb is None else expand(rgb))
             h, dec = torch.cat([h, h[dup:]], 0), torch.cat([dec, dec[dup:]], 0)
         else:
             h, dec, dists, _ = self.pose_featurenerf.render_inputs(pose, context_ref, mask_ref, tables=tables, dims=dims)
@@ -299,6 +316,18 @@ class BasicTransformerBlock(nn.Module):
         tok = h.reshape(b, hw * S, C)
         if tok.dtype != x.dtype:
             tok = tok.to(x.dtype)
+        if self.fused_ready(tok) and not os.environ.get("CD360_NO_RENDER_COMMUTE"):
+            # The volume render is linear in the features and its weights depend on `dec` only, so it commutes with the out projection
+            # of the pose-token attention: sum_s w_s (tok_s + o_s Wo^T + b) = R(tok) + R(o) Wo^T + fg b.  The [b hw S, C] x [C, C]
+            # GEMM (attention.py:586 applied per sample) becomes a [b hw, C] one, S = 24 times smaller; fp32 sums, fewer bf16 roundings.
+            tok = tok.contiguous()
+            o = self._pose_tokens_attn(tok, context, project=False)
+            rgb_raw = dec[..., :3] if self.rgb_predict else None
+            r_tok, fg, alphas, _, rgb = ops.volrender(tok.reshape(b, hw, S, C), dec[..., 3], dists, rgb_raw)
+            r_o = ops.volrender(o.reshape(b, hw, S, C), dec[..., 3], dists, None)[0]
+            wo, bo = self._packed()["o2"]
+            rendered = ops.gemm(r_o, wo, res=(r_tok.float() + fg * bo).to(torch.bfloat16))
+            return rendered, fg, None, alphas, rgb
         if self.fused_ready(tok):
             tok = self._pose_tokens_attn(tok.contiguous(), context)  # norm2 folded into the q GEMM, residual into the out GEMM
         else:
@@ -405,17 +434,24 @@ class BasicTransformerBlock(nn.Module):
         self._pack = (key, P)
         return P
 
-    def _pose_tokens_attn(self, tok: torch.Tensor, context) -> torch.Tensor:
-        """attn2(norm2(tok), context) + tok on the FeatureNeRF samples (attention.py:578-588) through the fused GEMMs."""
+    def _pose_tokens_attn(self, tok: torch.Tensor, context, project: bool = True, dup: int = 0) -> torch.Tensor:
+        """attn2(norm2(tok), context) + tok on the FeatureNeRF samples (attention.py:578-588) through the fused GEMMs; project=False
+        returns the attention output before to_out (the caller renders first, see reference_attn)."""
         P = self._packed()
         a2 = self.attn2
         k, v, nk = a2.project_context(context)
         w, ws, cb = P["q2"]
         ln = (ops.row_stats(tok), ws, self.norm2.eps)
+        if dup:  # de-duplicated CFG batch: tok holds 2 dup elements, the context 3 dup (only the fused kernel serves this)
+            if not (ops.qproj_attention_ok(tok, nk) and k.shape[0] == tok.shape[0] + dup):
+                return None
+            return ops.qproj_attention(tok, w, k, v, nk, a2.heads, bias=cb, ln=ln, dup=dup)
         if ops.qproj_attention_ok(tok, nk) and not os.environ.get("CD360_NO_QPROJ_ATTN"):
             o = ops.qproj_attention(tok, w, k, v, nk, a2.heads, bias=cb, ln=ln)  # q never leaves the registers (cd360_qproj_attn_bf16)
         else:
             o = ops.attention(ops.gemm(tok, w, bias=cb, ln=ln), k, v, a2.heads, nk)
+        if not project:
+            return o
         return ops.gemm(o, P["o2"][0], bias=P["o2"][1], res=tok)
 
     def _forward_fused(self, x, stats, context=None, context_ref=None, pose=None, mask_ref=None, prev_weights=None):

@@ -255,6 +255,14 @@ int cd360_gemm_bf16(const void* a, const void* w, void* out, int64_t M, int N, i
 int cd360_qproj_attn_bf16(const void* a, const void* w, void* out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldo,
                           const void* bias, const void* ln_stats, int ln_parts, int ln_dim, float ln_eps, const void* wsum, const void* k,
                           const void* v, int64_t k_sb, int64_t k_sn, int64_t v_sb, int64_t v_sn, int Nq, int Nk, float scale, void* stream);
+/* cd360_qproj_attn_bf16 for a CFG batch whose last `dup` query batch elements are each needed against TWO key / value sets (sample.py's
+ * 3-way CFG: the image-conditional and the image+text-conditional thirds have identical pose tokens and differ in the text context only):
+ * k, v hold B + dup batch elements (B = M / Nq), out (B + dup) * Nq rows; query element i >= B - dup writes batch i (keys of batch i) and
+ * batch i + dup (keys of batch i + dup).  The projection of those queries runs once. */
+int cd360_qproj_attn_dedup_bf16(const void* a, const void* w, void* out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldo,
+                                const void* bias, const void* ln_stats, int ln_parts, int ln_dim, float ln_eps, const void* wsum,
+                                const void* k, const void* v, int64_t k_sb, int64_t k_sn, int64_t v_sb, int64_t v_sn, int Nq, int Nk,
+                                float scale, int dup, void* stream);
 /* N-tile width (256 | 192 | 128) cd360_gemm_bf16 uses for an [M, N] output: stats_out holds ceil(N / that) partials per row. */
 int cd360_gemm_tile_n(int64_t M, int N);
 /* (sum, sum of squares) of every row of a bf16 [rows, C] matrix (row stride ld) as one fp32 partial per row: the `ln_stats` input for a

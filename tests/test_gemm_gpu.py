@@ -1,0 +1,39 @@
+"""cd360_gemm_bf16 / cd360_qproj_attn*_bf16 through the C ABI against fp32 torch references (`-m gpu`): every epilogue (bias, residual,
+LayerNorm fold, GEGLU, row statistics), every tiling, ragged shapes, bit-identical repeat launches; the fused q-projection + attention
+kernel incl. its de-duplicated CFG form.  The case lists live in tools/bench_gemm.py (the same functions time the kernels)."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+sys.path.insert(0, os.path.join(ROOT, "custom-diffusion360_amd"))
+
+pytestmark = pytest.mark.gpu
+
+
+def test_gemm_family_and_fused_qproj_attention_against_fp32_torch(monkeypatch):
+    import bench_gemm
+    monkeypatch.delenv("CD360_GEMM_CFG", raising=False)
+    assert bench_gemm.check()
+    os.environ.pop("CD360_GEMM_CFG", None)
+
+
+@pytest.mark.parametrize("b,dup,nq,C,nk", [(2, 1, 256, 128, 77), (4, 2, 512, 640, 77), (2, 1, 1024, 1280, 50), (1, 1, 256, 64, 20)])
+def test_qproj_attention_dedup_equals_the_expanded_batch(b, dup, nq, C, nk):
+    """cd360_qproj_attn_dedup_bf16: the last `dup` query batch elements meet two key / value sets (batch i and i + dup).  Must equal,
+    bit for bit, cd360_qproj_attn_bf16 on the batch with those elements repeated (sample.py's 3-way CFG: [null | image | image+text])."""
+    from bench_gemm import rnd
+    from cd360 import ops
+    heads, K = C // 64, C
+    a = (rnd(b, nq, K, seed=21) * (0.5 + rnd(b, nq, 1, seed=22).abs()) + 0.5 * rnd(b, nq, 1, seed=23)).to(torch.bfloat16)
+    gamma, beta = 1 + 0.2 * rnd(K, seed=5), 0.1 * rnd(K, seed=6)
+    wp, wsum, cb = ops.pack_ln_linear(rnd(C, K, seed=24, scale=K ** -0.5), None, gamma, beta)
+    kv = rnd(b + dup, max(80, nk), 2 * C, seed=25).to(torch.bfloat16)
+    k, v = kv[..., :C], kv[..., C:]
+    got = ops.qproj_attention(a, wp, k, v, nk, heads, bias=cb, ln=(ops.row_stats(a), wsum, 1e-5), dup=dup)
+    a3 = torch.cat([a, a[b - dup:]], 0).contiguous()
+    want = ops.qproj_attention(a3, wp, k, v, nk, heads, bias=cb, ln=(ops.row_stats(a3), wsum, 1e-5))
+    assert got.shape == (b + dup, nq, C) and torch.equal(got, want)
