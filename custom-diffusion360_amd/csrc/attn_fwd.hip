@@ -407,7 +407,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attn_self_kernel(Att
     }
     const float ma = fmaxf(fmaxf(m[0], m[1]), s[0][7]), mb = fmaxf(fmaxf(m[2], m[3]), s[0][15]);
     const float mx = fmaxf(fmaxf(ma, mb), fmaxf(s[1][7], s[1][15]));
-    return fmaxf(mx, __shfl_xor(mx, 32));
+    // both key halves: v_permlane32_swap (VALU) instead of a ds_bpermute round trip on the way to the end-of-tile branch
+    const auto sw = __builtin_amdgcn_permlane32_swap(__builtin_bit_cast(unsigned, mx), __builtin_bit_cast(unsigned, mx), false, false);
+    return fmaxf(__builtin_bit_cast(float, sw[0]), __builtin_bit_cast(float, sw[1]));
   };
   // the rare path: move m_ref of query block qb by d (>= 0 except on the first tile) and rescale what hangs on it
   auto move_ref = [&](int qb, float d, f32x16 (&s)[2]) {
