@@ -17,6 +17,7 @@
 // the gathered Y / zP rows are added with fp32 bilinear weights; SiLU; flash-style online softmax over views.
 // Each (lane, lane^32) pair owns one sample and reads one full 128-B line per texel corner.
 #include "cd360_geom.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -213,6 +214,272 @@ __global__ __launch_bounds__(256, 2) void nerf_fused_kernel(NerfParams p) {
   }
 }
 
+// ---- the same operator with the corner rows gathered by LDS-DMA -----------------------------------------------------------------------
+// nerf_fused_kernel is bound by the vector-memory RETURN path, not by its arithmetic (TD_TD_BUSY = 100 % of the kernel's CU-cycles;
+// builds without the sin / cos or without the SiLU transcendentals run no faster): with lane = sample every gather instruction returns
+// 32 different cache lines, 32 bytes of each, and every line is visited by four instructions.  Here the four corner rows of a view
+// travel as FULL 128-byte lines: buffer_load_dwordx4 ... lds, 8 lanes per row (lane i of piece j fetches 16-byte chunk i % 8 of sample
+// 8 j + i / 8, whose table pixel it gets from that sample's lane by ds_bpermute), 16 instructions x 8 lines per wave and view instead of
+// 32 x 32 line returns.  The rows land in a wave-private ring of four 4-KB slots (one per corner; 16-byte chunks XOR-swizzled by the sample
+// on the SOURCE side: the destination of a DMA is lane-linear) and are read back in the compute layout with conflict-free ds_read_b128.
+// No gather registers are left, so the loop is software-pipelined for free: corner c of view iv+1 is requested as soon as corner c of
+// view iv has been blended (its slot), the geometry of view iv+1 having been computed before view iv's encoding; the waits are counted
+// (s_waitcnt vmcnt(20): the 12 + 8 vector-memory operations issued after the piece being consumed).  zP (one or two distinct rows
+// per wave: consecutive samples share their ray) and the four logit texels stay ordinary loads, consumed one iteration after issue.
+#define NERF_LDS_AS3(p) ((__attribute__((address_space(3))) void*)(p))
+constexpr int RING_BYTES = 4 * 32 * 128;  // four corner slots of 32 samples x 128 B per wave
+
+__global__ __launch_bounds__(256, 2) void nerf_fused_dma_kernel(NerfParams p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_dma[];
+  unsigned char* const ring_all = smem_dma;                 // 4 waves x RING_BYTES
+  unsigned char* const Ws = smem_dma + 4 * RING_BYTES;      // CN x W_PITCH
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned char* const ring = ring_all + wave * RING_BYTES;
+  const int hw = p.r * p.r;
+  const long npts = (long)hw * p.S;
+
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int cc = wg / (p.b * p.ngroups);
+  const int rem = wg - cc * (p.b * p.ngroups);
+  const int bi = rem / p.ngroups, grp = rem - bi * p.ngroups;
+  const int ch0 = cc * CN;
+
+  for (int idx = tid; idx < CN * (KP / 8); idx += 256) {
+    const int row = idx / (KP / 8), c8 = idx - row * (KP / 8);
+    *reinterpret_cast<u32x4*>(Ws + row * W_PITCH + c8 * 16) = *reinterpret_cast<const u32x4*>(p.Wk + (long)(ch0 + row) * KP + c8 * 8);
+  }
+  __syncthreads();
+
+  const float hs = hh ? 2.f : 1.f;
+  const int arow0 = chan_pos(l31);
+  typedef const __attribute__((address_space(4))) float cfloat;
+  typedef const __attribute__((address_space(4))) int cint;
+  cfloat* const cams_c = (cfloat*)(p.cams);
+  cfloat* const cview_c = (cfloat*)(p.cview);
+  cint* const imap_c = (cint*)(p.img_map);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.Y, 0, 0xffffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.zP, 0, 0xffffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.lv, 0, 0xffffffff, 0x00020000);
+  const uint32_t row_bytes = (uint32_t)p.C * 2u;
+  const uint32_t lane_off = (uint32_t)(ch0 + 16 * hh) * 2u;  // this lane's 32 bytes of a 64-channel slice (block mb: + 64 B)
+  // DMA lane geometry: piece j moves samples 8 j .. 8 j + 7; this lane: sample 8 j + lane / 8, LDS chunk lane % 8 <- source chunk ^ swizzle
+  const int dsub = lane >> 3, dchunk = lane & 7;
+  // read-back: chunk 4 mb + 2 hh + t of sample l31 sits at chunk position (id ^ ((l31 >> 1) & 7))
+  const int rswz = (l31 >> 1) & 7;
+
+  for (int tw = 0; tw < TILES_PER_WAVE; ++tw) {
+    const long pt0 = (long)grp * PTS_PER_WG + (wave * TILES_PER_WAVE + tw) * 32;
+    if (pt0 >= npts) break;  // wave-uniform
+    const long pt = pt0 + l31;
+    const bool valid = pt < npts;
+    const long ptc = valid ? pt : npts - 1;
+    const int k = (int)(ptc / p.S), s = (int)(ptc - (long)k * p.S);
+    float P[3];
+    {
+      const Cam c0 = load_cam(p.cams + (long)bi * (p.n + 1) * 16);
+      float o[3], d[3];
+      patch_ray(c0, p.xs[k % p.r], p.ys[k / p.r], o, d);
+      const float ts = p.t[(long)k * p.t_ray_stride + s];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) P[j] = o[j] + ts * d[j];
+    }
+
+    struct Geo {
+      float q[3], w[4], lvv[4], cv;  // lvv: the four gathered logit texels, raw (combined one iteration after their loads were issued)
+      int pix[4];                    // table pixel (image included) of the four corners
+    };
+    auto geometry = [&](int iv, Geo& G) {  // projection, corners, weights of view iv; issues its four logit-texel loads
+      // (the per-view uniforms are read through the constant address space: scalar loads on the LDS / SMEM counter -- as vector loads
+      // they would, vmcnt being in-order, wait for every row piece in flight)
+      Cam ci;
+      {
+        const cfloat* cp = cams_c + ((long)bi * (p.n + 1) + 1 + iv) * 16;
+#pragma unroll
+        for (int i = 0; i < 9; ++i) ci.R[i] = cp[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ci.T[i] = cp[9 + i];
+        ci.f[0] = cp[12]; ci.f[1] = cp[13]; ci.c[0] = cp[14]; ci.c[1] = cp[15];
+      }
+      world_to_view(ci, P, G.q);
+      const Corner cr = bilinear_corner(grid_coord(ci.f[0], ci.c[0], G.q[0], G.q[2]), grid_coord(ci.f[1], ci.c[1], G.q[1], G.q[2]), p.r);
+      const int x0 = min(max(cr.x0, 0), p.r - 1), x1 = min(max(cr.x0 + 1, 0), p.r - 1);
+      const int y0 = min(max(cr.y0, 0), p.r - 1), y1 = min(max(cr.y0 + 1, 0), p.r - 1);
+      const int img = bi * p.n + iv;
+      const int yimg = p.img_map ? imap_c[img] : img;
+      G.pix[0] = yimg * hw + y0 * p.r + x0;
+      G.pix[1] = yimg * hw + y0 * p.r + x1;
+      G.pix[2] = yimg * hw + y1 * p.r + x0;
+      G.pix[3] = yimg * hw + y1 * p.r + x1;
+      G.w[0] = (1.f - cr.tx) * (1.f - cr.ty);
+      G.w[1] = cr.tx * (1.f - cr.ty);
+      G.w[2] = (1.f - cr.tx) * cr.ty;
+      G.w[3] = cr.tx * cr.ty;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) if (!((cr.mask >> c) & 1)) G.w[c] = 0.f;
+      G.cv = cview_c[img];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) G.lvv[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrsrc, (uint32_t)G.pix[c] * 4u, 0, 0));
+    };
+    u32x4 zp[2][2];
+    auto load_zp = [&](int iv) {
+      const uint32_t off = (uint32_t)((bi * p.n + iv) * hw + k) * row_bytes + lane_off;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        zp[mb][0] = __builtin_amdgcn_raw_buffer_load_b128(zrsrc, off + mb * 64, 0, 0);
+        zp[mb][1] = __builtin_amdgcn_raw_buffer_load_b128(zrsrc, off + mb * 64 + 16, 0, 0);
+      }
+    };
+    auto dma_corner = [&](int c, const Geo& G) {  // 4 pieces of 8 full rows into slot c
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int smp = 8 * j + dsub;
+        const int pix = __builtin_amdgcn_ds_bpermute(4 * smp, G.pix[c]);
+        const uint32_t off = (uint32_t)pix * row_bytes + (uint32_t)(ch0 * 2 + ((dchunk ^ ((smp >> 1) & 7)) << 4));
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, NERF_LDS_AS3(ring + c * 4096 + j * 1024), 16, off, 0, 0, 0);
+      }
+    };
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x16 g[2];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { g[0][i] = 0.f; g[1][i] = 0.f; }
+
+    // prologue: view 0 requested (the previous tile's last reads of the ring are complete: its blend consumed them)
+    Geo cur, nxt;
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    geometry(0, cur);
+    load_zp(0);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dma_corner(c, cur);
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int iv = 0; iv < p.n; ++iv) {
+      const bool more = iv + 1 < p.n;
+      if (more) geometry(iv + 1, nxt);
+      else nxt = cur;
+      __builtin_amdgcn_sched_barrier(0);
+
+      // ---- per-sample inputs in B-operand layout: lane half h handles frequencies 2*kfp + h ----
+      const float qh[3] = {cur.q[0] * hs, cur.q[1] * hs, cur.q[2] * hs};
+      f32x16 z[2];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { z[0][i] = 0.f; z[1][i] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 7; ++ks) {
+        uint32_t fw[4];
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+          const int wi = ks * 4 + pr;
+          if (wi < 24) {
+            const int comp = wi % 3, kfp = wi / 3;
+            const float rev = __builtin_amdgcn_fractf(qh[comp] * __builtin_bit_cast(float, (uint32_t)((127 + 2 * kfp - 9) << 23)));
+            fw[pr] = pack_bf16x2(__builtin_amdgcn_sinf(rev), __builtin_amdgcn_cosf(rev));
+          } else if (wi == 24) {
+            fw[pr] = pack_bf16x2(hh ? cur.q[2] : cur.q[0], hh ? 0.f : cur.q[1]);
+          } else {
+            fw[pr] = 0u;
+          }
+        }
+        u32x4 fv = {fw[0], fw[1], fw[2], fw[3]};
+        const bf16x8 fb = __builtin_bit_cast(bf16x8, fv);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ws + (mb * 32 + arow0) * W_PITCH + ks * 32 + hh * 16);
+          z[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, fb, z[mb], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // one k-step per scheduling region: bounds the live sin / cos temporaries
+      }
+
+      // ---- online softmax over views (texels and constant of this view were requested one iteration ago) ----
+      float logit = cur.cv;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) logit = fmaf(cur.w[c], cur.lvv[c], logit);
+      const float lg = logit * 1.4426950408889634f;
+      const float m_new = fmaxf(m_run, lg);
+      const float sc = __builtin_amdgcn_exp2f(m_run - m_new);
+      const float a = __builtin_amdgcn_exp2f(lg - m_new);
+      l_run = fmaf(l_run, sc, a);
+      m_run = m_new;
+      if (p.logits) {
+        if (valid && hh == 0 && cc == 0) p.logits[((long)bi * p.n + iv) * npts + pt] = logit;
+      }
+
+      // ---- z += zP, then the four corners in turn (the same order of additions as nerf_fused_kernel) ----
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            z[mb][half * 8 + 2 * e] += bf16lo_to_f32(zp[mb][half][e]);
+            z[mb][half * 8 + 2 * e + 1] += bf16hi_to_f32(zp[mb][half][e]);
+          }
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) load_zp(iv + 1);  // into the registers just consumed: one iteration of flight time
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        __builtin_amdgcn_sched_barrier(0);
+        // the pieces of this corner (requested one view ago) have landed: everything but the 20 vector-memory operations issued after
+        // them -- the later corners of this view (12 - 4 c), the next view's texels and zP (8), its earlier corners (4 c); last view: 0
+        if (more) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        u32x4 y[2][2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            y[mb][t] = *reinterpret_cast<const u32x4*>(ring + c * 4096 + l31 * 128 + (((4 * mb + 2 * hh + t) ^ rswz) << 4));
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              z[mb][half * 8 + 2 * e] = fmaf(cur.w[c], bf16lo_to_f32(y[mb][half][e]), z[mb][half * 8 + 2 * e]);
+              z[mb][half * 8 + 2 * e + 1] = fmaf(cur.w[c], bf16hi_to_f32(y[mb][half][e]), z[mb][half * 8 + 2 * e + 1]);
+            }
+        __builtin_amdgcn_sched_barrier(0);  // (the fmas above consumed the ds_reads: the slot is free)
+        if (more) dma_corner(c, nxt);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+
+      // ---- g = g*sc + a*silu(z) ----
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float zz = z[mb][r];
+          const float sv = zz * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * zz));
+          g[mb][r] = fmaf(a, sv, g[mb][r] * sc);
+        }
+      cur = nxt;
+    }
+
+    if (valid) {
+      const float inv = 1.f / l_run;
+      uint16_t* dst = p.g + ((long)bi * npts + pt) * p.C + ch0 + 16 * hh;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        u32x4 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o0[e] = pack_bf16x2(g[mb][2 * e] * inv, g[mb][2 * e + 1] * inv);
+          o1[e] = pack_bf16x2(g[mb][8 + 2 * e] * inv, g[mb][8 + 2 * e + 1] * inv);
+        }
+        *reinterpret_cast<u32x4*>(dst + mb * 32) = o0;
+        *reinterpret_cast<u32x4*>(dst + mb * 32 + 8) = o1;
+      }
+      if (p.lse && hh == 0 && cc == 0) {
+        p.lse[((long)bi * npts + pt) * 2] = m_run * 0.6931471805599453f;
+        p.lse[((long)bi * npts + pt) * 2 + 1] = l_run;
+      }
+    }
+  }
+}
+
 // (view, ray)-only inputs of plane_coefs.0: [enc8(plucker(target ray in ref-i frame)) 96 | dir 3]
 // (nerfsd_pytorch3d.py:104-112,130-131; utils_cameraray.py:201-242,270-292).  out [b, n, hw, 104] fp32 (99 + 5 zero pad)
 // BF = false: out [b, n, hw, 104] fp32 (99 + 5 zero pad); BF = true: out [b, n, hw, 128] bf16 (99 + 29 zero pad) -- the A operand of
@@ -305,7 +572,18 @@ extern "C" int cd360_nerf_mlp_aggregate(const void* cams, const void* xs, const 
   p.ngroups = (int)((npts + PTS_PER_WG - 1) / PTS_PER_WG);
   const long nwg = (long)p.ncc * b * p.ngroups;
   if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
-  hipLaunchKernelGGL(nerf_fused_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+  // LDS-DMA row gathers (nerf_fused_dma_kernel) whenever the tables are addressable with 32-bit byte offsets; CD360_NERF_DMA=0: the
+  // register-gather kernel
+  bool dma = (long)b * n * r * r * C * 2 < (1L << 32);
+  if (const char* e = getenv("CD360_NERF_DMA")) dma = dma && e[0] != '0';
+  if (dma) {
+    constexpr int LDS_DMA = 4 * RING_BYTES + CN * W_PITCH;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&nerf_fused_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DMA);
+    if (attr != hipSuccess) return CD360_ERR_LAUNCH;
+    hipLaunchKernelGGL(nerf_fused_dma_kernel, dim3((unsigned)nwg), dim3(256), LDS_DMA, (hipStream_t)stream, p);
+  } else {
+    hipLaunchKernelGGL(nerf_fused_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+  }
   CD360_LAUNCH_CHECK();
   return CD360_OK;
 }
