@@ -731,7 +731,7 @@ int launch_epi(const GemmParams& p0, hipStream_t stream) {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS of one CU");
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
-  int gm = 4;
+  int gm = 6;  // token tiles per group (swept 1 .. 48 on the block's shapes: 6 best or tied, tools/bench_gemm.py group_m)
   if (const char* e = getenv("CD360_GEMM_GROUP_M")) gm = atoi(e) > 0 ? atoi(e) : gm;
   p.group_m = gm;
   p.abl = 0;

@@ -234,6 +234,23 @@ def ablate():
         os.environ.pop(k, None)
 
 
+def group_m_sweep():
+    """Tile-group height (CD360_GEMM_GROUP_M: token tiles per group, the channel tile varying slowest inside a group) on the block's shapes."""
+    for name, M, N, K, geglu in (("L2 ff1", 3072, 10240, 1280, True), ("L2 qkv", 3072, 3840, 1280, False), ("L2 ff2", 3072, 1280, 5120, False),
+                                 ("L1 ff1", 12288, 5120, 640, True), ("L1 qkv", 12288, 1920, 640, False), ("L2 out", 3072, 1280, 1280, False)):
+        a = rnd(M, K, seed=1).to(torch.bfloat16)
+        w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
+        b32 = rnd(N, seed=3)
+        st, ws = ops.row_stats(a), w.float().sum(1).contiguous()
+        line = f"{name} M={M} N={N} K={K}:"
+        for gm in (1, 2, 3, 4, 6, 12, 48):
+            os.environ["CD360_GEMM_GROUP_M"] = str(gm)
+            t = timeit(lambda: ops.gemm(a, w, bias=b32, ln=(st, ws, 1e-5), geglu=geglu))
+            line += f" | gm{gm} {t:6.1f}"
+        print(line, flush=True)
+    os.environ.pop("CD360_GEMM_GROUP_M", None)
+
+
 def ablate_small():
     """The same what-if timings for the narrow-output shapes of the 1280 level (128 x 128 tilings, one workgroup per CU)."""
     for (M, N, K) in ((3072, 1280, 1280), (3072, 1280, 5120), (12288, 640, 2560)):
@@ -270,6 +287,8 @@ if __name__ == "__main__":
         ablate()
     if "ablate_small" in what:
         ablate_small()
+    if "group_m" in what:
+        group_m_sweep()
     if "one" in what:  # a few launches of one shape for rocprofv3 --pmc passes: one M N K (env CD360_GEMM_* select the variant)
         M, N, K = (int(v) for v in what[what.index("one") + 1:what.index("one") + 4])
         a = rnd(M, K, seed=1).to(torch.bfloat16)
