@@ -198,6 +198,30 @@ def test_fused_feature_nerf(C, r, n, S, b):
     assert rel(dec[..., 3:], sigma) < 1e-2 and rel(dec[..., :3], rgb) < 1e-2
 
 
+@pytest.mark.parametrize("C,r,n,S,b", [(64, 8, 2, 4, 2), (640, 16, 5, 24, 1), (1280, 8, 7, 6, 2), (128, 7, 3, 3, 1)])
+def test_render_kernel_lds_dma_row_gathers_equal_register_gathers(C, r, n, S, b, monkeypatch):
+    """nerf_fused_dma_kernel (corner rows by LDS-DMA into a per-wave slot ring, counted waits, views software-pipelined) against
+    nerf_fused_kernel (per-lane register gathers): the same additions in the same order -- bit-identical g, logits and lse, on repeated
+    launches too (a missed wait would show as a mismatch); (128, 7, ...) has a ragged last sample tile, n = 7 an odd view count."""
+    from cd360 import nerf, ops
+    w = nerf_weights(C, seed=C + n)
+    cams = cams_for(b, n, seed=C).to(DEV)
+    xref = bf(W.tensor("xref", (b, n, r * r, C), seed=C)).to(DEV, torch.bfloat16)
+    fw = nerf.FusedNerfWeights(*(w[k].to(DEV) for k in ("plane_coefs.0.weight", "plane_coefs.0.bias", "plane_coefs.2.weight", "plane_coefs.2.bias",
+                                                        "nviews.weight", "nviews.bias", "decoder.weight")))
+    xs = nerf.patch_positions(r, DEV)
+    t, _ = nerf.depth_samples(S, 2.0, 0.0, DEV, r * r)
+    Y, lv = nerf.reference_tables(fw, xref)
+    g = torch.Generator().manual_seed(C)
+    zP = bf(torch.randn(b * n, r * r, C, generator=g)).to(DEV, torch.bfloat16)
+    cview = nerf.view_constants(fw, cams)
+    outs = [ops.nerf_mlp_aggregate(cams, xs, xs, t, Y, zP, lv, cview, fw.Wk, want_logits=True) for _ in range(3)]
+    monkeypatch.setenv("CD360_NERF_DMA", "0")
+    ref = ops.nerf_mlp_aggregate(cams, xs, xs, t, Y, zP, lv, cview, fw.Wk, want_logits=True)
+    for o in outs:
+        assert all(torch.equal(a, b_) for a, b_ in zip(o, ref))
+
+
 # ------------------------------------------------------------------------------------------------ volume rendering (A10)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_volrender(dtype):
