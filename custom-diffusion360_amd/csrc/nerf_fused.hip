@@ -223,8 +223,8 @@ __global__ __launch_bounds__(256, 2) void nerf_fused_kernel(NerfParams p) {
 // 32 x 32 line returns.  The rows land in a wave-private ring of four 4-KB slots (one per corner; 16-byte chunks XOR-swizzled by the sample
 // on the SOURCE side: the destination of a DMA is lane-linear) and are read back in the compute layout with conflict-free ds_read_b128.
 // No gather registers are left, so the loop is software-pipelined for free: corner c of view iv+1 is requested as soon as corner c of
-// view iv has been blended (its slot), the geometry of view iv+1 having been computed before view iv's encoding; the waits are counted
-// (s_waitcnt vmcnt(20): the 12 + 8 vector-memory operations issued after the piece being consumed).  zP (one or two distinct rows
+// view iv has been blended (its slot), the geometry of view iv+1 having been computed before view iv's encoding; one vmcnt(0) + workgroup
+// barrier per view stands between the pieces' arrival and their first ds_read (see the comment there).  zP (one or two distinct rows
 // per wave: consecutive samples share their ray) and the four logit texels stay ordinary loads, consumed one iteration after issue.
 #define NERF_LDS_AS3(p) ((__attribute__((address_space(3))) void*)(p))
 constexpr int RING_BYTES = 4 * 32 * 128;  // four corner slots of 32 samples x 128 B per wave
@@ -330,14 +330,28 @@ __global__ __launch_bounds__(256, 2) void nerf_fused_dma_kernel(NerfParams p) {
         zp[mb][1] = __builtin_amdgcn_raw_buffer_load_b128(zrsrc, off + mb * 64 + 16, 0, 0);
       }
     };
-    auto dma_corner = [&](int c, const Geo& G) {  // 4 pieces of 8 full rows into slot c
+    // The row pieces of a view are addressed per DMA lane (sample 8 j + lane / 8): the 16 cross-lane fetches of the corner pixels are
+    // done in one batch right after the geometry (one LDS round trip), not piece by piece in front of each DMA instruction
+    int dpix[4][4];
+    auto dma_pixels = [&](const Geo& G) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) dpix[c][j] = __builtin_amdgcn_ds_bpermute(4 * (8 * j + dsub), G.pix[c]);
+    };
+    auto dma_corner = [&](int c) {  // 4 pieces of 8 full rows into slot c
+      // the four source offsets are computed into four DIFFERENT registers before the first piece is issued (the fence keeps them all
+      // live): with one register recomputed between back-to-back pieces, rows landed wrong now and then
+      uint32_t off[4];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int smp = 8 * j + dsub;
-        const int pix = __builtin_amdgcn_ds_bpermute(4 * smp, G.pix[c]);
-        const uint32_t off = (uint32_t)pix * row_bytes + (uint32_t)(ch0 * 2 + ((dchunk ^ ((smp >> 1) & 7)) << 4));
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, NERF_LDS_AS3(ring + c * 4096 + j * 1024), 16, off, 0, 0, 0);
+        off[j] = (uint32_t)dpix[c][j] * row_bytes + (uint32_t)(ch0 * 2 + ((dchunk ^ ((smp >> 1) & 7)) << 4));
       }
+      asm volatile("" : "+v"(off[0]), "+v"(off[1]), "+v"(off[2]), "+v"(off[3]));
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(yrsrc, NERF_LDS_AS3(ring + c * 4096 + j * 1024), 16, off[j], 0, 0, 0);
     };
 
     float m_run = -INFINITY, l_run = 0.f;
@@ -350,15 +364,20 @@ __global__ __launch_bounds__(256, 2) void nerf_fused_dma_kernel(NerfParams p) {
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     geometry(0, cur);
     load_zp(0);
+    dma_pixels(cur);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int c = 0; c < 4; ++c) dma_corner(c, cur);
+    for (int c = 0; c < 4; ++c) dma_corner(c);
     __builtin_amdgcn_sched_barrier(0);
 
     for (int iv = 0; iv < p.n; ++iv) {
       const bool more = iv + 1 < p.n;
-      if (more) geometry(iv + 1, nxt);
-      else nxt = cur;
+      if (more) {
+        geometry(iv + 1, nxt);
+        dma_pixels(nxt);
+      } else {
+        nxt = cur;
+      }
       __builtin_amdgcn_sched_barrier(0);
 
       // ---- per-sample inputs in B-operand layout: lane half h handles frequencies 2*kfp + h ----
@@ -416,15 +435,19 @@ __global__ __launch_bounds__(256, 2) void nerf_fused_dma_kernel(NerfParams p) {
             z[mb][half * 8 + 2 * e] += bf16lo_to_f32(zp[mb][half][e]);
             z[mb][half * 8 + 2 * e + 1] += bf16hi_to_f32(zp[mb][half][e]);
           }
+      // All row pieces of this view (requested one view ago, corner by corner) have landed: vmcnt(0) -- loads to registers and loads to
+      // LDS travel different return paths and may overtake each other, so a COUNTED wait that skips the ordinary loads issued since is
+      // not safe -- and then the workgroup barrier the LDS-DMA recipe prescribes between the wait and the first ds_read: vmcnt drops
+      // when the data has been handed to the LDS, not when it is readable (without it, or with a per-corner counted wait straight in
+      // front of the reads, a few rows per thousand launches came back stale).  One rendezvous per view; waves that ran out of tiles
+      // have exited and do not count.
       __builtin_amdgcn_sched_barrier(0);
-      if (more) load_zp(iv + 1);  // into the registers just consumed: one iteration of flight time
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) load_zp(iv + 1);  // into the registers consumed above: one iteration of flight time
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        __builtin_amdgcn_sched_barrier(0);
-        // the pieces of this corner (requested one view ago) have landed: everything but the 20 vector-memory operations issued after
-        // them -- the later corners of this view (12 - 4 c), the next view's texels and zP (8), its earlier corners (4 c); last view: 0
-        if (more) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_sched_barrier(0);
         u32x4 y[2][2];
 #pragma unroll
@@ -442,7 +465,7 @@ __global__ __launch_bounds__(256, 2) void nerf_fused_dma_kernel(NerfParams p) {
               z[mb][half * 8 + 2 * e + 1] = fmaf(cur.w[c], bf16hi_to_f32(y[mb][half][e]), z[mb][half * 8 + 2 * e + 1]);
             }
         __builtin_amdgcn_sched_barrier(0);  // (the fmas above consumed the ds_reads: the slot is free)
-        if (more) dma_corner(c, nxt);
+        if (more) dma_corner(c);
       }
       __builtin_amdgcn_sched_barrier(0);
 
@@ -572,10 +595,11 @@ extern "C" int cd360_nerf_mlp_aggregate(const void* cams, const void* xs, const 
   p.ngroups = (int)((npts + PTS_PER_WG - 1) / PTS_PER_WG);
   const long nwg = (long)p.ncc * b * p.ngroups;
   if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
-  // LDS-DMA row gathers (nerf_fused_dma_kernel) whenever the tables are addressable with 32-bit byte offsets; CD360_NERF_DMA=0: the
-  // register-gather kernel
-  bool dma = (long)b * n * r * r * C * 2 < (1L << 32);
-  if (const char* e = getenv("CD360_NERF_DMA")) dma = dma && e[0] != '0';
+  // CD360_NERF_DMA=1 selects the LDS-DMA row-gather kernel (tables addressable with 32-bit byte offsets).  It is correct (bit-identical,
+  // tests/test_kernels_gpu.py) only with the vmcnt(0) + workgroup barrier between the pieces' arrival and their first ds_read, and
+  // with that rendezvous per view it measures 0 % (1280 channels) / -5 % (640 channels) against the register-gather kernel: not the default.
+  bool dma = false;
+  if (const char* e = getenv("CD360_NERF_DMA")) dma = e[0] == '1' && (long)b * n * r * r * C * 2 < (1L << 32);
   if (dma) {
     constexpr int LDS_DMA = 4 * RING_BYTES + CN * W_PITCH;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&nerf_fused_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DMA);

@@ -200,9 +200,11 @@ def test_fused_feature_nerf(C, r, n, S, b):
 
 @pytest.mark.parametrize("C,r,n,S,b", [(64, 8, 2, 4, 2), (640, 16, 5, 24, 1), (1280, 8, 7, 6, 2), (128, 7, 3, 3, 1)])
 def test_render_kernel_lds_dma_row_gathers_equal_register_gathers(C, r, n, S, b, monkeypatch):
-    """nerf_fused_dma_kernel (corner rows by LDS-DMA into a per-wave slot ring, counted waits, views software-pipelined) against
-    nerf_fused_kernel (per-lane register gathers): the same additions in the same order -- bit-identical g, logits and lse, on repeated
-    launches too (a missed wait would show as a mismatch); (128, 7, ...) has a ragged last sample tile, n = 7 an odd view count."""
+    """nerf_fused_dma_kernel (opt-in, CD360_NERF_DMA=1: corner rows by LDS-DMA into a per-wave slot ring, one vmcnt(0) + workgroup barrier
+    per view, views software-pipelined) against nerf_fused_kernel (per-lane register gathers, the default): the same additions in the
+    same order -- bit-identical g, logits and lse on eight repeated launches (without the barrier between arrival and the first ds_read
+    a few rows per thousand launches came back stale: this test is the detector); (128, 7, ...) has a ragged last sample tile, waves
+    without tiles exit while the others keep meeting at the barrier."""
     from cd360 import nerf, ops
     w = nerf_weights(C, seed=C + n)
     cams = cams_for(b, n, seed=C).to(DEV)
@@ -215,9 +217,9 @@ def test_render_kernel_lds_dma_row_gathers_equal_register_gathers(C, r, n, S, b,
     g = torch.Generator().manual_seed(C)
     zP = bf(torch.randn(b * n, r * r, C, generator=g)).to(DEV, torch.bfloat16)
     cview = nerf.view_constants(fw, cams)
-    outs = [ops.nerf_mlp_aggregate(cams, xs, xs, t, Y, zP, lv, cview, fw.Wk, want_logits=True) for _ in range(3)]
-    monkeypatch.setenv("CD360_NERF_DMA", "0")
     ref = ops.nerf_mlp_aggregate(cams, xs, xs, t, Y, zP, lv, cview, fw.Wk, want_logits=True)
+    monkeypatch.setenv("CD360_NERF_DMA", "1")
+    outs = [ops.nerf_mlp_aggregate(cams, xs, xs, t, Y, zP, lv, cview, fw.Wk, want_logits=True) for _ in range(8)]
     for o in outs:
         assert all(torch.equal(a, b_) for a, b_ in zip(o, ref))
 
