@@ -629,6 +629,30 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     return (out, stats_out) if want_stats else out
 
 
+def gemm_cstats(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None):
+    """gemm(a, w, bias, res) for an output a GroupNorm reads next: -> (out, cstats) with cstats fp32 [rows / 64, N, 2] = per slab of 64
+    rows and channel the (sum, sum of squares) of the stored outputs (gn_silu's tile_stats after a reshape to [images, slabs, N, 2]);
+    cstats is None when the tiling chosen for this shape has no 64-row slabs or rows % 64 != 0 (plain gemm then)."""
+    _need_gpu(a, w, bias, res)
+    M, lda = _rows2d(a)
+    K, N = a.shape[-1], w.shape[0]
+    lib = _lib.load()
+    if M % 64 or lib.cd360_gemm_cstats_rows(M, N) != 64:
+        return gemm(a, w, bias=bias, res=res), None
+    assert w.dtype == torch.bfloat16 and w.dim() == 2 and w.shape[1] == K and w.stride(1) == 1
+    assert bias is None or (bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == N)
+    out = torch.empty(*a.shape[:-1], N, dtype=torch.bfloat16, device=a.device)
+    ldr = 0
+    if res is not None:
+        mr, ldr = _rows2d(res)
+        assert mr == M and res.shape[-1] == N
+    cstats = torch.empty(M // 64, N, 2, dtype=torch.float32, device=a.device)
+    with _timed("gemm8p", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N + (M * N if res is not None else 0))):
+        check(lib.cd360_gemm_cstats_bf16(_ptr(a), _ptr(w), _ptr(out), M, N, K, lda, w.stride(0), N, _ptr(bias), _ptr(res), ldr, _ptr(cstats), _stream()),
+              "cd360_gemm_cstats_bf16")
+    return out, cstats
+
+
 def qproj_attention_ok(a: torch.Tensor, nk: int) -> bool:
     """Shape envelope of qproj_attention: [b, Nq, K] queries with Nq % 256 == 0 (a 256-token tile stays inside one batch element),
     K % 64 == 0, at most 96 keys."""

@@ -99,7 +99,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
   constexpr int XP = BM / PR, WP = BN / PR;        // pieces per wave per K-tile
   constexpr int NP = XP + WP, NMMA = NCB * NMB;
   // epilogue: 0 linear, 1 GEGLU, 2 / 3 / 4 small-Nk attention on the projected tile with 1 / 2 / 3 blocks of 32 keys
-  constexpr bool GEGLU = EPI == 1, ATTN = EPI >= 2 && EPI <= 4, CONV = EPI == 5;
+  // EPI 6 = linear epilogue + the per-slab channel statistics of EPI 5 (a Linear whose output feeds a GroupNorm: SpatialTransformer.proj_out)
+  constexpr bool GEGLU = EPI == 1, ATTN = EPI >= 2 && EPI <= 4, CONV = EPI == 5, CSTATS = EPI == 5 || EPI == 6;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
 
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -634,8 +635,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
     // convolution epilogue accumulate in registers); chunk counts that do not divide 64 leave the last lanes idle
     constexpr int RPI = 64 / NCH;
     const int j = lane % NCH, rl = lane / NCH;
-    float cs[CONV ? 8 : 1], cq[CONV ? 8 : 1];
-    if constexpr (CONV) {
+    float cs[CSTATS ? 8 : 1], cq[CSTATS ? 8 : 1];
+    if constexpr (CSTATS) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) { cs[e] = 0.f; cq[e] = 0.f; }
     }
@@ -646,7 +647,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
       if (rl < RPI && r < NMB * 32 && m < p.M && ocol0 + j * 8 < nout && !(abl & 64)) {
         const u32x4 o = *reinterpret_cast<const u32x4*>(stage + r * RB + ((j ^ (r & SWZ)) << 4));
         *reinterpret_cast<u32x4*>(p.out + m * p.ldo + ocol0 + j * 8) = o;
-        if constexpr (CONV) {
+        if constexpr (CSTATS) {
           if (p.cstats) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -660,7 +661,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
         }
       }
     }
-    if constexpr (CONV) {
+    if constexpr (CSTATS) {
       if (p.cstats) {  // fold the RPI row groups (lanes j, j + NCH, ...) in a fixed order, lane j writes its 8 channels
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
@@ -681,7 +682,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
             cq[e] = q_;
           }
         }
-        if (lane < NCH && ocol0 + j * 8 < nout) {
+        if (lane < NCH && ocol0 + j * 8 < nout && m0 + wr * (NMB * 32) < p.M) {  // (a wave whose rows are all past M has no slab)
           const long slab = (m0 + wr * (NMB * 32)) / (NMB * 32);
           float* d = p.cstats + (slab * p.N + ocol0 + j * 8) * 2;
 #pragma unroll
@@ -785,6 +786,9 @@ int pick_cfg(int64_t M, int N, bool geglu) {
 // passes ceil(N / that) back as `ln_parts`.  Depends on the tiling the launch will choose -- ask with the same M, N.
 extern "C" int cd360_gemm_tile_n(int64_t M, int N) { return CFG_BN[pick_cfg(M, N, false)]; }
 
+// Rows per slab of the channel statistics cd360_gemm_cstats_bf16 writes for an [M, N] output (the launch's wave tiling decides)
+extern "C" int cd360_gemm_cstats_rows(int64_t M, int N) { return pick_cfg(M, N, false) == 2 || pick_cfg(M, N, false) == 4 ? 64 : 0; }
+
 // out[M, N] (bf16, row stride ldo) = epilogue(A[M, K] @ W[N, K]^T); A, W bf16 with row strides lda, ldw (elements, multiples of 8),
 // K % 64 == 0, N % 16 == 0, all base pointers 16-byte aligned.
 //   bias     fp32 [N] | NULL
@@ -821,6 +825,29 @@ extern "C" int cd360_gemm_bf16(const void* a, const void* w, void* out, int64_t 
     case 6: return geglu ? CD360_ERR_SHAPE : launch_epi<4, 2, 3, 2, 2, 0>(p, (hipStream_t)stream);
     default: return launch<2, 4, 2, 4, 2>(p, (hipStream_t)stream);
   }
+}
+
+// cd360_gemm_bf16(a, w, out, ..., bias, res) for an output that a GroupNorm reads next (SpatialTransformer.proj_out + its residual,
+// attention.py:880-886, followed by the next ResBlock's in_layers): additionally writes cstats fp32 [M / cd360_gemm_cstats_rows(M, N), N, 2]
+// = per slab of 64 rows and channel, (sum, sum of squares) of the stored bf16 outputs -- the `tile_stats` of cd360_gn_silu_bf16, like
+// the convolution epilogue's.  CD360_ERR_SHAPE when the tiling chosen for (M, N) has no 64-row slabs (cd360_gemm_cstats_rows == 0).
+extern "C" int cd360_gemm_cstats_bf16(const void* a, const void* w, void* out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldo,
+                                      const void* bias, const void* res, int64_t ldr, void* cstats, void* stream) {
+  if (!a || !w || !out || !cstats || M <= 0 || N <= 0 || K <= 0) return CD360_ERR_ARG;
+  if (K % 64 || N % 16 || lda % 8 || ldw % 8 || ldo % 8 || (res && ldr % 8) || lda < K || ldw < K || M % 64) return CD360_ERR_SHAPE;
+  if (((uintptr_t)a | (uintptr_t)w | (uintptr_t)out | (uintptr_t)res | (uintptr_t)cstats) % 16 || (uintptr_t)bias % 8) return CD360_ERR_ARG;
+  if (M > 0x7fffffffL || (M + 256) * lda * 2 >= (1L << 32) || ((long)N + 256) * ldw * 2 >= (1L << 32)) return CD360_ERR_SHAPE;
+  const int cfg = pick_cfg(M, N, false);
+  if (cfg != 2 && cfg != 4) return CD360_ERR_SHAPE;
+  GemmParams p;
+  p.a = (const uint16_t*)a; p.w = (const uint16_t*)w; p.out = (uint16_t*)out; p.bias = (const float*)bias; p.res = (const uint16_t*)res;
+  p.ln_stats = nullptr; p.wsum = nullptr; p.stats_out = nullptr;
+  p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.ldr = res ? ldr : 0;
+  p.M = (int)M; p.N = N; p.K = K; p.ln_parts = 0; p.ln_dim = 0; p.ln_eps = 0.f; p.geglu = 0;
+  p.tiles_m = p.tiles_n = p.group_m = 0;
+  p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f; p.a_dup = p.a_dup_from = 0;
+  p.cv_H = p.cv_W = p.cv_kg = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = (float*)cstats;
+  return cfg == 2 ? launch_epi<2, 4, 1, 2, 2, 6>(p, (hipStream_t)stream) : launch_epi<2, 4, 1, 2, 4, 6>(p, (hipStream_t)stream);
 }
 
 // out[M, N] = softmax_keys((A W^T [LayerNorm-folded] + bias) K_h^T * scale) V_h per head h (N = heads * 64): the query projection of a

@@ -30,7 +30,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from cd360 import ops
-from ..modules.diffusionmodules.util import checkpoint, group_norm_tokens, tokens_to_image, zero_module  # noqa: F401
+from ..modules.diffusionmodules.util import checkpoint, group_norm_tokens, tag_gn_stats, tokens_to_image, zero_module  # noqa: F401
 from ..modules.nerfsd_pytorch3d import NerfSDModule, VolRender
 from ..util import default, exists
 
@@ -661,7 +661,13 @@ class SpatialTransformer(nn.Module):
             return ops.gemm(group_norm_tokens(self.norm, img, silu=False), wi, bias=bi, want_stats=True)
 
         def leave(t, img):
-            return tokens_to_image(ops.gemm(t, wo, bias=bo, res=tokens_of(img)), H, W)
+            # proj_out + the SpatialTransformer's residual; the epilogue also takes the channel statistics of its output for the
+            # GroupNorm of the ResBlock / SpatialTransformer that reads it next (tag picked up by group_norm_tokens)
+            if os.environ.get("CD360_NO_GN_STATS") or (H * W) % 64:
+                return tokens_to_image(ops.gemm(t, wo, bias=bo, res=tokens_of(img)), H, W)
+            out, cst = ops.gemm_cstats(t, wo, bias=bo, res=tokens_of(img))
+            image = tokens_to_image(out, H, W)
+            return image if cst is None else tag_gn_stats(image, cst.reshape(out.shape[0], (H * W) // 64, out.shape[-1], 2))
 
         sampling = xr is None and pose is not None and any(getattr(b, "reference_choices", None) is not None for b in self.transformer_blocks)
         t, st = enter(x)

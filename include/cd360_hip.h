@@ -265,6 +265,13 @@ int cd360_qproj_attn_dedup_bf16(const void* a, const void* w, void* out, int64_t
                                 float scale, int dup, void* stream);
 /* N-tile width (256 | 192 | 128) cd360_gemm_bf16 uses for an [M, N] output: stats_out holds ceil(N / that) partials per row. */
 int cd360_gemm_tile_n(int64_t M, int N);
+/* cd360_gemm_bf16(a, w, out, ..., bias, res) for an output that a GroupNorm reads next -- SpatialTransformer.proj_out plus its residual
+ * (attention.py:880-886) feeding the next ResBlock's in_layers: also writes cstats fp32 [M / 64, N, 2] = per slab of 64 rows and channel
+ * the (sum, sum of squares) of the stored bf16 outputs, i.e. the `tile_stats` of cd360_gn_silu_bf16 (as the convolution epilogue does).
+ * Needs M % 64 == 0 and cd360_gemm_cstats_rows(M, N) == 64 (the 128 x 128 tilings); CD360_ERR_SHAPE otherwise. */
+int cd360_gemm_cstats_rows(int64_t M, int N);
+int cd360_gemm_cstats_bf16(const void* a, const void* w, void* out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldo,
+                           const void* bias, const void* res, int64_t ldr, void* cstats, void* stream);
 /* (sum, sum of squares) of every row of a bf16 [rows, C] matrix (row stride ld) as one fp32 partial per row: the `ln_stats` input for a
  * tensor that did not come out of cd360_gemm_bf16 (C % 8 == 0). */
 int cd360_row_stats_bf16(const void* x, void* stats, int64_t rows, int C, int64_t ld, void* stream);
