@@ -89,9 +89,20 @@ __device__ __forceinline__ float gelu_erf(float x) {
     FENCE();                       \
   } while (0)
 
-template <int WM, int WN, int NCB, int NMB, int NBUF, int EPI>
-__global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
-  constexpr int NW = WM * WN;                      // waves
+template <int WM, int WN, int NCB, int NMB, int NBUF, int KS, int EPI>
+__global__ __launch_bounds__(64 * WM * WN * KS) void gemm_mfma_kernel(GemmParams p) {
+  // KS = 2: two groups of WM x WN waves share the tile, group kg multiplying k-steps 2 kg, 2 kg + 1 of every 64-deep K-tile (an
+  // in-workgroup split of K): a wave then owns twice the output block for the same number of waves per SIMD -- a 128 x 128 tile is
+  // eight waves of 64 x 64 on half the K-steps instead of eight of 64 x 32 on all of them, 64 KB instead of 96 KB of fragment reads per
+  // K-tile (the LDS, shared with the DMA writes, is what the 128 x 128 tilings run out of) -- and the two partial accumulators meet
+  // once, through the LDS, in front of the epilogue: each group hands the other one half of its channel blocks and finishes the half it
+  // keeps, so all eight waves run the epilogue on 64 x 32 as in the unsplit tiling.
+  static_assert(KS == 1 || KS == 2, "k-step groups");
+  static_assert(KS == 1 || ((EPI == 0 || EPI == 5 || EPI == 6) && NCB % KS == 0), "split K: linear / convolution epilogues");
+  constexpr int ECB = NCB / KS;                    // channel blocks a wave finishes in the epilogue
+  constexpr int NWT = WM * WN;                     // waves of one k-step group (one output block each)
+  constexpr int NW = NWT * KS;                     // waves
+  constexpr int KPW = 4 / KS;                      // k-steps of a K-tile that one wave multiplies
   constexpr int BM = WM * NMB * 32, BN = WN * NCB * 32;
   constexpr uint32_t XB = BM * 128, WB = BN * 128;  // bytes of one buffer of each operand (64-deep K-tile, 128-byte rows)
   constexpr uint32_t XREG = 0, WREG = NBUF * XB;   // LDS map: NBUF token buffers, then NBUF channel buffers
@@ -105,7 +116,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
 
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wr = wave / WN, wc = wave % WN;  // token / channel position of the wave in the tile
+  const int kg = wave / NWT, wv = wave - kg * NWT;  // k-step group, wave inside it
+  const int wr = wv / WN, wc = wv % WN;      // token / channel position of the wave in the tile
 
   // ---- tile of this workgroup: XCD-contiguous ranges, group_m token tiles per group with the channel tile varying slowest ----
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
@@ -182,11 +194,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
 
   // ---- fragment read geometry: per lane one byte offset per k-step and operand (current buffer); blocks are immediates ----
   const int cp = chan_pos(l31);
-  uint32_t xo[4], wo[4];
+  uint32_t xo[KPW], wo[KPW];
 #pragma unroll
-  for (int ks = 0; ks < 4; ++ks) {
-    xo[ks] = XREG + (uint32_t)((wr * NMB * 32 + l31) * 128 + (((2 * ks + hh) ^ ((l31 >> 1) & 7)) << 4));
-    wo[ks] = WREG + (uint32_t)((wc * NCB * 32 + cp) * 128 + (((2 * ks + hh) ^ ((cp >> 1) & 7)) << 4));
+  for (int i = 0; i < KPW; ++i) {
+    const int ks = kg * KPW + i;
+    xo[i] = XREG + (uint32_t)((wr * NMB * 32 + l31) * 128 + (((2 * ks + hh) ^ ((l31 >> 1) & 7)) << 4));
+    wo[i] = WREG + (uint32_t)((wc * NCB * 32 + cp) * 128 + (((2 * ks + hh) ^ ((cp >> 1) & 7)) << 4));
   }
   bf16x8 fx[2][NMB], fw[2][NCB];
   auto read_ks = [&](int set, int ks) {
@@ -245,18 +258,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
     for (int t = 0; t < nk; ++t) {
       // fences pin the order "reads of k-step ks+1, then the MFMAs of ks": the compiler otherwise sinks the reads to the end of the
       // MFMA run (exposing the LDS latency) or hoists later k-steps' reads (spilling)
-      read_ks(1, 1);
-      FENCE();
-      mma_ks(0);
-      FENCE();
-      read_ks(0, 2);
-      FENCE();
-      mma_ks(1);
-      FENCE();
-      read_ks(1, 3);
-      FENCE();
-      mma_ks(0);
-      FENCE();
+#pragma unroll
+      for (int i = 0; i + 1 < KPW; ++i) {  // (the wave's last k-step, fragment set 1, runs below with the DMA issue)
+        read_ks((i + 1) & 1, i + 1);
+        FENCE();
+        mma_ks(i & 1);
+        FENCE();
+      }
       if (t + 1 < nk) {
         if (!(abl & 32)) WAIT_LGKM0();  // this wave's reads of the buffer are done ...
         // ... and its pieces of tile t+1 have landed (issued NBUF-1 tiles ago; tiles t+2 .. t+NBUF-1 may still be in flight)
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
         FENCE();
         const uint32_t ax = bnext == 0 ? 0u - (NBUF - 1) * XB : XB, aw = bnext == 0 ? 0u - (NBUF - 1) * WB : WB;
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
+        for (int ks = 0; ks < KPW; ++ks) {
           xo[ks] += ax;
           wo[ks] += aw;
         }
@@ -305,7 +313,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
   // Output staging: the bf16 results go through a wave-private LDS image [token][channel] (16-byte chunks XOR-swizzled by the token)
   // and leave as FULL 128-byte-or-longer row segments: the natural MFMA layout gives every lane 16-byte pieces of 32 different rows
   // per store instruction (8 partial writes per cache line), which measured 13-30 % of the whole kernel on the short-K shapes.
-  constexpr int OCH = (GEGLU ? NCB * 16 : NCB * 32);     // output channels of one wave
+  constexpr int OCH = (GEGLU ? NCB * 16 : ECB * 32);     // output channels of one wave
+  const int cbase = wc * (NCB * 32) + kg * (ECB * 32);   // first channel (inside the tile) of the blocks this wave finishes
   constexpr int NCH = OCH / 8, RB = OCH * 2;              // 16-byte chunks / bytes per token row of the wave's image
   constexpr int SWZ = (NCH % 8 == 0) ? 7 : 3;             // chunk index bits that may be XORed without leaving the row
   static_assert(NCH % 4 == 0, "row of at least 4 chunks");
@@ -387,11 +396,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
     for (int mb = 0; mb < NMB; ++mb) embrow[mb] = ((m0 + mrow0 + mb * 32) / hw) * p.emb_stride;
   }
 #pragma unroll
-  for (int nb = 0; nb < NCB; ++nb) {
+  for (int nb = 0; nb < ECB; ++nb) {
 #pragma unroll
     for (int c8 = 0; c8 < 2; ++c8) {
       FENCE();  // bound the scheduling region: hoisting every block's loads next to 256 live accumulators spills
-      const int n = n0 + wc * (NCB * 32) + nb * 32 + 16 * hh + 8 * c8;
+      const int n = n0 + cbase + nb * 32 + 16 * hh + 8 * c8;
       if (n >= p.N) continue;  // N % 16 == 0
       float bv[8], sv[8];
 #pragma unroll
@@ -623,13 +632,50 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
   else k_loop(std::false_type{});
   __syncthreads();  // every wave is past its last fragment read: the K-loop buffers become the output staging area
   if constexpr (ATTN) {
+    static_assert(!ATTN || KS == 1, "the attention epilogues own their tile");
     attn_tile();
     return;
+  }
+  if constexpr (KS == 2) {
+    // The two k-step groups' partial sums meet: group kg keeps channel blocks [kg ECB, (kg + 1) ECB) and receives the other group's
+    // partials of them (fp32, lane-linear 16-byte pieces behind the staging image); its result ends up in acc[0 .. ECB-1].
+    constexpr int XF = ECB * NMB * 16 * 64;  // floats one wave sends
+    float* const xbase = reinterpret_cast<float*>(lds + BM * BN * 2) + lane * 4;
+    if (has_ch) {
+      float* const snd = xbase + wave * XF;
+#pragma unroll
+      for (int nb = 0; nb < ECB; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+            if (kg == 0) v = f32x4{acc[ECB + nb][mb][4 * q], acc[ECB + nb][mb][4 * q + 1], acc[ECB + nb][mb][4 * q + 2], acc[ECB + nb][mb][4 * q + 3]};
+            else v = f32x4{acc[nb][mb][4 * q], acc[nb][mb][4 * q + 1], acc[nb][mb][4 * q + 2], acc[nb][mb][4 * q + 3]};
+            *reinterpret_cast<f32x4*>(snd + ((nb * NMB + mb) * 4 + q) * 256) = v;
+          }
+    }
+    __syncthreads();
+    if (has_ch) {
+      const float* const rcv = xbase + (wv + (1 - kg) * NWT) * XF;
+#pragma unroll
+      for (int nb = 0; nb < ECB; ++nb)
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb) {
+          if (kg == 1) acc[nb][mb] = acc[ECB + nb][mb];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(rcv + ((nb * NMB + mb) * 4 + q) * 256);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[nb][mb][4 * q + e] += v[e];
+          }
+        }
+    }
   }
   if (has_ch) {
     store_tile();
     // (wave-private image: the compiler's lgkmcnt wait orders the ds_writes before the ds_reads, no barrier)
-    const int ocol0 = (GEGLU ? (n0 >> 1) : n0) + wc * OCH;
+    const int ocol0 = GEGLU ? (n0 >> 1) + wc * OCH : n0 + cbase;
     const int nout = GEGLU ? (p.N >> 1) : p.N;
     // lane -> (row it * RPI + lane / NCH, chunk lane % NCH): a lane keeps its 8 channels over all rows (the per-channel sums of the
     // convolution epilogue accumulate in registers); chunk counts that do not divide 64 leave the last lanes idle
@@ -700,7 +746,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
       const float s = rsum[mb] + __shfl_xor(rsum[mb], 32);
       const float q = rsq[mb] + __shfl_xor(rsq[mb], 32);
       if (hh == 0) {
-        float* d = red + ((wc * BM) + mrow0 + mb * 32) * 2;
+        float* d = red + (((wc * KS + kg) * BM) + mrow0 + mb * 32) * 2;
         d[0] = s;
         d[1] = q;
       }
@@ -711,7 +757,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
       if (m < p.M) {
         float s = 0.f, q = 0.f;
 #pragma unroll
-        for (int c = 0; c < WN; ++c) {
+        for (int c = 0; c < WN * KS; ++c) {
           s += red[(c * BM + tid) * 2];
           q += red[(c * BM + tid) * 2 + 1];
         }
@@ -723,11 +769,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_mfma_kernel(GemmParams p) {
   }
 }
 
-template <int WM, int WN, int NCB, int NMB, int NBUF, int EPI>
-int launch_epi(const GemmParams& p0, hipStream_t stream) {
+template <int WM, int WN, int NCB, int NMB, int NBUF, int KS, int EPI>
+int launch_ks(const GemmParams& p0, hipStream_t stream) {
   GemmParams p = p0;
   constexpr int BM = WM * NMB * 32, BN = WN * NCB * 32;
-  constexpr int RING_BYTES = NBUF * (BM + BN) * 128, STAGE_BYTES = BM * BN * 2;  // K-loop buffers, reused as the output staging image
+  // K-loop buffers, reused as the output staging image (+ the fp32 partial tile of the second k-step group)
+  constexpr int RING_BYTES = NBUF * (BM + BN) * 128, STAGE_BYTES = BM * BN * 2 + (KS == 2 ? BM * BN * 4 : 0);
   constexpr int LDS_BYTES = RING_BYTES > STAGE_BYTES ? RING_BYTES : STAGE_BYTES;
   static_assert(LDS_BYTES <= 160 * 1024, "LDS of one CU");
   p.tiles_m = (p.M + BM - 1) / BM;
@@ -739,12 +786,33 @@ int launch_epi(const GemmParams& p0, hipStream_t stream) {
   if (const char* e = getenv("CD360_GEMM_ABL")) p.abl = atoi(e);
   const long nwg = (long)p.tiles_m * p.tiles_n;
   if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_kernel<WM, WN, NCB, NMB, NBUF, EPI>),
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_kernel<WM, WN, NCB, NMB, NBUF, KS, EPI>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   if (attr != hipSuccess) return CD360_ERR_LAUNCH;
-  hipLaunchKernelGGL((gemm_mfma_kernel<WM, WN, NCB, NMB, NBUF, EPI>), dim3((unsigned)nwg), dim3(64 * WM * WN), LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((gemm_mfma_kernel<WM, WN, NCB, NMB, NBUF, KS, EPI>), dim3((unsigned)nwg), dim3(64 * WM * WN * KS), LDS_BYTES, stream, p);
   CD360_LAUNCH_CHECK();
   return CD360_OK;
+}
+
+template <int WM, int WN, int NCB, int NMB, int NBUF, int EPI>
+int launch_epi(const GemmParams& p, hipStream_t stream) {
+  return launch_ks<WM, WN, NCB, NMB, NBUF, 1, EPI>(p, stream);
+}
+
+// The 128 x 128 tiling with four LDS buffers (launches of at most one workgroup per CU), as EPI 0 / 5 / 6, in its wave arrangements:
+// eight waves of 64 x 32, every wave on all four k-steps of a K-tile (mode 0), or eight waves of 64 x 64 in two k-step groups (mode 1:
+// a third fewer fragment reads per K-tile against one exchange of partial sums through the LDS in front of the epilogue).  Measured on
+// the 1280-level shapes, interleaved on one box (tools/bench_gemm.py ksplit, us, mode 0 / mode 1): K = 1280 19.9 / 20.7, K = 2560
+// 30.0 / 29.7, K = 5120 51.9 / 49.3, the 3 x 3 convolutions at 32^2 (K = 11520 .. 23040) 112.7 / 108.4, 166.5 / 156.5, 220.0 / 206.0 --
+// so the split serves K >= 3072.  (Mode 2, four waves of 64 x 64 with one wave per SIMD, is 10 % slower everywhere: kept for A/B only.)
+// CD360_GEMM_KSPLIT = 0 | 1 | 2 forces a mode.
+template <int EPI>
+int launch_128x4(const GemmParams& p, hipStream_t stream) {
+  const char* e = getenv("CD360_GEMM_KSPLIT");
+  const int mode = e ? atoi(e) : (p.K >= 3072 ? 1 : 0);
+  if (mode == 1) return launch_ks<2, 2, 2, 2, 4, 2, EPI>(p, stream);
+  if (mode == 2) return launch_ks<2, 2, 2, 2, 4, 1, EPI>(p, stream);
+  return launch_ks<2, 4, 1, 2, 4, 1, EPI>(p, stream);
 }
 
 template <int WM, int WN, int NCB, int NMB, int NBUF>
@@ -820,7 +888,7 @@ extern "C" int cd360_gemm_bf16(const void* a, const void* w, void* out, int64_t 
   switch (pick_cfg(M, N, geglu)) {
     case 1: return launch<2, 2, 2, 2, 2>(p, (hipStream_t)stream);
     case 2: return geglu ? CD360_ERR_SHAPE : launch_epi<2, 4, 1, 2, 2, 0>(p, (hipStream_t)stream);
-    case 4: return geglu ? CD360_ERR_SHAPE : launch_epi<2, 4, 1, 2, 4, 0>(p, (hipStream_t)stream);
+    case 4: return geglu ? CD360_ERR_SHAPE : launch_128x4<0>(p, (hipStream_t)stream);
     case 5: return launch<4, 2, 2, 2, 3>(p, (hipStream_t)stream);
     case 6: return geglu ? CD360_ERR_SHAPE : launch_epi<4, 2, 3, 2, 2, 0>(p, (hipStream_t)stream);
     default: return launch<2, 4, 2, 4, 2>(p, (hipStream_t)stream);
@@ -847,7 +915,7 @@ extern "C" int cd360_gemm_cstats_bf16(const void* a, const void* w, void* out, i
   p.tiles_m = p.tiles_n = p.group_m = 0;
   p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f; p.a_dup = p.a_dup_from = 0;
   p.cv_H = p.cv_W = p.cv_kg = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = (float*)cstats;
-  return cfg == 2 ? launch_epi<2, 4, 1, 2, 2, 6>(p, (hipStream_t)stream) : launch_epi<2, 4, 1, 2, 4, 6>(p, (hipStream_t)stream);
+  return cfg == 2 ? launch_epi<2, 4, 1, 2, 2, 6>(p, (hipStream_t)stream) : launch_128x4<6>(p, (hipStream_t)stream);
 }
 
 // out[M, N] = softmax_keys((A W^T [LayerNorm-folded] + bias) K_h^T * scale) V_h per head h (N = heads * 64): the query projection of a
@@ -957,7 +1025,7 @@ extern "C" int cd360_conv3x3_dma_bf16(const void* x, const void* w_packed, const
     case 1: return launch_epi<4, 2, 5, 2, 2, 5>(p, (hipStream_t)stream);
     case 2: return launch_epi<4, 2, 2, 2, 3, 5>(p, (hipStream_t)stream);
     case 3: return launch_epi<2, 4, 2, 4, 2, 5>(p, (hipStream_t)stream);
-    default: return launch_epi<2, 4, 1, 2, 4, 5>(p, (hipStream_t)stream);
+    default: return launch_128x4<5>(p, (hipStream_t)stream);
   }
 }
 

@@ -21,6 +21,30 @@ def test_gemm_family_and_fused_qproj_attention_against_fp32_torch(monkeypatch):
     os.environ.pop("CD360_GEMM_CFG", None)
 
 
+def test_gemm_k_step_groups_of_the_128x128_tiling(monkeypatch):
+    """The in-workgroup split of K (two groups of waves on alternate k-step pairs, partial sums exchanged through the LDS): parity of
+    every epilogue it serves against fp32 torch, the convolution form against the unsplit kernel, repeat-equal launches."""
+    import bench_gemm
+    assert bench_gemm.ksplit(time=False)
+    for k in ("CD360_GEMM_CFG", "CD360_CONV_CFG", "CD360_GEMM_KSPLIT"):
+        os.environ.pop(k, None)
+
+
+@pytest.mark.parametrize("ksplit", ["0", "1"])
+def test_gemm_cstats_in_both_wave_arrangements(monkeypatch, ksplit):
+    from bench_gemm import rnd
+    from cd360 import ops
+    monkeypatch.setenv("CD360_GEMM_KSPLIT", ksplit)
+    M, N, K = 3072, 1280, 1280
+    a, w = rnd(M, K, seed=31).to(torch.bfloat16), rnd(N, K, seed=32, scale=K ** -0.5).to(torch.bfloat16)
+    b, r = rnd(N, seed=33), rnd(M, N, seed=34).to(torch.bfloat16)
+    out, cst = ops.gemm_cstats(a, w, bias=b, res=r)
+    assert cst is not None and torch.equal(out, ops.gemm(a, w, bias=b, res=r))
+    ref = out.float().reshape(M // 64, 64, N)
+    rel = lambda x, y: ((x - y).abs().max() / y.abs().max().clamp_min(1e-6)).item()
+    assert rel(cst[..., 0], ref.sum(1)) < 1e-5 and rel(cst[..., 1], (ref * ref).sum(1)) < 1e-5
+
+
 @pytest.mark.parametrize("b,dup,nq,C,nk", [(2, 1, 256, 128, 77), (4, 2, 512, 640, 77), (2, 1, 1024, 1280, 50), (1, 1, 256, 64, 20)])
 def test_qproj_attention_dedup_equals_the_expanded_batch(b, dup, nq, C, nk):
     """cd360_qproj_attn_dedup_bf16: the last `dup` query batch elements meet two key / value sets (batch i and i + dup).  Must equal,
