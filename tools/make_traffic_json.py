@@ -17,7 +17,7 @@ def load(counter):
         key = next((v for k, v in NAMES.items() if k in r["kernel"]), None)
         if key is None:
             continue
-        if key == "gemm8p":  # gemm_mfma_kernel<WM, WN, NCB, NMB, NBUF, EPI>: EPI 2-4 = fused q-projection + attention, 5 = 3x3 convolution
+        if key == "gemm8p":  # gemm_mfma_kernel<WM, WN, NCB, NMB, NBUF, KS, EPI>: EPI 2-4 = fused q-projection + attention, 5 = 3x3 convolution
             import re
             m = re.search(r"gemm_mfma_kernel<[^>]*?(\d+)>", r["kernel"])
             if m and int(m.group(1)) == 5:
