@@ -345,6 +345,15 @@ if __name__ == "__main__":
         ablate_small()
     if "group_m" in what:
         group_m_sweep()
+    if "qattn_one" in what:  # a few launches of the fused pose-token attention (A3) at both pose levels for rocprofv3 --pmc passes
+        for b, nq, C in ((3, 98304, 640), (3, 24576, 1280)):
+            a = rnd(b, nq, C, seed=1).to(torch.bfloat16)
+            w = rnd(C, C, seed=2, scale=C ** -0.5).to(torch.bfloat16)
+            kv = rnd(b, 80, 2 * C, seed=4).to(torch.bfloat16)
+            st, ws, cb = ops.row_stats(a), w.float().sum(1).contiguous(), rnd(C, seed=3)
+            for _ in range(4):
+                ops.qproj_attention(a, w, kv[..., :C], kv[..., C:], 77, C // 64, bias=cb, ln=(st, ws, 1e-5))
+        torch.cuda.synchronize()
     if "one" in what:  # a few launches of one shape for rocprofv3 --pmc passes: one M N K (env CD360_GEMM_* select the variant)
         M, N, K = (int(v) for v in what[what.index("one") + 1:what.index("one") + 4])
         a = rnd(M, K, seed=1).to(torch.bfloat16)
