@@ -328,9 +328,27 @@ def ksplit(time=True):
     return ok
 
 
+def narrow():
+    """The short launches of the block (auto tiling, bias + residual + row statistics) and the 3 x 3 convolutions: best of three rounds."""
+    line = []
+    for name, M, N, K in (("L2 out", 3072, 1280, 1280), ("L2 ff2", 3072, 1280, 5120), ("L1 out", 12288, 640, 640), ("L1 ff2", 12288, 640, 2560)):
+        a = rnd(M, K, seed=1).to(torch.bfloat16)
+        w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
+        b32, r = rnd(N, seed=3), rnd(M, N, seed=4).to(torch.bfloat16)
+        line.append(f"{name} {min(timeit(lambda: ops.gemm(a, w, bias=b32, res=r, want_stats=True)) for _ in range(3)):6.1f}")
+    for (N_, H, W, cin, cout) in ((3, 32, 32, 1280, 1280), (3, 64, 64, 640, 640), (3, 128, 128, 320, 320)):
+        x = torch.randn(N_, H * W, cin, device=dev).to(torch.bfloat16)
+        wp = (torch.randn(cout, 9 * cin, device=dev) / (9 * cin) ** 0.5).to(torch.bfloat16)
+        bias, emb = torch.randn(cout, device=dev), torch.randn(N_, cout, device=dev).to(torch.bfloat16)
+        line.append(f"conv{H} {min(timeit(lambda: ops.conv_igemm(x, wp, bias, N_, H, W, 9, emb=emb, want_stats=True)) for _ in range(3)):6.1f}")
+    print(" | ".join(line), flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["check", "time"]
     good = True
+    if "narrow" in what:
+        narrow()
     if "ksplit" in what:
         good = ksplit()
     if "check" in what:
