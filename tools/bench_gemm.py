@@ -148,6 +148,33 @@ def timeit(fn, iters=40, warm=8):
     return best * 1e3  # us
 
 
+def timeit_graph(fn, n=50, reps=5):
+    """GPU-side time per call: n calls captured in one hipGraph and replayed (the Python / ctypes launch path costs ~15 us per call,
+    more than the short kernels run -- `timeit` on those measures the host)."""
+    s = torch.cuda.Stream()
+    s.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(s):
+        for _ in range(3):
+            fn()
+    torch.cuda.current_stream().wait_stream(s)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = 1e9
+    for _ in range(reps):
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        best = min(best, e0.elapsed_time(e1) / n)
+    return best * 1e3
+
+
 SHAPES = [  # (name, M, N, K, epilogue) at cfg-B: b = 3; level 1: 4096 tokens x 640, level 2: 1024 tokens x 1280
     ("L1 qkv", 12288, 1920, 640, "ln"), ("L1 out", 12288, 640, 640, "res"), ("L1 ff1", 12288, 5120, 640, "geglu"), ("L1 ff2", 12288, 640, 2560, "res"),
     ("L2 qkv", 3072, 3840, 1280, "ln"), ("L2 out", 3072, 1280, 1280, "res"), ("L2 ff1", 3072, 10240, 1280, "geglu"), ("L2 ff2", 3072, 1280, 5120, "res"),
@@ -335,18 +362,37 @@ def narrow():
         a = rnd(M, K, seed=1).to(torch.bfloat16)
         w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
         b32, r = rnd(N, seed=3), rnd(M, N, seed=4).to(torch.bfloat16)
-        line.append(f"{name} {min(timeit(lambda: ops.gemm(a, w, bias=b32, res=r, want_stats=True)) for _ in range(3)):6.1f}")
+        line.append(f"{name} {timeit_graph(lambda: ops.gemm(a, w, bias=b32, res=r, want_stats=True)):6.1f}")
     for (N_, H, W, cin, cout) in ((3, 32, 32, 1280, 1280), (3, 64, 64, 640, 640), (3, 128, 128, 320, 320)):
         x = torch.randn(N_, H * W, cin, device=dev).to(torch.bfloat16)
         wp = (torch.randn(cout, 9 * cin, device=dev) / (9 * cin) ** 0.5).to(torch.bfloat16)
         bias, emb = torch.randn(cout, device=dev), torch.randn(N_, cout, device=dev).to(torch.bfloat16)
-        line.append(f"conv{H} {min(timeit(lambda: ops.conv_igemm(x, wp, bias, N_, H, W, 9, emb=emb, want_stats=True)) for _ in range(3)):6.1f}")
+        line.append(f"conv{H} {timeit_graph(lambda: ops.conv_igemm(x, wp, bias, N_, H, W, 9, emb=emb, want_stats=True)):6.1f}")
     print(" | ".join(line), flush=True)
+
+
+def fixed_cost():
+    """Launch time against K on the 1280-level C -> C shape (M = 3072, N = 1280): the intercept is what a launch costs besides its K loop."""
+    M, N = 3072, 1280
+    b32, r = rnd(N, seed=3), rnd(M, N, seed=4).to(torch.bfloat16)
+    for K in (64, 128, 256, 512, 1280, 2560):
+        a = rnd(M, K, seed=1).to(torch.bfloat16)
+        w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
+        line = f"K={K:5d}: full epilogue {timeit_graph(lambda: ops.gemm(a, w, bias=b32, res=r, want_stats=True)):6.1f}"
+        line += f" | plain {timeit_graph(lambda: ops.gemm(a, w)):6.1f}"
+        os.environ["CD360_GEMM_ABL"] = "64"
+        line += f" | plain, no stores {timeit_graph(lambda: ops.gemm(a, w)):6.1f}"
+        os.environ.pop("CD360_GEMM_ABL")
+        print(line, flush=True)
+    x = torch.zeros(64, device=dev)
+    print(f"torch elementwise on 64 floats (launch floor in a graph): {timeit_graph(lambda: x.add_(1.0)):6.1f}", flush=True)
 
 
 if __name__ == "__main__":
     what = sys.argv[1:] or ["check", "time"]
     good = True
+    if "fixed" in what:
+        fixed_cost()
     if "narrow" in what:
         narrow()
     if "ksplit" in what:
