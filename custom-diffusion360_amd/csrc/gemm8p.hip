@@ -54,7 +54,8 @@ struct GemmParams {
   float a_scale_log2e;
   int a_dup_from, a_dup;  // query batch elements >= a_dup_from attend to TWO key / value sets (batch i and i + a_dup; output rows of
                           // batch i and i + a_dup): the de-duplicated CFG branch, whose q is projected once
-  int abl;  // what-if timing knob (CD360_GEMM_ABL; results are wrong when set): 8 no DMA wait, 16 no barrier, 32 no LDS wait, 4 no DMA
+  int abl;  // what-if timing knob (CD360_GEMM_ABL; results are wrong when set): 8 no DMA wait, 16 no barrier, 32 no LDS wait, 4 no DMA,
+            // 64 no stores, 512 no fragment reads / MFMAs / epilogue (the loop as a pure L2 -> LDS streamer)
   // EPI 5: A is the implicit im2col matrix of a 3x3 / stride 1 / pad 1 convolution over a channels-last [images, H, W, Cin] tensor
   // (lda = Cin, K = 9 Cin in cd360_conv_k_order order: K-tile kt = (group * 9 + tap) * cv_kg + j reads channel chunk group * cv_kg + j
   // of the pixel shifted by the tap); out [M = images H W, N = Cout]
@@ -62,6 +63,9 @@ struct GemmParams {
   const uint16_t* emb;  // [images, Cout] bf16 per-image addend (row stride emb_stride elements) or null
   long emb_stride;
   float* cstats;        // [M / (NMB 32), Cout, 2] fp32: per slab of NMB * 32 pixels and channel, (sum, sumsq) of the stored outputs, or null
+#ifdef CD360_GEMM_STAMP
+  uint32_t* stamp;      // probe build (tools/probe/gemm_stamp.py): [workgroup][wave][K-tile][4] s_memtime stamps, or null
+#endif
 };
 
 __device__ __forceinline__ int chan_pos(int i) { return 16 * ((i >> 2) & 1) + (i & 3) + 4 * (i >> 3); }
@@ -220,7 +224,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_mfma_kernel(GemmParams
   const int nk = p.K >> 6;
   const int abl = p.abl;
   // a wave whose channels are all beyond N (last channel tile of N = 640 = 2.5 tiles) moves data and synchronises but does not multiply
-  const bool has_ch = n0 + wc * (NCB * 32) < p.N;
+  const bool has_ch = n0 + wc * (NCB * 32) < p.N && !(abl & 512);  // (what-if bit 512: every wave only moves data)
 
   // ---- prologue: tiles 0 .. NBUF-1 in flight (one per buffer), tile 0 landed ----
   // counted wait: everything but the `later` most recently issued tiles has landed (s_waitcnt takes an immediate)
@@ -253,25 +257,64 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_mfma_kernel(GemmParams
           acc[i % NCB][i / NCB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[set][i % NCB], fx[set][i / NCB], acc[i % NCB][i / NCB], 0, 0, 0);
       }
     };
-    uint32_t bx = 0, bw = 0;  // buffers of tile t
-    int bnext = 1;            // index of the buffer of tile t+1
+    // With three or more buffers the NP pieces that refill a released buffer are SPREAD over a whole tile's worth of MFMAs -- the
+    // first share between the MFMAs of this tile's last k-step (as soon as the barrier has released the buffer), the rest between the
+    // MFMAs of the next tile's earlier k-steps -- instead of all of them in the last k-step: every wave issuing its pieces at the
+    // same moment queues 32 KB on the CU's one address path while the matrix pipe has two MFMAs per wave to chew on.  The counted
+    // waits are unchanged (every piece of tile t+NBUF-1 is still issued before tile t's wait, none of tile t+NBUF).
+    constexpr bool SPREAD = NBUF >= 3;
+    constexpr int NSLOT = KPW * NMMA;
+    auto slot_pieces = [&](int j, int i, int tile, uint32_t obx, uint32_t obw) {  // pieces of `tile` that go behind MFMA i of k-step group j
+#pragma unroll
+      for (int q = 0; q < NP; ++q)
+        if ((q * NSLOT / NP) / NMMA == j && (q * NSLOT / NP) % NMMA == i) piece(tile, q, obx, obw);
+    };
+    uint32_t bx = 0, bw = 0;    // buffers of tile t
+    uint32_t pbx = 0, pbw = 0;  // buffers of tile t-1 (being refilled with tile t-1+NBUF while tile t is multiplied)
+    int bnext = 1;              // index of the buffer of tile t+1
     for (int t = 0; t < nk; ++t) {
       // fences pin the order "reads of k-step ks+1, then the MFMAs of ks": the compiler otherwise sinks the reads to the end of the
       // MFMA run (exposing the LDS latency) or hoists later k-steps' reads (spilling)
+      const bool prev_more = SPREAD && t >= 1 && t - 1 + NBUF < nk && !(abl & 4);
+#ifdef CD360_GEMM_STAMP
+      const uint64_t stA = __builtin_amdgcn_s_memtime();
+      uint64_t stB = stA, stD = stA, stC1 = stA, stC2 = stA;
+#endif
 #pragma unroll
       for (int i = 0; i + 1 < KPW; ++i) {  // (the wave's last k-step, fragment set 1, runs below with the DMA issue)
         read_ks((i + 1) & 1, i + 1);
         FENCE();
-        mma_ks(i & 1);
+        if constexpr (SPREAD) {
+#pragma unroll
+          for (int m = 0; m < NMMA; ++m) {
+            if constexpr (MUL)
+              acc[m % NCB][m / NCB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[i & 1][m % NCB], fx[i & 1][m / NCB], acc[m % NCB][m / NCB], 0, 0, 0);
+            if (prev_more) slot_pieces(i + 1, m, t - 1 + NBUF, pbx, pbw);
+          }
+        } else {
+          mma_ks(i & 1);
+        }
         FENCE();
       }
       if (t + 1 < nk) {
+#ifdef CD360_GEMM_STAMP
+        stB = __builtin_amdgcn_s_memtime();
+#endif
         if (!(abl & 32)) WAIT_LGKM0();  // this wave's reads of the buffer are done ...
+#ifdef CD360_GEMM_STAMP
+        stC1 = __builtin_amdgcn_s_memtime();
+#endif
         // ... and its pieces of tile t+1 have landed (issued NBUF-1 tiles ago; tiles t+2 .. t+NBUF-1 may still be in flight)
         wait_tiles_in_flight((nk - 1 < t + NBUF - 1 ? nk - 1 : t + NBUF - 1) - (t + 1));
         FENCE();
+#ifdef CD360_GEMM_STAMP
+        stC2 = __builtin_amdgcn_s_memtime();
+#endif
         if (!(abl & 16)) __builtin_amdgcn_s_barrier();
         FENCE();
+#ifdef CD360_GEMM_STAMP
+        stD = __builtin_amdgcn_s_memtime();
+#endif
         const uint32_t ax = bnext == 0 ? 0u - (NBUF - 1) * XB : XB, aw = bnext == 0 ? 0u - (NBUF - 1) * WB : WB;
 #pragma unroll
         for (int ks = 0; ks < KPW; ++ks) {
@@ -291,13 +334,28 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_mfma_kernel(GemmParams
         for (int i = 0; i < NMMA; ++i) {
           if constexpr (MUL)
             acc[i % NCB][i / NCB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[1][i % NCB], fx[1][i / NCB], acc[i % NCB][i / NCB], 0, 0, 0);
-          if (more) {  // pieces [i NP / NMMA, (i+1) NP / NMMA): all NP of them, evenly spread over the MFMAs
+          if (more) {
+            if constexpr (SPREAD) {
+              slot_pieces(0, i, t + NBUF, bx, bw);
+            } else {  // pieces [i NP / NMMA, (i+1) NP / NMMA): all NP of them, evenly spread over the MFMAs
 #pragma unroll
-            for (int q = i * NP / NMMA; q < (i + 1) * NP / NMMA; ++q) piece(t + NBUF, q, bx, bw);
+              for (int q = i * NP / NMMA; q < (i + 1) * NP / NMMA; ++q) piece(t + NBUF, q, bx, bw);
+            }
           }
         }
       }
       FENCE();
+#ifdef CD360_GEMM_STAMP
+      if (p.stamp && t < 64) {  // stamps parked in the LDS behind the ring (a global store would count in vmcnt); lane 0 of each wave
+        const uint64_t stE = __builtin_amdgcn_s_memtime();
+        if (lane == 0) {
+          uint32_t* d = reinterpret_cast<uint32_t*>(lds + NBUF * (XB + WB)) + (wave * 64 + t) * 8;
+          d[0] = (uint32_t)stA; d[1] = (uint32_t)stB; d[2] = (uint32_t)stD; d[3] = (uint32_t)stE; d[4] = (uint32_t)stC1; d[5] = (uint32_t)stC2;
+        }
+      }
+#endif
+      pbx = bx;
+      pbw = bw;
       bx = bnext * XB;
       bw = bnext * WB;
       bnext = bnext + 1 == NBUF ? 0 : bnext + 1;
@@ -631,6 +689,13 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_mfma_kernel(GemmParams
   if (has_ch) k_loop(std::true_type{});
   else k_loop(std::false_type{});
   __syncthreads();  // every wave is past its last fragment read: the K-loop buffers become the output staging area
+#ifdef CD360_GEMM_STAMP
+  if (p.stamp) {
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(lds + NBUF * (XB + WB));
+    for (int i = tid; i < NW * 64 * 8; i += 64 * NW) p.stamp[(long)blockIdx.x * (NW * 64 * 8) + i] = src[i];
+    __syncthreads();
+  }
+#endif
   if constexpr (ATTN) {
     static_assert(!ATTN || KS == 1, "the attention epilogues own their tile");
     attn_tile();
@@ -775,7 +840,13 @@ int launch_ks(const GemmParams& p0, hipStream_t stream) {
   constexpr int BM = WM * NMB * 32, BN = WN * NCB * 32;
   // K-loop buffers, reused as the output staging image (+ the fp32 partial tile of the second k-step group)
   constexpr int RING_BYTES = NBUF * (BM + BN) * 128, STAGE_BYTES = BM * BN * 2 + (KS == 2 ? BM * BN * 4 : 0);
+#ifdef CD360_GEMM_STAMP
+  constexpr int BASE_BYTES = RING_BYTES > STAGE_BYTES ? RING_BYTES : STAGE_BYTES;
+  constexpr int STAMP_BYTES = BASE_BYTES + WM * WN * KS * 64 * 32 <= 160 * 1024 ? WM * WN * KS * 64 * 32 : 0;
+  constexpr int LDS_BYTES = BASE_BYTES + STAMP_BYTES;
+#else
   constexpr int LDS_BYTES = RING_BYTES > STAGE_BYTES ? RING_BYTES : STAGE_BYTES;
+#endif
   static_assert(LDS_BYTES <= 160 * 1024, "LDS of one CU");
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
@@ -784,6 +855,10 @@ int launch_ks(const GemmParams& p0, hipStream_t stream) {
   p.group_m = gm;
   p.abl = 0;
   if (const char* e = getenv("CD360_GEMM_ABL")) p.abl = atoi(e);
+#ifdef CD360_GEMM_STAMP
+  p.stamp = nullptr;
+  if (const char* e = getenv("CD360_GEMM_STAMP_PTR")) p.stamp = STAMP_BYTES ? reinterpret_cast<uint32_t*>(strtoull(e, nullptr, 16)) : nullptr;
+#endif
   const long nwg = (long)p.tiles_m * p.tiles_n;
   if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_kernel<WM, WN, NCB, NMB, NBUF, KS, EPI>),

@@ -388,9 +388,44 @@ def fixed_cost():
     print(f"torch elementwise on 64 floats (launch floor in a graph): {timeit_graph(lambda: x.add_(1.0)):6.1f}", flush=True)
 
 
+def whatif():
+    """hipGraph-timed what-if builds of the 128 x 128 four-buffer tiling on the long-K shape (results invalid by construction)."""
+    M, N = 3072, 1280
+    for K in (1280, 5120):
+        a = rnd(M, K, seed=1).to(torch.bfloat16)
+        w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
+        for ks in ("0", "1"):
+            os.environ["CD360_GEMM_KSPLIT"] = ks
+            line = f"K={K} ksplit={ks}:"
+            for abl, name in ((0, "full"), (64, "no stores"), (512, "DMA + rendezvous only"), (512 + 16, "DMA only, no barrier"), (512 + 16 + 8, "DMA issue only, no waits"),
+                              (4 + 64, "no DMA, no stores"), (4 + 8 + 16 + 32 + 64, "reads + MFMAs only")):
+                os.environ["CD360_GEMM_ABL"] = str(abl)
+                line += f" | {name} {timeit_graph(lambda: ops.gemm(a, w)):6.1f}"
+            print(line, flush=True)
+    for k in ("CD360_GEMM_ABL", "CD360_GEMM_KSPLIT"):
+        os.environ.pop(k, None)
+
+
+def stride_sweep():
+    """Does the row stride of the operands matter (rows of a K-tile 2560 / 10240 bytes apart fall on few L2 channels)?  Same GEMM with the
+    A and W rows padded by 0 / 64 / 32 / 8 elements."""
+    for name, M, N, K in (("L2 out", 3072, 1280, 1280), ("L2 ff2", 3072, 1280, 5120), ("L1 out", 12288, 640, 640), ("L2 qkv", 3072, 3840, 1280)):
+        line = f"{name:8s} M={M:6d} N={N:5d} K={K:4d}:"
+        for pad_a, pad_w in ((0, 0), (64, 0), (0, 64), (64, 64), (32, 32), (8, 8), (192, 192)):
+            a = rnd(M, K + pad_a, seed=1).to(torch.bfloat16)[:, :K]
+            w = rnd(N, K + pad_w, seed=2, scale=K ** -0.5).to(torch.bfloat16)[:, :K]
+            b32 = rnd(N, seed=3)
+            line += f" | a+{pad_a} w+{pad_w}: {timeit_graph(lambda: ops.gemm(a, w, bias=b32)):6.1f}"
+        print(line, flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["check", "time"]
     good = True
+    if "stride" in what:
+        stride_sweep()
+    if "whatif" in what:
+        whatif()
     if "fixed" in what:
         fixed_cost()
     if "narrow" in what:
