@@ -93,8 +93,13 @@ __device__ __forceinline__ float gelu_erf(float x) {
     FENCE();                       \
   } while (0)
 
-template <int WM, int WN, int NCB, int NMB, int NBUF, int KS, int EPI>
-__global__ __launch_bounds__(64 * WM * WN * KS) void gemm_mfma_kernel(GemmParams p) {
+template <int WM, int WN, int NCB, int NMB, int NBUF, int KS, int MV, int EPI>
+__global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(GemmParams p) {
+  // MV > 0: MV extra "mover" waves issue ALL the LDS-DMA pieces and the WM x WN x KS others only read fragments and multiply.  On the
+  // 128 x 128 tilings the CU's address path needs 0.35 us to take the 32 pieces of a K-tile and the fragment reads + MFMAs 0.40 us, but
+  // with every wave doing both (and all of them meeting once per tile) a tile costs 0.6 us (tools/bench_gemm.py whatif): a wave that is
+  // queueing pieces is not feeding the matrix pipe.  The movers queue them back to back; the hand-off stays what it was -- each mover
+  // waits for its own pieces (counted vmcnt), then the workgroup barrier, which all waves take once per K-tile.
   // KS = 2: two groups of WM x WN waves share the tile, group kg multiplying k-steps 2 kg, 2 kg + 1 of every 64-deep K-tile (an
   // in-workgroup split of K): a wave then owns twice the output block for the same number of waves per SIMD -- a 128 x 128 tile is
   // eight waves of 64 x 64 on half the K-steps instead of eight of 64 x 32 on all of them, 64 KB instead of 96 KB of fragment reads per
@@ -105,12 +110,15 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_mfma_kernel(GemmParams
   static_assert(KS == 1 || ((EPI == 0 || EPI == 5 || EPI == 6) && NCB % KS == 0), "split K: linear / convolution epilogues");
   constexpr int ECB = NCB / KS;                    // channel blocks a wave finishes in the epilogue
   constexpr int NWT = WM * WN;                     // waves of one k-step group (one output block each)
-  constexpr int NW = NWT * KS;                     // waves
+  constexpr int NWC = NWT * KS;                    // waves that multiply
+  constexpr int NW = NWC + MV;                     // waves
+  constexpr int NWD = MV ? MV : NW;                // waves that move data
+  static_assert(MV == 0 || (EPI == 0 || EPI == 5 || EPI == 6), "mover waves: linear / convolution epilogues");
   constexpr int KPW = 4 / KS;                      // k-steps of a K-tile that one wave multiplies
   constexpr int BM = WM * NMB * 32, BN = WN * NCB * 32;
   constexpr uint32_t XB = BM * 128, WB = BN * 128;  // bytes of one buffer of each operand (64-deep K-tile, 128-byte rows)
   constexpr uint32_t XREG = 0, WREG = NBUF * XB;   // LDS map: NBUF token buffers, then NBUF channel buffers
-  constexpr int PR = 8 * NW;                       // rows one DMA piece of the whole workgroup covers (8 per wave)
+  constexpr int PR = 8 * NWD;                      // rows one DMA piece of all moving waves covers (8 per wave)
   constexpr int XP = BM / PR, WP = BN / PR;        // pieces per wave per K-tile
   constexpr int NP = XP + WP, NMMA = NCB * NMB;
   // epilogue: 0 linear, 1 GEGLU, 2 / 3 / 4 small-Nk attention on the projected tile with 1 / 2 / 3 blocks of 32 keys
@@ -120,7 +128,9 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_mfma_kernel(GemmParams
 
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int kg = wave / NWT, wv = wave - kg * NWT;  // k-step group, wave inside it
+  const bool mover = MV > 0 && wave >= NWC;
+  const int dwave = MV ? (mover ? wave - NWC : 0) : wave;  // index among the moving waves
+  const int kg = mover ? 0 : wave / NWT, wv = mover ? 0 : wave - kg * NWT;  // k-step group, wave inside it
   const int wr = wv / WN, wc = wv % WN;      // token / channel position of the wave in the tile
 
   // ---- tile of this workgroup: XCD-contiguous ranges, group_m token tiles per group with the channel tile varying slowest ----
@@ -138,12 +148,12 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_mfma_kernel(GemmParams
   const __amdgpu_buffer_rsrc_t xrsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)(CONV ? (long)p.M * p.lda * 2 : ((long)p.M - 1) * p.lda * 2 + (long)p.K * 2), 0x00020000);
   const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)(((long)p.N - 1) * p.ldw * 2 + (long)p.K * 2), 0x00020000);
-  const int srow = wave * 8 + (lane >> 3);
+  const int srow = dwave * 8 + (lane >> 3);
   const int schunk = (lane & 7) ^ ((srow >> 1) & 7);
   const uint32_t xoff0 = (uint32_t)((m0 + srow) * p.lda * 2 + schunk * 16);
   const uint32_t woff0 = (uint32_t)(((long)n0 + srow) * p.ldw * 2 + schunk * 16);
   const uint32_t xstep = (uint32_t)(PR * p.lda * 2), wstep = (uint32_t)(PR * p.ldw * 2);
-  unsigned char* const dma_base = lds + wave * 1024;
+  unsigned char* const dma_base = lds + dwave * 1024;
   // Convolution: bit `tap` of xmask[i] = the pixel of this lane's row of piece i has an in-image neighbour under that tap (rows past M:
   // none).  The shifted pixel is the same row offset plus a wave-uniform tap offset; a padding neighbour reads from an offset past the
   // end of the buffer descriptor, i.e. zeros.
@@ -224,7 +234,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_mfma_kernel(GemmParams
   const int nk = p.K >> 6;
   const int abl = p.abl;
   // a wave whose channels are all beyond N (last channel tile of N = 640 = 2.5 tiles) moves data and synchronises but does not multiply
-  const bool has_ch = n0 + wc * (NCB * 32) < p.N && !(abl & 512);  // (what-if bit 512: every wave only moves data)
+  const bool has_ch = n0 + wc * (NCB * 32) < p.N && !(abl & 512) && !mover;  // (what-if bit 512: every wave only moves data)
 
   // ---- prologue: tiles 0 .. NBUF-1 in flight (one per buffer), tile 0 landed ----
   // counted wait: everything but the `later` most recently issued tiles has landed (s_waitcnt takes an immediate)
@@ -236,20 +246,22 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_mfma_kernel(GemmParams
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NP) : "memory");
   };
   static_assert(NBUF >= 2 && NBUF <= 4 && (NBUF - 1) * NP <= 63, "counted waits: up to 3 tiles, 6-bit vmcnt");
+  if (!MV || mover) {
 #pragma unroll
-  for (int b = 0; b < NBUF; ++b)
-    if (b < nk) {
-      if constexpr (CONV) conv_next();
+    for (int b = 0; b < NBUF; ++b)
+      if (b < nk) {
+        if constexpr (CONV) conv_next();
 #pragma unroll
-      for (int i = 0; i < NP; ++i) piece(b, i, b * XB, b * WB);
-    }
-  wait_tiles_in_flight((nk < NBUF ? nk : NBUF) - 1);
+        for (int i = 0; i < NP; ++i) piece(b, i, b * XB, b * WB);
+      }
+    wait_tiles_in_flight((nk < NBUF ? nk : NBUF) - 1);
+  }
   BARRIER();
   read_ks(0, 0);
 
   // the loop exists twice: waves with output channels multiply, the others only move data
-  auto k_loop = [&](auto mul_tag) {
-    constexpr bool MUL = decltype(mul_tag)::value;
+  auto k_loop = [&](auto mul_tag, auto move_tag) {
+    constexpr bool MUL = decltype(mul_tag)::value, MOVE = decltype(move_tag)::value;
     auto mma_ks = [&](int set) {
       if constexpr (MUL) {
 #pragma unroll
@@ -275,7 +287,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_mfma_kernel(GemmParams
     for (int t = 0; t < nk; ++t) {
       // fences pin the order "reads of k-step ks+1, then the MFMAs of ks": the compiler otherwise sinks the reads to the end of the
       // MFMA run (exposing the LDS latency) or hoists later k-steps' reads (spilling)
-      const bool prev_more = SPREAD && t >= 1 && t - 1 + NBUF < nk && !(abl & 4);
+      const bool prev_more = MOVE && SPREAD && t >= 1 && t - 1 + NBUF < nk && !(abl & 4);
 #ifdef CD360_GEMM_STAMP
       const uint64_t stA = __builtin_amdgcn_s_memtime();
       uint64_t stB = stA, stD = stA, stC1 = stA, stC2 = stA;
@@ -305,7 +317,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_mfma_kernel(GemmParams
         stC1 = __builtin_amdgcn_s_memtime();
 #endif
         // ... and its pieces of tile t+1 have landed (issued NBUF-1 tiles ago; tiles t+2 .. t+NBUF-1 may still be in flight)
-        wait_tiles_in_flight((nk - 1 < t + NBUF - 1 ? nk - 1 : t + NBUF - 1) - (t + 1));
+        if constexpr (MOVE) wait_tiles_in_flight((nk - 1 < t + NBUF - 1 ? nk - 1 : t + NBUF - 1) - (t + 1));
         FENCE();
 #ifdef CD360_GEMM_STAMP
         stC2 = __builtin_amdgcn_s_memtime();
@@ -326,7 +338,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_mfma_kernel(GemmParams
       }
       {  // last k-step: its MFMAs with the DMA pieces of tile t+NBUF (into the buffer just released) spread between them.  The MFMAs
          // are unconditional code: accumulators defined in two branch arms make the register allocator copy and spill them.
-        const bool more = t + NBUF < nk && !(abl & 4);
+        const bool more = MOVE && t + NBUF < nk && !(abl & 4);
         if constexpr (CONV) {
           if (more) conv_next();
         }
@@ -346,7 +358,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_mfma_kernel(GemmParams
       }
       FENCE();
 #ifdef CD360_GEMM_STAMP
-      if (p.stamp && t < 64) {  // stamps parked in the LDS behind the ring (a global store would count in vmcnt); lane 0 of each wave
+      if (p.stamp && t < 64 && wave < NWC) {  // stamps parked in the LDS behind the ring (a global store would count in vmcnt); lane 0 of each wave
         const uint64_t stE = __builtin_amdgcn_s_memtime();
         if (lane == 0) {
           uint32_t* d = reinterpret_cast<uint32_t*>(lds + NBUF * (XB + WB)) + (wave * 64 + t) * 8;
@@ -686,13 +698,19 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_mfma_kernel(GemmParams
       }  // rep
     }
   };
-  if (has_ch) k_loop(std::true_type{});
-  else k_loop(std::false_type{});
+  if constexpr (MV > 0) {
+    if (mover) k_loop(std::false_type{}, std::true_type{});
+    else if (has_ch) k_loop(std::true_type{}, std::false_type{});
+    else k_loop(std::false_type{}, std::false_type{});
+  } else {
+    if (has_ch) k_loop(std::true_type{}, std::true_type{});
+    else k_loop(std::false_type{}, std::true_type{});
+  }
   __syncthreads();  // every wave is past its last fragment read: the K-loop buffers become the output staging area
 #ifdef CD360_GEMM_STAMP
   if (p.stamp) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(lds + NBUF * (XB + WB));
-    for (int i = tid; i < NW * 64 * 8; i += 64 * NW) p.stamp[(long)blockIdx.x * (NW * 64 * 8) + i] = src[i];
+    for (int i = tid; i < NWC * 64 * 8; i += 64 * NW) p.stamp[(long)blockIdx.x * (NWC * 64 * 8) + i] = src[i];
     __syncthreads();
   }
 #endif
@@ -810,7 +828,7 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_mfma_kernel(GemmParams
     for (int mb = 0; mb < NMB; ++mb) {
       const float s = rsum[mb] + __shfl_xor(rsum[mb], 32);
       const float q = rsq[mb] + __shfl_xor(rsq[mb], 32);
-      if (hh == 0) {
+      if (hh == 0 && !mover) {
         float* d = red + (((wc * KS + kg) * BM) + mrow0 + mb * 32) * 2;
         d[0] = s;
         d[1] = q;
@@ -834,8 +852,8 @@ __global__ __launch_bounds__(64 * WM * WN * KS) void gemm_mfma_kernel(GemmParams
   }
 }
 
-template <int WM, int WN, int NCB, int NMB, int NBUF, int KS, int EPI>
-int launch_ks(const GemmParams& p0, hipStream_t stream) {
+template <int WM, int WN, int NCB, int NMB, int NBUF, int KS, int MV, int EPI>
+int launch_mv(const GemmParams& p0, hipStream_t stream) {
   GemmParams p = p0;
   constexpr int BM = WM * NMB * 32, BN = WN * NCB * 32;
   // K-loop buffers, reused as the output staging image (+ the fp32 partial tile of the second k-step group)
@@ -861,12 +879,28 @@ int launch_ks(const GemmParams& p0, hipStream_t stream) {
 #endif
   const long nwg = (long)p.tiles_m * p.tiles_n;
   if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
-  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_kernel<WM, WN, NCB, NMB, NBUF, KS, EPI>),
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_kernel<WM, WN, NCB, NMB, NBUF, KS, MV, EPI>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   if (attr != hipSuccess) return CD360_ERR_LAUNCH;
-  hipLaunchKernelGGL((gemm_mfma_kernel<WM, WN, NCB, NMB, NBUF, KS, EPI>), dim3((unsigned)nwg), dim3(64 * WM * WN * KS), LDS_BYTES, stream, p);
+  hipLaunchKernelGGL((gemm_mfma_kernel<WM, WN, NCB, NMB, NBUF, KS, MV, EPI>), dim3((unsigned)nwg), dim3(64 * (WM * WN * KS + MV)), LDS_BYTES, stream, p);
   CD360_LAUNCH_CHECK();
   return CD360_OK;
+}
+
+// Mover waves (MV = 4: one per SIMD) where the multiplying waves leave the registers for a third wave per SIMD (<= 168) and the epilogue
+// is a linear / convolution one.  CD360_GEMM_MOVERS=0 turns them off, =4 on for every arrangement that can take them; unset = the
+// arrangements they were measured to help (tools/bench_gemm.py movers).
+template <int WM, int WN, int NCB, int NMB, int NBUF, int KS, int EPI>
+int launch_ks(const GemmParams& p, hipStream_t stream) {
+  constexpr bool CAN = (EPI == 0 || EPI == 5 || EPI == 6) && NCB * NMB <= 6;
+  if constexpr (CAN) {
+    // measured (hipGraph-timed, interleaved): the four- and three-buffer arrangements -5 ... -10 % (C -> C 18.7 -> 17.8 us, FF2 50.1 -> 47.0,
+    // 3 x 3 convolutions at 32^2 / 64^2 108 -> 98 / 176 -> 161), 256 x 192 -2.6 %, the two-buffer 128 x 128 with two workgroups per CU +-0
+    constexpr bool DEFAULT_ON = NBUF >= 3 || NCB == 3;
+    const char* e = getenv("CD360_GEMM_MOVERS");
+    if (e ? atoi(e) == 4 : DEFAULT_ON) return launch_mv<WM, WN, NCB, NMB, NBUF, KS, 4, EPI>(p, stream);
+  }
+  return launch_mv<WM, WN, NCB, NMB, NBUF, KS, 0, EPI>(p, stream);
 }
 
 template <int WM, int WN, int NCB, int NMB, int NBUF, int EPI>

@@ -388,6 +388,85 @@ def fixed_cost():
     print(f"torch elementwise on 64 floats (launch floor in a graph): {timeit_graph(lambda: x.add_(1.0)):6.1f}", flush=True)
 
 
+def movers():
+    """Dedicated mover waves (CD360_GEMM_MOVERS=4: four extra waves issue all LDS-DMA pieces, the eight others only multiply) on the
+    128 x 128 four-buffer tiling, unsplit and with the k-step groups: bit-identical results, hipGraph-timed, interleaved."""
+    ok = True
+    variants = (("ks0", "0", "0"), ("ks0+mv", "0", "4"), ("ks1", "1", "0"), ("ks1+mv", "1", "4"))
+    for name, M, N, K in (("L2 out", 3072, 1280, 1280), ("L2 pose", 3072, 1280, 2560), ("L2 ff2", 3072, 1280, 5120), ("ragged", 1000, 640, 640), ("tiny", 300, 272, 320)):
+        a = rnd(M, K, seed=1).to(torch.bfloat16)
+        w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
+        b32, r = rnd(N, seed=3), rnd(M, N, seed=4).to(torch.bfloat16)
+        os.environ["CD360_GEMM_CFG"] = "4"
+        best, outs = {v[0]: 1e9 for v in variants}, {}
+        for _ in range(3):
+            for tag, ks, mv in variants:
+                os.environ["CD360_GEMM_KSPLIT"], os.environ["CD360_GEMM_MOVERS"] = ks, mv
+                outs[tag] = ops.gemm(a, w, bias=b32, res=r, want_stats=True)
+                best[tag] = min(best[tag], timeit_graph(lambda: ops.gemm(a, w, bias=b32, res=r, want_stats=True)))
+        same = all(torch.equal(outs[x][i], outs[x + "+mv"][i]) for x in ("ks0", "ks1") for i in (0, 1))
+        ok &= same
+        print(f"{name:8s} M={M:6d} N={N:5d} K={K:4d} | " + " | ".join(f"{k} {v:6.1f}" for k, v in best.items()) + f" | movers == plain: {same}", flush=True)
+    os.environ.pop("CD360_GEMM_CFG", None)
+    for (N_, H, W, cin, cout) in ((3, 32, 32, 1280, 1280), (3, 32, 32, 2560, 1280), (2, 16, 16, 128, 192)):
+        x = torch.randn(N_, H * W, cin, device=dev).to(torch.bfloat16)
+        wp = (torch.randn(cout, 9 * cin, device=dev) / (9 * cin) ** 0.5).to(torch.bfloat16)
+        bias, emb = torch.randn(cout, device=dev), torch.randn(N_, cout, device=dev).to(torch.bfloat16)
+        os.environ["CD360_CONV_CFG"] = "4"
+        best, outs = {v[0]: 1e9 for v in variants}, {}
+        for _ in range(3):
+            for tag, ks, mv in variants:
+                os.environ["CD360_GEMM_KSPLIT"], os.environ["CD360_GEMM_MOVERS"] = ks, mv
+                outs[tag] = ops.conv_igemm(x, wp, bias, N_, H, W, 9, emb=emb, want_stats=True)
+                best[tag] = min(best[tag], timeit_graph(lambda: ops.conv_igemm(x, wp, bias, N_, H, W, 9, emb=emb, want_stats=True)))
+        same = all(torch.equal(outs[x_][i], outs[x_ + "+mv"][i]) for x_ in ("ks0", "ks1") for i in (0, 1))
+        ok &= same
+        print(f"conv {N_}x{H}x{W} {cin}->{cout}: " + " | ".join(f"{k} {v:6.1f}" for k, v in best.items()) + f" | movers == plain: {same}", flush=True)
+    for k in ("CD360_CONV_CFG", "CD360_GEMM_KSPLIT", "CD360_GEMM_MOVERS"):
+        os.environ.pop(k, None)
+    print("MOVERS", "PASSED" if ok else "FAILED", flush=True)
+    return ok
+
+
+def movers_all():
+    """CD360_GEMM_MOVERS = 0 against 4 on the shapes of the other tilings (auto tiling), hipGraph-timed, interleaved, bit-equality checked."""
+    ok = True
+    for name, M, N, K, epi in (("L1 out", 12288, 640, 640, "res"), ("L1 ff2", 12288, 640, 2560, "res"), ("L1 pose", 12288, 640, 1280, "res"),
+                               ("L2 qkv", 3072, 3840, 1280, "ln"), ("L1 qkv", 12288, 1920, 640, "ln"), ("L2 out", 3072, 1280, 1280, "res"), ("L2 ff2", 3072, 1280, 5120, "res")):
+        a = rnd(M, K, seed=1).to(torch.bfloat16)
+        w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
+        b32, r = rnd(N, seed=3), rnd(M, N, seed=4).to(torch.bfloat16)
+        st, ws = ops.row_stats(a), w.float().sum(1).contiguous()
+        fn = (lambda: ops.gemm(a, w, bias=b32, res=r, want_stats=True)) if epi == "res" else (lambda: ops.gemm(a, w, bias=b32, ln=(st, ws, 1e-5)))
+        best, outs = {"0": 1e9, "4": 1e9}, {}
+        for _ in range(3):
+            for mv in ("0", "4"):
+                os.environ["CD360_GEMM_MOVERS"] = mv
+                outs[mv] = fn()
+                best[mv] = min(best[mv], timeit_graph(fn))
+        o0, o4 = (outs[k] if isinstance(outs[k], tuple) else (outs[k],) for k in ("0", "4"))
+        same = all(torch.equal(x, y) for x, y in zip(o0, o4))
+        ok &= same
+        print(f"{name:8s} M={M:6d} N={N:5d} K={K:4d} tile_n={ops._lib.load().cd360_gemm_tile_n(M, N)} | movers 0: {best['0']:6.1f} | 4: {best['4']:6.1f} | equal: {same}", flush=True)
+    for (N_, H, W, cin, cout) in ((3, 64, 64, 640, 640), (3, 64, 64, 1280, 640), (3, 64, 64, 1920, 640), (3, 128, 128, 320, 320), (3, 32, 32, 1280, 1280)):
+        x = torch.randn(N_, H * W, cin, device=dev).to(torch.bfloat16)
+        wp = (torch.randn(cout, 9 * cin, device=dev) / (9 * cin) ** 0.5).to(torch.bfloat16)
+        bias, emb = torch.randn(cout, device=dev), torch.randn(N_, cout, device=dev).to(torch.bfloat16)
+        fn = lambda: ops.conv_igemm(x, wp, bias, N_, H, W, 9, emb=emb, want_stats=True)
+        best, outs = {"0": 1e9, "4": 1e9}, {}
+        for _ in range(3):
+            for mv in ("0", "4"):
+                os.environ["CD360_GEMM_MOVERS"] = mv
+                outs[mv] = fn()
+                best[mv] = min(best[mv], timeit_graph(fn))
+        same = torch.equal(outs["0"][0], outs["4"][0]) and torch.equal(outs["0"][1], outs["4"][1])
+        ok &= same
+        print(f"conv {N_}x{H}x{W} {cin}->{cout}: movers 0: {best['0']:6.1f} | 4: {best['4']:6.1f} | equal: {same}", flush=True)
+    os.environ.pop("CD360_GEMM_MOVERS", None)
+    print("MOVERS_ALL", "PASSED" if ok else "FAILED", flush=True)
+    return ok
+
+
 def whatif():
     """hipGraph-timed what-if builds of the 128 x 128 four-buffer tiling on the long-K shape (results invalid by construction)."""
     M, N = 3072, 1280
@@ -422,6 +501,10 @@ def stride_sweep():
 if __name__ == "__main__":
     what = sys.argv[1:] or ["check", "time"]
     good = True
+    if "movers" in what:
+        good = movers() and good
+    if "movers_all" in what:
+        good = movers_all() and good
     if "stride" in what:
         stride_sweep()
     if "whatif" in what:
