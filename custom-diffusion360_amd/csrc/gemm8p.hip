@@ -113,7 +113,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   constexpr int NWC = NWT * KS;                    // waves that multiply
   constexpr int NW = NWC + MV;                     // waves
   constexpr int NWD = MV ? MV : NW;                // waves that move data
-  static_assert(MV == 0 || (EPI == 0 || EPI == 5 || EPI == 6), "mover waves: linear / convolution epilogues");
+  static_assert(MV == 0 || (EPI == 0 || EPI == 1 || EPI == 5 || EPI == 6), "mover waves: linear / GEGLU / convolution epilogues");
   constexpr int KPW = 4 / KS;                      // k-steps of a K-tile that one wave multiplies
   constexpr int BM = WM * NMB * 32, BN = WN * NCB * 32;
   constexpr uint32_t XB = BM * 128, WB = BN * 128;  // bytes of one buffer of each operand (64-deep K-tile, 128-byte rows)
@@ -892,7 +892,7 @@ int launch_mv(const GemmParams& p0, hipStream_t stream) {
 // arrangements they were measured to help (tools/bench_gemm.py movers).
 template <int WM, int WN, int NCB, int NMB, int NBUF, int KS, int EPI>
 int launch_ks(const GemmParams& p, hipStream_t stream) {
-  constexpr bool CAN = (EPI == 0 || EPI == 5 || EPI == 6) && NCB * NMB <= 6;
+  constexpr bool CAN = (EPI == 0 || EPI == 1 || EPI == 5 || EPI == 6) && NCB * NMB <= 6;
   if constexpr (CAN) {
     // measured (hipGraph-timed, interleaved): the four- and three-buffer arrangements -5 ... -10 % (C -> C 18.7 -> 17.8 us, FF2 50.1 -> 47.0,
     // 3 x 3 convolutions at 32^2 / 64^2 108 -> 98 / 176 -> 161), 256 x 192 -2.6 %, the two-buffer 128 x 128 with two workgroups per CU +-0

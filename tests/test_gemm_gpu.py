@@ -30,6 +30,16 @@ def test_gemm_k_step_groups_of_the_128x128_tiling(monkeypatch):
         os.environ.pop(k, None)
 
 
+def test_gemm_mover_waves_change_no_bit(monkeypatch):
+    """CD360_GEMM_MOVERS=4 (four extra waves issue every LDS-DMA piece, the others only multiply) against 0 on the four-buffer 128 x 128
+    tiling, unsplit and with the k-step groups, Linear and convolution epilogues, ragged shapes: outputs and statistics bit-identical;
+    and the default dispatch (movers on where they help) passes the family's parity list in the test above."""
+    import bench_gemm
+    assert bench_gemm.movers(time=False)
+    for k in ("CD360_GEMM_CFG", "CD360_CONV_CFG", "CD360_GEMM_KSPLIT", "CD360_GEMM_MOVERS"):
+        os.environ.pop(k, None)
+
+
 @pytest.mark.parametrize("ksplit", ["0", "1"])
 def test_gemm_cstats_in_both_wave_arrangements(monkeypatch, ksplit):
     from bench_gemm import rnd

@@ -388,7 +388,7 @@ def fixed_cost():
     print(f"torch elementwise on 64 floats (launch floor in a graph): {timeit_graph(lambda: x.add_(1.0)):6.1f}", flush=True)
 
 
-def movers():
+def movers(time=True):
     """Dedicated mover waves (CD360_GEMM_MOVERS=4: four extra waves issue all LDS-DMA pieces, the eight others only multiply) on the
     128 x 128 four-buffer tiling, unsplit and with the k-step groups: bit-identical results, hipGraph-timed, interleaved."""
     ok = True
@@ -403,7 +403,8 @@ def movers():
             for tag, ks, mv in variants:
                 os.environ["CD360_GEMM_KSPLIT"], os.environ["CD360_GEMM_MOVERS"] = ks, mv
                 outs[tag] = ops.gemm(a, w, bias=b32, res=r, want_stats=True)
-                best[tag] = min(best[tag], timeit_graph(lambda: ops.gemm(a, w, bias=b32, res=r, want_stats=True)))
+                if time:
+                    best[tag] = min(best[tag], timeit_graph(lambda: ops.gemm(a, w, bias=b32, res=r, want_stats=True)))
         same = all(torch.equal(outs[x][i], outs[x + "+mv"][i]) for x in ("ks0", "ks1") for i in (0, 1))
         ok &= same
         print(f"{name:8s} M={M:6d} N={N:5d} K={K:4d} | " + " | ".join(f"{k} {v:6.1f}" for k, v in best.items()) + f" | movers == plain: {same}", flush=True)
@@ -418,7 +419,8 @@ def movers():
             for tag, ks, mv in variants:
                 os.environ["CD360_GEMM_KSPLIT"], os.environ["CD360_GEMM_MOVERS"] = ks, mv
                 outs[tag] = ops.conv_igemm(x, wp, bias, N_, H, W, 9, emb=emb, want_stats=True)
-                best[tag] = min(best[tag], timeit_graph(lambda: ops.conv_igemm(x, wp, bias, N_, H, W, 9, emb=emb, want_stats=True)))
+                if time:
+                    best[tag] = min(best[tag], timeit_graph(lambda: ops.conv_igemm(x, wp, bias, N_, H, W, 9, emb=emb, want_stats=True)))
         same = all(torch.equal(outs[x_][i], outs[x_ + "+mv"][i]) for x_ in ("ks0", "ks1") for i in (0, 1))
         ok &= same
         print(f"conv {N_}x{H}x{W} {cin}->{cout}: " + " | ".join(f"{k} {v:6.1f}" for k, v in best.items()) + f" | movers == plain: {same}", flush=True)
@@ -467,6 +469,27 @@ def movers_all():
     return ok
 
 
+def ff1_tilings():
+    """FF1 + GEGLU: 256 x 256 tiles (no room for mover waves) against 256 x 128 tiles with and without them."""
+    for name, M, N, K in (("L2 ff1", 3072, 10240, 1280), ("L1 ff1", 12288, 5120, 640)):
+        a = rnd(M, K, seed=1).to(torch.bfloat16)
+        w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
+        b32 = rnd(N, seed=3)
+        st, ws = ops.row_stats(a), w.float().sum(1).contiguous()
+        fn = lambda: ops.gemm(a, w, bias=b32, ln=(st, ws, 1e-5), geglu=True)
+        variants = (("256x256", "3", "0"), ("256x128", "5", "0"), ("256x128+movers", "5", "4"), ("128x128/4w", "1", "0"), ("128x128/4w+movers", "1", "4"))
+        best, outs = {v[0]: 1e9 for v in variants}, {}
+        for _ in range(3):
+            for tag, cfg, mv in variants:
+                os.environ["CD360_GEMM_CFG"], os.environ["CD360_GEMM_MOVERS"] = cfg, mv
+                outs[tag] = fn()
+                best[tag] = min(best[tag], timeit_graph(fn, n=20))
+        same = torch.equal(outs["256x128"], outs["256x128+movers"])
+        print(f"{name:8s} M={M:6d} N={N:5d} K={K:4d} | " + " | ".join(f"{k} {v:6.1f}" for k, v in best.items()) + f" | movers == plain: {same}", flush=True)
+    for k in ("CD360_GEMM_CFG", "CD360_GEMM_MOVERS"):
+        os.environ.pop(k, None)
+
+
 def whatif():
     """hipGraph-timed what-if builds of the 128 x 128 four-buffer tiling on the long-K shape (results invalid by construction)."""
     M, N = 3072, 1280
@@ -503,6 +526,8 @@ if __name__ == "__main__":
     good = True
     if "movers" in what:
         good = movers() and good
+    if "ff1" in what:
+        ff1_tilings()
     if "movers_all" in what:
         good = movers_all() and good
     if "stride" in what:
