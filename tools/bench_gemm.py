@@ -182,7 +182,7 @@ SHAPES = [  # (name, M, N, K, epilogue) at cfg-B: b = 3; level 1: 4096 tokens x 
 ]
 
 
-VARIANTS = [(3, 0), (6, 0), (5, 0), (1, 0), (2, 0), (4, 0)]
+VARIANTS = [(0, 0)]  # 0 = the tiling pick_cfg chooses (the product path); CD360_GEMM_CFG=n forces one
 
 
 def time_qattn():
@@ -213,30 +213,30 @@ def time_all():
         b16 = b32.to(torch.bfloat16)
         r = rnd(M, N, seed=4).to(torch.bfloat16) if epi == "res" else None
         flops = 2.0 * M * N * K
-        t_lib = timeit(lambda: F.linear(a, w, b16))
+        t_lib = timeit_graph(lambda: F.linear(a, w, b16), n=20)
         line = f"{name:8s} M={M:6d} N={N:5d} K={K:4d} | hipBLASLt {t_lib:7.1f} us {flops / t_lib * 1e-6:6.0f} TF"
         for cfg, sched in VARIANTS:
             if epi == "geglu" and cfg in (2, 4, 6):
                 continue
-            os.environ["CD360_GEMM_CFG"] = str(cfg)
-            os.environ["CD360_GEMM_SCHED"] = str(sched)
-            t_plain = timeit(lambda: ops.gemm(a, w, bias=b32))
-            line += f" | cfg{cfg} plain {t_plain:7.1f} us {flops / t_plain * 1e-6:6.0f} TF"
+            if cfg:
+                os.environ["CD360_GEMM_CFG"] = str(cfg)
+            t_plain = timeit_graph(lambda: ops.gemm(a, w, bias=b32), n=20)
+            line += f" | cd360 {'auto' if not cfg else 'cfg%d' % cfg} plain {t_plain:7.1f} us {flops / t_plain * 1e-6:6.0f} TF"
             if epi == "ln":
                 st = ops.row_stats(a)
                 ws = w.float().sum(1).contiguous()
-                t = timeit(lambda: ops.gemm(a, w, bias=b32, ln=(st, ws, 1e-5)))
+                t = timeit_graph(lambda: ops.gemm(a, w, bias=b32, ln=(st, ws, 1e-5)), n=20)
                 line += f" ln {t:7.1f}"
             elif epi == "res":
-                t = timeit(lambda: ops.gemm(a, w, bias=b32, res=r, want_stats=True))
+                t = timeit_graph(lambda: ops.gemm(a, w, bias=b32, res=r, want_stats=True), n=20)
                 line += f" res+stats {t:7.1f}"
             elif epi == "geglu":
                 st = ops.row_stats(a)
                 ws = w.float().sum(1).contiguous()
-                t = timeit(lambda: ops.gemm(a, w, bias=b32, ln=(st, ws, 1e-5), geglu=True))
+                t = timeit_graph(lambda: ops.gemm(a, w, bias=b32, ln=(st, ws, 1e-5), geglu=True), n=20)
                 line += f" ln+geglu {t:7.1f}"
         if epi == "geglu":  # what the fused call replaces: library GEMM + geglu pass (+ the LayerNorm pass in front, not timed here)
-            t2 = timeit(lambda: ops.geglu(F.linear(a, w, b16)))
+            t2 = timeit_graph(lambda: ops.geglu(F.linear(a, w, b16)), n=20)
             line += f" | lib+geglu {t2:7.1f}"
         print(line, flush=True)
     os.environ.pop("CD360_GEMM_CFG", None)
