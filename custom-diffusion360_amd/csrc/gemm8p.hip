@@ -892,7 +892,7 @@ int launch_mv(const GemmParams& p0, hipStream_t stream) {
 // arrangements they were measured to help (tools/bench_gemm.py movers).
 template <int WM, int WN, int NCB, int NMB, int NBUF, int KS, int EPI>
 int launch_ks(const GemmParams& p, hipStream_t stream) {
-  constexpr bool CAN = (EPI == 0 || EPI == 1 || EPI == 5 || EPI == 6) && NCB * NMB <= 6;
+  constexpr bool CAN = (EPI == 0 || EPI == 1 || EPI == 5 || EPI == 6) && NCB * NMB <= 6 && WM * WN * KS + 4 <= 16;
   if constexpr (CAN) {
     // measured (hipGraph-timed, interleaved): the four- and three-buffer arrangements -5 ... -10 % (C -> C 18.7 -> 17.8 us, FF2 50.1 -> 47.0,
     // 3 x 3 convolutions at 32^2 / 64^2 108 -> 98 / 176 -> 161), 256 x 192 -2.6 %, the two-buffer 128 x 128 with two workgroups per CU +-0
@@ -932,14 +932,14 @@ int launch(const GemmParams& p, hipStream_t stream) {
 // Tilings (tokens x channels, waves, LDS buffers): 1 = 128 x 128, 4 waves of 64 x 64, 2 buffers (two workgroups per CU);
 // 2 = 128 x 128, 8 waves of 64 x 32, 2 buffers; 3 = 256 x 256, 8 waves of 128 x 64, 2 buffers; 4 = as 2 with 4 buffers (3 tiles in
 // flight: long K loops of launches with one workgroup per CU); 5 = 256 x 128, 8 waves of 64 x 64, 3 buffers; 6 = 256 x 192, 8 waves of
-// 64 x 96, 2 buffers
-constexpr int NCFG = 6;
-constexpr int CFG_BM[NCFG + 1] = {0, 128, 128, 256, 128, 256, 256}, CFG_BN[NCFG + 1] = {0, 128, 128, 256, 128, 128, 192};
+// 64 x 96, 2 buffers; 7 = 256 x 256, SIXTEEN waves of 64 x 64 (four per SIMD), 2 buffers
+constexpr int NCFG = 7;
+constexpr int CFG_BM[NCFG + 1] = {0, 128, 128, 256, 128, 256, 256, 256}, CFG_BN[NCFG + 1] = {0, 128, 128, 256, 128, 128, 192, 256};
 int pick_cfg(int64_t M, int N, bool geglu) {
   int cfg = 0;
   if (const char* e = getenv("CD360_GEMM_CFG")) cfg = atoi(e);  // tuning / A-B override
   if (cfg >= 1 && cfg <= NCFG && !(geglu && (cfg == 2 || cfg == 4 || cfg == 6))) return cfg;
-  if (geglu) return 3;
+  if (geglu) return 7;  // FF1 + GEGLU: sixteen waves of 64 x 64 on the 256 x 256 tile, -3 % against eight of 128 x 64 (bit-identical results)
   // Measured on the SDXL shapes (tools/bench_gemm.py, profiles/r02_gemm_shapes.txt).  Narrow outputs (the C -> C projections and the
   // feed-forward's second Linear): 128 x 128 tiles -- with four LDS buffers when the launch has at most one workgroup per CU (the
   // 1280-wide level: 240 tiles), two otherwise (two workgroups per CU overlap each other's prologue / epilogue) -- except for very
@@ -999,6 +999,7 @@ extern "C" int cd360_gemm_bf16(const void* a, const void* w, void* out, int64_t 
     case 2: return geglu ? CD360_ERR_SHAPE : launch_epi<2, 4, 1, 2, 2, 0>(p, (hipStream_t)stream);
     case 4: return geglu ? CD360_ERR_SHAPE : launch_128x4<0>(p, (hipStream_t)stream);
     case 5: return launch<4, 2, 2, 2, 3>(p, (hipStream_t)stream);
+    case 7: return launch<4, 4, 2, 2, 2>(p, (hipStream_t)stream);  // 256 x 256 as sixteen waves of 64 x 64 (four per SIMD): A/B only
     case 6: return geglu ? CD360_ERR_SHAPE : launch_epi<4, 2, 3, 2, 2, 0>(p, (hipStream_t)stream);
     default: return launch<2, 4, 2, 4, 2>(p, (hipStream_t)stream);
   }

@@ -117,13 +117,16 @@ def check():
     ok &= check_qattn(2, 256, 1280, 1280, 50)
     ok &= check_qattn(1, 768, 256, 320, 96)
     ok &= check_qattn(2, 256, 128, 192, 20)
-    for cfg in (1, 2, 3, 4, 5, 6):
+    for cfg in (1, 2, 3, 4, 5, 6, 7):
         for (M, N, K) in [(256, 256, 64), (256, 256, 128), (512, 512, 192), (300, 272, 320), (128, 128, 64), (1000, 640, 640), (3072, 1280, 1280)]:
             ok &= check_case(M, N, K, cfg=cfg)
         ok &= check_case(520, 640, 320, bias=True, res=True, stats=True, cfg=cfg)
         ok &= check_case(777, 1280, 640, bias=True, ln=True, cfg=cfg)
         ok &= check_case(1024, 384, 256, bias=True, ln=True, res=True, stats=True, cfg=cfg, lda=512)
     ok &= check_case(515, 1280, 320, bias=True, ln=True, geglu=True)
+    for cfg in (3, 5, 7):  # GEGLU on every tiling that has value / gate block pairs
+        ok &= check_case(515, 1280, 320, bias=True, ln=True, geglu=True, cfg=cfg)
+        ok &= check_case(777, 640, 192, bias=True, geglu=True, cfg=cfg)
     ok &= check_case(3072, 10240, 1280, bias=True, ln=True, geglu=True)
     ok &= check_case(12288, 1920, 640, bias=True, ln=True)
     ok &= check_case(12288, 640, 2560, bias=True, res=True, stats=True)
@@ -477,7 +480,7 @@ def ff1_tilings():
         b32 = rnd(N, seed=3)
         st, ws = ops.row_stats(a), w.float().sum(1).contiguous()
         fn = lambda: ops.gemm(a, w, bias=b32, ln=(st, ws, 1e-5), geglu=True)
-        variants = (("256x256", "3", "0"), ("256x128", "5", "0"), ("256x128+movers", "5", "4"), ("128x128/4w", "1", "0"), ("128x128/4w+movers", "1", "4"))
+        variants = (("256x256", "3", "0"), ("256x256/16w", "7", "0"), ("256x128", "5", "0"), ("256x128+movers", "5", "4"))
         best, outs = {v[0]: 1e9 for v in variants}, {}
         for _ in range(3):
             for tag, cfg, mv in variants:
@@ -485,7 +488,8 @@ def ff1_tilings():
                 outs[tag] = fn()
                 best[tag] = min(best[tag], timeit_graph(fn, n=20))
         same = torch.equal(outs["256x128"], outs["256x128+movers"])
-        print(f"{name:8s} M={M:6d} N={N:5d} K={K:4d} | " + " | ".join(f"{k} {v:6.1f}" for k, v in best.items()) + f" | movers == plain: {same}", flush=True)
+        e16 = relerr(outs["256x256/16w"], outs["256x256"].float())
+        print(f"{name:8s} M={M:6d} N={N:5d} K={K:4d} | " + " | ".join(f"{k} {v:6.1f}" for k, v in best.items()) + f" | movers == plain: {same} | 16w vs 8w err {e16:.1e}", flush=True)
     for k in ("CD360_GEMM_CFG", "CD360_GEMM_MOVERS"):
         os.environ.pop(k, None)
 
