@@ -128,6 +128,22 @@ def test_library_exports_every_declared_symbol():
     assert lib.cd360_conv_stats_slabs(320) == 4 and lib.cd360_conv_stats_slabs(640) == 2 and lib.cd360_conv_k_order(1280, 9) == 5
 
 
+def test_gemm_dispatch_contract_of_the_sdxl_shapes():
+    """The host side sizes two buffers from what the GEMM dispatcher will choose (no GPU needed to ask): the row-statistics partials of a
+    residual-stream GEMM (one per `cd360_gemm_tile_n` columns, consumed by the next LayerNorm fold) and the 64-row channel statistics
+    of `proj_out` (consumed by the next GroupNorm).  Pin both for the shapes of the SDXL UNet at cfg-A / cfg-B batch sizes."""
+    from cd360 import _lib
+    lib = _lib.load()
+    for b in (1, 2, 3):
+        for tokens, C in ((4096, 640), (1024, 1280), (1024 // 4, 1280), (4096 // 4, 640)):  # 1024^2 and 512^2 images
+            M = b * tokens
+            assert lib.cd360_gemm_tile_n(M, C) in (128, 256), (M, C)           # C -> C, FF2: narrow outputs
+            assert lib.cd360_gemm_tile_n(M, 3 * C) in (128, 192, 256), (M, C)   # q|k|v
+            assert lib.cd360_gemm_cstats_rows(M, C) in (0, 64)                 # proj_out: 64-row slabs or the plain path
+    assert lib.cd360_gemm_cstats_rows(3072, 1280) == 64 and lib.cd360_gemm_cstats_rows(12288, 640) == 64
+    assert lib.cd360_gemm_tile_n(3072, 1280) == 128 and lib.cd360_gemm_tile_n(3072, 3840) == 192
+
+
 # ------------------------------------------------------------------------------------------------ fused-render algebra
 def _emulate_fused_kernel(fw, cams, xref, S, far):
     """Test-only torch restatement of csrc/nerf_fused.hip + cd360/nerf.py (fp32): validates the weight re-layouts and the algebra."""
