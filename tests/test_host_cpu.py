@@ -144,6 +144,33 @@ def test_gemm_dispatch_contract_of_the_sdxl_shapes():
     assert lib.cd360_gemm_tile_n(3072, 1280) == 128 and lib.cd360_gemm_tile_n(3072, 3840) == 192
 
 
+@pytest.mark.parametrize("cin", [64, 320, 640, 960, 1280, 1920, 2560])
+def test_packed_conv_weight_follows_the_kernels_k_tile_walk(cin):
+    """ops.pack_conv_weight against the K-tile walk of the implicit-im2col convolution (gemm8p.hip `conv_next`: K-tile after K-tile, chunk
+    in group fastest, then tap, then group, with cd360_conv_k_order(Cin, 9) chunks per group): K-tile kt of the packed matrix must be the
+    64-channel chunk and the tap the kernel shifts the input pixel by for that tile."""
+    from cd360 import _lib, ops
+    kg = _lib.load().cd360_conv_k_order(cin, 9)
+    assert (cin // 64) % kg == 0 and 1 <= kg <= 5
+    cout = 16
+    ci, tap = torch.arange(cin).view(1, cin, 1, 1), torch.arange(9).view(1, 1, 3, 3)
+    w = (ci * 9 + tap).expand(cout, cin, 3, 3).float() + torch.arange(cout).view(cout, 1, 1, 1) * 0.0  # value = code of (channel, tap)
+    wp = ops.pack_conv_weight(w.to(torch.float32)).float()  # bf16-rounded codes: compare against the same rounding
+    want = w.to(torch.bfloat16).float()
+    j = t = cg = 0
+    for kt in range(9 * cin // 64):
+        chunk = cg * kg + j
+        assert torch.equal(wp[:, kt * 64:(kt + 1) * 64], want[:, chunk * 64:(chunk + 1) * 64, t // 3, t % 3]), (kt, chunk, t)
+        j += 1
+        if j == kg:
+            j = 0
+            t += 1
+            if t == 9:
+                t = 0
+                cg += 1
+    assert cg == cin // 64 // kg and j == 0 and t == 0  # the walk ends exactly at the last group
+
+
 # ------------------------------------------------------------------------------------------------ fused-render algebra
 def _emulate_fused_kernel(fw, cams, xref, S, far):
     """Test-only torch restatement of csrc/nerf_fused.hip + cd360/nerf.py (fp32): validates the weight re-layouts and the algebra."""
