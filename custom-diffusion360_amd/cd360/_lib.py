@@ -9,7 +9,8 @@ import os
 from ctypes import c_float, c_int, c_int64, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_HERE), "lib", "libcd360_hip.so")
+# CD360_LIB: another build of the SAME library (tools/probe/whatif_build.sh, gemm_stamp.sh) -- a path, never a fallback
+LIB_PATH = os.environ.get("CD360_LIB") or os.path.join(os.path.dirname(_HERE), "lib", "libcd360_hip.so")
 
 _P = c_void_p
 _F32P = ctypes.POINTER(ctypes.c_float)
@@ -60,6 +61,27 @@ SIGNATURES = {
     "cd360_row_stats_bf16": (c_int, [_P, _P, c_int64, c_int, c_int64, _P]),
     "cd360_gn_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "cd360_gn_silu_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P, c_int, _P]),
+    "cd360_set_tuning": (c_int, [_P]),
+    "cd360_get_tuning": (c_int, [_P]),
+    "cd360_whatif_build": (c_int, []),
+}
+
+TUNING_FIELDS = ("gemm_cfg", "gemm_group_m", "gemm_movers", "gemm_ksplit", "conv_cfg", "conv_dma", "conv_kgroup", "conv_wide", "conv_wmajor",
+                 "conv_split", "attn_smallk", "attn_smallk_wgs", "attn_self", "attn_fast", "nerf_kernel", "qattn_cfg", "whatif")
+
+
+class Tuning(ctypes.Structure):
+    """struct cd360_tuning of include/cd360_hip.h: -1 = choose by shape (the default of every field)."""
+    _fields_ = [("size", ctypes.c_int32)] + [(f, ctypes.c_int32) for f in TUNING_FIELDS] + [("reserved", ctypes.c_int32 * 6)]
+
+
+# environment variable -> tuning field: read ONCE, when the library is loaded (the C side never reads the environment)
+TUNING_ENV = {
+    "CD360_GEMM_CFG": "gemm_cfg", "CD360_GEMM_GROUP_M": "gemm_group_m", "CD360_GEMM_MOVERS": "gemm_movers", "CD360_GEMM_KSPLIT": "gemm_ksplit",
+    "CD360_CONV_CFG": "conv_cfg", "CD360_CONV_DMA": "conv_dma", "CD360_CONV_KGROUP": "conv_kgroup", "CD360_CONV_WIDE": "conv_wide",
+    "CD360_CONV_WMAJOR": "conv_wmajor", "CD360_CONV_SPLIT": "conv_split", "CD360_ATTN_SMALLK": "attn_smallk", "CD360_SMALLK_WGS": "attn_smallk_wgs",
+    "CD360_ATTN_SELF": "attn_self", "CD360_ATTN_FAST": "attn_fast", "CD360_NERF_KERNEL": "nerf_kernel", "CD360_QATTN_CFG": "qattn_cfg",
+    "CD360_GEMM_ABL": "whatif",
 }
 
 _lib = None
@@ -89,7 +111,50 @@ def load(check_symbols: bool = True):
             continue
         fn.restype, fn.argtypes = res, args
     _lib = lib
+    env = {field: int(os.environ[name]) for name, field in TUNING_ENV.items() if os.environ.get(name, "") != ""}
+    if env:
+        set_tuning(**env)
     return lib
+
+
+def get_tuning() -> dict:
+    t = Tuning()
+    check(load().cd360_get_tuning(ctypes.byref(t)), "cd360_get_tuning")
+    return {f: getattr(t, f) for f in TUNING_FIELDS}
+
+
+def set_tuning(**fields) -> None:
+    """Override tiling / kernel choices of the C ABI (include/cd360_hip.h: cd360_tuning); unnamed fields keep their value, -1 restores
+    a field's default; set_tuning() with no arguments changes nothing, reset_tuning() restores every default."""
+    lib = _lib if _lib is not None else load()
+    t = Tuning()
+    check(lib.cd360_get_tuning(ctypes.byref(t)), "cd360_get_tuning")
+    for k, v in fields.items():
+        if k not in TUNING_FIELDS:
+            raise KeyError(f"unknown tuning field {k}")
+        setattr(t, k, int(v))
+    t.size = ctypes.sizeof(Tuning)
+    check(lib.cd360_set_tuning(ctypes.byref(t)), "cd360_set_tuning")
+
+
+def reset_tuning() -> None:
+    check(load().cd360_set_tuning(None), "cd360_set_tuning")
+
+
+class tuning:
+    """with tuning(gemm_cfg=4, gemm_movers=0): ...  -- the fields are restored on exit (A/B harnesses, tests)."""
+
+    def __init__(self, **fields):
+        self.fields = fields
+
+    def __enter__(self):
+        self.saved = get_tuning()
+        set_tuning(**self.fields)
+        return self
+
+    def __exit__(self, *a):
+        set_tuning(**self.saved)
+        return False
 
 
 _ERR = {-1: "invalid argument (null/misaligned pointer or non-positive size)", -2: "unsupported shape or stride", -3: "HIP launch failure"}
@@ -98,3 +163,30 @@ _ERR = {-1: "invalid argument (null/misaligned pointer or non-positive size)", -
 def check(code: int, what: str) -> None:
     if code != 0:
         raise Cd360Error(f"{what} failed: {_ERR.get(code, code)}")
+
+
+class TuningEnv:
+    """Dict-like view of the tuning struct under the historical CD360_* variable names (tools/bench_gemm.py's A/B loops were written
+    against os.environ): `ENV["CD360_GEMM_CFG"] = "4"` sets gemm_cfg = 4 through cd360_set_tuning, `ENV.pop(name, None)` restores
+    the field's default.  Names that are not tuning fields go to os.environ unchanged."""
+
+    def __setitem__(self, name, value):
+        if name in TUNING_ENV:
+            set_tuning(**{TUNING_ENV[name]: int(value)})
+        else:
+            os.environ[name] = value
+
+    def pop(self, name, default=None):
+        if name in TUNING_ENV:
+            set_tuning(**{TUNING_ENV[name]: -1})
+            return default
+        return os.environ.pop(name, default)
+
+    def get(self, name, default=None):
+        if name in TUNING_ENV:
+            v = get_tuning()[TUNING_ENV[name]]
+            return default if v < 0 else str(v)
+        return os.environ.get(name, default)
+
+
+ENV = TuningEnv()

@@ -18,6 +18,7 @@
 //   * all tensors are addressed through explicit strides, so the kernel reads the projection outputs
 //     [b, N, H*64] in place and writes [b, N, H*64] directly: no head split/merge copies.
 #include "cd360_common.h"
+#include "cd360_tuning.h"
 #include <stdlib.h>
 
 #define LDS_AS3(p) ((__attribute__((address_space(3))) void*)(p))
@@ -413,7 +414,9 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attn_self_kernel(Att
   };
   // the rare path: move m_ref of query block qb by d (>= 0 except on the first tile) and rescale what hangs on it
   auto move_ref = [&](int qb, float d, f32x16 (&s)[2]) {
-    const float alpha = __builtin_amdgcn_exp2f(-d);
+    // d < 0 happens on the first tile only (m_ref starts at 0, l and O at 0): nothing to rescale yet, and exp2(-d) of a first tile whose
+    // scores all sit below -128 would be +inf (0 * inf = NaN in l and O) -- clamp the factor's exponent at 0
+    const float alpha = __builtin_amdgcn_exp2f(-fmaxf(d, 0.f));
     l_run[qb] *= alpha;
 #pragma unroll
     for (int i = 0; i < 16; ++i) {
@@ -758,14 +761,14 @@ static int attn_launch(const void* q, const void* k, const void* v, void* o, int
     p.inv_sq = 1.f / sq; p.inv_sk = 1.f / sk; p.inv_sv = 1.f / sv;
     p.scale_log2e *= sq * sk;     // scores come out in units of sq * sk
     p.o_scale = sv / 256.f;       // V in units of sv, P in units of 1 / 256
-  } else if (const char* e = getenv("CD360_ATTN_SMALLK")) {
-    smallk = smallk && e[0] != '0';  // tuning override: 0 = always the tiled kernel
+  } else if (cd360_tune().attn_smallk == 0) {
+    smallk = false;  // tuning override: always the tiled kernel
   }
   if (smallk) {
     // one workgroup = one (batch, head) x one chunk of 32-query blocks; ~2 workgroups per CU in total, at least one block per wave
     const int nqb = (Nq + 31) / 32;
     long target = 512;  // two resident workgroups per CU (swept 240 ... 8192: 480-512 best for the pose-token shapes, text shapes flat)
-    if (const char* e = getenv("CD360_SMALLK_WGS")) target = atol(e) > 0 ? atol(e) : target;  // tuning override
+    if (cd360_tune().attn_smallk_wgs > 0) target = cd360_tune().attn_smallk_wgs;  // tuning override
     long chunks = (target + (long)B * H - 1) / ((long)B * H);
     const long max_chunks = (nqb + 3) / 4;
     if (chunks > max_chunks) chunks = max_chunks;
@@ -788,10 +791,10 @@ static int attn_launch(const void* q, const void* k, const void* v, void* o, int
   }
   // Second-generation self-attention kernel (whole tiles).  Its q pre-scaling costs one more bf16 rounding of q unless the caller
   // folded the scale into the projection (cd360_attn_fwd_prescaled_bf16: exact), so plain calls keep the first generation unless
-  // CD360_ATTN_SELF says otherwise: 0 = first generation, 1 = 4 waves x 32 queries, 2 = 8 waves x 64 queries, unset = by shape.
+  // cd360_tuning.attn_self says otherwise: 0 = first generation, 1 = 4 waves x 32 queries, 2 = 8 waves x 64 queries, unset = by shape.
   int gen2 = (Nk % 64 == 0 && Nq % 128 == 0 && (long)Nk * p.k_sn * 2 < (1L << 31) && (long)Nk * p.v_sn * 2 < (1L << 31)) ? 1 : 0;
   int pick = prescaled ? -1 : 0;
-  if (const char* e = getenv("CD360_ATTN_SELF")) pick = atoi(e);
+  if (cd360_tune().attn_self >= 0) pick = cd360_tune().attn_self;
   if (gen2 && pick) {
     bool wide = Nq % 512 == 0 && (long)B * H * (Nq / 512) >= 240;  // enough 512-query workgroups for every CU
     if (pick > 0) wide = pick == 2 && Nq % 512 == 0;
@@ -805,7 +808,7 @@ static int attn_launch(const void* q, const void* k, const void* v, void* o, int
   }
   p.n_qtiles = (Nq + 127) / 128;
   p.fast = ((long)Nk * p.k_sn * 2 < (1L << 31) && (long)Nk * p.v_sn * 2 < (1L << 31)) ? 1 : 0;
-  if (const char* e = getenv("CD360_ATTN_FAST")) p.fast = p.fast && e[0] != '0';  // tuning/debug: 0 forces the guarded path
+  if (cd360_tune().attn_fast == 0) p.fast = 0;  // tuning / debug: forces the guarded path
   const long nwg = (long)p.n_qtiles * B * H;
   if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
   hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);

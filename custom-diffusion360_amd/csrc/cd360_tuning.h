@@ -1,0 +1,35 @@
+// Tuning / A-B state of libcd360_hip.so (declared publicly in include/cd360_hip.h: cd360_tuning, cd360_set_tuning, cd360_get_tuning).
+// The launch functions read the ONE process-wide copy through cd360_tune(); nothing in a launch path calls getenv.  Every field is
+// -1 by default = "the measured best for the shape"; the Python binding fills the struct once from the CD360_* environment variables
+// when it loads the library (cd360/_lib.py) and tools / tests change it explicitly (cd360.ops.tuning(...)).
+#pragma once
+#include <stdint.h>
+
+extern "C" {
+typedef struct cd360_tuning {
+  int32_t size;             // sizeof(cd360_tuning): ABI check of cd360_set_tuning
+  int32_t gemm_cfg;         // 1..8: tiling of cd360_gemm_bf16 (gemm8p.hip: pick_cfg)
+  int32_t gemm_group_m;     // > 0: token tiles per tile group
+  int32_t gemm_movers;      // 0 | 4: mover waves off / on wherever the arrangement can take them
+  int32_t gemm_ksplit;      // 0 | 1 | 2: wave arrangement of the 128 x 128 four-buffer tiling
+  int32_t conv_cfg;         // 1..4: tiling of cd360_conv3x3_dma_bf16
+  int32_t conv_dma;         // 0: 3 x 3 / 1 x 1 convolutions on the register-staged kernel
+  int32_t conv_kgroup;      // > 0: K-order group size (set BEFORE weights are packed)
+  int32_t conv_wide;        // 0: register-staged kernel never uses its 160-channel tiles
+  int32_t conv_wmajor;      // 0 | 1: register-staged kernel's tile order
+  int32_t conv_split;       // 1 | 2: register-staged kernel's in-workgroup split-K
+  int32_t attn_smallk;      // 0: <= 96-key attention on the tiled kernel
+  int32_t attn_smallk_wgs;  // > 0: workgroup target of the register-resident kernel
+  int32_t attn_self;        // 0 | 1 | 2: self-attention kernel generation / tiling
+  int32_t attn_fast;        // 0: guarded (masked) path of the first-generation kernel
+  int32_t nerf_kernel;      // 0 | 1: render kernel with register gathers / full-line gathers through the wave's LDS block
+  int32_t qattn_cfg;        // 1 | 2: tile of cd360_qproj_attn_bf16 (256 x 256 / 128 x 128)
+  int32_t whatif;           // what-if timing bits of the GEMM core: honoured by -DCD360_WHATIF builds only (results are wrong when set)
+  int32_t reserved[6];
+} cd360_tuning;
+
+int cd360_set_tuning(const cd360_tuning* t);
+int cd360_get_tuning(cd360_tuning* t);
+}
+
+const cd360_tuning& cd360_tune();  // the current process-wide copy (tuning.hip)

@@ -13,6 +13,7 @@
 // (32-byte stores); both LDS tiles use the 16-B XOR swizzle of attn_fwd.hip (conflict-free ds_read_b128); the next K-step's
 // tiles travel HBM -> registers while the current one is multiplied (LDS double-buffered, one barrier per step).
 #include "cd360_common.h"
+#include "cd360_tuning.h"
 #include <type_traits>
 #include <stdlib.h>
 
@@ -335,14 +336,14 @@ extern "C" int cd360_conv_k_order(int Cin, int taps) {
   const int kchunks = Cin / 64;
   if (taps != 9 || kchunks <= 0) return kchunks > 0 ? kchunks : 1;
   int gmax = 5;
-  if (const char* e = getenv("CD360_CONV_KGROUP")) gmax = atoi(e) > 0 ? atoi(e) : gmax;  // tuning override (set before weights are packed)
+  if (cd360_tune().conv_kgroup > 0) gmax = cd360_tune().conv_kgroup;  // tuning override (set before weights are packed)
   for (int g = gmax < kchunks ? gmax : kchunks; g > 1; --g)
     if (kchunks % g == 0) return g;
   return 1;
 }
 
 // Pixel slabs per 128-pixel tile of the optional `tile_stats` output (the wave tiling the launch will use for this Cout)
-extern "C" int cd360_conv_stats_slabs(int Cout) { return (Cout % 160 == 0 && Cout % 128 != 0 && !(getenv("CD360_CONV_WIDE") && getenv("CD360_CONV_WIDE")[0] == '0')) ? 4 : 2; }
+extern "C" int cd360_conv_stats_slabs(int Cout) { return (Cout % 160 == 0 && Cout % 128 != 0 && cd360_tune().conv_wide != 0) ? 4 : 2; }
 
 // tile_stats (optional): fp32 [N*H*W / 128 * cd360_conv_stats_slabs(Cout), Cout, 2] = per pixel slab (32 or 64 consecutive pixels)
 // and channel, the sum and the sum of squares of the bf16 outputs -- the first pass of the GroupNorm that follows the conv
@@ -367,7 +368,7 @@ extern "C" int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const 
   if (cd360_conv_dma_slab_rows(N, H, W, Cin, Cout, taps, stride) > 0)  // 3 x 3 / stride 1: the LDS-DMA core (gemm8p.hip, EPI 5)
     return cd360_conv3x3_dma_bf16(x, w_packed, bias, emb, emb_stride, res, out, N, H, W, Cin, Cout, tile_stats, stream);
   // 1 x 1 (the ResBlock skip_connection convs, openaimodel.py:335-343): a plain Linear over the pixels -- the same core through its GEMM entry
-  if (taps == 1 && stride == 1 && !emb && !tile_stats && Cin % 64 == 0 && Cout % 16 == 0 && !(getenv("CD360_CONV_DMA") && getenv("CD360_CONV_DMA")[0] == '0')) {
+  if (taps == 1 && stride == 1 && !emb && !tile_stats && Cin % 64 == 0 && Cout % 16 == 0 && cd360_tune().conv_dma != 0) {
     const int rc = cd360_gemm_bf16(x, w_packed, out, (int64_t)N * H * W, Cout, Cin, Cin, Cin, Cout, bias, res, Cout, nullptr, 0, 0, 0.f, nullptr, nullptr, 0, stream);
     if (rc != CD360_ERR_SHAPE) return rc;
   }
@@ -387,7 +388,7 @@ extern "C" int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const 
   p.n_mtiles = (int)((p.M + BM - 1) / BM);
   // 160-channel tiles (4 waves of 160 x 32) when Cout is a multiple of 160 but not of 128 (Cout = 320): exact tiling
   bool wide = Cout % 160 == 0 && Cout % 128 != 0;
-  if (const char* e = getenv("CD360_CONV_WIDE")) wide = wide && e[0] != '0';  // tuning override: 0 = always 128-channel tiles
+  if (cd360_tune().conv_wide == 0) wide = false;  // tuning override: always 128-channel tiles
   const int bnc = wide ? 160 : 128;
   p.n_ntiles = (Cout + bnc - 1) / bnc;
   p.kgroup = cd360_conv_k_order(Cin, taps);
@@ -397,7 +398,7 @@ extern "C" int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const 
   // weights are at least ~0.9x the pixels AND that footprint is < ~3 MB (the 32x32 level: FETCH_SIZE 180 -> 81 MB per launch);
   // 1280->1280 at 64x64 (96 pixel tiles) went 287 -> 1080 MB weight-major with G = 5 and stays pixel-major.  Time is unaffected.
   p.w_major = (long)Cout * taps * 10 >= p.M * 9 && (long)p.n_mtiles * p.kgroup <= 160;
-  if (const char* e = getenv("CD360_CONV_WMAJOR")) p.w_major = e[0] == '1';  // tuning override
+  if (cd360_tune().conv_wmajor >= 0) p.w_major = cd360_tune().conv_wmajor == 1;  // tuning override
   const long nwg = (long)p.n_mtiles * p.n_ntiles;
   if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
   // in-workgroup split-K when the launch has no more tiles than CUs (one 4-wave workgroup per CU otherwise)
@@ -407,10 +408,8 @@ extern "C" int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const 
     return n;
   }();
   int split = (!wide && nwg <= cus && taps * (Cin / 64) >= 8) ? 2 : 1;
-  if (const char* e = getenv("CD360_CONV_SPLIT")) {  // tuning override: 1 or 2
-    if (e[0] == '1') split = 1;
-    if (e[0] == '2' && !wide) split = 2;
-  }
+  if (cd360_tune().conv_split == 1) split = 1;  // tuning override: 1 or 2
+  if (cd360_tune().conv_split == 2 && !wide) split = 2;
   const int stage_bytes = (BM + bnc) * 64 * 2;
   if (wide) {  // 2 x 36 KB stages = 72 KB: above the 64 KB default, still two workgroups per CU
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&conv_igemm_kernel<1, 1, 5, 1>),

@@ -26,6 +26,7 @@
 // (per-row partial sums of the residual stream written by the GEMM that produced it: `stats_out`), + residual, GEGLU
 // (x * gelu(gate), weight rows interleaved per 64 at pack time so value and gate of a column sit in the same lane).
 #include "cd360_common.h"
+#include "cd360_tuning.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -54,8 +55,8 @@ struct GemmParams {
   float a_scale_log2e;
   int a_dup_from, a_dup;  // query batch elements >= a_dup_from attend to TWO key / value sets (batch i and i + a_dup; output rows of
                           // batch i and i + a_dup): the de-duplicated CFG branch, whose q is projected once
-  int abl;  // what-if timing knob (CD360_GEMM_ABL; results are wrong when set): 8 no DMA wait, 16 no barrier, 32 no LDS wait, 4 no DMA,
-            // 64 no stores, 512 no fragment reads / MFMAs / epilogue (the loop as a pure L2 -> LDS streamer)
+  int abl;  // what-if timing knob (cd360_tuning.whatif, -DCD360_WHATIF probe builds only; results are wrong when set): 8 no DMA wait,
+            // 16 no barrier, 32 no LDS wait, 4 no DMA, 64 no stores, 512 no fragment reads / MFMAs / epilogue (a pure L2 -> LDS streamer)
   // EPI 5: A is the implicit im2col matrix of a 3x3 / stride 1 / pad 1 convolution over a channels-last [images, H, W, Cin] tensor
   // (lda = Cin, K = 9 Cin in cd360_conv_k_order order: K-tile kt = (group * 9 + tap) * cv_kg + j reads channel chunk group * cv_kg + j
   // of the pixel shifted by the tap); out [M = images H W, N = Cout]
@@ -232,7 +233,11 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
       for (int i = 0; i < 16; ++i) acc[nb][mb][i] = 0.f;
 
   const int nk = p.K >> 6;
+#ifdef CD360_WHATIF
   const int abl = p.abl;
+#else
+  constexpr int abl = 0;  // product build: the what-if branches below fold away
+#endif
   // a wave whose channels are all beyond N (last channel tile of N = 640 = 2.5 tiles) moves data and synchronises but does not multiply
   const bool has_ch = n0 + wc * (NCB * 32) < p.N && !(abl & 512) && !mover;  // (what-if bit 512: every wave only moves data)
 
@@ -868,14 +873,16 @@ int launch_mv(const GemmParams& p0, hipStream_t stream) {
   static_assert(LDS_BYTES <= 160 * 1024, "LDS of one CU");
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
-  int gm = 6;  // token tiles per group (swept 1 .. 48 on the block's shapes: 6 best or tied, tools/bench_gemm.py group_m)
-  if (const char* e = getenv("CD360_GEMM_GROUP_M")) gm = atoi(e) > 0 ? atoi(e) : gm;
-  p.group_m = gm;
+  const cd360_tuning& tune = cd360_tune();
+  p.group_m = tune.gemm_group_m > 0 ? tune.gemm_group_m : 6;  // token tiles per group (swept 1 .. 48 on the block's shapes: 6 best or tied)
   p.abl = 0;
-  if (const char* e = getenv("CD360_GEMM_ABL")) p.abl = atoi(e);
+#ifdef CD360_WHATIF
+  if (tune.whatif > 0) p.abl = tune.whatif;
+#endif
 #ifdef CD360_GEMM_STAMP
   p.stamp = nullptr;
-  if (const char* e = getenv("CD360_GEMM_STAMP_PTR")) p.stamp = STAMP_BYTES ? reinterpret_cast<uint32_t*>(strtoull(e, nullptr, 16)) : nullptr;
+  if (STAMP_BYTES && !(tune.reserved[0] == -1 && tune.reserved[1] == -1))  // probe build: device pointer of the stamp buffer in reserved[0..1]
+    p.stamp = reinterpret_cast<uint32_t*>(((uint64_t)(uint32_t)tune.reserved[1] << 32) | (uint64_t)(uint32_t)tune.reserved[0]);
 #endif
   const long nwg = (long)p.tiles_m * p.tiles_n;
   if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
@@ -888,7 +895,7 @@ int launch_mv(const GemmParams& p0, hipStream_t stream) {
 }
 
 // Mover waves (MV = 4: one per SIMD) where the multiplying waves leave the registers for a third wave per SIMD (<= 168) and the epilogue
-// is a linear / convolution one.  CD360_GEMM_MOVERS=0 turns them off, =4 on for every arrangement that can take them; unset = the
+// is a linear / convolution one.  cd360_tuning.gemm_movers = 0 turns them off, 4 on for every arrangement that can take them; -1 = the
 // arrangements they were measured to help (tools/bench_gemm.py movers).
 template <int WM, int WN, int NCB, int NMB, int NBUF, int KS, int EPI>
 int launch_ks(const GemmParams& p, hipStream_t stream) {
@@ -897,8 +904,8 @@ int launch_ks(const GemmParams& p, hipStream_t stream) {
     // measured (hipGraph-timed, interleaved): the four- and three-buffer arrangements -5 ... -10 % (C -> C 18.7 -> 17.8 us, FF2 50.1 -> 47.0,
     // 3 x 3 convolutions at 32^2 / 64^2 108 -> 98 / 176 -> 161), 256 x 192 -2.6 %, the two-buffer 128 x 128 with two workgroups per CU +-0
     constexpr bool DEFAULT_ON = NBUF >= 3 || NCB == 3;
-    const char* e = getenv("CD360_GEMM_MOVERS");
-    if (e ? atoi(e) == 4 : DEFAULT_ON) return launch_mv<WM, WN, NCB, NMB, NBUF, KS, 4, EPI>(p, stream);
+    const int mv = cd360_tune().gemm_movers;
+    if (mv >= 0 ? mv == 4 : DEFAULT_ON) return launch_mv<WM, WN, NCB, NMB, NBUF, KS, 4, EPI>(p, stream);
   }
   return launch_mv<WM, WN, NCB, NMB, NBUF, KS, 0, EPI>(p, stream);
 }
@@ -914,11 +921,11 @@ int launch_epi(const GemmParams& p, hipStream_t stream) {
 // the 1280-level shapes, interleaved on one box (tools/bench_gemm.py ksplit, us, mode 0 / mode 1): K = 1280 19.9 / 20.7, K = 2560
 // 30.0 / 29.7, K = 5120 51.9 / 49.3, the 3 x 3 convolutions at 32^2 (K = 11520 .. 23040) 112.7 / 108.4, 166.5 / 156.5, 220.0 / 206.0 --
 // so the split serves K >= 3072.  (Mode 2, four waves of 64 x 64 with one wave per SIMD, is 10 % slower everywhere: kept for A/B only.)
-// CD360_GEMM_KSPLIT = 0 | 1 | 2 forces a mode.
+// cd360_tuning.gemm_ksplit = 0 | 1 | 2 forces a mode.
 template <int EPI>
 int launch_128x4(const GemmParams& p, hipStream_t stream) {
-  const char* e = getenv("CD360_GEMM_KSPLIT");
-  const int mode = e ? atoi(e) : (p.K >= 3072 ? 1 : 0);
+  const int forced = cd360_tune().gemm_ksplit;
+  const int mode = forced >= 0 ? forced : (p.K >= 3072 ? 1 : 0);
   if (mode == 1) return launch_ks<2, 2, 2, 2, 4, 2, EPI>(p, stream);
   if (mode == 2) return launch_ks<2, 2, 2, 2, 4, 1, EPI>(p, stream);
   return launch_ks<2, 4, 1, 2, 4, 1, EPI>(p, stream);
@@ -936,8 +943,7 @@ int launch(const GemmParams& p, hipStream_t stream) {
 constexpr int NCFG = 7;
 constexpr int CFG_BM[NCFG + 1] = {0, 128, 128, 256, 128, 256, 256, 256}, CFG_BN[NCFG + 1] = {0, 128, 128, 256, 128, 128, 192, 256};
 int pick_cfg(int64_t M, int N, bool geglu) {
-  int cfg = 0;
-  if (const char* e = getenv("CD360_GEMM_CFG")) cfg = atoi(e);  // tuning / A-B override
+  const int cfg = cd360_tune().gemm_cfg;  // tuning / A-B override
   if (cfg >= 1 && cfg <= NCFG && !(geglu && (cfg == 2 || cfg == 4 || cfg == 6))) return cfg;
   if (geglu) return 7;  // FF1 + GEGLU: sixteen waves of 64 x 64 on the 256 x 256 tile, -3 % against eight of 128 x 64 (bit-identical results)
   // Measured on the SDXL shapes (tools/bench_gemm.py, profiles/r02_gemm_shapes.txt).  Narrow outputs (the C -> C projections and the
@@ -1078,8 +1084,8 @@ namespace {
 // 3 = 256 x 256, 4 = 128 x 128 / 4 buffers (the 32^2 level: 240 tiles)
 constexpr int CONV_BM[5] = {0, 256, 256, 256, 128}, CONV_BN[5] = {0, 320, 128, 256, 128}, CONV_SLAB[5] = {0, 64, 64, 128, 64};
 int pick_conv_cfg(long M, int Cout) {
-  if (const char* e = getenv("CD360_CONV_CFG")) {
-    const int c = atoi(e);
+  {
+    const int c = cd360_tune().conv_cfg;
     if (c >= 1 && c <= 4 && !(c == 1 && Cout % 320)) return c;
   }
   static const double weight[5] = {0, 1.0, 0.93, 1.0, 0.85};  // relative speed of the tilings on full tiles (tools/bench_kernels.py conv)
@@ -1094,7 +1100,7 @@ int pick_conv_cfg(long M, int Cout) {
   return best;
 }
 bool conv_dma_ok(int N, int H, int W, int Cin, int Cout, int taps, int stride) {
-  if (const char* e = getenv("CD360_CONV_DMA")) if (e[0] == '0') return false;
+  if (cd360_tune().conv_dma == 0) return false;
   if (taps != 9 || stride != 1 || Cin % 64 || Cout % 16 || N <= 0 || H <= 0 || W <= 0) return false;
   const long M = (long)N * H * W;
   return M * Cin * 2 < (1L << 31) && ((long)Cout + 320) * 9 * Cin * 2 < (1L << 32);

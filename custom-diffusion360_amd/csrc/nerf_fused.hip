@@ -17,6 +17,7 @@
 // the gathered Y / zP rows are added with fp32 bilinear weights; SiLU; flash-style online softmax over views.
 // Each (lane, lane^32) pair owns one sample and reads one full 128-B line per texel corner.
 #include "cd360_geom.h"
+#include "cd360_tuning.h"
 #include <stdlib.h>
 
 namespace {
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(256, 2) void nerf_fused_kernel(NerfParams p) {
   }
 }
 
+#ifdef CD360_WHATIF  // probe builds only (tools/probe/README.md): kept as the record of what LDS-DMA row gathers cost and need
 // ---- the same operator with the corner rows gathered by LDS-DMA -----------------------------------------------------------------------
 // nerf_fused_kernel is bound by the vector-memory RETURN path, not by its arithmetic (TD_TD_BUSY = 100 % of the kernel's CU-cycles;
 // builds without the sin / cos or without the SiLU transcendentals run no faster): with lane = sample every gather instruction returns
@@ -502,6 +504,8 @@ __global__ __launch_bounds__(256, 2) void nerf_fused_dma_kernel(NerfParams p) {
   }
 }
 
+#endif  // CD360_WHATIF
+
 // (view, ray)-only inputs of plane_coefs.0: [enc8(plucker(target ray in ref-i frame)) 96 | dir 3]
 // (nerfsd_pytorch3d.py:104-112,130-131; utils_cameraray.py:201-242,270-292).  out [b, n, hw, 104] fp32 (99 + 5 zero pad)
 // BF = false: out [b, n, hw, 104] fp32 (99 + 5 zero pad); BF = true: out [b, n, hw, 128] bf16 (99 + 29 zero pad) -- the A operand of
@@ -594,19 +598,20 @@ extern "C" int cd360_nerf_mlp_aggregate(const void* cams, const void* xs, const 
   p.ngroups = (int)((npts + PTS_PER_WG - 1) / PTS_PER_WG);
   const long nwg = (long)p.ncc * b * p.ngroups;
   if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
-  // CD360_NERF_DMA=1 selects the LDS-DMA row-gather kernel (tables addressable with 32-bit byte offsets).  It is correct (bit-identical,
-  // tests/test_kernels_gpu.py) only with the vmcnt(0) + workgroup barrier between the pieces' arrival and their first ds_read, and
-  // with that rendezvous per view it measures 0 % (1280 channels) / -5 % (640 channels) against the register-gather kernel: not the default.
-  bool dma = false;
-  if (const char* e = getenv("CD360_NERF_DMA")) dma = e[0] == '1' && (long)b * n * r * r * C * 2 < (1L << 32);
-  if (dma) {
+#ifdef CD360_WHATIF
+  // cd360_tuning.nerf_kernel = 2 (probe builds) selects the LDS-DMA row-gather kernel (tables addressable with 32-bit byte offsets).  It is
+  // correct (bit-identical) only with the vmcnt(0) + workgroup barrier between the pieces' arrival and their first ds_read, and with that
+  // rendezvous per view it measures 0 % (1280 channels) / -5 % (640 channels) against the register-gather kernel.
+  if (cd360_tune().nerf_kernel == 2 && (long)b * n * r * r * C * 2 < (1L << 32)) {
     constexpr int LDS_DMA = 4 * RING_BYTES + CN * W_PITCH;
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&nerf_fused_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_DMA);
     if (attr != hipSuccess) return CD360_ERR_LAUNCH;
     hipLaunchKernelGGL(nerf_fused_dma_kernel, dim3((unsigned)nwg), dim3(256), LDS_DMA, (hipStream_t)stream, p);
-  } else {
-    hipLaunchKernelGGL(nerf_fused_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
+    CD360_LAUNCH_CHECK();
+    return CD360_OK;
   }
+#endif
+  hipLaunchKernelGGL(nerf_fused_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
   CD360_LAUNCH_CHECK();
   return CD360_OK;
 }

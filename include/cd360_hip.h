@@ -7,8 +7,9 @@
  *
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (torch allocates; nothing is allocated here);
- *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, no hidden synchronisation,
- *     no global mutable state: re-entrant across streams;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, no hidden synchronisation; re-entrant across
+ *     streams.  No entry point reads the environment.  The only process-wide state is the tuning struct below
+ *     (cd360_set_tuning): an explicit A/B interface whose defaults (-1 everywhere) are the measured-best choices;
  *   - workspace sizes come from the *_workspace_bytes() queries, the caller provides the buffer;
  *   - return 0 on success, <0 on error (CD360_ERR_*): the Python side raises;
  *   - bf16 tensors are raw uint16 storage; "fp32"/"int32" as named;
@@ -27,6 +28,36 @@ extern "C" {
 #define CD360_ERR_ARG (-1)    /* null / misaligned pointer, non-positive size */
 #define CD360_ERR_SHAPE (-2)  /* unsupported shape or stride */
 #define CD360_ERR_LAUNCH (-3) /* HIP launch failure */
+
+/* ---- tuning / A-B interface --------------------------------------------------------------------------------
+ * Kernel and tiling choices are made per call from the shapes.  A harness that wants to compare two tilings in one process
+ * overrides them here (field = -1: choose by shape).  `size` must be sizeof(cd360_tuning).  cd360_set_tuning(NULL) restores the
+ * defaults.  Set it between launches, not concurrently with them.  `whatif` (timing experiments that produce wrong results) is
+ * ignored unless the library was built with -DCD360_WHATIF (cd360_whatif_build() == 1); the product build has no such code. */
+typedef struct cd360_tuning {
+  int32_t size;
+  int32_t gemm_cfg;         /* 1..8: tiling of cd360_gemm_bf16 */
+  int32_t gemm_group_m;     /* > 0: token tiles per tile group */
+  int32_t gemm_movers;      /* 0 | 4: mover waves off / on */
+  int32_t gemm_ksplit;      /* 0 | 1 | 2: wave arrangement of the 128 x 128 four-buffer tiling */
+  int32_t conv_cfg;         /* 1..4: tiling of cd360_conv3x3_dma_bf16 */
+  int32_t conv_dma;         /* 0: convolutions on the register-staged kernel */
+  int32_t conv_kgroup;      /* > 0: K-order group size (before weights are packed) */
+  int32_t conv_wide;        /* 0: no 160-channel tiles in the register-staged kernel */
+  int32_t conv_wmajor;      /* 0 | 1: tile order of the register-staged kernel */
+  int32_t conv_split;       /* 1 | 2: in-workgroup split-K of the register-staged kernel */
+  int32_t attn_smallk;      /* 0: <= 96-key attention on the tiled kernel */
+  int32_t attn_smallk_wgs;  /* > 0: workgroup target of the register-resident kernel */
+  int32_t attn_self;        /* 0 | 1 | 2: self-attention kernel generation / tiling */
+  int32_t attn_fast;        /* 0: guarded path of the first-generation kernel */
+  int32_t nerf_kernel;      /* 0 | 1: FeatureNeRF render kernel with register gathers / full-line gathers */
+  int32_t qattn_cfg;        /* 1 | 2: tile of cd360_qproj_attn_bf16 (256 x 256 / 128 x 128) */
+  int32_t whatif;           /* -DCD360_WHATIF builds only */
+  int32_t reserved[6];
+} cd360_tuning;
+int cd360_set_tuning(const cd360_tuning* t);
+int cd360_get_tuning(cd360_tuning* t);
+int cd360_whatif_build(void);
 
 /* ---- attention ---------------------------------------------------------------------------------------------
  * replaces xformers.ops.memory_efficient_attention(q, k, v, attn_bias=None, op=None)

@@ -21,3 +21,13 @@ def pytest_configure(config):
 @pytest.fixture(scope="session")
 def golden_dir():
     return os.path.join(ROOT, "tests", "golden")
+
+
+@pytest.fixture
+def tune():
+    """tune(gemm_cfg=4, ...) overrides tiling / kernel choices of the C ABI (cd360_set_tuning) for one test; every field is restored
+    afterwards.  The C side reads no environment variables."""
+    from cd360 import _lib
+    saved = _lib.get_tuning()
+    yield _lib.set_tuning
+    _lib.set_tuning(**saved)

@@ -14,37 +14,31 @@ sys.path.insert(0, os.path.join(ROOT, "custom-diffusion360_amd"))
 pytestmark = pytest.mark.gpu
 
 
-def test_gemm_family_and_fused_qproj_attention_against_fp32_torch(monkeypatch):
+def test_gemm_family_and_fused_qproj_attention_against_fp32_torch(tune):
     import bench_gemm
-    monkeypatch.delenv("CD360_GEMM_CFG", raising=False)
     assert bench_gemm.check()
-    os.environ.pop("CD360_GEMM_CFG", None)
 
 
-def test_gemm_k_step_groups_of_the_128x128_tiling(monkeypatch):
+def test_gemm_k_step_groups_of_the_128x128_tiling(tune):
     """The in-workgroup split of K (two groups of waves on alternate k-step pairs, partial sums exchanged through the LDS): parity of
     every epilogue it serves against fp32 torch, the convolution form against the unsplit kernel, repeat-equal launches."""
     import bench_gemm
     assert bench_gemm.ksplit(time=False)
-    for k in ("CD360_GEMM_CFG", "CD360_CONV_CFG", "CD360_GEMM_KSPLIT"):
-        os.environ.pop(k, None)
 
 
-def test_gemm_mover_waves_change_no_bit(monkeypatch):
-    """CD360_GEMM_MOVERS=4 (four extra waves issue every LDS-DMA piece, the others only multiply) against 0 on the four-buffer 128 x 128
+def test_gemm_mover_waves_change_no_bit(tune):
+    """cd360_tuning.gemm_movers = 4 (four extra waves issue every LDS-DMA piece, the others only multiply) against 0 on the four-buffer 128 x 128
     tiling, unsplit and with the k-step groups, Linear and convolution epilogues, ragged shapes: outputs and statistics bit-identical;
     and the default dispatch (movers on where they help) passes the family's parity list in the test above."""
     import bench_gemm
     assert bench_gemm.movers(time=False)
-    for k in ("CD360_GEMM_CFG", "CD360_CONV_CFG", "CD360_GEMM_KSPLIT", "CD360_GEMM_MOVERS"):
-        os.environ.pop(k, None)
 
 
-@pytest.mark.parametrize("ksplit", ["0", "1"])
-def test_gemm_cstats_in_both_wave_arrangements(monkeypatch, ksplit):
+@pytest.mark.parametrize("ksplit", [0, 1])
+def test_gemm_cstats_in_both_wave_arrangements(tune, ksplit):
     from bench_gemm import rnd
     from cd360 import ops
-    monkeypatch.setenv("CD360_GEMM_KSPLIT", ksplit)
+    tune(gemm_ksplit=ksplit)
     M, N, K = 3072, 1280, 1280
     a, w = rnd(M, K, seed=31).to(torch.bfloat16), rnd(N, K, seed=32, scale=K ** -0.5).to(torch.bfloat16)
     b, r = rnd(N, seed=33), rnd(M, N, seed=34).to(torch.bfloat16)

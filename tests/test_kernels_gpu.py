@@ -67,27 +67,30 @@ def test_attention_xformers_layout_and_online_softmax_rescale():
     assert rel(out, O.attention_core(q, k, v)) < 1e-2
 
 
+@pytest.mark.parametrize("neg", [3.0, 16.0])
 @pytest.mark.parametrize("gen", ["0", "1", "2"])
 @pytest.mark.parametrize("B,H,N", [(1, 2, 256), (2, 3, 1024), (1, 1, 4096)])
-def test_self_attention_generations_agree_with_oracle(gen, B, H, N, monkeypatch):
+def test_self_attention_generations_agree_with_oracle(gen, B, H, N, neg, tune):
     """The whole-tile self-attention kernel (attn_self_kernel: lazy running maximum, pre-scaled q, LDS-DMA ring; CD360_ATTN_SELF =
     1: 4 waves x 32 queries, 2: 8 waves x 64 queries) and the first-generation tiled kernel (0) against the fp32 oracle, on the merged
     q|k|v layout.
     Query 10 meets a dominating key late in the sequence (m_ref must move mid-stream), query 20 starts on a tile of strongly
-    negative scores (m_ref must move UP by far more than the 2^8 slack right after the first tile); lse as the training forward
-    returns it."""
+    negative scores (m_ref must move UP by far more than the 2^8 slack right after the first tile; with neg = 16 every score of its
+    first tile is below -128 in exp2 units, where an unclamped first rescale factor exp2(-max) overflows to inf and 0 * inf poisons the
+    row); lse as the training forward returns it."""
     from cd360 import ops
     if gen == "2" and N % 512:
         pytest.skip("the 8-wave x 64-query variant needs 512 queries per workgroup")
-    monkeypatch.setenv("CD360_ATTN_SELF", gen)
+    tune(attn_self=int(gen))
     g = torch.Generator().manual_seed(N + H)
     qkv = bf(torch.randn(B, N, 3 * H * 64, generator=g))
     q, k, v = qkv[..., :H * 64], qkv[..., H * 64:2 * H * 64], qkv[..., 2 * H * 64:]
     k[:, N - 70] = 8.0 * q[:, 10]
-    k[:, :64] = -3.0 * q[:, 20:21]
+    k[:, :64] = -neg * q[:, 20:21]
     qkv = bf(qkv)
     d = qkv.to(DEV, torch.bfloat16)
     out, lse = ops.attention(d[..., :H * 64], d[..., H * 64:2 * H * 64], d[..., 2 * H * 64:], H, want_lse=True)
+    assert torch.isfinite(out.float()).all() and torch.isfinite(lse).all()
 
     def split(t):
         return t.reshape(B, N, H, 64).permute(0, 2, 1, 3).reshape(B * H, N, 64)
@@ -198,13 +201,18 @@ def test_fused_feature_nerf(C, r, n, S, b):
     assert rel(dec[..., 3:], sigma) < 1e-2 and rel(dec[..., :3], rgb) < 1e-2
 
 
+@pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("C,r,n,S,b", [(64, 8, 2, 4, 2), (640, 16, 5, 24, 1), (1280, 8, 7, 6, 2), (128, 7, 3, 3, 1)])
-def test_render_kernel_lds_dma_row_gathers_equal_register_gathers(C, r, n, S, b, monkeypatch):
-    """nerf_fused_dma_kernel (opt-in, CD360_NERF_DMA=1: corner rows by LDS-DMA into a per-wave slot ring, one vmcnt(0) + workgroup barrier
-    per view, views software-pipelined) against nerf_fused_kernel (per-lane register gathers, the default): the same additions in the
-    same order -- bit-identical g, logits and lse on eight repeated launches (without the barrier between arrival and the first ds_read
-    a few rows per thousand launches came back stale: this test is the detector); (128, 7, ...) has a ragged last sample tile, waves
-    without tiles exit while the others keep meeting at the barrier."""
+def test_render_kernel_full_line_gathers_equal_register_gathers(C, r, n, S, b, variant, tune):
+    """The render kernel's full-line gather variants (cd360_tuning.nerf_kernel) against nerf_fused_kernel (per-lane register gathers):
+    the same additions in the same order -- bit-identical g, logits and lse on eight repeated launches.  Variant 1: corner rows as
+    full 128-byte lines through the wave's own LDS block (ordinary loads + ds_write / ds_read, ordered by the wave's own counters).
+    Variant 2 (probe builds with -DCD360_WHATIF only): rows by LDS-DMA with one vmcnt(0) + workgroup barrier per view -- without
+    that barrier a few rows per thousand launches came back stale, and this test is the detector.  (128, 7, ...) has a ragged last
+    sample tile."""
+    from cd360 import _lib
+    if variant == 2 and not _lib.load().cd360_whatif_build():
+        pytest.skip("the LDS-DMA render kernel exists in -DCD360_WHATIF probe builds only")
     from cd360 import nerf, ops
     w = nerf_weights(C, seed=C + n)
     cams = cams_for(b, n, seed=C).to(DEV)
@@ -218,7 +226,7 @@ def test_render_kernel_lds_dma_row_gathers_equal_register_gathers(C, r, n, S, b,
     zP = bf(torch.randn(b * n, r * r, C, generator=g)).to(DEV, torch.bfloat16)
     cview = nerf.view_constants(fw, cams)
     ref = ops.nerf_mlp_aggregate(cams, xs, xs, t, Y, zP, lv, cview, fw.Wk, want_logits=True)
-    monkeypatch.setenv("CD360_NERF_DMA", "1")
+    tune(nerf_kernel=variant)
     outs = [ops.nerf_mlp_aggregate(cams, xs, xs, t, Y, zP, lv, cview, fw.Wk, want_logits=True) for _ in range(8)]
     for o in outs:
         assert all(torch.equal(a, b_) for a, b_ in zip(o, ref))
@@ -293,15 +301,14 @@ def test_add_layernorm(rows, C):
 @pytest.mark.parametrize("N,H,W,Cin,Cout,taps,extras", [(2, 9, 7, 64, 48, 9, False), (1, 16, 16, 128, 320, 9, True), (3, 32, 32, 320, 640, 9, True),
                                                        (2, 5, 5, 192, 64, 1, True), (1, 1, 1, 64, 16, 9, False), (2, 9, 7, 128, 320, 9, True), (1, 12, 12, 64, 160, 9, False)])
 @pytest.mark.parametrize("split", ["auto", "1", "2"])
-def test_conv_igemm(N, H, W, Cin, Cout, taps, extras, split, monkeypatch):
+def test_conv_igemm(N, H, W, Cin, Cout, taps, extras, split, tune):
     """implicit-GEMM conv3x3 / GEMM with fused bias + per-image addend + residual vs torch's fp32 conv2d on the same bf16 inputs.
     `split`: the in-workgroup split-K variant (512 threads, odd K-steps on the second 4 waves) forced on / off / chosen by the
     launch heuristic; (3,32,32,320,640) has an ODD number of K-steps (45), (1,16,16,128,320) the minimum of 2 chunks per tap.
     Cout = 320 / 160 take the 160-channel tiling (4 waves of 160 x 32), with ragged pixel tiles in (2,9,7,...)."""
     from cd360 import ops
     if split != "auto":  # the register-staged kernel and its split-K variant (3 x 3 / stride 1 otherwise runs on the LDS-DMA core)
-        monkeypatch.setenv("CD360_CONV_SPLIT", split)
-        monkeypatch.setenv("CD360_CONV_DMA", "0")
+        tune(conv_split=int(split), conv_dma=0)
     g = torch.Generator().manual_seed(N * 100 + H + Cin + Cout)
     k = 3 if taps == 9 else 1
     x = bf(torch.randn(N, Cin, H, W, generator=g))
@@ -348,7 +355,7 @@ def test_conv_epilogue_groupnorm_statistics(N, H, W, Cin, Cout):
 
 @pytest.mark.parametrize("cfg", ["1", "2", "3", "4"])
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(2, 9, 7, 128, 320), (3, 32, 32, 320, 640), (1, 16, 16, 64, 48), (2, 16, 24, 192, 1280), (3, 16, 8, 64, 320)])
-def test_conv3x3_on_the_dma_gemm_core_all_tilings(cfg, N, H, W, Cin, Cout, monkeypatch):
+def test_conv3x3_on_the_dma_gemm_core_all_tilings(cfg, N, H, W, Cin, Cout, tune):
     """cd360_conv3x3_dma_bf16 (gemm8p.hip EPI 5: implicit im2col through LDS-DMA, padding through the buffer range check) in each of its
     four tilings (CD360_CONV_CFG: 256 x 320, 256 x 128, 256 x 256, 128 x 128) against torch's fp32 conv2d and against the register-
     staged kernel: bias + per-image addend + residual, ragged pixel / channel tiles, tiles straddling images, the per-slab channel
@@ -357,7 +364,7 @@ def test_conv3x3_on_the_dma_gemm_core_all_tilings(cfg, N, H, W, Cin, Cout, monke
     from cd360 import ops
     if cfg == "1" and Cout % 320:
         pytest.skip("the 320-channel tiling needs Cout % 320 == 0")
-    monkeypatch.setenv("CD360_CONV_CFG", cfg)
+    tune(conv_cfg=int(cfg))
     g = torch.Generator().manual_seed(N * 100 + H + Cin + Cout)
     x = bf(torch.randn(N, Cin, H, W, generator=g))
     w = bf(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
@@ -378,7 +385,7 @@ def test_conv3x3_on_the_dma_gemm_core_all_tilings(cfg, N, H, W, Cin, Cout, monke
         ref = out.float().reshape(N, slabs, H * W // slabs, Cout)
         assert rel(stats[..., 0], ref.sum(2)) < 1e-5 and rel(stats[..., 1], (ref * ref).sum(2)) < 1e-5
         assert torch.isfinite(stats).all()
-    monkeypatch.setenv("CD360_CONV_DMA", "0")
+    tune(conv_dma=0)
     assert rel(got, ops.conv_igemm(*args)) < 4e-3  # same sums in another order, both rounded to bf16
 
 

@@ -10,6 +10,7 @@ import torch
 import torch.nn.functional as F
 
 from cd360 import ops
+from cd360._lib import ENV  # CD360_* tiling switches -> cd360_set_tuning (the C side reads no environment)
 
 dev = torch.device("cuda:0")
 
@@ -25,9 +26,9 @@ def relerr(got, want):
 
 def check_case(M, N, K, bias=False, res=False, ln=False, geglu=False, stats=False, cfg=None, lda=None):
     if cfg:
-        os.environ["CD360_GEMM_CFG"] = str(cfg)
+        ENV["CD360_GEMM_CFG"] = str(cfg)
     else:
-        os.environ.pop("CD360_GEMM_CFG", None)
+        ENV.pop("CD360_GEMM_CFG", None)
     a_full = rnd(M, lda or K, seed=1).to(torch.bfloat16)
     a = a_full[:, :K]
     if ln:  # rows with a mean and a scale, like a residual stream
@@ -222,7 +223,7 @@ def time_all():
             if epi == "geglu" and cfg in (2, 4, 6):
                 continue
             if cfg:
-                os.environ["CD360_GEMM_CFG"] = str(cfg)
+                ENV["CD360_GEMM_CFG"] = str(cfg)
             t_plain = timeit_graph(lambda: ops.gemm(a, w, bias=b32), n=20)
             line += f" | cd360 {'auto' if not cfg else 'cfg%d' % cfg} plain {t_plain:7.1f} us {flops / t_plain * 1e-6:6.0f} TF"
             if epi == "ln":
@@ -242,8 +243,8 @@ def time_all():
             t2 = timeit_graph(lambda: ops.geglu(F.linear(a, w, b16)), n=20)
             line += f" | lib+geglu {t2:7.1f}"
         print(line, flush=True)
-    os.environ.pop("CD360_GEMM_CFG", None)
-    os.environ.pop("CD360_GEMM_SCHED", None)
+    ENV.pop("CD360_GEMM_CFG", None)
+    ENV.pop("CD360_GEMM_SCHED", None)
 
 
 def ablate():
@@ -253,15 +254,15 @@ def ablate():
         w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
         print(f"M={M} N={N} K={K}")
         for cfg in (3, 6, 1):
-            os.environ["CD360_GEMM_CFG"] = str(cfg)
+            ENV["CD360_GEMM_CFG"] = str(cfg)
             line = f"cfg{cfg}:"
             for abl, name in ((0, "full"), (64, "no stores"), (16, "no barrier"), (56, "no waits at all"), (4, "no DMA"), (60, "no DMA no waits"), (124, "no DMA/waits/stores")):
-                os.environ["CD360_GEMM_ABL"] = str(abl)
+                ENV["CD360_GEMM_ABL"] = str(abl)
                 t = timeit(lambda: ops.gemm(a, w), iters=20, warm=3)
                 line += f" | {name} {t:6.1f}"
             print(line, flush=True)
     for k in ("CD360_GEMM_ABL", "CD360_GEMM_CFG"):
-        os.environ.pop(k, None)
+        ENV.pop(k, None)
 
 
 def group_m_sweep():
@@ -274,11 +275,11 @@ def group_m_sweep():
         st, ws = ops.row_stats(a), w.float().sum(1).contiguous()
         line = f"{name} M={M} N={N} K={K}:"
         for gm in (1, 2, 3, 4, 6, 12, 48):
-            os.environ["CD360_GEMM_GROUP_M"] = str(gm)
+            ENV["CD360_GEMM_GROUP_M"] = str(gm)
             t = timeit(lambda: ops.gemm(a, w, bias=b32, ln=(st, ws, 1e-5), geglu=geglu))
             line += f" | gm{gm} {t:6.1f}"
         print(line, flush=True)
-    os.environ.pop("CD360_GEMM_GROUP_M", None)
+    ENV.pop("CD360_GEMM_GROUP_M", None)
 
 
 def ablate_small():
@@ -289,19 +290,19 @@ def ablate_small():
         z = torch.zeros_like(a), torch.zeros_like(w)
         print(f"M={M} N={N} K={K}")
         for cfg in (4, 2, 1, 5):
-            os.environ["CD360_GEMM_CFG"] = str(cfg)
+            ENV["CD360_GEMM_CFG"] = str(cfg)
             line = f"cfg{cfg}:"
             for abl, name in ((0, "full"), (64, "no stores"), (16, "no barrier"), (8, "no DMA wait"), (32, "no LDS wait"), (56, "no waits"), (4, "no DMA"),
                               (60, "no DMA no waits"), (124, "no DMA/waits/stores")):
-                os.environ["CD360_GEMM_ABL"] = str(abl)
+                ENV["CD360_GEMM_ABL"] = str(abl)
                 t = timeit(lambda: ops.gemm(a, w), iters=20, warm=3)
                 line += f" | {name} {t:6.1f}"
-            os.environ["CD360_GEMM_ABL"] = "0"
+            ENV["CD360_GEMM_ABL"] = "0"
             t = timeit(lambda: ops.gemm(z[0], z[1]), iters=20, warm=3)
             line += f" | zeros {t:6.1f}"
             print(line, flush=True)
     for k in ("CD360_GEMM_ABL", "CD360_GEMM_CFG"):
-        os.environ.pop(k, None)
+        ENV.pop(k, None)
 
 
 def ksplit(time=True):
@@ -310,7 +311,7 @@ def ksplit(time=True):
     and the 32^2 convolutions."""
     ok = True
     for mode in (1, 2):
-        os.environ["CD360_GEMM_KSPLIT"] = str(mode)
+        ENV["CD360_GEMM_KSPLIT"] = str(mode)
         for (M, N, K) in [(256, 256, 64), (256, 256, 128), (512, 512, 192), (300, 272, 320), (128, 128, 64), (1000, 640, 640), (3072, 1280, 1280)]:
             ok &= check_case(M, N, K, cfg=4)
         ok &= check_case(520, 640, 320, bias=True, res=True, stats=True, cfg=4)
@@ -324,23 +325,23 @@ def ksplit(time=True):
         w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
         b32 = rnd(N, seed=3)
         r = rnd(M, N, seed=4).to(torch.bfloat16)
-        os.environ["CD360_GEMM_CFG"] = "4"
+        ENV["CD360_GEMM_CFG"] = "4"
         best = {0: 1e9, 1: 1e9, 2: 1e9}
         for _ in range(3):
             for mode in (0, 1, 2):
-                os.environ["CD360_GEMM_KSPLIT"] = str(mode)
+                ENV["CD360_GEMM_KSPLIT"] = str(mode)
                 best[mode] = min(best[mode], timeit(lambda: ops.gemm(a, w, bias=b32, res=r, want_stats=True)))
         print(f"{name:8s} M={M:6d} N={N:5d} K={K:4d} | " + " | ".join(f"mode{m} {t:6.1f}" for m, t in best.items()), flush=True)
-    os.environ.pop("CD360_GEMM_CFG", None)
+    ENV.pop("CD360_GEMM_CFG", None)
     for (N_, H, W, cin, cout) in ((3, 32, 32, 1280, 1280), (3, 32, 32, 2560, 1280), (3, 32, 32, 1920, 1280)):
         x = torch.randn(N_, H * W, cin, device=dev).to(torch.bfloat16)
         wp = (torch.randn(cout, 9 * cin, device=dev) / (9 * cin) ** 0.5).to(torch.bfloat16)
         bias = torch.randn(cout, device=dev)
-        os.environ["CD360_CONV_CFG"] = "4"
+        ENV["CD360_CONV_CFG"] = "4"
         outs, best = {}, {0: 1e9, 1: 1e9, 2: 1e9}
         for _ in range(3 if time else 1):
             for mode in (0, 1, 2):
-                os.environ["CD360_GEMM_KSPLIT"] = str(mode)
+                ENV["CD360_GEMM_KSPLIT"] = str(mode)
                 outs[mode] = ops.conv_igemm(x, wp, bias, N_, H, W, 9, want_stats=True)
                 if time:
                     best[mode] = min(best[mode], timeit(lambda: ops.conv_igemm(x, wp, bias, N_, H, W, 9)))
@@ -354,7 +355,7 @@ def ksplit(time=True):
             line += f" | mode{mode} err {e:.1e} stats {es:.1e}"
         print(line, flush=True)
     for k in ("CD360_CONV_CFG", "CD360_GEMM_KSPLIT"):
-        os.environ.pop(k, None)
+        ENV.pop(k, None)
     return ok
 
 
@@ -383,9 +384,9 @@ def fixed_cost():
         w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
         line = f"K={K:5d}: full epilogue {timeit_graph(lambda: ops.gemm(a, w, bias=b32, res=r, want_stats=True)):6.1f}"
         line += f" | plain {timeit_graph(lambda: ops.gemm(a, w)):6.1f}"
-        os.environ["CD360_GEMM_ABL"] = "64"
+        ENV["CD360_GEMM_ABL"] = "64"
         line += f" | plain, no stores {timeit_graph(lambda: ops.gemm(a, w)):6.1f}"
-        os.environ.pop("CD360_GEMM_ABL")
+        ENV.pop("CD360_GEMM_ABL")
         print(line, flush=True)
     x = torch.zeros(64, device=dev)
     print(f"torch elementwise on 64 floats (launch floor in a graph): {timeit_graph(lambda: x.add_(1.0)):6.1f}", flush=True)
@@ -400,27 +401,27 @@ def movers(time=True):
         a = rnd(M, K, seed=1).to(torch.bfloat16)
         w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
         b32, r = rnd(N, seed=3), rnd(M, N, seed=4).to(torch.bfloat16)
-        os.environ["CD360_GEMM_CFG"] = "4"
+        ENV["CD360_GEMM_CFG"] = "4"
         best, outs = {v[0]: 1e9 for v in variants}, {}
         for _ in range(3):
             for tag, ks, mv in variants:
-                os.environ["CD360_GEMM_KSPLIT"], os.environ["CD360_GEMM_MOVERS"] = ks, mv
+                ENV["CD360_GEMM_KSPLIT"], ENV["CD360_GEMM_MOVERS"] = ks, mv
                 outs[tag] = ops.gemm(a, w, bias=b32, res=r, want_stats=True)
                 if time:
                     best[tag] = min(best[tag], timeit_graph(lambda: ops.gemm(a, w, bias=b32, res=r, want_stats=True)))
         same = all(torch.equal(outs[x][i], outs[x + "+mv"][i]) for x in ("ks0", "ks1") for i in (0, 1))
         ok &= same
         print(f"{name:8s} M={M:6d} N={N:5d} K={K:4d} | " + " | ".join(f"{k} {v:6.1f}" for k, v in best.items()) + f" | movers == plain: {same}", flush=True)
-    os.environ.pop("CD360_GEMM_CFG", None)
+    ENV.pop("CD360_GEMM_CFG", None)
     for (N_, H, W, cin, cout) in ((3, 32, 32, 1280, 1280), (3, 32, 32, 2560, 1280), (2, 16, 16, 128, 192)):
         x = torch.randn(N_, H * W, cin, device=dev).to(torch.bfloat16)
         wp = (torch.randn(cout, 9 * cin, device=dev) / (9 * cin) ** 0.5).to(torch.bfloat16)
         bias, emb = torch.randn(cout, device=dev), torch.randn(N_, cout, device=dev).to(torch.bfloat16)
-        os.environ["CD360_CONV_CFG"] = "4"
+        ENV["CD360_CONV_CFG"] = "4"
         best, outs = {v[0]: 1e9 for v in variants}, {}
         for _ in range(3):
             for tag, ks, mv in variants:
-                os.environ["CD360_GEMM_KSPLIT"], os.environ["CD360_GEMM_MOVERS"] = ks, mv
+                ENV["CD360_GEMM_KSPLIT"], ENV["CD360_GEMM_MOVERS"] = ks, mv
                 outs[tag] = ops.conv_igemm(x, wp, bias, N_, H, W, 9, emb=emb, want_stats=True)
                 if time:
                     best[tag] = min(best[tag], timeit_graph(lambda: ops.conv_igemm(x, wp, bias, N_, H, W, 9, emb=emb, want_stats=True)))
@@ -428,7 +429,7 @@ def movers(time=True):
         ok &= same
         print(f"conv {N_}x{H}x{W} {cin}->{cout}: " + " | ".join(f"{k} {v:6.1f}" for k, v in best.items()) + f" | movers == plain: {same}", flush=True)
     for k in ("CD360_CONV_CFG", "CD360_GEMM_KSPLIT", "CD360_GEMM_MOVERS"):
-        os.environ.pop(k, None)
+        ENV.pop(k, None)
     print("MOVERS", "PASSED" if ok else "FAILED", flush=True)
     return ok
 
@@ -446,7 +447,7 @@ def movers_all():
         best, outs = {"0": 1e9, "4": 1e9}, {}
         for _ in range(3):
             for mv in ("0", "4"):
-                os.environ["CD360_GEMM_MOVERS"] = mv
+                ENV["CD360_GEMM_MOVERS"] = mv
                 outs[mv] = fn()
                 best[mv] = min(best[mv], timeit_graph(fn))
         o0, o4 = (outs[k] if isinstance(outs[k], tuple) else (outs[k],) for k in ("0", "4"))
@@ -461,13 +462,13 @@ def movers_all():
         best, outs = {"0": 1e9, "4": 1e9}, {}
         for _ in range(3):
             for mv in ("0", "4"):
-                os.environ["CD360_GEMM_MOVERS"] = mv
+                ENV["CD360_GEMM_MOVERS"] = mv
                 outs[mv] = fn()
                 best[mv] = min(best[mv], timeit_graph(fn))
         same = torch.equal(outs["0"][0], outs["4"][0]) and torch.equal(outs["0"][1], outs["4"][1])
         ok &= same
         print(f"conv {N_}x{H}x{W} {cin}->{cout}: movers 0: {best['0']:6.1f} | 4: {best['4']:6.1f} | equal: {same}", flush=True)
-    os.environ.pop("CD360_GEMM_MOVERS", None)
+    ENV.pop("CD360_GEMM_MOVERS", None)
     print("MOVERS_ALL", "PASSED" if ok else "FAILED", flush=True)
     return ok
 
@@ -484,14 +485,14 @@ def ff1_tilings():
         best, outs = {v[0]: 1e9 for v in variants}, {}
         for _ in range(3):
             for tag, cfg, mv in variants:
-                os.environ["CD360_GEMM_CFG"], os.environ["CD360_GEMM_MOVERS"] = cfg, mv
+                ENV["CD360_GEMM_CFG"], ENV["CD360_GEMM_MOVERS"] = cfg, mv
                 outs[tag] = fn()
                 best[tag] = min(best[tag], timeit_graph(fn, n=20))
         same = torch.equal(outs["256x128"], outs["256x128+movers"])
         e16 = relerr(outs["256x256/16w"], outs["256x256"].float())
         print(f"{name:8s} M={M:6d} N={N:5d} K={K:4d} | " + " | ".join(f"{k} {v:6.1f}" for k, v in best.items()) + f" | movers == plain: {same} | 16w vs 8w err {e16:.1e}", flush=True)
     for k in ("CD360_GEMM_CFG", "CD360_GEMM_MOVERS"):
-        os.environ.pop(k, None)
+        ENV.pop(k, None)
 
 
 def whatif():
@@ -501,15 +502,15 @@ def whatif():
         a = rnd(M, K, seed=1).to(torch.bfloat16)
         w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
         for ks in ("0", "1"):
-            os.environ["CD360_GEMM_KSPLIT"] = ks
+            ENV["CD360_GEMM_KSPLIT"] = ks
             line = f"K={K} ksplit={ks}:"
             for abl, name in ((0, "full"), (64, "no stores"), (512, "DMA + rendezvous only"), (512 + 16, "DMA only, no barrier"), (512 + 16 + 8, "DMA issue only, no waits"),
                               (4 + 64, "no DMA, no stores"), (4 + 8 + 16 + 32 + 64, "reads + MFMAs only")):
-                os.environ["CD360_GEMM_ABL"] = str(abl)
+                ENV["CD360_GEMM_ABL"] = str(abl)
                 line += f" | {name} {timeit_graph(lambda: ops.gemm(a, w)):6.1f}"
             print(line, flush=True)
     for k in ("CD360_GEMM_ABL", "CD360_GEMM_KSPLIT"):
-        os.environ.pop(k, None)
+        ENV.pop(k, None)
 
 
 def stride_sweep():

@@ -25,10 +25,18 @@ buf = torch.zeros(NWG * NW * NT * 8, dtype=torch.int32, device=dev)
 for _ in range(5):
     ops.gemm(a, w, bias=bias, res=res, want_stats=True)
 torch.cuda.synchronize()
-os.environ["CD360_GEMM_STAMP_PTR"] = hex(buf.data_ptr())
+# the stamp buffer's device pointer travels in cd360_tuning.reserved[0..1] (probe build only)
+import ctypes
+
+t = _lib.Tuning()
+_lib.load().cd360_get_tuning(ctypes.byref(t))
+ptr = buf.data_ptr()
+t.reserved[0], t.reserved[1] = ctypes.c_int32(ptr & 0xFFFFFFFF).value, ctypes.c_int32(ptr >> 32).value
+_lib.load().cd360_set_tuning(ctypes.byref(t))
 ops.gemm(a, w, bias=bias, res=res, want_stats=True)
 torch.cuda.synchronize()
-os.environ.pop("CD360_GEMM_STAMP_PTR")
+t.reserved[0] = t.reserved[1] = -1
+_lib.load().cd360_set_tuning(ctypes.byref(t))
 nk = K // 64
 st = buf.cpu().numpy().astype("int64").reshape(NWG, NW, NT, 8) & 0xFFFFFFFF
 used = [i for i in range(NWG) if st[i].any()]
