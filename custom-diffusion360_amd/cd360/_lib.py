@@ -61,6 +61,10 @@ SIGNATURES = {
     "cd360_row_stats_bf16": (c_int, [_P, _P, c_int64, c_int, c_int64, _P]),
     "cd360_gn_workspace_bytes": (c_int64, [c_int, c_int, c_int]),
     "cd360_gn_silu_bf16": (c_int, [_P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_float, c_int, _P, c_int, _P]),
+    "cd360_rowdot4_bwd_slabs": (c_int, [c_int64]),
+    "cd360_rowdot4_bwd_bf16": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P]),
+    "cd360_gemm_tn_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
+    "cd360_gemm_tn_bf16": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int64, c_int64, c_int, _P, _P]),
     "cd360_set_tuning": (c_int, [_P]),
     "cd360_get_tuning": (c_int, [_P]),
     "cd360_whatif_build": (c_int, []),

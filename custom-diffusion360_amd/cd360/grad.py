@@ -1,8 +1,8 @@
 """Autograd recording of the differentiable cd360 operators (BASELINE config 4: the fine-tuning loop differentiates the pose
 path; the reference relies on torch autograd through xformers, grid_sample, nn.Linear ... -- diffusion.py:226-241, main.py).
 
-Every class is a torch.autograd.Function whose forward AND backward are HIP kernels behind the C ABI (ops.py); plain library
-GEMMs (nn.Linear, torch.mm) stay with torch's own autograd.  ops.* dispatch here when an input requires grad and grad mode is
+Every class is a torch.autograd.Function whose forward AND backward are HIP kernels behind the C ABI (ops.py), the Linear layers
+included (LinearFn: cd360_gemm_bf16 forward and data gradient, cd360_gemm_tn_bf16 weight gradient).  ops.* dispatch here when an input requires grad and grad mode is
 on; under torch.no_grad() (sampling) nothing in this file runs.  Parameters that the shipped configs never train through these
 operators (norm affines, conv weights: trainkeys in {pose, poseattn}, diffusion.py:117-150) get no wgrad kernel: asking for one
 raises instead of silently returning None."""
@@ -17,6 +17,47 @@ def _no_wgrad(name: str, *params):
     for p in params:
         if p is not None and p.requires_grad:
             raise NotImplementedError(f"{name}: no weight-gradient kernel (the reference's trainkeys pose / poseattn never train these)")
+
+
+class LinearFn(torch.autograd.Function):
+    """ops.linear: y = x W^T + b (+ res) (nn.Linear / F.linear at attention.py:89-115,323-329,368-372,422,515-516,748,786; openaimodel.py
+    time / label / ResBlock embeddings) on cd360_gemm_bf16.  Backward: dX = dY W is the SAME kernel on the transposed weight (cached for
+    frozen weights); dW = dY^T X is cd360_gemm_tn_bf16 (fp32 accumulation, only for weights that train: trainkeys pose -> pose_emb_layers,
+    plane_coefs); db = column sums of dY; d_res = dY."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, res):
+        w = weight.detach()
+        if w.stride(1) != 1 or w.stride(0) % 8:
+            w = w.contiguous()
+        out = ops.gemm(x.detach(), w, bias=ops.bias_f32(bias), res=None if res is None else res.detach())
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        ctx.bias_dtype = None if bias is None else bias.dtype
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        N, K = weight.shape
+        dy = dy.contiguous()
+        dy2, x2 = dy.reshape(-1, N), x.reshape(-1, K)
+        dx = dw = db = dres = None
+        if ctx.needs_input_grad[0]:
+            if ops.gemm_ok(dy2.shape[0], K, N):
+                dx = ops.gemm(dy2, ops.weight_t(weight)).reshape(x.shape)
+            else:  # outside the kernel's envelope (N % 64 != 0): not a shape of the shipped configs
+                dx = torch.mm(dy2, weight.detach()).reshape(x.shape)
+        if ctx.needs_input_grad[1]:
+            if ops.gemm_tn_ok(dy2, x2):
+                dw = ops.gemm_tn(dy2, x2, out_dtype=torch.bfloat16).to(weight.dtype)
+            else:
+                dw = torch.mm(dy2.t(), x2).to(weight.dtype)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = dy2.sum(0, dtype=torch.float32).to(ctx.bias_dtype)
+        if ctx.needs_input_grad[3]:
+            dres = dy
+        return dx, dw, db, dres
 
 
 class AttentionFn(torch.autograd.Function):
@@ -168,7 +209,7 @@ class NerfAggregateFn(torch.autograd.Function):
         b, n, npts, C = dz.shape
         S = t.shape[-1]
         dzP = dz.reshape(b * n, npts // S, S, C).sum(2, dtype=torch.float32).to(zP.dtype)
-        dWk = torch.mm(dz.reshape(-1, C).t(), F.reshape(-1, F.shape[-1])).to(Wk.dtype)
+        dWk = ops.gemm_tn(dz.reshape(-1, C), F.reshape(-1, F.shape[-1])).to(Wk.dtype)
         return None, None, None, None, dY.to(Y.dtype), dzP, dlv, dcview, dWk, None
 
 
@@ -176,21 +217,26 @@ class NerfRenderFn(torch.autograd.Function):
     """The fused render from the reference FEATURES and the live weights (the training path): Y = xref Wf^T and lv = xref . vf are
     formed here, and the backward never scatters into those tables.  With xg = bilinear_gather(xref) at the sample positions
     (cd360_feature_gather, the same corner arithmetic as the fused kernel),
-        dWf^T = xg^T dz          dvf = xg^T dlogit          dzP = sum_s dz          dcview = sum dlogit          dWk = dz^T F
-    are four library GEMMs / reductions over tensors the backward kernel wrote once; the 4 x C atomic adds per (sample, view) of the
-    table form (NerfAggregateFn) measured 22 ms per render at the training shapes, this form a fraction of it.  xref itself gets
-    no gradient (the reference stream runs under no_grad: attention.py:845-857)."""
+        dWf = dz^T xg          dvf = dlogit^T xg          dzP = sum_s dz          dcview = sum dlogit          dWk = dz^T F
+    are three weight-gradient GEMMs (cd360_gemm_tn_bf16) and two reductions over tensors the backward kernel wrote once; the 4 x C atomic
+    adds per (sample, view) of the table form (NerfAggregateFn) measured 22 ms per render at the training shapes, this form a fraction
+    of it.  xref itself gets no gradient (the reference stream runs under no_grad: attention.py:845-857).  Wf [C_out, C_in] is the
+    Linear-layout slice plane_coefs.0.weight[:, :C]."""
 
     @staticmethod
-    def forward(ctx, cams, xs, ys, t, xref, Wf_t, vf, zP, cview, Wk):
+    def forward(ctx, cams, xs, ys, t, xref, Wf, vf, zP, cview, Wk):
         if xref.requires_grad:
             raise NotImplementedError("gradients with respect to the reference features are not provided (the reference stream is no_grad)")
         b, n, hw, C = xref.shape
         x2 = xref.reshape(b * n * hw, C)
-        Y = torch.mm(x2.to(Wf_t.dtype), Wf_t).reshape(b * n, hw, C).contiguous()
+        if ops.linear_ok(x2, Wf):
+            Y = ops.linear(x2.detach(), Wf.detach()).reshape(b * n, hw, C)
+        else:
+            Y = torch.mm(x2.to(Wf.dtype), Wf.detach().t()).reshape(b * n, hw, C).contiguous()
         lv = torch.mv(x2.float(), vf).reshape(b * n, hw).contiguous()
         g, logits, lse = ops.nerf_mlp_aggregate(cams, xs, ys, t, Y, zP, lv, cview, Wk, want_logits=True)
         ctx.save_for_backward(cams, xs, ys, t, xref, Y, lv, zP, cview, Wk, g, lse)
+        ctx.wf_dtype = Wf.dtype
         ctx.mark_non_differentiable(logits, lse)
         return g, logits, lse
 
@@ -204,17 +250,24 @@ class NerfRenderFn(torch.autograd.Function):
         grid = ops.ray_project_index(cams, xs, ys, t, want_points=False, want_index=False)["grid"].reshape(b * n, npts, 2)
         xg = ops.feature_gather(xref.reshape(b * n, hw, C).to(dz.dtype), grid).reshape(b * n * npts, C)
         dz2 = dz.reshape(b * n * npts, C)
-        dWf_t = torch.mm(xg.t(), dz2)                                                  # [C_in, C_out], the layout of Wf_t
-        dvf = torch.mm(dlogit.reshape(1, -1).to(xg.dtype), xg).reshape(C).float()
+        if ops.gemm_tn_ok(dz2, xg):
+            dWf = ops.gemm_tn(dz2, xg).to(ctx.wf_dtype)                                 # [C_out, C_in], the layout of Wf
+            dl8 = torch.zeros(b * n * npts, 8, dtype=xg.dtype, device=xg.device)         # dlogit as column 0 of an [M, 8] operand
+            dl8[:, 0] = dlogit.reshape(-1)
+            dvf = ops.gemm_tn(dl8, xg, out_dtype=torch.float32)[0].contiguous()
+            dWk = ops.gemm_tn(dz2, F.reshape(-1, F.shape[-1])).to(Wk.dtype)
+        else:
+            dWf = torch.mm(dz2.t(), xg).to(ctx.wf_dtype)
+            dvf = torch.mm(dlogit.reshape(1, -1).to(xg.dtype), xg).reshape(C).float()
+            dWk = torch.mm(dz2.t(), F.reshape(-1, F.shape[-1])).to(Wk.dtype)
         dzP = dz.reshape(b * n, hw, S, C).sum(2, dtype=torch.float32).to(zP.dtype)
         dcview = dlogit.reshape(b, n, npts).sum(-1)
-        dWk = torch.mm(dz2.t(), F.reshape(-1, F.shape[-1])).to(Wk.dtype)
-        return None, None, None, None, None, dWf_t, dvf, dzP, dcview, dWk
+        return None, None, None, None, None, dWf, dvf, dzP, dcview, dWk
 
 
 class RowDot4Fn(torch.autograd.Function):
-    """ops.rowdot4 (FeatureNeRFEncoding.decoder, Linear(C -> 4, no bias), nerfsd_pytorch3d.py:49-51,160); its backward is two
-    K = 4 library GEMMs."""
+    """ops.rowdot4 (FeatureNeRFEncoding.decoder, Linear(C -> 4, no bias), nerfsd_pytorch3d.py:49-51,160); backward =
+    cd360_rowdot4_bwd_bf16 (dh = d w in one pass, dw = d^T h as a slab-wise column reduction)."""
 
     @staticmethod
     def forward(ctx, h, w):
@@ -224,11 +277,7 @@ class RowDot4Fn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, d_out):
         h, w = ctx.saved_tensors
-        C = h.shape[-1]
-        d2 = d_out.reshape(-1, 4).float()
-        dh = torch.mm(d2, w).to(h.dtype).reshape(h.shape) if ctx.needs_input_grad[0] else None
-        dw = torch.mm(d2.t().to(h.dtype), h.reshape(-1, C)).float() if ctx.needs_input_grad[1] else None
-        return dh, dw
+        return ops.rowdot4_bwd(d_out, h, w, ctx.needs_input_grad[0], ctx.needs_input_grad[1])
 
 
 class ConvIgemmFn(torch.autograd.Function):

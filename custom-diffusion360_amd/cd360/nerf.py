@@ -9,8 +9,8 @@ and w_v = nviews.weight split as [ vf (C) | enc16(q_0), q_0 (99) | o_i^tgt (3) |
   logit_i      = bilinear(lv_i)(sample) + c_i  (+ terms common to all views)        lv_i = xref_i vf,  zP_i = Wp.feat + b1
   h(sample)    = W2 . sum_i softmax_i(logit) SiLU(z_i) + b2                          (softmax weights sum to 1)
 
-The three tables (Y, zP, lv) are plain library GEMMs over n*hw rows (S = 24 times fewer rows than the
-reference's per-sample Linear) and the rest happens inside one HIP kernel (csrc/nerf_fused.hip).
+The three tables (Y, zP, lv) are GEMMs over n*hw rows (S = 24 times fewer rows than the reference's per-sample
+Linear) on cd360_gemm_bf16 (ops.linear, forward and backward) and the rest happens inside one HIP kernel (csrc/nerf_fused.hip).
 """
 from __future__ import annotations
 
@@ -86,13 +86,12 @@ class FusedNerfWeights:
         self.v_otgt_enc = wvf[C + 102:C + 198].contiguous()
         self.bv = bv.float().reshape(())
         self.Wd = Wd.float().contiguous()  # [4, C]
-        if not live:  # Linear-layout bf16 copies for the table GEMMs on cd360_gemm_bf16 (inference)
-            self.Wf = W1f[:, :C].contiguous().to(torch.bfloat16)                      # [C, C]:   Y = xref Wf^T
-            wp = torch.zeros(C, 128, dtype=torch.float32, device=dev)
-            wp[:, :99] = W1f[:, C + 99:C + 198]
-            self.Wp = wp.to(torch.bfloat16).contiguous()                               # [C, 128]: zP = plucker Wp^T + b1
-            self.W2 = W2.detach().to(torch.bfloat16).contiguous()                      # [C, C]:   h = g W2^T + b2
-            self.b2_f32 = b2.detach().float().contiguous()
+        # Linear-layout bf16 operands of the table GEMMs on cd360_gemm_bf16 (ops.linear).  live: slices / pads / casts are recorded by
+        # autograd, so the GEMMs' weight gradients (grad.LinearFn -> cd360_gemm_tn_bf16) flow back into plane_coefs
+        self.Wf = W1f[:, :C].contiguous().to(torch.bfloat16)                                              # [C, C]:   Y = xref Wf^T
+        self.Wp = torch.cat([W1f[:, C + 99:C + 198], W1f.new_zeros(C, 29)], 1).to(torch.bfloat16)        # [C, 128]: zP = plucker Wp^T + b1
+        self.W2 = W2.to(torch.bfloat16) if live else W2.detach().to(torch.bfloat16).contiguous()          # [C, C]:   h = g W2^T + b2
+        self.b2_f32 = b2.float() if live else b2.detach().float().contiguous()
         self.live = live
 
 
@@ -158,19 +157,20 @@ def fused_feature_nerf(fw: FusedNerfWeights, cams: torch.Tensor, xref: Optional[
     xs = patch_positions(r, dev, None if xy_jitter is None else xy_jitter[0])
     ys = patch_positions(r, dev, None if xy_jitter is None else xy_jitter[1])
     t, dists = depth_samples(num_samples, far, near, dev, hw, depth_jitter)
-    # no gradient recorded (sampling, eval): the three table GEMMs run on cd360_gemm_bf16 -- Plucker features written as bf16 rows of
-    # 128 by their kernel (no fp32 intermediate, no cast pass), bias fused; under autograd they stay on torch (fp32 features)
-    fused = not torch.is_grad_enabled() and not fw.live and C % 64 == 0 and not os.environ.get("CD360_LIBRARY_LINEAR")
+    # the three table GEMMs run on cd360_gemm_bf16 in every mode (ops.linear: recorded by autograd when the weights are live) -- Plucker
+    # features written as bf16 rows of 128 by their kernel (no fp32 intermediate, no cast pass), bias fused; CD360_LIBRARY_LINEAR=1 = the
+    # round-1 torch GEMMs (A/B)
+    fused = cams.is_cuda and C % 64 == 0 and fw.Wp.dtype == torch.bfloat16 and not os.environ.get("CD360_LIBRARY_LINEAR")
     if fused:
-        zP = ops.gemm(ops.plucker_features_bf16(cams, xs, ys).reshape(b * n * hw, 128), fw.Wp, bias=fw.b1).reshape(b * n, hw, C)
+        zP = ops.linear(ops.plucker_features_bf16(cams, xs, ys).reshape(b * n * hw, 128), fw.Wp, fw.b1).reshape(b * n, hw, C)
     else:
         pf = ops.plucker_features(cams, xs, ys).reshape(b * n * hw, 104)
         zP = torch.addmm(fw.b1, pf, fw.Wp_t).to(torch.bfloat16).reshape(b * n, hw, C)
     cview = view_constants(fw, cams)
-    if tables is None and torch.is_grad_enabled() and any(w.requires_grad for w in (fw.Wf_t, fw.vf, fw.Wk, zP, cview)):
+    if tables is None and torch.is_grad_enabled() and any(w.requires_grad for w in (fw.Wf, fw.vf, fw.Wk, zP, cview)):
         # training: live weights; the render and its backward go through grad.NerfRenderFn (no table scatters)
         from . import grad
-        g, logits, lse = grad.NerfRenderFn.apply(cams, xs, ys, t, xref, fw.Wf_t, fw.vf, zP, cview, fw.Wk)
+        g, logits, lse = grad.NerfRenderFn.apply(cams, xs, ys, t, xref, fw.Wf, fw.vf, zP, cview, fw.Wk)
     else:
         if tables is None:
             tables = reference_tables(fw, xref)
@@ -178,7 +178,7 @@ def fused_feature_nerf(fw: FusedNerfWeights, cams: torch.Tensor, xref: Optional[
         img_map = tables[2] if len(tables) > 2 else None
         g, logits, lse = ops.nerf_mlp_aggregate(cams, xs, ys, t, Y, zP, lv, cview, fw.Wk, want_logits=want_view_weights, img_map=img_map)
     if fused:
-        h = ops.gemm(g.reshape(-1, C), fw.W2, bias=fw.b2_f32).reshape(b, hw, num_samples, C)
+        h = ops.linear(g.reshape(-1, C), fw.W2, fw.b2_f32).reshape(b, hw, num_samples, C)
     else:
         h = torch.addmm(fw.b2, g.reshape(-1, C), fw.W2_t).reshape(b, hw, num_samples, C)
     dec = ops.rowdot4(h, fw.Wd)
@@ -193,8 +193,8 @@ def reference_tables(fw: FusedNerfWeights, xref: torch.Tensor):
     Y = xref @ Wf^T (bf16) and lv = xref @ vf (fp32)."""
     b, n, hw, C = xref.shape
     x2 = xref.reshape(b * n * hw, C)
-    if x2.is_cuda and x2.dtype == torch.bfloat16 and not torch.is_grad_enabled() and not fw.live and C % 64 == 0 and not os.environ.get("CD360_LIBRARY_LINEAR"):
-        Y = ops.gemm(x2.contiguous(), fw.Wf).reshape(b * n, hw, C)
+    if x2.is_cuda and x2.dtype == torch.bfloat16 and C % 64 == 0 and not os.environ.get("CD360_LIBRARY_LINEAR"):
+        Y = ops.linear(x2, fw.Wf).reshape(b * n, hw, C)
     else:
         Y = torch.mm(x2.to(fw.Wf_t.dtype), fw.Wf_t).reshape(b * n, hw, C)
     lv = torch.mv(x2.float(), fw.vf).reshape(b * n, hw)

@@ -400,6 +400,21 @@ def rowdot4(h: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def rowdot4_bwd(d_out: torch.Tensor, h: torch.Tensor, w: torch.Tensor, need_dh: bool = True, need_dw: bool = True):
+    """Backward of rowdot4: d_out [..., 4] fp32 -> (dh [..., C] bf16 | None, dw [4, C] fp32 | None) (cd360_rowdot4_bwd_bf16)."""
+    _need_gpu(d_out, h, w)
+    C = h.shape[-1]
+    rows = h.numel() // C
+    d2 = d_out.reshape(rows, 4).float().contiguous()
+    assert h.dtype == torch.bfloat16 and h.is_contiguous() and w.shape == (4, C) and w.dtype == torch.float32 and w.is_contiguous()
+    lib = _lib.load()
+    dh = torch.empty_like(h) if need_dh else None
+    part = torch.empty(lib.cd360_rowdot4_bwd_slabs(rows), 4, C, dtype=torch.float32, device=h.device) if need_dw else None
+    with _timed("rowdot4_bwd", 0.0, 2.0 * rows * C * (int(need_dh) + int(need_dw))):
+        check(lib.cd360_rowdot4_bwd_bf16(_ptr(d2), _ptr(h), _ptr(w), _ptr(dh), _ptr(part), rows, C, _stream()), "cd360_rowdot4_bwd_bf16")
+    return dh, (None if part is None else part.sum(0))
+
+
 # ----------------------------------------------------------------------------------------------- GroupNorm (+SiLU)
 def gn_silu(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, groups: int, eps: float, silu: bool,
             out: Optional[torch.Tensor] = None, tile_stats: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -594,7 +609,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
          want_stats: bool = False, geglu: bool = False, out: Optional[torch.Tensor] = None):
     """a [..., K] @ w[N, K]^T with the fused epilogues of cd360_gemm_bf16 -> out [..., N] (N / 2 with geglu), bf16.
     bias fp32 [N]; res bf16 [..., N]; ln = (stats fp32 [rows, parts, 2], wsum fp32 [N], eps) with w / bias from pack_ln_linear;
-    want_stats=True returns (out, stats fp32 [rows, parts_out, 2]) for the next LayerNorm fold.  Forward only (inference path)."""
+    want_stats=True returns (out, stats fp32 [rows, parts_out, 2]) for the next LayerNorm fold.  Not recorded by autograd: the
+    differentiable form is linear() (grad.LinearFn)."""
     _need_gpu(a, w, bias, res)
     M, lda = _rows2d(a)
     K = a.shape[-1]
@@ -627,6 +643,103 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
         check(lib.cd360_gemm_bf16(_ptr(a), _ptr(w), _ptr(out), M, N, K, lda, w.stride(0), ldo, _ptr(bias), _ptr(res), ldr, _ptr(stats_in), parts,
                                   ln_dim, float(eps), _ptr(wsum), _ptr(stats_out), 1 if geglu else 0, _stream()), "cd360_gemm_bf16")
     return (out, stats_out) if want_stats else out
+
+
+def gemm_ok(M: int, N: int, K: int, lda: Optional[int] = None, ldw: Optional[int] = None) -> bool:
+    """Shape envelope of cd360_gemm_bf16 (K % 64, N % 16, 32-bit buffer offsets): callers outside it keep their tensors on torch."""
+    lda, ldw = (K if lda is None else lda), (K if ldw is None else ldw)
+    return (M > 0 and K > 0 and N > 0 and K % 64 == 0 and N % 16 == 0 and lda % 8 == 0 and ldw % 8 == 0 and M < 2 ** 31
+            and (M + 256) * lda * 2 < 2 ** 32 and (N + 256) * ldw * 2 < 2 ** 32)
+
+
+_F32_CACHE = {}  # id(tensor) -> (weakref, version, fp32 copy): biases of frozen Linears as the fp32 vectors the GEMM epilogue reads
+_WT_CACHE = {}   # id(weight) -> (weakref, version, weight^T contiguous): the data-gradient GEMM's operand
+
+
+def _cached(cache: dict, t: torch.Tensor, make):
+    import weakref
+    ent = cache.get(id(t))
+    if ent is not None and ent[0]() is t and ent[1] == t._version:
+        return ent[2]
+    if len(cache) > 4096:  # entries of tensors that died (ids are reused): drop them
+        for k in [k for k, e in cache.items() if e[0]() is None]:
+            del cache[k]
+    val = make(t)
+    cache[id(t)] = (weakref.ref(t), t._version, val)
+    return val
+
+
+def bias_f32(b: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    if b is None or (b.dtype == torch.float32 and b.is_contiguous() and not b.requires_grad):
+        return b
+    return _cached(_F32_CACHE, b, lambda t: t.detach().float().contiguous())
+
+
+def weight_t(w: torch.Tensor) -> torch.Tensor:
+    """w [N, K] -> w^T [K, N] contiguous bf16, cached per (tensor, version): dX = dY W is cd360_gemm_bf16(dY, W^T)."""
+    return _cached(_WT_CACHE, w, lambda t: t.detach().t().contiguous())
+
+
+def linear_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    """True when F.linear(x, weight) can run on cd360_gemm_bf16 (bf16 on the GPU, inside the kernel's shape envelope)."""
+    if not (x.is_cuda and x.dtype == torch.bfloat16 and weight.dtype == torch.bfloat16 and weight.dim() == 2 and x.shape[-1] == weight.shape[1]):
+        return False
+    N, K = weight.shape
+    M = x.numel() // max(K, 1)
+    return gemm_ok(M, N, K)
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """F.linear(x, weight, bias) (+ res) on the hand-written MFMA GEMM, in every mode: no tape -> one cd360_gemm_bf16 launch; under
+    autograd -> grad.LinearFn (forward the same launch; data gradient the same kernel on W^T; weight gradient cd360_gemm_tn_bf16).
+    The one Linear of every route: the fused inference blocks, the plain module route (sample.py's patched forwards, hooks) and the
+    fine-tuning step all end here.  x [..., K] bf16, weight [N, K] bf16 (nn.Linear layout); bias any float dtype."""
+    assert linear_ok(x, weight), "cd360 linear: bf16 GPU tensors with K % 64 == 0 and N % 16 == 0 (use linear_ok() to test)"
+    if x.stride(-1) != 1:
+        x = x.contiguous()
+    try:
+        _rows2d(x)
+    except Cd360Error:
+        x = x.contiguous()
+    if res is not None and (res.dtype != torch.bfloat16 or res.stride(-1) != 1):
+        res = res.to(torch.bfloat16).contiguous()
+    if _wants_grad(x, weight, bias, res):
+        from . import grad
+        return grad.LinearFn.apply(x, weight, bias, res)
+    w = weight.detach()
+    if w.stride(1) != 1 or w.stride(0) % 8:
+        w = w.contiguous()
+    return gemm(x.detach(), w, bias=bias_f32(bias), res=None if res is None else res.detach())
+
+
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.bfloat16) -> torch.Tensor:
+    """a [M, N]^T @ b [M, K] -> [N, K] (fp32 accumulation; cd360_gemm_tn_bf16): the weight gradient dW = dY^T X of a Linear.
+    a, b bf16 with contiguous last dims and uniform row strides (multiples of 8); N, K multiples of 8.  Deterministic."""
+    _need_gpu(a, b)
+    M, lda = _rows2d(a)
+    Mb, ldb = _rows2d(b)
+    N, K = a.shape[-1], b.shape[-1]
+    assert M == Mb and out_dtype in (torch.bfloat16, torch.float32)
+    lib = _lib.load()
+    out = torch.empty(N, K, dtype=out_dtype, device=a.device)
+    ws = torch.empty(max(16, lib.cd360_gemm_tn_workspace_bytes(M, N, K)), dtype=torch.uint8, device=a.device)
+    with _timed("gemm_tn", 2.0 * M * N * K, 2.0 * (M * N + M * K) + out.element_size() * N * K):
+        check(lib.cd360_gemm_tn_bf16(_ptr(a), _ptr(b), _ptr(out), M, N, K, lda, ldb, 1 if out_dtype == torch.bfloat16 else 0, _ptr(ws), _stream()),
+              "cd360_gemm_tn_bf16")
+    return out
+
+
+def gemm_tn_ok(a: torch.Tensor, b: torch.Tensor) -> bool:
+    if not (a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.stride(-1) == 1 and b.stride(-1) == 1):
+        return False
+    try:
+        M, lda = _rows2d(a)
+        Mb, ldb = _rows2d(b)
+    except Cd360Error:
+        return False
+    N, K = a.shape[-1], b.shape[-1]
+    return (M == Mb and N % 8 == 0 and K % 8 == 0 and lda % 8 == 0 and ldb % 8 == 0 and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0
+            and (M + 64) * lda * 2 < 2 ** 31 and (M + 64) * ldb * 2 < 2 ** 31)
 
 
 def gemm_cstats(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None):

@@ -287,3 +287,73 @@ extern "C" int cd360_rowdot4_bf16(const void* h, const void* w, void* out, int64
   CD360_LAUNCH_CHECK();
   return CD360_OK;
 }
+
+// Backward of cd360_rowdot4_bf16 (the FeatureNeRF decoder is trained: trainkeys = pose, diffusion.py:139-144):
+//   dh[row, c] = sum_j d[row, j] w[j, c]   (bf16, the layout of h)          dw[j, c] = sum_row d[row, j] h[row, c]   (fp32)
+// dh is one pass (reads 16 B of d per row, writes the row); dw is a column reduction over all rows: each workgroup reduces a slab of
+// rows for 256 channels into a partial [slab, 4, C], summed by the caller in slab order (deterministic, no atomics).
+namespace {
+__global__ __launch_bounds__(256) void rowdot4_bwd_dh_kernel(const float* __restrict__ d, const float* __restrict__ w, uint16_t* __restrict__ dh,
+                                                             long rows, int C) {
+  const int cpv = C >> 3;
+  const long total = rows * cpv;
+  for (long gid = (long)blockIdx.x * blockDim.x + threadIdx.x; gid < total; gid += (long)gridDim.x * blockDim.x) {
+    const long row = gid / cpv;
+    const int c = (int)(gid - row * cpv) * 8;
+    const f32x4 dv = *reinterpret_cast<const f32x4*>(d + row * 4);
+    u32x4 o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        v0 = fmaf(dv[j], w[(long)j * C + c + 2 * e], v0);
+        v1 = fmaf(dv[j], w[(long)j * C + c + 2 * e + 1], v1);
+      }
+      o[e] = pack_bf16x2(v0, v1);
+    }
+    *reinterpret_cast<u32x4*>(dh + row * (long)C + c) = o;
+  }
+}
+
+constexpr int DW_SLAB_ROWS = 512;
+__global__ __launch_bounds__(256) void rowdot4_bwd_dw_kernel(const float* __restrict__ d, const uint16_t* __restrict__ h, float* __restrict__ part,
+                                                             long rows, int C) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const long r0 = (long)blockIdx.y * DW_SLAB_ROWS, r1 = r0 + DW_SLAB_ROWS < rows ? r0 + DW_SLAB_ROWS : rows;
+  float a[4] = {0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    for (long r = r0; r < r1; ++r) {
+      const float hv = bf16_to_f32(h[r * C + c]);
+      const f32x4 dv = *reinterpret_cast<const f32x4*>(d + r * 4);  // wave-uniform address: one broadcast load
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] = fmaf(dv[j], hv, a[j]);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) part[((long)blockIdx.y * 4 + j) * C + c] = a[j];
+  }
+}
+}  // namespace
+
+extern "C" int cd360_rowdot4_bwd_slabs(int64_t rows) { return (int)((rows + DW_SLAB_ROWS - 1) / DW_SLAB_ROWS); }
+
+// d [rows, 4] fp32 (gradient of the output), h [rows, C] bf16, w [4, C] fp32 -> dh [rows, C] bf16 (NULL to skip),
+// dw_part [cd360_rowdot4_bwd_slabs(rows), 4, C] fp32 partial sums of dw (NULL to skip; the caller sums the slabs)
+extern "C" int cd360_rowdot4_bwd_bf16(const void* d, const void* h, const void* w, void* dh, void* dw_part, int64_t rows, int C, void* stream) {
+  if (!d || !h || !w || rows <= 0 || C <= 0) return CD360_ERR_ARG;
+  if (C % 8 || ((uintptr_t)d | (uintptr_t)h | (uintptr_t)dh) % 16) return CD360_ERR_SHAPE;
+  if (dh) {
+    const long total = rows * (C / 8), blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(rowdot4_bwd_dh_kernel, dim3((unsigned)(blocks > 8192 ? 8192 : blocks)), dim3(256), 0, (hipStream_t)stream, (const float*)d,
+                       (const float*)w, (uint16_t*)dh, (long)rows, C);
+    CD360_LAUNCH_CHECK();
+  }
+  if (dw_part) {
+    const long slabs = (rows + DW_SLAB_ROWS - 1) / DW_SLAB_ROWS;
+    if (slabs > 65535) return CD360_ERR_SHAPE;
+    hipLaunchKernelGGL(rowdot4_bwd_dw_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)slabs), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)d, (const uint16_t*)h, (float*)dw_part, (long)rows, C);
+    CD360_LAUNCH_CHECK();
+  }
+  return CD360_OK;
+}

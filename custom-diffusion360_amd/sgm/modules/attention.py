@@ -30,7 +30,7 @@ import torch.nn.functional as F
 from torch import nn
 
 from cd360 import ops
-from ..modules.diffusionmodules.util import checkpoint, group_norm_tokens, tag_gn_stats, tokens_to_image, zero_module  # noqa: F401
+from ..modules.diffusionmodules.util import HipLayerNorm, HipLinear, checkpoint, group_norm_tokens, tag_gn_stats, tokens_to_image, zero_module  # noqa: F401
 from ..modules.nerfsd_pytorch3d import NerfSDModule, VolRender
 from ..util import default, exists
 
@@ -59,7 +59,7 @@ trunc_exp = _TruncExp.apply
 class GEGLU(nn.Module):
     def __init__(self, dim_in, dim_out):
         super().__init__()
-        self.proj = nn.Linear(dim_in, dim_out * 2)
+        self.proj = HipLinear(dim_in, dim_out * 2)
 
     def forward(self, x):
         p = self.proj(x)
@@ -74,11 +74,29 @@ class FeedForward(nn.Module):
         super().__init__()
         inner_dim = int(dim * mult)
         dim_out = default(dim_out, dim)
-        project_in = nn.Sequential(nn.Linear(dim, inner_dim), nn.GELU()) if not glu else GEGLU(dim, inner_dim)
-        self.net = nn.Sequential(project_in, nn.Dropout(dropout), nn.Linear(inner_dim, dim_out))
+        project_in = nn.Sequential(HipLinear(dim, inner_dim), nn.GELU()) if not glu else GEGLU(dim, inner_dim)
+        self.net = nn.Sequential(project_in, nn.Dropout(dropout), HipLinear(inner_dim, dim_out))
 
     def forward(self, x):
         return self.net(x)
+
+
+def _linear(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
+    """F.linear on the hand-written GEMM whenever it can serve the call (bf16, GPU, K % 64 == 0), in every grad mode."""
+    if ops.linear_ok(x, weight) and not os.environ.get("CD360_LIBRARY_LINEAR"):
+        return ops.linear(x, weight, bias)
+    return F.linear(x, weight, bias)
+
+
+def _watched(*mods: nn.Module) -> bool:
+    """True when somebody observes one of `mods` or their submodules through torch's module protocol: forward (pre-)hooks (the references
+    harvest, diffusion.py:151-163; attention-map capture) or an instance-level `forward` (sample.py:247-262 rebinds the blocks'
+    forward).  Paths that read raw weights instead of calling the submodule would skip such observers, so they step aside."""
+    for mod in mods:
+        for m in mod.modules():
+            if m._forward_hooks or m._forward_pre_hooks or "forward" in m.__dict__:
+                return True
+    return False
 
 
 def Normalize(in_channels):
@@ -102,10 +120,10 @@ class MemoryEfficientCrossAttention(nn.Module):
         inner_dim = dim_head * heads
         context_dim = default(context_dim, query_dim)
         self.heads, self.dim_head, self.add_lora = heads, dim_head, add_lora
-        self.to_q = nn.Linear(query_dim, inner_dim, bias=False)
-        self.to_k = nn.Linear(context_dim, inner_dim, bias=False)
-        self.to_v = nn.Linear(context_dim, inner_dim, bias=False)
-        self.to_out = nn.Sequential(nn.Linear(inner_dim, query_dim), nn.Dropout(dropout))
+        self.to_q = HipLinear(query_dim, inner_dim, bias=False)
+        self.to_k = HipLinear(context_dim, inner_dim, bias=False)
+        self.to_v = HipLinear(context_dim, inner_dim, bias=False)
+        self.to_out = nn.Sequential(HipLinear(inner_dim, query_dim), nn.Dropout(dropout))
         self.attention_op = None
         self._merged = {}
         self._kv_cache = None
@@ -139,11 +157,7 @@ class MemoryEfficientCrossAttention(nn.Module):
         inner = self.heads * self.dim_head
         ctx = _pad_tokens(context)
         wkv = self._merged_weight("kv")
-        if (ctx.is_cuda and ctx.dtype == torch.bfloat16 and wkv.dtype == torch.bfloat16 and not torch.is_grad_enabled() and ctx.shape[-1] % 64 == 0
-                and not os.environ.get("CD360_LIBRARY_LINEAR")):
-            kv = ops.gemm(ctx.contiguous(), wkv)  # the same hand-written GEMM as the rest of the block
-        else:
-            kv = F.linear(ctx, wkv)
+        kv = _linear(ctx, wkv)  # the same hand-written GEMM as the rest of the block
         out = (kv[..., :inner], kv[..., inner:], context.shape[1])
         # the keyed tensors are held by the entry: their addresses cannot be recycled for other content while the entry is alive
         self._kv_cache = (key, out, (context, wk, wv)) if use_cache else None
@@ -152,7 +166,7 @@ class MemoryEfficientCrossAttention(nn.Module):
     def attend(self, x: torch.Tensor, kv) -> torch.Tensor:
         """softmax(q k^T / sqrt(d)) v and the output projection for precomputed (k, v, nk)."""
         k, v, nk = kv
-        q = F.linear(x, self.to_q.weight)
+        q = _linear(x, self.to_q.weight)
         return self._finish(x, q, k, v, nk)
 
     def _finish(self, x, q, k, v, nk):
@@ -169,9 +183,12 @@ class MemoryEfficientCrossAttention(nn.Module):
             raise NotImplementedError("additional_tokens / cross-frame attention are not used by the shipped config")
         if exists(mask):
             raise NotImplementedError  # as the reference (attention.py:411-412)
+        if _watched(self.to_q, self.to_k, self.to_v):  # observers on the projections: the reference's call sequence (attention.py:368-372)
+            ctx = _pad_tokens(default(context, x))
+            return self._finish(x, self.to_q(x), self.to_k(ctx), self.to_v(ctx), default(context, x).shape[1])
         if context is None:  # self-attention: q, k, v are the three column slices of one GEMM, read in place by the kernel
             inner = self.heads * self.dim_head
-            qkv = F.linear(x, self._merged_weight("qkv"))
+            qkv = _linear(x, self._merged_weight("qkv"))
             if qkv.dtype == torch.bfloat16 and qkv.requires_grad and torch.is_grad_enabled():
                 return self.to_out(ops.self_attention_qkv(qkv, self.heads))  # training: one d(q|k|v) buffer written by the backward kernel
             return self._finish(x, qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:], x.shape[1])
@@ -204,15 +221,15 @@ class BasicTransformerBlock(nn.Module):
         self.attn2 = attn_cls(query_dim=dim, context_dim=context_dim, heads=n_heads, dim_head=d_head, dropout=dropout, add_lora=add_lora,
                               backend=sdp_backend)
         if image_cross:
-            self.pose_emb_layers = nn.Linear(2 * dim, dim, bias=False)
+            self.pose_emb_layers = HipLinear(2 * dim, dim, bias=False)
             nn.init.eye_(self.pose_emb_layers.weight)
             self.pose_featurenerf = NerfSDModule(mode=mode, out_channels=dim, far_plane=far, num_samples=num_samples,
                                                  rgb_predict=rgb_predict, average=average, num_freqs=num_freqs, stratified=stratified,
                                                  imp_sampling_percent=imp_sampling_percent, near_plane=near_plane)
             self.renderer = VolRender()
-        self.norm1 = nn.LayerNorm(dim)
-        self.norm2 = nn.LayerNorm(dim)
-        self.norm3 = nn.LayerNorm(dim)
+        self.norm1 = HipLayerNorm(dim)
+        self.norm2 = HipLayerNorm(dim)
+        self.norm3 = HipLayerNorm(dim)
         self.checkpoint = checkpoint
         self._pose_split = None
         self._ref_tables = None
@@ -233,9 +250,16 @@ class BasicTransformerBlock(nn.Module):
         return self._pose_split[1], self._pose_split[2]
 
     def pose_embed(self, x: torch.Tensor, xref: torch.Tensor) -> torch.Tensor:
-        """pose_emb_layers(cat[x, xref]) without the concat (attention.py:634): x Wa^T + xref Wb^T."""
+        """pose_emb_layers(cat[x, xref]) without the concat (attention.py:634): x Wa^T + xref Wb^T as two launches of the hand-written
+        GEMM, the second taking the first as its residual input; Wa / Wb are the two column halves of the weight read in place (row
+        stride 2C).  Under autograd both go through grad.LinearFn: the halves' weight gradients land in the two halves of the parameter's."""
+        w = self.pose_emb_layers.weight
+        c = w.shape[0]
+        if ops.linear_ok(x, w[:, :c]) and xref.is_cuda and not os.environ.get("CD360_LIBRARY_LINEAR"):
+            half = ops.linear(xref.to(x.dtype), w[:, c:])
+            return ops.linear(x, w[:, :c], None, res=half)
         wa, wb = self._pose_weights()
-        b, n, c = x.shape
+        b, n, _ = x.shape
         out = torch.mm(x.reshape(-1, c), wa)
         out.addmm_(xref.reshape(-1, c).to(out.dtype), wb)
         return out.reshape(b, n, c)
@@ -245,14 +269,22 @@ class BasicTransformerBlock(nn.Module):
         is cached (49 of 50 steps), so it is kept beside it (`_rendered_proj`) and the step runs ONE GEMM, x Wa^T with the kept
         half as the accumulator input, instead of two.  The kept half is tied to the (tensor object, version) it was computed
         from and to the weight split; anything else recomputes it."""
-        wa, wb = self._pose_weights()
         rf = self.rendered_feat
         b, n, c = x.shape
         tag = self._rendered_proj
+        w = self.pose_emb_layers.weight
+        hip = ops.linear_ok(x, w[:, :c]) and not torch.is_grad_enabled() and not os.environ.get("CD360_LIBRARY_LINEAR")
+        wb = self._packed()["pose"][1] if (hip and self.fused_ready(x)) else self._pose_weights()[1]
         if tag is None or tag[0] is not rf or tag[1] != rf._version or tag[2] is not wb or os.environ.get("CD360_NO_POSE_PROJ_CACHE"):
-            tag = (rf, rf._version, wb, torch.mm(rf.reshape(-1, c).to(x.dtype), wb))
+            if hip:
+                half = ops.linear(rf.reshape(-1, c).to(x.dtype), w.detach()[:, c:])
+            else:
+                half = torch.mm(rf.reshape(-1, c).to(x.dtype), wb)
+            tag = (rf, rf._version, wb, half)
             self._rendered_proj = tag
-        return torch.addmm(tag[3], x.reshape(-1, c), wa).reshape(b, n, c)
+        if hip:
+            return ops.linear(x, w.detach()[:, :c], None, res=tag[3].reshape(x.shape))
+        return torch.addmm(tag[3].reshape(-1, c), x.reshape(-1, c), self._pose_weights()[0]).reshape(b, n, c)
 
     def pin_rendered(self):
         """Move the cached render and its pose_emb_layers half (`rendered_feat @ Wb^T`) into buffers that stay put across images, so a
@@ -398,9 +430,16 @@ class BasicTransformerBlock(nn.Module):
     def fused_ready(self, x: torch.Tensor) -> bool:
         """The no-grad bf16 path on cd360_gemm_bf16: every Linear of the block is the hand-written MFMA GEMM with the LayerNorm in
         front of it folded into its epilogue, GEGLU / bias / residual fused, and the LayerNorm row statistics carried from one GEMM's
-        epilogue to the next GEMM (no LayerNorm, GEGLU or residual-add launch is left).  Training keeps the autograd path."""
-        return (x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled() and self.norm1.weight.dtype == torch.bfloat16
-                and x.shape[-1] % 64 == 0 and isinstance(self.ff.net[0], GEGLU) and not os.environ.get("CD360_LIBRARY_LINEAR"))
+        epilogue to the next GEMM (no LayerNorm, GEGLU or residual-add launch is left).  Under a tape the module route runs the same
+        GEMM through HipLinear / ops.linear (grad.LinearFn), un-fused."""
+        c = x.shape[-1]
+        return self._fused_ready(x.is_cuda, x.dtype, x.numel() // max(c, 1), c)
+
+    def _fused_ready(self, is_cuda: bool, dtype, rows: int, c: int) -> bool:
+        return (is_cuda and dtype == torch.bfloat16 and not torch.is_grad_enabled() and self.norm1.weight.dtype == torch.bfloat16
+                and c % 64 == 0 and isinstance(self.ff.net[0], GEGLU) and not os.environ.get("CD360_LIBRARY_LINEAR")
+                and ops.gemm_ok(rows, c, c)  # 32-bit buffer offsets of the GEMM core: a larger batch takes the module route
+                and not (self.training and any(isinstance(m, nn.Dropout) and m.p > 0 for m in (self.attn1.to_out[1], self.attn2.to_out[1], self.ff.net[1]))))
 
     def _packed(self):
         """Weights in the form the fused GEMM epilogues want, rebuilt when any source parameter changes:
@@ -509,18 +548,21 @@ class BasicTransformerBlock(nn.Module):
                 n_times_crossframe_attn_in_self=0):
         if additional_tokens is not None or n_times_crossframe_attn_in_self:
             raise NotImplementedError("additional_tokens / cross-frame attention are not used by the shipped config")
-        if self.fused_ready(x):
+        watched = _watched(self)
+        if not watched and self.fused_ready(x):
             return self._forward_fused(x, None, context, context_ref, pose, mask_ref, prev_weights)[:5]
-        return self._forward(x, context, context_ref, pose, mask_ref, prev_weights)
+        return self._forward(x, context, context_ref, pose, mask_ref, prev_weights, strict=watched)
 
     def _forward(self, x, context=None, context_ref=None, pose=None, mask_ref=None, prev_weights=None, additional_tokens=None,
-                 n_times_crossframe_attn_in_self=0, pending=None, defer=False):
+                 n_times_crossframe_attn_in_self=0, pending=None, defer=False, strict=False):
         """`pending`: the previous block's feed-forward output whose residual add has not happened yet (it is folded into this
         block's first add+LayerNorm launch); `defer=True` returns this block's own feed-forward output un-added as a 6th tuple
-        element instead of `ff + x`.  Only SpatialTransformer uses these, and only when no forward hooks watch the block."""
+        element instead of `ff + x`.  Only SpatialTransformer uses these, and only when no forward hooks watch the block.
+        `strict=True` (somebody observes a submodule): every submodule is called through the module protocol, in the reference's order
+        (norm1 -> attn1 -> norm2 -> attn2 -> norm3 -> ff, attention.py:609-636), so hooks see exactly the reference's values."""
         fg_mask = weights = alphas = predicted_rgb = None
         pose_active = context_ref is not None
-        fused = x.is_cuda and x.dtype == torch.bfloat16 and self.norm1.weight.dtype == torch.bfloat16 and x.shape[-1] <= 2048
+        fused = x.is_cuda and x.dtype == torch.bfloat16 and self.norm1.weight.dtype == torch.bfloat16 and x.shape[-1] <= 2048 and not strict
         n3 = None
         if fused:  # residual adds fused into the following LayerNorm (cd360_add_layernorm_bf16)
             x = x.contiguous()
@@ -589,7 +631,7 @@ class SpatialTransformer(nn.Module):
         inner_dim = n_heads * d_head
         self.norm = Normalize(in_channels)
         self.image_cross, self.poscontrol_interval = image_cross, poscontrol_interval
-        self.proj_in = nn.Linear(in_channels, inner_dim)
+        self.proj_in = HipLinear(in_channels, inner_dim)
         self.transformer_blocks = nn.ModuleList([
             BasicTransformerBlock(
                 inner_dim, n_heads, d_head, dropout=dropout, context_dim=context_dim[d], disable_self_attn=disable_self_attn,
@@ -601,7 +643,7 @@ class SpatialTransformer(nn.Module):
                                       and depth >= poscontrol_interval and d < (depth // poscontrol_interval) * poscontrol_interval),
                 stratified=stratified, imp_sampling_percent=imp_sampling_percent, near_plane=near_plane)
             for d in range(depth)])
-        self.proj_out = zero_module(nn.Linear(inner_dim, in_channels))
+        self.proj_out = zero_module(HipLinear(inner_dim, in_channels))
         self.use_linear = use_linear
         self._ppack = None
 
@@ -616,8 +658,8 @@ class SpatialTransformer(nn.Module):
         """One block on one stream with the feed-forward residual deferred into the next block's add+LayerNorm launch
         (saves one elementwise pass per block).  Falls back to the public call when hooks (e.g. the references harvest,
         diffusion.py:151-163) or a patched forward (sample.py:247-262) are attached, so those see exactly the reference's values."""
-        plain = type(block).forward is BasicTransformerBlock.forward and "forward" not in block.__dict__
-        if plain and not block._forward_hooks and not block._forward_pre_hooks and not torch.is_grad_enabled():
+        plain = type(block).forward is BasicTransformerBlock.forward
+        if plain and not torch.is_grad_enabled() and not _watched(block):
             x, fg, w, al, rgb, d = block._forward(t, kw.get("context"), kw.get("context_ref"), kw.get("pose"), kw.get("mask_ref"),
                                                   kw.get("prev_weights"), pending=pend, defer=True)
             return (x, fg, w, al, rgb), d
@@ -629,16 +671,21 @@ class SpatialTransformer(nn.Module):
     def _settle(t, pend):
         return t if pend is None else pend + t
 
-    def _fused_route(self, x) -> bool:
-        """True when every block can take the fused inference path and nobody watches the blocks' public forward (hooks such as the
-        references harvest, diffusion.py:151-163, or sample.py's patched forwards, sample.py:247-262, see exactly the reference's
-        call sequence through the other route)."""
+    def _fused_ok(self, x) -> bool:
+        """Every block can take the fused path (shapes, dtypes, plain class forward) and nobody watches this module tree -- grad mode aside."""
+        if _watched(self):
+            return False
         for blk in self.transformer_blocks:
-            plain = type(blk).forward is BasicTransformerBlock.forward and "forward" not in blk.__dict__
-            if not plain or blk._forward_hooks or blk._forward_pre_hooks:
+            if type(blk).forward is not BasicTransformerBlock.forward:
                 return False
-        return (x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled() and self.proj_in.weight.dtype == torch.bfloat16
-                and self.transformer_blocks[0].fused_ready(x.new_empty(1, 1, self.proj_in.out_features)))
+        return x.is_cuda and x.dtype == torch.bfloat16 and self.proj_in.weight.dtype == torch.bfloat16
+
+    def _fused_route(self, x) -> bool:
+        """True when the whole call runs without a tape on the fused inference path (hooks such as the references harvest,
+        diffusion.py:151-163, or sample.py's patched forwards, sample.py:247-262, see exactly the reference's call sequence through the
+        module route -- which runs the same hand-written GEMM through HipLinear, un-fused)."""
+        return (not torch.is_grad_enabled() and self._fused_ok(x)
+                and self.transformer_blocks[0]._fused_ready(x.is_cuda, x.dtype, x.shape[0] * x.shape[2] * x.shape[3], self.proj_in.out_features))
 
     def _proj_pack(self):
         ps = (self.proj_in.weight, self.proj_in.bias, self.proj_out.weight, self.proj_out.bias)
@@ -647,28 +694,28 @@ class SpatialTransformer(nn.Module):
             self._ppack = (key, tuple(t.detach().to(torch.bfloat16 if t.dim() == 2 else torch.float32).contiguous() for t in ps))
         return self._ppack[1]
 
+    def _enter(self, img):
+        """GroupNorm -> proj_in on the fused path: tokens [b, hw, inner] and their LayerNorm row statistics (from the GEMM's epilogue)."""
+        wi, bi, _, _ = self._proj_pack()
+        return ops.gemm(group_norm_tokens(self.norm, img, silu=False), wi, bias=bi, want_stats=True)
+
+    def _leave(self, t, img):
+        """proj_out + the SpatialTransformer's residual; the epilogue also takes the channel statistics of its output for the GroupNorm
+        of the ResBlock / SpatialTransformer that reads it next (tag picked up by group_norm_tokens)."""
+        _, _, wo, bo = self._proj_pack()
+        H, W = img.shape[2], img.shape[3]
+        r = img.permute(0, 2, 3, 1)
+        r = (r if r.is_contiguous() else r.contiguous()).reshape(img.shape[0], H * W, img.shape[1])
+        if os.environ.get("CD360_NO_GN_STATS") or (H * W) % 64:
+            return tokens_to_image(ops.gemm(t, wo, bias=bo, res=r), H, W)
+        out, cst = ops.gemm_cstats(t, wo, bias=bo, res=r)
+        image = tokens_to_image(out, H, W)
+        return image if cst is None else tag_gn_stats(image, cst.reshape(out.shape[0], (H * W) // 64, out.shape[-1], 2))
+
     def _forward_fused(self, x, xr, context, contextr, pose, mask_ref):
         """forward() on the fused GEMM path: proj_in writes the first block's LayerNorm statistics, every block hands its output's
         statistics to the next, proj_out adds the SpatialTransformer's residual in its epilogue."""
-        wi, bi, wo, bo = self._proj_pack()
-        H, W = x.shape[2], x.shape[3]
-
-        def tokens_of(img):
-            t = img.permute(0, 2, 3, 1)
-            return (t if t.is_contiguous() else t.contiguous()).reshape(img.shape[0], H * W, img.shape[1])
-
-        def enter(img):
-            return ops.gemm(group_norm_tokens(self.norm, img, silu=False), wi, bias=bi, want_stats=True)
-
-        def leave(t, img):
-            # proj_out + the SpatialTransformer's residual; the epilogue also takes the channel statistics of its output for the
-            # GroupNorm of the ResBlock / SpatialTransformer that reads it next (tag picked up by group_norm_tokens)
-            if os.environ.get("CD360_NO_GN_STATS") or (H * W) % 64:
-                return tokens_to_image(ops.gemm(t, wo, bias=bo, res=tokens_of(img)), H, W)
-            out, cst = ops.gemm_cstats(t, wo, bias=bo, res=tokens_of(img))
-            image = tokens_to_image(out, H, W)
-            return image if cst is None else tag_gn_stats(image, cst.reshape(out.shape[0], (H * W) // 64, out.shape[-1], 2))
-
+        enter, leave = self._enter, self._leave
         sampling = xr is None and pose is not None and any(getattr(b, "reference_choices", None) is not None for b in self.transformer_blocks)
         t, st = enter(x)
         tr = str_ = None
@@ -712,19 +759,30 @@ class SpatialTransformer(nn.Module):
 
         fg_masks, alphas, rgbs = [], [], []
         t = self._tokens(x)
-        tr = pend = pendr = None
+        tr = pend = pendr = str_ = None
+        # The reference stream runs under no_grad (attention.py:845-857) even inside a fine-tuning step: it takes the fused inference
+        # path (LayerNorm folds, GEGLU / residual epilogues) while the target stream, which carries the tape, takes the module route.
+        ref_fused = False
         if xr is not None:
             with torch.no_grad():
-                tr = self._tokens(xr)
+                ref_fused = self._fused_ok(xr) and self.transformer_blocks[0]._fused_ready(
+                    xr.is_cuda, xr.dtype, xr.shape[0] * xr.shape[2] * xr.shape[3], self.proj_in.out_features)
+                if ref_fused:
+                    tr, str_ = self._enter(xr)
+                else:
+                    tr = self._tokens(xr)
         for i, block in enumerate(self.transformer_blocks):
             ci = i if len(context) > 1 else 0
             pose_block = self.image_cross and (i % self.poscontrol_interval == 0)
             if tr is not None:
                 with torch.no_grad():
-                    outr_, pendr = self._run(block, tr, pendr, context=contextr[ci])
-                    tr = outr_[0]
-                    if pose_block:
-                        tr, pendr = self._settle(tr, pendr), None  # a pose block reads the reference stream's tokens
+                    if ref_fused:
+                        tr, _, _, _, _, str_ = block._forward_fused(tr, str_, contextr[ci])
+                    else:
+                        outr_, pendr = self._run(block, tr, pendr, context=contextr[ci])
+                        tr = outr_[0]
+                        if pose_block:
+                            tr, pendr = self._settle(tr, pendr), None  # a pose block reads the reference stream's tokens
             if pose_block:
                 cref = tr.detach() if tr is not None else t  # sample.py passes context_ref=x as a non-None marker (sample.py:57)
                 (t, fg, _, al, rgb), pend = self._run(block, t, pend, context=context[ci], context_ref=cref, pose=pose, mask_ref=mask_ref,
@@ -741,7 +799,7 @@ class SpatialTransformer(nn.Module):
         outr = None
         if tr is not None:
             with torch.no_grad():
-                outr = self._image(self._settle(tr, pendr), xr_in).detach()
+                outr = (self._leave(tr, xr_in) if ref_fused else self._image(self._settle(tr, pendr), xr_in)).detach()
         if len(fg_masks) > 0:
             return out, outr, fg_masks, None, (alphas if alphas else None), (rgbs if rgbs else None)
         return out, outr, None, None, None, None

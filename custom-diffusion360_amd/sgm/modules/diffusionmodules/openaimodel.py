@@ -272,7 +272,11 @@ class UNetModel(nn.Module):
             w = torch.cat([b.emb_layers[1].weight.detach() for b in blocks], 0).contiguous()
             bias = torch.cat([b.emb_layers[1].bias.detach() for b in blocks], 0).contiguous()
             self._emb_cat = (key, w, bias)
-        allp = torch.nn.functional.linear(torch.nn.functional.silu(emb), self._emb_cat[1], self._emb_cat[2])  # [b, sum(out_channels)]
+        act = torch.nn.functional.silu(emb)
+        if ops.linear_ok(act, self._emb_cat[1]) and not os.environ.get("CD360_LIBRARY_LINEAR"):
+            allp = ops.linear(act, self._emb_cat[1], self._emb_cat[2])  # [b, sum(out_channels)] on the hand-written GEMM (M = batch rows)
+        else:
+            allp = torch.nn.functional.linear(act, self._emb_cat[1], self._emb_cat[2])
         outs, off = {}, 0
         for blk in blocks:
             c = blk.out_channels

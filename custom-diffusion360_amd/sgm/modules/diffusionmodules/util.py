@@ -227,8 +227,32 @@ def conv_nd(dims, *args, **kwargs):
     raise ValueError(f"unsupported dimensions: {dims}")
 
 
+class HipLinear(nn.Linear):
+    """nn.Linear (same parameters, same state_dict keys) whose bf16 GPU forward is the hand-written MFMA GEMM in EVERY mode: no tape ->
+    one cd360_gemm_bf16 launch with the bias fused; under autograd -> cd360.grad.LinearFn (data gradient on the same kernel, weight
+    gradient on cd360_gemm_tn_bf16).  Whatever route reaches the module -- the fused inference blocks read its weight directly, but
+    sample.py's patched forwards (sample.py:247-262), hooked blocks (diffusion.py:151-163) and the fine-tuning step call it -- runs the
+    same kernel.  Other dtypes / devices / shapes outside the kernel's envelope (K % 64, N % 16) take torch's F.linear."""
+
+    def forward(self, x):
+        if ops.linear_ok(x, self.weight) and not os.environ.get("CD360_LIBRARY_LINEAR"):
+            return ops.linear(x, self.weight, self.bias)
+        return torch.nn.functional.linear(x, self.weight, self.bias)
+
+
+class HipLayerNorm(nn.LayerNorm):
+    """nn.LayerNorm whose bf16 GPU forward is cd360_add_layernorm_bf16 (differentiable: cd360_add_layernorm_bwd_bf16), so that a route
+    that calls `self.norm1(x)` itself (sample.py:33-80) stays on the HIP kernels."""
+
+    def forward(self, x):
+        if (x.is_cuda and x.dtype == torch.bfloat16 and self.weight is not None and self.weight.dtype == torch.bfloat16 and self.bias is not None
+                and len(self.normalized_shape) == 1 and x.shape[-1] <= 2048 and x.shape[-1] % 8 == 0 and not os.environ.get("CD360_LIBRARY_LINEAR")):
+            return ops.add_layernorm(x.contiguous(), None, self.weight, self.bias, self.eps)[1]
+        return super().forward(x)
+
+
 def linear(*args, **kwargs):
-    return nn.Linear(*args, **kwargs)
+    return HipLinear(*args, **kwargs)
 
 
 def avg_pool_nd(dims, *args, **kwargs):

@@ -179,6 +179,12 @@ int cd360_volrender_bwd(const void* feats, const void* sigma_raw, const void* rg
 /* replaces FeatureNeRFEncoding.decoder, Linear(C -> 1+3, bias=False) (nerfsd_pytorch3d.py:49-51,160) and the channel split in
  * NerfSDModule.forward (:443-449): h [rows, C] bf16, w [4, C] fp32 -> out [rows, 4] fp32 = (rgb_raw 0..2, sigma_raw 3). */
 int cd360_rowdot4_bf16(const void* h, const void* w, void* out, int64_t rows, int C, void* stream);
+/* Backward of cd360_rowdot4_bf16 (the decoder is in the reference's trainkeys `pose`, sgm/models/diffusion.py:139-144; the reference
+ * differentiates nn.Linear through autograd): d [rows, 4] fp32 = gradient of the output; dh [rows, C] bf16 = d w (NULL to skip);
+ * dw_part [cd360_rowdot4_bwd_slabs(rows), 4, C] fp32 = per slab of rows the partial sums of dw = d^T h (NULL to skip; the caller
+ * sums the slabs in order: deterministic). */
+int cd360_rowdot4_bwd_slabs(int64_t rows);
+int cd360_rowdot4_bwd_bf16(const void* d, const void* h, const void* w, void* dh, void* dw_part, int64_t rows, int C, void* stream);
 
 /* ---- GroupNorm (+SiLU) ---------------------------------------------------------------------------------------------
  * replaces GroupNorm32 -> SiLU (sgm/modules/diffusionmodules/util.py:309-311, openaimodel.py:280-283,315-318) and
@@ -277,6 +283,17 @@ int cd360_pose_embed_bf16(const void* x, const void* xref, const void* wa, const
 int cd360_gemm_bf16(const void* a, const void* w, void* out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldo, const void* bias,
                     const void* res, int64_t ldr, const void* ln_stats, int ln_parts, int ln_dim, float ln_eps, const void* wsum,
                     void* stats_out, int flags, void* stream);
+/* Backward of nn.Linear on the fine-tuning path (BASELINE configs[3]; the reference trains through torch autograd of F.linear:
+ * sgm/modules/attention.py:515-516,634 pose_emb_layers, sgm/modules/nerfsd_pytorch3d.py:40-51 plane_coefs / decoder).
+ *   data gradient   dX[M, K] = dY[M, N] W[N, K]      = cd360_gemm_bf16(a = dY, w = W^T [K, N]) -- the same kernel on the transposed weight;
+ *   weight gradient dW[N, K] = dY[M, N]^T X[M, K]    = cd360_gemm_tn_bf16 below: both operands row-major over the CONTRACTION index
+ *     (LDS-DMA staging, transposing LDS reads ds_read_b64_tr_b16 for both MFMA operands, fp32 accumulation, M split over slabs of
+ *     workgroups whose fp32 partial tiles are summed in a fixed order: deterministic, no atomics).
+ * out[N, K] = A[M, N]^T B[M, K]; A, B bf16, row strides lda >= N, ldb >= K (elements, multiples of 8), N % 8 == 0, K % 8 == 0, 16-byte
+ * aligned pointers; out_dtype 0: fp32, 1: bf16; ws = cd360_gemm_tn_workspace_bytes(M, N, K) bytes of scratch. */
+int64_t cd360_gemm_tn_workspace_bytes(int64_t M, int N, int K);
+int cd360_gemm_tn_bf16(const void* a, const void* b, void* out, int64_t M, int N, int K, int64_t lda, int64_t ldb, int out_dtype, void* ws,
+                       void* stream);
 /* replaces to_q (nn.Linear, attention.py:323,368) + xformers.ops.memory_efficient_attention (attention.py:406) of a cross-attention whose
  * context has Nk <= 96 tokens -- attn2 over the 77 text tokens, in every transformer block (attention.py:620-625) and on the FeatureNeRF
  * pose tokens (attention.py:578-588, the north-star kernel: 98 304 queries per batch element at 1024^2): the query projection and
