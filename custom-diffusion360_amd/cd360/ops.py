@@ -767,9 +767,9 @@ def gemm_cstats(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
 
 
 def qproj_attention_ok(a: torch.Tensor, nk: int) -> bool:
-    """Shape envelope of qproj_attention: [b, Nq, K] queries with Nq % 256 == 0 (a 256-token tile stays inside one batch element),
+    """Shape envelope of qproj_attention: [b, Nq, K] queries with Nq % 128 == 0 (a token tile stays inside one batch element),
     K % 64 == 0, at most 96 keys."""
-    return a.dim() == 3 and a.shape[1] % 256 == 0 and a.shape[2] % 64 == 0 and nk <= 96
+    return a.dim() == 3 and a.shape[1] % 128 == 0 and a.shape[2] % 64 == 0 and nk <= 96
 
 
 def qproj_attention(a: torch.Tensor, w: torch.Tensor, k: torch.Tensor, v: torch.Tensor, nk: int, heads: int,

@@ -114,7 +114,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   constexpr int NWC = NWT * KS;                    // waves that multiply
   constexpr int NW = NWC + MV;                     // waves
   constexpr int NWD = MV ? MV : NW;                // waves that move data
-  static_assert(MV == 0 || (EPI == 0 || EPI == 1 || EPI == 5 || EPI == 6), "mover waves: linear / GEGLU / convolution epilogues");
+  static_assert(MV == 0 || (EPI >= 0 && EPI <= 6), "mover waves: every epilogue (in the attention epilogues they only help stage K / V)");
   constexpr int KPW = 4 / KS;                      // k-steps of a K-tile that one wave multiplies
   constexpr int BM = WM * NMB * 32, BN = WN * NCB * 32;
   constexpr uint32_t XB = BM * 128, WB = BN * 128;  // bytes of one buffer of each operand (64-deep K-tile, 128-byte rows)
@@ -541,7 +541,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   constexpr int NKB = ATTN ? EPI - 1 : 1, NKEYS = NKB * 32, HEAD_LDS = 2 * NKEYS * 128;  // per head: K rows then V rows, 128 B each
   auto attn_tile = [&]() {
     if constexpr (ATTN) {
-      static_assert(!ATTN || (NCB == 2 && NMB == 4 && WN == 4), "one head per wave");
+      static_assert(!ATTN || NCB == 2, "one head (64 channels) per wave; any number of 32-token blocks and of heads per tile");
       unsigned char* const Ks = lds + wc * HEAD_LDS;
       unsigned char* const Vs = Ks + NKEYS * 128;
       unsigned char* const Os = lds + WN * HEAD_LDS + wave * (32 * 128);  // this wave's 32-token output block
@@ -862,7 +862,10 @@ int launch_mv(const GemmParams& p0, hipStream_t stream) {
   GemmParams p = p0;
   constexpr int BM = WM * NMB * 32, BN = WN * NCB * 32;
   // K-loop buffers, reused as the output staging image (+ the fp32 partial tile of the second k-step group)
-  constexpr int RING_BYTES = NBUF * (BM + BN) * 128, STAGE_BYTES = BM * BN * 2 + (KS == 2 ? BM * BN * 4 : 0);
+  // (the attention epilogues stage K / V rows of the tile's WN heads, 2 x NKB x 32 rows of 128 bytes each, plus a 4-KB output block per wave)
+  constexpr int ATTN_BYTES = (EPI >= 2 && EPI <= 4) ? WN * 2 * (EPI - 1) * 32 * 128 + (WM * WN * KS + MV) * 4096 : 0;
+  constexpr int RING_BYTES = NBUF * (BM + BN) * 128, STAGE_BYTES0 = BM * BN * 2 + (KS == 2 ? BM * BN * 4 : 0);
+  constexpr int STAGE_BYTES = STAGE_BYTES0 > ATTN_BYTES ? STAGE_BYTES0 : ATTN_BYTES;
 #ifdef CD360_GEMM_STAMP
   constexpr int BASE_BYTES = RING_BYTES > STAGE_BYTES ? RING_BYTES : STAGE_BYTES;
   constexpr int STAMP_BYTES = BASE_BYTES + WM * WN * KS * 64 * 32 <= 160 * 1024 ? WM * WN * KS * 64 * 32 : 0;
@@ -899,7 +902,7 @@ int launch_mv(const GemmParams& p0, hipStream_t stream) {
 // arrangements they were measured to help (tools/bench_gemm.py movers).
 template <int WM, int WN, int NCB, int NMB, int NBUF, int KS, int EPI>
 int launch_ks(const GemmParams& p, hipStream_t stream) {
-  constexpr bool CAN = (EPI == 0 || EPI == 1 || EPI == 5 || EPI == 6) && NCB * NMB <= 6 && WM * WN * KS + 4 <= 16;
+  constexpr bool CAN = NCB * NMB <= 6 && WM * WN * KS + 4 <= 16;
   if constexpr (CAN) {
     // measured (hipGraph-timed, interleaved): the four- and three-buffer arrangements -5 ... -10 % (C -> C 18.7 -> 17.8 us, FF2 50.1 -> 47.0,
     // 3 x 3 convolutions at 32^2 / 64^2 108 -> 98 / 176 -> 161), 256 x 192 -2.6 %, the two-buffer 128 x 128 with two workgroups per CU +-0
@@ -1037,7 +1040,7 @@ extern "C" int cd360_gemm_cstats_bf16(const void* a, const void* w, void* out, i
 // out[M, N] = softmax_keys((A W^T [LayerNorm-folded] + bias) K_h^T * scale) V_h per head h (N = heads * 64): the query projection of a
 // cross-attention over Nk <= 96 keys fused with the attention itself -- Q never exists in memory.  A, W, bias, ln_stats, wsum as in
 // cd360_gemm_bf16; k, v bf16 [B, >= Nk, N] (element strides k_sb / k_sn, v_sb / v_sn: batch, key; head h at columns 64 h .. 64 h + 63),
-// M = B * Nq with Nq % 256 == 0 (a 256-token tile never straddles two batch elements).
+// M = B * Nq with Nq % 128 == 0 (a token tile never straddles two batch elements; 256-token tiles need Nq % 256 == 0).
 // `dup` > 0: the last `dup` of the B = M / Nq query batch elements each attend to TWO key / value sets -- k, v then hold B + dup batch
 // elements and out (B + dup) Nq rows: query element i >= B - dup writes batch i (keys of batch i) and batch i + dup (keys of batch
 // i + dup).  The 3-way CFG batch of sample.py has identical pose tokens in its two image-conditional thirds: q is projected once.
@@ -1046,7 +1049,13 @@ extern "C" int cd360_qproj_attn_dedup_bf16(const void* a, const void* w, void* o
                                            const void* k, const void* v, int64_t k_sb, int64_t k_sn, int64_t v_sb, int64_t v_sn, int Nq, int Nk,
                                            float scale, int dup, void* stream) {
   if (!a || !w || !out || !k || !v || M <= 0 || N <= 0 || K <= 0 || Nq <= 0 || Nk <= 0 || dup < 0 || (int64_t)dup * Nq > M) return CD360_ERR_ARG;
-  if (K % 64 || N % 64 || lda % 8 || ldw % 8 || ldo % 8 || lda < K || ldw < K || Nk > 96 || Nq % 256 || M % Nq) return CD360_ERR_SHAPE;
+  if (K % 64 || N % 64 || lda % 8 || ldw % 8 || ldo % 8 || lda < K || ldw < K || Nk > 96 || Nq % 128 || M % Nq) return CD360_ERR_SHAPE;
+  // tile: 256 tokens x 256 channels (four heads, eight waves of 128 x 64: the FeatureNeRF pose tokens, 10^5 rows) or 128 x 128 (two
+  // heads, eight waves of 32 x 64 + four mover waves, four LDS buffers: the text cross-attention of every block, M = 3072 ... 12288, where
+  // 256 x 256 tiles would leave most of the 256 CUs idle)
+  int qcfg = cd360_tune().qattn_cfg;
+  if (qcfg != 1 && qcfg != 2) qcfg = (M / 256) * ((N + 255) / 256) >= 200 ? 1 : 2;
+  if (Nq % 256) qcfg = 2;
   if (k_sb % 8 || k_sn % 8 || v_sb % 8 || v_sn % 8) return CD360_ERR_SHAPE;
   if (((uintptr_t)a | (uintptr_t)w | (uintptr_t)out | (uintptr_t)k | (uintptr_t)v) % 16) return CD360_ERR_ARG;
   if (((uintptr_t)bias | (uintptr_t)ln_stats | (uintptr_t)wsum) % 8) return CD360_ERR_ARG;
@@ -1062,6 +1071,11 @@ extern "C" int cd360_qproj_attn_dedup_bf16(const void* a, const void* w, void* o
   p.a_nq = Nq; p.a_nk = Nk; p.a_scale_log2e = scale * 1.4426950408889634f;
   p.a_dup = dup; p.a_dup_from = (int)(M / Nq) - dup;
   p.cv_H = p.cv_W = p.cv_kg = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = nullptr;
+  if (qcfg == 2) {
+    if (Nk <= 32) return launch_epi<4, 2, 2, 1, 4, 2>(p, (hipStream_t)stream);
+    if (Nk <= 64) return launch_epi<4, 2, 2, 1, 4, 3>(p, (hipStream_t)stream);
+    return launch_epi<4, 2, 2, 1, 4, 4>(p, (hipStream_t)stream);
+  }
   if (Nk <= 32) return launch_epi<2, 4, 2, 4, 2, 2>(p, (hipStream_t)stream);
   if (Nk <= 64) return launch_epi<2, 4, 2, 4, 2, 3>(p, (hipStream_t)stream);
   return launch_epi<2, 4, 2, 4, 2, 4>(p, (hipStream_t)stream);

@@ -26,6 +26,8 @@ constexpr int CN = 64;          // channels per workgroup
 constexpr int KP = 112;         // padded K of the per-sample GEMM (7 k-steps of 16)
 constexpr int W_PITCH = 240;    // bytes per Wk row in LDS (224 + 16 pad: conflict-free ds_read_b128)
 constexpr int TILES_PER_WAVE = 4;
+constexpr bool NERF_LINE_DEFAULT = true;  // which render kernel cd360_tuning.nerf_kernel = -1 selects: the full-line kernel measures -3 % (1280
+                                          // channels) / -8 ... -9 % (640 channels) against the register-gather kernel, bit-identical
 constexpr int PTS_PER_WG = 4 * 32 * TILES_PER_WAVE;
 
 struct NerfParams {
@@ -203,6 +205,305 @@ __global__ __launch_bounds__(256, 2) void nerf_fused_kernel(NerfParams p) {
         for (int e = 0; e < 4; ++e) {
           o0[e] = pack_bf16x2(g[mb][2 * e] * inv, g[mb][2 * e + 1] * inv);
           o1[e] = pack_bf16x2(g[mb][8 + 2 * e] * inv, g[mb][8 + 2 * e + 1] * inv);
+        }
+        *reinterpret_cast<u32x4*>(dst + mb * 32) = o0;
+        *reinterpret_cast<u32x4*>(dst + mb * 32 + 8) = o1;
+      }
+      if (p.lse && hh == 0 && cc == 0) {
+        p.lse[((long)bi * npts + pt) * 2] = m_run * 0.6931471805599453f;
+        p.lse[((long)bi * npts + pt) * 2 + 1] = l_run;
+      }
+    }
+  }
+}
+
+// ---- the same operator with FULL-LINE gathers staged through the wave's own LDS block ------------------------------------------------
+// nerf_fused_kernel is bound by the vector-memory RETURN path, not by its arithmetic (TD_TD_BUSY = 100 % of the kernel's CU-cycles; builds
+// without the sin / cos or without the SiLU transcendentals run no faster): with lane = sample every gather instruction returns 32
+// different cache lines, 32 bytes of each, and every line is visited by four instructions.  Here the four corner rows of a view travel as
+// FULL 128-byte lines: 8 lanes per row (lane i of piece j fetches the 16-byte chunk i % 8 of sample 8 j + i / 8, whose table pixel it
+// gets from that sample's lane by ds_bpermute), 16 load instructions x 8 lines per wave and view instead of 32 x 32 line returns -- the
+// "coalesced gather with LDS staging" of the north star.  The rows arrive in REGISTERS (ordinary buffer loads, so the wave's own vmcnt
+// orders them -- unlike LDS-DMA pieces, which need a workgroup barrier before they can be read and cost this kernel its gain, see the
+// probe kernel below), are written to a wave-private LDS block of four 4-KB corner slots (16-byte chunks XOR-swizzled by the sample:
+// conflict-free ds_write_b128 / ds_read_b128) and read back in the compute layout (lane = sample, 2 x 16 channels).  Software pipeline,
+// one view ahead: the loads of view iv+1 are issued before the encoding MFMAs of view iv and written to the slots after view iv's blend
+// has consumed them, so neither the gather latency nor the LDS round trip is exposed.  The arithmetic and its order are those of
+// nerf_fused_kernel: bit-identical outputs.  No workgroup barrier in the loop.
+constexpr int SLOT_BYTES = 32 * 128;            // one corner: 32 samples x 128 B
+constexpr int WAVE_LDS = 4 * SLOT_BYTES;        // four corners per wave
+
+__global__ __launch_bounds__(256, 2) void nerf_fused_line_kernel(NerfParams p) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char smem_line[];
+  unsigned char* const Ws = smem_line + 4 * WAVE_LDS;       // CN x W_PITCH
+  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  unsigned char* const slots = smem_line + wave * WAVE_LDS;
+  const int hw = p.r * p.r;
+  const long npts = (long)hw * p.S;
+
+  const int wg = xcd_remap(blockIdx.x, gridDim.x);
+  const int cc = wg / (p.b * p.ngroups);
+  const int rem = wg - cc * (p.b * p.ngroups);
+  const int bi = rem / p.ngroups, grp = rem - bi * p.ngroups;
+  const int ch0 = cc * CN;
+
+  for (int idx = tid; idx < CN * (KP / 8); idx += 256) {
+    const int row = idx / (KP / 8), c8 = idx - row * (KP / 8);
+    *reinterpret_cast<u32x4*>(Ws + row * W_PITCH + c8 * 16) = *reinterpret_cast<const u32x4*>(p.Wk + (long)(ch0 + row) * KP + c8 * 8);
+  }
+  __syncthreads();
+
+  const float hs = hh ? 2.f : 1.f;
+  const int arow0 = chan_pos(l31);
+  typedef const __attribute__((address_space(4))) float cfloat;
+  typedef const __attribute__((address_space(4))) int cint;
+  cfloat* const cams_c = (cfloat*)(p.cams);
+  cfloat* const cview_c = (cfloat*)(p.cview);
+  cint* const imap_c = (cint*)(p.img_map);
+  const __amdgpu_buffer_rsrc_t yrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.Y, 0, 0xffffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t zrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.zP, 0, 0xffffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t lrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.lv, 0, 0xffffffff, 0x00020000);
+  const uint32_t row_bytes = (uint32_t)p.C * 2u;
+  const uint32_t lane_off = (uint32_t)(ch0 + 16 * hh) * 2u;  // this lane's 32 bytes of a 64-channel slice (block mb: + 64 B)
+  // loader role: piece j moves samples 8 j .. 8 j + 7; this lane: sample 8 j + lane / 8, chunk lane % 8 of its 128-byte row
+  const int dsub = lane >> 3, dchunk = lane & 7;
+  const uint32_t ld_off = (uint32_t)(ch0 * 2 + dchunk * 16);
+  // LDS: sample s, chunk q at s * 128 + ((q ^ ((s >> 1) & 7)) << 4); loader writes (8 j + dsub, dchunk), compute reads (l31, 4 mb + 2 hh + t)
+  int wr_off[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int smp = 8 * j + dsub;
+    wr_off[j] = smp * 128 + ((dchunk ^ ((smp >> 1) & 7)) << 4);
+  }
+  const int rswz = (l31 >> 1) & 7;
+
+  for (int tw = 0; tw < TILES_PER_WAVE; ++tw) {
+    const long pt0 = (long)grp * PTS_PER_WG + (wave * TILES_PER_WAVE + tw) * 32;
+    if (pt0 >= npts) break;  // wave-uniform
+    const long pt = pt0 + l31;
+    const bool valid = pt < npts;
+    const long ptc = valid ? pt : npts - 1;
+    const int k = (int)(ptc / p.S), s = (int)(ptc - (long)k * p.S);
+    float P[3];
+    {
+      const Cam c0 = load_cam(p.cams + (long)bi * (p.n + 1) * 16);
+      float o[3], d[3];
+      patch_ray(c0, p.xs[k % p.r], p.ys[k / p.r], o, d);
+      const float ts = p.t[(long)k * p.t_ray_stride + s];
+#pragma unroll
+      for (int j = 0; j < 3; ++j) P[j] = o[j] + ts * d[j];
+    }
+
+    struct Geo {
+      float q[3], w[4], lvv[4], cv;  // lvv: the four gathered logit texels, raw (combined one iteration after their loads were issued)
+      int pix[4];                    // table pixel (image included) of the four corners
+    };
+    auto geometry = [&](int iv, Geo& G) {  // projection, corners, weights of view iv; issues its four logit-texel loads
+      Cam ci;
+      {
+        const cfloat* cp = cams_c + ((long)bi * (p.n + 1) + 1 + iv) * 16;  // per-view uniforms: scalar loads
+#pragma unroll
+        for (int i = 0; i < 9; ++i) ci.R[i] = cp[i];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) ci.T[i] = cp[9 + i];
+        ci.f[0] = cp[12]; ci.f[1] = cp[13]; ci.c[0] = cp[14]; ci.c[1] = cp[15];
+      }
+      world_to_view(ci, P, G.q);
+      const Corner cr = bilinear_corner(grid_coord(ci.f[0], ci.c[0], G.q[0], G.q[2]), grid_coord(ci.f[1], ci.c[1], G.q[1], G.q[2]), p.r);
+      const int x0 = min(max(cr.x0, 0), p.r - 1), x1 = min(max(cr.x0 + 1, 0), p.r - 1);
+      const int y0 = min(max(cr.y0, 0), p.r - 1), y1 = min(max(cr.y0 + 1, 0), p.r - 1);
+      const int img = bi * p.n + iv;
+      const int yimg = p.img_map ? imap_c[img] : img;
+      G.pix[0] = yimg * hw + y0 * p.r + x0;
+      G.pix[1] = yimg * hw + y0 * p.r + x1;
+      G.pix[2] = yimg * hw + y1 * p.r + x0;
+      G.pix[3] = yimg * hw + y1 * p.r + x1;
+      G.w[0] = (1.f - cr.tx) * (1.f - cr.ty);
+      G.w[1] = cr.tx * (1.f - cr.ty);
+      G.w[2] = (1.f - cr.tx) * cr.ty;
+      G.w[3] = cr.tx * cr.ty;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) if (!((cr.mask >> c) & 1)) G.w[c] = 0.f;
+      G.cv = cview_c[img];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) G.lvv[c] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(lrsrc, (uint32_t)G.pix[c] * 4u, 0, 0));
+    };
+    u32x4 zp[2][2];
+    auto load_zp = [&](int iv) {
+      const uint32_t off = (uint32_t)((bi * p.n + iv) * hw + k) * row_bytes + lane_off;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        zp[mb][0] = __builtin_amdgcn_raw_buffer_load_b128(zrsrc, off + mb * 64, 0, 0);
+        zp[mb][1] = __builtin_amdgcn_raw_buffer_load_b128(zrsrc, off + mb * 64 + 16, 0, 0);
+      }
+    };
+    // the 16 full-line loads of a view travel as two halves through the SAME 32 registers: corners 0, 1 then corners 2, 3;
+    // L[c][j] = chunk dchunk of the row of sample 8 j + dsub under corner 2 half + c
+    u32x4 L[2][4];
+    auto load_rows = [&](const Geo& G, int half) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int px = __builtin_amdgcn_ds_bpermute(4 * (8 * j + dsub), half ? G.pix[2 + c] : G.pix[c]);
+          L[c][j] = __builtin_amdgcn_raw_buffer_load_b128(yrsrc, (uint32_t)px * row_bytes + ld_off, 0, 0);
+        }
+    };
+    auto store_rows = [&](int half) {
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) *reinterpret_cast<u32x4*>(slots + (2 * half + c) * SLOT_BYTES + wr_off[j]) = L[c][j];
+    };
+
+    float m_run = -INFINITY, l_run = 0.f;
+    f32x2 g[2][8];  // channel pairs: the blend / SiLU / accumulate passes run on packed fp32 instructions (v_pk_fma_f32, v_pk_mul_f32,
+                    // v_pk_add_f32: two channels per issue slot, each half rounded exactly like the scalar instruction)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { g[0][i] = f32x2{0.f, 0.f}; g[1][i] = f32x2{0.f, 0.f}; }
+
+    // prologue: corners 0, 1 of view 0 in their slots, corners 2, 3 in flight (the previous tile's reads of the slots are complete: its
+    // blend consumed them)
+    Geo cur, nxt;
+    geometry(0, cur);
+    load_zp(0);
+    load_rows(cur, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    store_rows(0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_rows(cur, 1);
+    __builtin_amdgcn_sched_barrier(0);
+
+    for (int iv = 0; iv < p.n; ++iv) {
+      const bool more = iv + 1 < p.n;
+      // corners 2, 3 of THIS view (requested before the previous view's SiLU pass) -> slots 2, 3, which the previous blend has released
+      store_rows(1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) {
+        geometry(iv + 1, nxt);
+        load_rows(nxt, 0);  // corners 0, 1 of the next view: in flight during this view's encoding and blend
+      } else {
+        nxt = cur;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+
+      // ---- per-sample inputs in B-operand layout: lane half h handles frequencies 2*kfp + h ----
+      const float qh[3] = {cur.q[0] * hs, cur.q[1] * hs, cur.q[2] * hs};
+      f32x16 z[2];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) { z[0][i] = 0.f; z[1][i] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 7; ++ks) {
+        uint32_t fw[4];
+#pragma unroll
+        for (int pr = 0; pr < 4; ++pr) {
+          const int wi = ks * 4 + pr;
+          if (wi < 24) {
+            const int comp = wi % 3, kfp = wi / 3;
+            const float rev = __builtin_amdgcn_fractf(qh[comp] * __builtin_bit_cast(float, (uint32_t)((127 + 2 * kfp - 9) << 23)));
+            fw[pr] = pack_bf16x2(__builtin_amdgcn_sinf(rev), __builtin_amdgcn_cosf(rev));
+          } else if (wi == 24) {
+            fw[pr] = pack_bf16x2(hh ? cur.q[2] : cur.q[0], hh ? 0.f : cur.q[1]);
+          } else {
+            fw[pr] = 0u;
+          }
+        }
+        u32x4 fv = {fw[0], fw[1], fw[2], fw[3]};
+        const bf16x8 fb = __builtin_bit_cast(bf16x8, fv);
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb) {
+          const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ws + (mb * 32 + arow0) * W_PITCH + ks * 32 + hh * 16);
+          z[mb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, fb, z[mb], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);  // one k-step per scheduling region: bounds the live sin / cos temporaries
+      }
+
+      // ---- online softmax over views (texels and constant of this view were requested one iteration ago) ----
+      float logit = cur.cv;
+#pragma unroll
+      for (int c = 0; c < 4; ++c) logit = fmaf(cur.w[c], cur.lvv[c], logit);
+      const float lg = logit * 1.4426950408889634f;
+      const float m_new = fmaxf(m_run, lg);
+      const float sc = __builtin_amdgcn_exp2f(m_run - m_new);
+      const float a = __builtin_amdgcn_exp2f(lg - m_new);
+      l_run = fmaf(l_run, sc, a);
+      m_run = m_new;
+      if (p.logits) {
+        if (valid && hh == 0 && cc == 0) p.logits[((long)bi * p.n + iv) * npts + pt] = logit;
+      }
+
+      // ---- z += zP, then the four corners in turn (the same order of additions as nerf_fused_kernel) ----
+      f32x2 zv[2][8];
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t d = zp[mb][half][e];
+            zv[mb][half * 4 + e] = f32x2{z[mb][half * 8 + 2 * e], z[mb][half * 8 + 2 * e + 1]} + f32x2{bf16lo_to_f32(d), bf16hi_to_f32(d)};
+          }
+      __builtin_amdgcn_sched_barrier(0);
+      if (more) load_zp(iv + 1);  // into the registers consumed above: one iteration of flight time
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        __builtin_amdgcn_sched_barrier(0);  // one corner per scheduling region: bounds the live read-back registers
+        u32x4 y[2][2];
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int t = 0; t < 2; ++t)
+            y[mb][t] = *reinterpret_cast<const u32x4*>(slots + c * SLOT_BYTES + l31 * 128 + (((4 * mb + 2 * hh + t) ^ rswz) << 4));
+        const f32x2 wc = {cur.w[c], cur.w[c]};
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int half = 0; half < 2; ++half)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const uint32_t d = y[mb][half][e];
+              zv[mb][half * 4 + e] = __builtin_elementwise_fma(wc, f32x2{bf16lo_to_f32(d), bf16hi_to_f32(d)}, zv[mb][half * 4 + e]);
+            }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      // slots 0, 1 are free (the blend has consumed every read of them): the next view's corners 0, 1, requested before the encoding, go
+      // in, and its corners 2, 3 are requested into the same registers -- they land during the SiLU pass and the next view's geometry
+      if (more) {
+        store_rows(0);
+        __builtin_amdgcn_sched_barrier(0);
+        load_rows(nxt, 1);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+
+      // ---- g = g*sc + a*silu(z) ----
+      {
+        const f32x2 av = {a, a}, scv = {sc, sc}, one = {1.f, 1.f}, nl2e = {-1.4426950408889634f, -1.4426950408889634f};
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+          for (int i = 0; i < 8; ++i) {
+            const f32x2 zz = zv[mb][i];
+            const f32x2 t = nl2e * zz;
+            const f32x2 den = one + f32x2{__builtin_amdgcn_exp2f(t[0]), __builtin_amdgcn_exp2f(t[1])};
+            const f32x2 sv = zz * f32x2{__builtin_amdgcn_rcpf(den[0]), __builtin_amdgcn_rcpf(den[1])};
+            g[mb][i] = __builtin_elementwise_fma(av, sv, g[mb][i] * scv);
+          }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      cur = nxt;
+    }
+
+    if (valid) {
+      const float inv = 1.f / l_run;
+      uint16_t* dst = p.g + ((long)bi * npts + pt) * p.C + ch0 + 16 * hh;
+#pragma unroll
+      for (int mb = 0; mb < 2; ++mb) {
+        u32x4 o0, o1;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          o0[e] = pack_bf16x2(g[mb][e][0] * inv, g[mb][e][1] * inv);
+          o1[e] = pack_bf16x2(g[mb][4 + e][0] * inv, g[mb][4 + e][1] * inv);
         }
         *reinterpret_cast<u32x4*>(dst + mb * 32) = o0;
         *reinterpret_cast<u32x4*>(dst + mb * 32 + 8) = o1;
@@ -611,6 +912,18 @@ extern "C" int cd360_nerf_mlp_aggregate(const void* cams, const void* xs, const 
     return CD360_OK;
   }
 #endif
+  // cd360_tuning.nerf_kernel: 0 = register gathers (32-byte pieces of 32 lines per instruction), 1 = full-line gathers staged through the
+  // wave's LDS block (tables addressable with 32-bit byte offsets); -1 = the measured default
+  const int variant = cd360_tune().nerf_kernel;
+  const bool lines = (variant == 1 || (variant < 0 && NERF_LINE_DEFAULT)) && (long)b * n * r * r * C * 2 < (1L << 32) && (long)b * n * r * r * 4 < (1L << 32);
+  if (lines) {
+    constexpr int LDS_LINE = 4 * WAVE_LDS + CN * W_PITCH;
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&nerf_fused_line_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_LINE);
+    if (attr != hipSuccess) return CD360_ERR_LAUNCH;
+    hipLaunchKernelGGL(nerf_fused_line_kernel, dim3((unsigned)nwg), dim3(256), LDS_LINE, (hipStream_t)stream, p);
+    CD360_LAUNCH_CHECK();
+    return CD360_OK;
+  }
   hipLaunchKernelGGL(nerf_fused_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
   CD360_LAUNCH_CHECK();
   return CD360_OK;

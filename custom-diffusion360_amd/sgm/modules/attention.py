@@ -508,9 +508,12 @@ class BasicTransformerBlock(nn.Module):
         o = ops.attention(qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:], a1.heads, x.shape[1], prescaled=True)
         x, stats = ops.gemm(o, P["o1"][0], bias=P["o1"][1], res=x, want_stats=True)
         w, ws, cb = P["q2"]
-        q = ops.gemm(x, w, bias=cb, ln=(stats, ws, self.norm2.eps))
         k, v, nk = a2.project_context(context)
-        o = ops.attention(q, k, v, a2.heads, nk)
+        if ops.qproj_attention_ok(x, nk) and k.shape[0] == x.shape[0] and not os.environ.get("CD360_NO_A2_FUSE"):
+            # text cross-attention (attention.py:620-625): LayerNorm fold + q projection + softmax(q K^T) V in ONE kernel, q never in HBM
+            o = ops.qproj_attention(x, w, k, v, nk, a2.heads, bias=cb, ln=(stats, ws, self.norm2.eps))
+        else:
+            o = ops.attention(ops.gemm(x, w, bias=cb, ln=(stats, ws, self.norm2.eps)), k, v, a2.heads, nk)
         if context_ref is None:
             x, stats = ops.gemm(o, P["o2"][0], bias=P["o2"][1], res=x, want_stats=True)
         else:

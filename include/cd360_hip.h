@@ -299,7 +299,7 @@ int cd360_gemm_tn_bf16(const void* a, const void* b, void* out, int64_t M, int N
  * pose tokens (attention.py:578-588, the north-star kernel: 98 304 queries per batch element at 1024^2): the query projection and
  * softmax(q k^T * scale) v run in ONE kernel, Q never exists in memory.  a / w / bias / ln_stats / wsum as in cd360_gemm_bf16 (optional
  * LayerNorm fold of norm2 in front of to_q); N = heads * 64; k, v bf16 [B, >= Nk, N] with element strides (batch, key), head h at
- * columns 64 h; out bf16 [M, N] (row stride ldo), M = B * Nq, Nq % 256 == 0. */
+ * columns 64 h; out bf16 [M, N] (row stride ldo), M = B * Nq, Nq % 128 == 0 (tiles of 256 x 256 for tall problems, 128 x 128 when those would not fill the 256 CUs). */
 int cd360_qproj_attn_bf16(const void* a, const void* w, void* out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldo,
                           const void* bias, const void* ln_stats, int ln_parts, int ln_dim, float ln_eps, const void* wsum, const void* k,
                           const void* v, int64_t k_sb, int64_t k_sn, int64_t v_sb, int64_t v_sn, int Nq, int Nk, float scale, void* stream);

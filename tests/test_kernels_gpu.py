@@ -225,6 +225,7 @@ def test_render_kernel_full_line_gathers_equal_register_gathers(C, r, n, S, b, v
     g = torch.Generator().manual_seed(C)
     zP = bf(torch.randn(b * n, r * r, C, generator=g)).to(DEV, torch.bfloat16)
     cview = nerf.view_constants(fw, cams)
+    tune(nerf_kernel=0)
     ref = ops.nerf_mlp_aggregate(cams, xs, xs, t, Y, zP, lv, cview, fw.Wk, want_logits=True)
     tune(nerf_kernel=variant)
     outs = [ops.nerf_mlp_aggregate(cams, xs, xs, t, Y, zP, lv, cview, fw.Wk, want_logits=True) for _ in range(8)]

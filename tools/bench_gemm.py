@@ -81,8 +81,18 @@ def check_case(M, N, K, bias=False, res=False, ln=False, geglu=False, stats=Fals
     return ok
 
 
-def check_qattn(b, nq, C, K, nk, ln=True):
-    """qproj_attention against fp32 torch: LayerNorm -> Linear -> softmax(q k^T / 8) v per head."""
+def check_qattn(b, nq, C, K, nk, ln=True, qcfg=None):
+    """qproj_attention against fp32 torch: LayerNorm -> Linear -> softmax(q k^T / 8) v per head.  qcfg forces the tile (1: 256 x 256,
+    2: 128 x 128 with mover waves); None = the launch's own choice."""
+    if qcfg:
+        ENV["CD360_QATTN_CFG"] = str(qcfg)
+    try:
+        return _check_qattn(b, nq, C, K, nk, ln, qcfg)
+    finally:
+        ENV.pop("CD360_QATTN_CFG", None)
+
+
+def _check_qattn(b, nq, C, K, nk, ln, qcfg):
     heads = C // 64
     a = (rnd(b, nq, K, seed=11) * (0.5 + rnd(b, nq, 1, seed=12).abs()) + 0.5 * rnd(b, nq, 1, seed=13)).to(torch.bfloat16)
     w = rnd(C, K, seed=14, scale=K ** -0.5)
@@ -106,7 +116,7 @@ def check_qattn(b, nq, C, K, nk, ln=True):
     e = relerr(got[0], want)
     same = all(torch.equal(got[0], g) for g in got[1:])
     ok = same and e < 1e-2 and bool(torch.isfinite(got[0]).all())
-    print(("ok   " if ok else "FAIL ") + f"qproj_attention b={b} nq={nq} C={C} K={K} nk={nk} ln={int(ln)}: err {e:.2e} repeat-equal {same}", flush=True)
+    print(("ok   " if ok else "FAIL ") + f"qproj_attention b={b} nq={nq} C={C} K={K} nk={nk} ln={int(ln)} tile={qcfg or 'auto'}: err {e:.2e} repeat-equal {same}", flush=True)
     return ok
 
 
@@ -118,6 +128,12 @@ def check():
     ok &= check_qattn(2, 256, 1280, 1280, 50)
     ok &= check_qattn(1, 768, 256, 320, 96)
     ok &= check_qattn(2, 256, 128, 192, 20)
+    for qcfg in (1, 2):  # both tiles on the same shapes; 128-token multiples only on the 128 x 128 tile
+        ok &= check_qattn(3, 1024, 1280, 1280, 77, qcfg=qcfg)
+        ok &= check_qattn(2, 512, 640, 640, 77, qcfg=qcfg)
+        ok &= check_qattn(1, 256, 192, 128, 33, qcfg=qcfg)
+    ok &= check_qattn(2, 384, 320, 320, 77, qcfg=2)
+    ok &= check_qattn(3, 128, 128, 64, 20, ln=False, qcfg=2)
     for cfg in (1, 2, 3, 4, 5, 6, 7):
         for (M, N, K) in [(256, 256, 64), (256, 256, 128), (512, 512, 192), (300, 272, 320), (128, 128, 64), (1000, 640, 640), (3072, 1280, 1280)]:
             ok &= check_case(M, N, K, cfg=cfg)
@@ -190,7 +206,8 @@ VARIANTS = [(0, 0)]  # 0 = the tiling pick_cfg chooses (the product path); CD360
 
 
 def time_qattn():
-    """The pose-token attention (A3) and the text cross-attention (A2) at cfg-B: fused kernel against q GEMM + small-Nk attention."""
+    """The pose-token attention (A3) and the text cross-attention (A2) at cfg-B: fused kernel (both tiles) against q GEMM + small-Nk
+    attention; hipGraph-timed."""
     for name, b, nq, C in (("A3 L1", 3, 98304, 640), ("A3 L2", 3, 24576, 1280), ("A2 L1", 3, 4096, 640), ("A2 L2", 3, 1024, 1280)):
         heads = C // 64
         a = rnd(b, nq, C, seed=1).to(torch.bfloat16)
@@ -200,13 +217,18 @@ def time_qattn():
         kv = rnd(b, 80, 2 * C, seed=4).to(torch.bfloat16)
         k, v = kv[..., :C], kv[..., C:]
         st = ops.row_stats(a)
-        t_f = timeit(lambda: ops.qproj_attention(a, w, k, v, 77, heads, bias=cb, ln=(st, ws, 1e-5)), iters=20, warm=3)
-        t_g = timeit(lambda: ops.gemm(a, w, bias=cb, ln=(st, ws, 1e-5)), iters=20, warm=3)
+        n = 10 if nq > 50000 else 30
+        t_f = {}
+        for qcfg in (1, 2):
+            ENV["CD360_QATTN_CFG"] = str(qcfg)
+            t_f[qcfg] = timeit_graph(lambda: ops.qproj_attention(a, w, k, v, 77, heads, bias=cb, ln=(st, ws, 1e-5)), n=n)
+        ENV.pop("CD360_QATTN_CFG", None)
+        t_g = timeit_graph(lambda: ops.gemm(a, w, bias=cb, ln=(st, ws, 1e-5)), n=n)
         q = ops.gemm(a, w, bias=cb, ln=(st, ws, 1e-5))
-        t_a = timeit(lambda: ops.attention(q, k, v, heads, 77), iters=20, warm=3)
-        t_l = timeit(lambda: F.linear(a, w), iters=20, warm=3)
+        t_a = timeit_graph(lambda: ops.attention(q, k, v, heads, 77), n=n)
         flops = b * nq * (2.0 * C * C + 4.0 * 77 * C)
-        print(f"{name}: fused q-proj+attention {t_f:7.1f} us ({flops / t_f * 1e-6:5.0f} TF/s) | q GEMM {t_g:7.1f} + attention {t_a:7.1f} = {t_g + t_a:7.1f} | library q GEMM {t_l:7.1f}", flush=True)
+        print(f"{name}: fused 256x256 {t_f[1]:7.1f} us ({flops / t_f[1] * 1e-6:5.0f} TF/s) | fused 128x128 {t_f[2]:7.1f} us ({flops / t_f[2] * 1e-6:5.0f} TF/s) | "
+              f"q GEMM {t_g:7.1f} + attention {t_a:7.1f} = {t_g + t_a:7.1f}", flush=True)
 
 
 def time_all():
