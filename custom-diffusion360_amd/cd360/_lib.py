@@ -49,6 +49,7 @@ SIGNATURES = {
     "cd360_conv_stats_rows": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "cd360_conv_dma_slab_rows": (c_int, [c_int, c_int, c_int, c_int, c_int, c_int, c_int]),
     "cd360_conv3x3_dma_bf16": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P]),
+    "cd360_conv_up2x_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "cd360_pose_embed_bf16": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P]),
     "cd360_gemm_bf16": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, c_int, c_int, c_float, _P, _P, c_int, _P]),
     "cd360_qproj_attn_bf16": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int64, c_int64, c_int64, _P, _P, c_int, c_int, c_float, _P, _P, _P,

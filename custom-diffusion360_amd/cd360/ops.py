@@ -555,6 +555,43 @@ def conv_igemm(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Ten
     return (out, stats) if want_stats else out
 
 
+def pack_upsample_conv_weight(w: torch.Tensor) -> torch.Tensor:
+    """nn.Conv2d weight [Cout, Cin, 3, 3] of an Upsample block -> [4, Cout, 4*Cin] bf16 for conv_up2x: phase (a, b) = (row, column parity of
+    the output pixel) sees the source rows {i + a - 1, i + a}; of the three kernel rows ky, those that land on the same source row are
+    summed (a = 0: {0}, {1, 2}; a = 1: {0, 1}, {2}), likewise the columns -- fp32 sums, one rounding.  K order as pack_conv_weight with
+    tap slot t = 2 ty + tx."""
+    cout, cin, kh, kw = w.shape
+    assert kh == 3 and kw == 3 and cin % 64 == 0
+    w32 = w.detach().float()
+    sets = {0: ((0,), (1, 2)), 1: ((0, 1), (2,))}
+    g = _lib.load().cd360_conv_k_order(cin, 9)
+    phases = []
+    for a in (0, 1):
+        for b in (0, 1):
+            taps = [sum(w32[:, :, ky, kx] for ky in sets[a][ty] for kx in sets[b][tx]) for ty in (0, 1) for tx in (0, 1)]  # 4 x [Cout, Cin]
+            we = torch.stack(taps, -1)  # [Cout, Cin, 4]
+            wp = we.reshape(cout, cin // (64 * g), g, 64, 4).permute(0, 1, 4, 2, 3)  # [co, group, tap, chunk-in-group, 64]
+            phases.append(wp.reshape(cout, -1))
+    return torch.stack(phases, 0).to(torch.bfloat16).contiguous()
+
+
+def conv_up2x(x: torch.Tensor, w_phases: torch.Tensor, bias: Optional[torch.Tensor], N: int, H: int, W: int) -> torch.Tensor:
+    """Upsample.forward: nearest 2x + conv3x3 in one launch (cd360_conv_up2x_bf16).  x [N, H*W, Cin] channels-last bf16 (the SOURCE
+    image), w_phases from pack_upsample_conv_weight -> [N, 4*H*W, Cout] (the 2H x 2W image).  Forward only."""
+    _need_gpu(x, w_phases, bias)
+    cin = x.shape[-1]
+    cout = w_phases.shape[1]
+    assert x.dtype == torch.bfloat16 and x.is_contiguous() and x.numel() == N * H * W * cin
+    assert w_phases.dtype == torch.bfloat16 and w_phases.is_contiguous() and w_phases.shape == (4, cout, 4 * cin)
+    assert bias is None or (bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == cout)
+    out = torch.empty(N, 4 * H * W, cout, dtype=torch.bfloat16, device=x.device)
+    m = N * H * W
+    # algorithmic accounting = the operator replaced: a 3 x 3 convolution over the 2H x 2W image (what the reference computes)
+    with _timed("conv_igemm", 2.0 * 4 * m * 9 * cin * cout, 2.0 * (m * cin + 4 * m * cout + 9 * cin * cout)):
+        check(_lib.load().cd360_conv_up2x_bf16(_ptr(x), _ptr(w_phases), _ptr(bias), _ptr(out), N, H, W, cin, cout, _stream()), "cd360_conv_up2x_bf16")
+    return out
+
+
 # ----------------------------------------------------------------------------------------------- Linear layers (cd360_gemm_bf16)
 def _rows2d(t: torch.Tensor):
     """(rows, row stride) of a bf16 tensor [..., C] whose leading dims collapse to uniformly strided rows (last dim contiguous)."""

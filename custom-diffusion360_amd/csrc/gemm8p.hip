@@ -61,6 +61,10 @@ struct GemmParams {
   // (lda = Cin, K = 9 Cin in cd360_conv_k_order order: K-tile kt = (group * 9 + tap) * cv_kg + j reads channel chunk group * cv_kg + j
   // of the pixel shifted by the tap); out [M = images H W, N = Cout]
   int cv_H, cv_W, cv_kg;
+  int cv_up;  // 1: nearest-neighbour 2x upsample folded into the convolution (Upsample.forward, openaimodel.py:114-181): the launch covers the
+              // four output phases (a, b) = (row, column parity), phase slowest in the tile order; phase (a, b) is a 2 x 2-tap convolution
+              // of the SOURCE image (taps dy = (t >> 1) + a - 1, dx = (t & 1) + b - 1; K = 4 Cin; weights w + phase * N * ldw, the 3 x 3
+              // taps that read the same source pixel summed at pack time) whose row (n, i, j) is output pixel (n, 2 i + a, 2 j + b)
   const uint16_t* emb;  // [images, Cout] bf16 per-image addend (row stride emb_stride elements) or null
   long emb_stride;
   float* cstats;        // [M / (NMB 32), Cout, 2] fp32: per slab of NMB * 32 pixels and channel, (sum, sumsq) of the stored outputs, or null
@@ -135,7 +139,17 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   const int wr = wv / WN, wc = wv % WN;      // token / channel position of the wave in the tile
 
   // ---- tile of this workgroup: XCD-contiguous ranges, group_m token tiles per group with the channel tile varying slowest ----
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  int tile = xcd_remap(blockIdx.x, gridDim.x);
+  int up_a = 0, up_b = 0, up_phase = 0;
+  if constexpr (EPI == 5) {
+    if (p.cv_up) {
+      const int per_phase = p.tiles_m * p.tiles_n;
+      up_phase = tile / per_phase;
+      tile -= up_phase * per_phase;
+      up_a = up_phase >> 1;
+      up_b = up_phase & 1;
+    }
+  }
   const int per_group = p.group_m * p.tiles_n;
   const int grp = tile / per_group, in_grp = tile - grp * per_group;
   const int first_m = grp * p.group_m;
@@ -148,7 +162,8 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   // Rows past M / N are past the end of the buffer descriptor: the hardware returns zeros (they only feed masked outputs).
   const __amdgpu_buffer_rsrc_t xrsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)p.a, 0, (int)(CONV ? (long)p.M * p.lda * 2 : ((long)p.M - 1) * p.lda * 2 + (long)p.K * 2), 0x00020000);
-  const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)(((long)p.N - 1) * p.ldw * 2 + (long)p.K * 2), 0x00020000);
+  const __amdgpu_buffer_rsrc_t wrsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (long)up_phase * p.N * p.ldw), 0, (int)(((long)p.N - 1) * p.ldw * 2 + (long)p.K * 2), 0x00020000);
   const int srow = dwave * 8 + (lane >> 3);
   const int schunk = (lane & 7) ^ ((srow >> 1) & 7);
   const uint32_t xoff0 = (uint32_t)((m0 + srow) * p.lda * 2 + schunk * 16);
@@ -169,8 +184,8 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
         const int rem = (int)(m % hw), y = rem / p.cv_W, x = rem - y * p.cv_W;
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap) {
-          const int yy = y + tap / 3 - 1, xx = x + tap % 3 - 1;
-          if (yy >= 0 && yy < p.cv_H && xx >= 0 && xx < p.cv_W) mk |= 1u << tap;
+          const int yy = p.cv_up ? y + (tap >> 1) + up_a - 1 : y + tap / 3 - 1, xx = p.cv_up ? x + (tap & 1) + up_b - 1 : x + tap % 3 - 1;
+          if (yy >= 0 && yy < p.cv_H && xx >= 0 && xx < p.cv_W && (!p.cv_up || tap < 4)) mk |= 1u << tap;
         }
       }
       xmask[i] = mk;
@@ -181,11 +196,11 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   uint32_t is_tapoff = 0;
   auto conv_next = [&]() {  // wave-uniform: byte offset of the next K-tile's (tap shift, channel chunk) relative to the output pixel's row
     is_tap = cv_tap;
-    const int dy = cv_tap / 3, dx = cv_tap - 3 * dy;
+    const int dy = p.cv_up ? (cv_tap >> 1) + up_a : cv_tap / 3, dx = p.cv_up ? (cv_tap & 1) + up_b : cv_tap - 3 * (cv_tap / 3);
     is_tapoff = (uint32_t)((((dy - 1) * p.cv_W + (dx - 1)) * (int)p.lda + (cv_cg * p.cv_kg + cv_j) * 64) * 2);
     if (++cv_j == p.cv_kg) {
       cv_j = 0;
-      if (++cv_tap == 9) {
+      if (++cv_tap == (p.cv_up ? 4 : 9)) {
         cv_tap = 0;
         ++cv_cg;
       }
@@ -780,7 +795,16 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
       const long m = m0 + wr * (NMB * 32) + r;
       if (rl < RPI && r < NMB * 32 && m < p.M && ocol0 + j * 8 < nout && !(abl & 64)) {
         const u32x4 o = *reinterpret_cast<const u32x4*>(stage + r * RB + ((j ^ (r & SWZ)) << 4));
-        *reinterpret_cast<u32x4*>(p.out + m * p.ldo + ocol0 + j * 8) = o;
+        long orow_ = m;
+        if constexpr (CONV) {
+          if (p.cv_up) {  // source pixel (n, i, j) of phase (a, b) -> pixel (n, 2 i + a, 2 j + b) of the 2 H x 2 W output
+            const int hw = p.cv_H * p.cv_W;
+            const long n_ = m / hw;
+            const int rem = (int)(m - n_ * hw), i_ = rem / p.cv_W, j_ = rem - i_ * p.cv_W;
+            orow_ = (n_ * (2 * p.cv_H) + 2 * i_ + up_a) * (2L * p.cv_W) + 2 * j_ + up_b;
+          }
+        }
+        *reinterpret_cast<u32x4*>(p.out + orow_ * p.ldo + ocol0 + j * 8) = o;
         if constexpr (CSTATS) {
           if (p.cstats) {
 #pragma unroll
@@ -887,7 +911,7 @@ int launch_mv(const GemmParams& p0, hipStream_t stream) {
   if (STAMP_BYTES && !(tune.reserved[0] == -1 && tune.reserved[1] == -1))  // probe build: device pointer of the stamp buffer in reserved[0..1]
     p.stamp = reinterpret_cast<uint32_t*>(((uint64_t)(uint32_t)tune.reserved[1] << 32) | (uint64_t)(uint32_t)tune.reserved[0]);
 #endif
-  const long nwg = (long)p.tiles_m * p.tiles_n;
+  const long nwg = (long)p.tiles_m * p.tiles_n * ((EPI == 5 && p.cv_up) ? 4 : 1);
   if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_kernel<WM, WN, NCB, NMB, NBUF, KS, MV, EPI>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
@@ -1002,7 +1026,7 @@ extern "C" int cd360_gemm_bf16(const void* a, const void* w, void* out, int64_t 
   p.M = (int)M; p.N = N; p.K = K; p.ln_parts = ln_parts; p.ln_dim = ln_dim; p.ln_eps = ln_eps; p.geglu = geglu ? 1 : 0;
   p.tiles_m = p.tiles_n = p.group_m = 0;
   p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f; p.a_dup = p.a_dup_from = 0;
-  p.cv_H = p.cv_W = p.cv_kg = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = nullptr;
+  p.cv_H = p.cv_W = p.cv_kg = p.cv_up = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = nullptr;
   switch (pick_cfg(M, N, geglu)) {
     case 1: return launch<2, 2, 2, 2, 2>(p, (hipStream_t)stream);
     case 2: return geglu ? CD360_ERR_SHAPE : launch_epi<2, 4, 1, 2, 2, 0>(p, (hipStream_t)stream);
@@ -1033,7 +1057,7 @@ extern "C" int cd360_gemm_cstats_bf16(const void* a, const void* w, void* out, i
   p.M = (int)M; p.N = N; p.K = K; p.ln_parts = 0; p.ln_dim = 0; p.ln_eps = 0.f; p.geglu = 0;
   p.tiles_m = p.tiles_n = p.group_m = 0;
   p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f; p.a_dup = p.a_dup_from = 0;
-  p.cv_H = p.cv_W = p.cv_kg = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = (float*)cstats;
+  p.cv_H = p.cv_W = p.cv_kg = p.cv_up = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = (float*)cstats;
   return cfg == 2 ? launch_epi<2, 4, 1, 2, 2, 6>(p, (hipStream_t)stream) : launch_128x4<6>(p, (hipStream_t)stream);
 }
 
@@ -1070,7 +1094,7 @@ extern "C" int cd360_qproj_attn_dedup_bf16(const void* a, const void* w, void* o
   p.ak = (const uint16_t*)k; p.av = (const uint16_t*)v; p.ak_sb = k_sb; p.ak_sn = k_sn; p.av_sb = v_sb; p.av_sn = v_sn;
   p.a_nq = Nq; p.a_nk = Nk; p.a_scale_log2e = scale * 1.4426950408889634f;
   p.a_dup = dup; p.a_dup_from = (int)(M / Nq) - dup;
-  p.cv_H = p.cv_W = p.cv_kg = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = nullptr;
+  p.cv_H = p.cv_W = p.cv_kg = p.cv_up = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = nullptr;
   if (qcfg == 2) {
     if (Nk <= 32) return launch_epi<4, 2, 2, 1, 4, 2>(p, (hipStream_t)stream);
     if (Nk <= 64) return launch_epi<4, 2, 2, 1, 4, 3>(p, (hipStream_t)stream);
@@ -1149,9 +1173,39 @@ extern "C" int cd360_conv3x3_dma_bf16(const void* x, const void* w_packed, const
   p.M = (int)M; p.N = Cout; p.K = 9 * Cin; p.ln_parts = 0; p.ln_dim = 0; p.ln_eps = 0.f; p.geglu = 0;
   p.tiles_m = p.tiles_n = p.group_m = 0;
   p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f; p.a_dup = p.a_dup_from = 0;
-  p.cv_H = H; p.cv_W = W; p.cv_kg = cd360_conv_k_order(Cin, 9);
+  p.cv_H = H; p.cv_W = W; p.cv_kg = cd360_conv_k_order(Cin, 9); p.cv_up = 0;
   p.emb = (const uint16_t*)emb; p.emb_stride = emb ? emb_stride : 0; p.cstats = (float*)tile_stats;
   switch (cfg) {
+    case 1: return launch_epi<4, 2, 5, 2, 2, 5>(p, (hipStream_t)stream);
+    case 2: return launch_epi<4, 2, 2, 2, 3, 5>(p, (hipStream_t)stream);
+    case 3: return launch_epi<2, 4, 2, 4, 2, 5>(p, (hipStream_t)stream);
+    default: return launch_128x4<5>(p, (hipStream_t)stream);
+  }
+}
+
+// Upsample.forward (openaimodel.py:114-181): nearest-neighbour 2x interpolation followed by conv3x3 / pad 1, as ONE launch that never
+// builds the upsampled image.  Output pixel (2 i + a, 2 j + b) only sees the 2 x 2 source pixels {i + a - 1, i + a} x {j + b - 1, j + b}:
+// three of the nine taps of each row / column pair read the same source pixel, so phase (a, b) is a 2 x 2-tap convolution of the SOURCE
+// image with the coinciding taps' weights summed -- 4 / 9 of the multiply-adds and no 4x-sized intermediate.  x [N, H, W, Cin] bf16
+// channels-last; w_phases [4, Cout, 4 Cin] bf16: phase 2 a + b, K order of cd360_conv_k_order(Cin, 9) with tap slot t = 2 ty + tx
+// (cd360.ops.pack_upsample_conv_weight); bias fp32 [Cout] | NULL; out [N, 2H, 2W, Cout] bf16.  Cin % 64 == 0, Cout % 16 == 0.
+extern "C" int cd360_conv_up2x_bf16(const void* x, const void* w_phases, const void* bias, void* out, int N, int H, int W, int Cin, int Cout,
+                                    void* stream) {
+  if (!x || !w_phases || !out || N <= 0 || H <= 0 || W <= 0) return CD360_ERR_ARG;
+  if (Cin % 64 || Cout % 16) return CD360_ERR_SHAPE;
+  if (((uintptr_t)x | (uintptr_t)w_phases | (uintptr_t)out) % 16 || (uintptr_t)bias % 8) return CD360_ERR_ARG;
+  const long M = (long)N * H * W;
+  if (M * Cin * 2 >= (1L << 31) || ((long)4 * Cout + 320) * 4 * Cin * 2 >= (1L << 32) || 4 * M * Cout * 2 >= (1L << 40)) return CD360_ERR_SHAPE;
+  GemmParams p;
+  p.a = (const uint16_t*)x; p.w = (const uint16_t*)w_phases; p.out = (uint16_t*)out; p.bias = (const float*)bias; p.res = nullptr;
+  p.ln_stats = nullptr; p.wsum = nullptr; p.stats_out = nullptr;
+  p.lda = Cin; p.ldw = 4L * Cin; p.ldo = Cout; p.ldr = 0;
+  p.M = (int)M; p.N = Cout; p.K = 4 * Cin; p.ln_parts = 0; p.ln_dim = 0; p.ln_eps = 0.f; p.geglu = 0;
+  p.tiles_m = p.tiles_n = p.group_m = 0;
+  p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f; p.a_dup = p.a_dup_from = 0;
+  p.cv_H = H; p.cv_W = W; p.cv_kg = cd360_conv_k_order(Cin, 9); p.cv_up = 1;
+  p.emb = nullptr; p.emb_stride = 0; p.cstats = nullptr;
+  switch (pick_conv_cfg(4 * M, Cout)) {  // the four phases share the launch: tile count of the full-resolution output
     case 1: return launch_epi<4, 2, 5, 2, 2, 5>(p, (hipStream_t)stream);
     case 2: return launch_epi<4, 2, 2, 2, 3, 5>(p, (hipStream_t)stream);
     case 3: return launch_epi<2, 4, 2, 4, 2, 5>(p, (hipStream_t)stream);

@@ -83,8 +83,26 @@ class Upsample(nn.Module):
         if use_conv:
             self.conv = conv_nd(dims, self.channels, self.out_channels, kernel_size, padding=padding)
 
+    def _phase_weights(self):
+        """The conv's weight as four 2 x 2-tap phase kernels (ops.pack_upsample_conv_weight), rebuilt when the parameters change."""
+        w, b = self.conv.weight, self.conv.bias
+        key = (w.data_ptr(), w._version, None if b is None else b._version)
+        if getattr(self, "_up_pack", None) is None or self._up_pack[0] != key:
+            self._up_pack = (key, ops.pack_upsample_conv_weight(w), None if b is None else b.detach().float().contiguous())
+        return self._up_pack[1], self._up_pack[2]
+
     def forward(self, x):
         assert x.shape[1] == self.channels
+        conv = self.conv if self.use_conv else None
+        if (conv is not None and x.is_cuda and x.dtype == torch.bfloat16 and self.scale_factor == 2 and conv.kernel_size == (3, 3) and conv.padding == (1, 1)
+                and conv.stride == (1, 1) and conv.weight.dtype == torch.bfloat16 and self.channels % 64 == 0 and self.out_channels % 16 == 0
+                and not torch.is_grad_enabled() and not os.environ.get("CD360_NO_UPSAMPLE_FOLD")):
+            # nearest 2x + conv3x3 as four 2 x 2-tap phase convolutions of the source image: no upsampled intermediate, 4 / 9 of the MACs
+            N, _, H, W = x.shape
+            xt = x.permute(0, 2, 3, 1)
+            xt = (xt if xt.is_contiguous() else xt.contiguous()).reshape(N, H * W, -1)
+            wp, bias = self._phase_weights()
+            return tokens_to_image(ops.conv_up2x(xt, wp, bias, N, H, W), 2 * H, 2 * W)
         x = F.interpolate(x, scale_factor=self.scale_factor, mode="nearest")
         if not self.use_conv:
             return x

@@ -246,6 +246,13 @@ int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const void* bias,
 /* tile_stats (optional, NULL to skip): fp32 [N*H*W/128 * cd360_conv_stats_slabs(Cout), Cout, 2] = per pixel slab and channel the
  * sum and the sum of squares of the bf16 outputs: the statistics pass of the GroupNorm that follows the conv (openaimodel.py:
  * 352-376 h = out_layers(GN -> SiLU -> conv)), handed to cd360_gn_silu_bf16.  Requires H*W % 128 == 0. */
+/* replaces Upsample.forward (openaimodel.py:114-181): F.interpolate(x, scale_factor=2, mode="nearest") followed by conv3x3 / pad 1, in one
+ * launch that never builds the upsampled image: output pixel (2i + a, 2j + b) reads only the 2 x 2 source pixels {i+a-1, i+a} x {j+b-1, j+b},
+ * so each of the four phases (a, b) is a 2 x 2-tap convolution of the SOURCE image whose weights are the sums of the 3 x 3 taps that
+ * coincide (4 / 9 of the multiply-adds).  x [N*H*W, Cin] bf16; w_phases [4, Cout, 4*Cin] bf16 (phase 2a + b; K order of
+ * cd360_conv_k_order(Cin, 9) with tap slot 2 ty + tx: cd360.ops.pack_upsample_conv_weight); bias fp32 [Cout] | NULL;
+ * out [N*2H*2W, Cout] bf16.  Cin % 64 == 0, Cout % 16 == 0. */
+int cd360_conv_up2x_bf16(const void* x, const void* w_phases, const void* bias, void* out, int N, int H, int W, int Cin, int Cout, void* stream);
 int cd360_conv_stats_slabs(int Cout);
 /* Pixels per slab of `tile_stats` for this very call (the kernel that serves it decides: 64 or 128 on the LDS-DMA core that runs the
  * 3 x 3 / stride 1 convolutions, 128 / cd360_conv_stats_slabs(Cout) otherwise): tile_stats is fp32 [N*Ho*Wo / rows, Cout, 2]. */

@@ -390,6 +390,31 @@ def test_conv3x3_on_the_dma_gemm_core_all_tilings(cfg, N, H, W, Cin, Cout, tune)
     assert rel(got, ops.conv_igemm(*args)) < 4e-3  # same sums in another order, both rounded to bf16
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(3, 32, 32, 1280, 1280), (3, 64, 64, 640, 640), (2, 8, 8, 64, 64), (1, 5, 7, 128, 320), (2, 16, 12, 192, 80)])
+def test_upsample_nearest2x_folded_into_the_convolution(N, H, W, Cin, Cout, tune):
+    """Upsample.forward (openaimodel.py:114-181): nearest 2x + conv3x3 as ONE launch of four 2 x 2-tap phase convolutions of the source image
+    (cd360_conv_up2x_bf16) against torch's fp32 interpolate + conv2d on the same bf16 values, and against the un-folded HIP path (the
+    interpolated image through the 3 x 3 kernel); ragged / odd image sizes, every tiling the launch heuristic can choose."""
+    from cd360 import ops
+    g = torch.Generator().manual_seed(N * 100 + H + Cin + Cout)
+    x = bf(torch.randn(N, Cin, H, W, generator=g))
+    w = bf(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
+    bias = torch.randn(Cout, generator=g)
+    want = torch.nn.functional.conv2d(torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest"), w, bias, padding=1)
+    xt = x.permute(0, 2, 3, 1).reshape(N, H * W, Cin).to(DEV, torch.bfloat16).contiguous()
+    wp = ops.pack_upsample_conv_weight(w.to(DEV))
+    cfgs = [None] + [c for c in (2, 3, 4) if True]
+    for cfg in cfgs:
+        tune(conv_cfg=-1 if cfg is None else cfg)
+        got = ops.conv_up2x(xt, wp, bias.to(DEV), N, H, W).reshape(N, 2 * H, 2 * W, Cout).permute(0, 3, 1, 2)
+        assert rel(got, want) < 1e-2, cfg
+        assert torch.equal(got, ops.conv_up2x(xt, wp, bias.to(DEV), N, H, W).reshape(N, 2 * H, 2 * W, Cout).permute(0, 3, 1, 2))
+    tune(conv_cfg=-1)
+    up = torch.nn.functional.interpolate(x, scale_factor=2, mode="nearest").permute(0, 2, 3, 1).reshape(N, 4 * H * W, Cin).to(DEV, torch.bfloat16).contiguous()
+    plain = ops.conv_igemm(up, ops.pack_conv_weight(w.to(DEV)), bias.to(DEV), N, 2 * H, 2 * W, 9).reshape(N, 2 * H, 2 * W, Cout).permute(0, 3, 1, 2)
+    assert rel(got, plain) < 8e-3  # same sums with the coinciding taps' weights added before the bf16 rounding instead of after
+
+
 @pytest.mark.parametrize("N,H,W,Cin,Cout,stride", [(2, 16, 16, 64, 64, 2), (3, 32, 32, 320, 320, 2), (1, 8, 12, 128, 160, 2), (2, 16, 16, 4, 320, 1), (2, 16, 16, 320, 4, 1)])
 def test_conv_stride2_and_padded_channels_through_the_module_wrapper(N, H, W, Cin, Cout, stride):
     """Downsample.op (conv3x3 stride 2 pad 1, openaimodel.py:190-213) and the UNet's 4 -> 320 / 320 -> 4 convs (:663-670,967-973)
