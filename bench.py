@@ -241,6 +241,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying the steady-state step from a hipGraph")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the fine-tuning step measurement appended after the timed region (BASELINE configs[3])")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -313,7 +314,11 @@ def main():
         smp.use_graph = not args.no_graph
 
     tmax = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    rank_ms = [elapsed / steps_done * 1e3]
     if world > 1:
+        every = [torch.zeros_like(tmax) for _ in range(world)]
+        dist.all_gather(every, tmax)  # per-rank elapsed: the line shows the spread, `value` uses the slowest rank
+        rank_ms = [float(t.item()) / steps_done * 1e3 for t in every]
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         gathered = shard.gather_latents(torch.cat(finals, 0), n_poses)  # the job's one exchange: final latents of every pose
         assert gathered.shape[0] == n_poses and torch.isfinite(gathered).all()
@@ -324,7 +329,13 @@ def main():
     if rank == 0:
         # ---- rooflines.  `achieved` = ALGORITHMIC flops (MFMA-bound kernels) or bytes (HBM-bound) of the launches / their HIP-event time on
         # the launch stream (ops._timed: SURVEY.md section 8d formulas, stated per kernel in DESIGN.md section 7b) ----
-        MFMA_KERNELS = {"gemm8p", "qproj_attn", "attn_self", "conv_igemm", "nerf_mlp_aggregate"}
+        MFMA_KERNELS = {"gemm8p", "qproj_attn", "qproj_attn_text", "attn_self", "conv_igemm", "nerf_mlp_aggregate"}
+        try:
+            from cd360 import _lib
+            with open(_lib.LIB_PATH, "rb") as f:
+                lib_bytes = f.read()
+        except Exception:  # noqa: BLE001
+            lib_bytes = b""
 
         def roofline_of(name):
             e = prof[name]
@@ -338,12 +349,19 @@ def main():
                      alg_flops_per_launch=round(e["flops"] / e["n"]))
             # HBM traffic per launch comes from the committed rocprofv3 PMC passes over this same command (profiles/*_pmc_traffic.json:
             # FETCH_SIZE and WRITE_SIZE in separate runs, gfx950 1/2-FETCH correction applied)
+            # -- and is reported only while every kernel symbol that pass measured still exists in the library that is running: a
+            # traffic figure of a kernel that has since been rewritten is refused (traffic = null, `traffic_stale` says which symbol)
             try:
                 import glob
                 pm_file = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_pmc_traffic.json")))[-1]
                 with open(pm_file) as f:
-                    r["traffic"] = json.load(f)["kernels"][name]["hbm_bytes_per_launch"]
-                r["traffic_source"] = os.path.relpath(pm_file, ROOT)
+                    ent = json.load(f)["kernels"][name]
+                gone = [sym for sym in ent.get("symbols", ["<no symbol list: profile predates the check>"]) if sym.encode() not in lib_bytes]
+                if gone:
+                    r["traffic_stale"] = f"{os.path.relpath(pm_file, ROOT)} measured {gone[0]}, which the loaded library no longer contains"
+                else:
+                    r["traffic"] = ent["hbm_bytes_per_launch"]
+                    r["traffic_source"] = os.path.relpath(pm_file, ROOT)
             except Exception:  # noqa: BLE001
                 r["traffic"] = None
             return r
@@ -355,10 +373,13 @@ def main():
             notes = {"gemm8p": "every Linear of the transformer blocks (cd360_gemm_bf16: LayerNorm fold / GEGLU / residual epilogues)",
                      "qproj_attn": "pose-token cross-attention A3, FUSED form: q projection + softmax(q k^T) v over 77 keys in one kernel; flops = 2 M C^2 + 4 M 77 C "
                                    "(the out projection runs as a gemm8p launch with the residual fused); render step only",
+                     "qproj_attn_text": "text cross-attention A2 of every block on the same fused kernel (128 x 128 tile, mover waves): LayerNorm fold + "
+                                        "q projection + softmax(q k^T) v over 77 keys, q never in HBM; flops = 2 M C^2 + 4 M 77 C",
                      "attn_self": "self-attention attn1 (tiled flash kernel), core form 4 B H N^2 64, projections in gemm8p",
-                     "attn_smallk": "text cross-attention attn2 core over 77 keys (register-resident K / V): HBM-bound streaming of q and o",
-                     "nerf_mlp_aggregate": "FeatureNeRF gather + per-sample MLP + view softmax (A5-A8) after the algebraic restructuring: VALU-bound "
-                                           "(projection, sin / cos, bilinear blend, SiLU); flops = 2 M 99 C MFMA part only; render step only",
+                     "attn_smallk": "cross-attention core over <= 96 keys on the register-resident kernel (shapes the fused kernel does not serve)",
+                     "nerf_mlp_aggregate": "FeatureNeRF gather + per-sample MLP + view softmax (A5-A8) after the algebraic restructuring: full-line "
+                                           "gathers staged through LDS, VALU / latency-bound (projection, sin / cos, bilinear blend, SiLU); flops = 2 M 99 C "
+                                           "MFMA part only; render step only",
                      "volrender": "volume render scan (A10), HBM-bound; render step only",
                      "conv_igemm": "all 51 convolutions (implicit GEMM)"}
             for k in notes:
@@ -384,10 +405,32 @@ def main():
                        "n_ref": args.refs, "poses": n_poses, "poses_per_gpu": len(mine), "world_size": world,
                        "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1, "parallelism": "pose-dp%d" % world,
                        "hipgraph": not args.no_graph, "hipgraph_render_step": smp.rgraph is not None,
-                       "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}},
+                       "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)},
+                       "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
+                       "kernel_ms_per_step_source": "a separate EAGER replay of the same K steps after the timed region, HIP events around every launch "
+                                                    "(events cannot bracket kernels inside a hipGraph replay): its sum exceeds ms_per_step by the "
+                                                    "eager launch gaps the graph does not have"},
             "roofline": roof,
             "rooflines": roofs,
         }
+        if world == 1 and not args.no_train_step:
+            # BASELINE configs[3] under the driver's eyes: one fine-tuning optimisation step at SDXL size (512^2 images, batch 4, 4 reference
+            # views, trainkeys = pose: forward of both streams, four-term loss, backward, AdamW on fp32 masters) -- one warm + three timed
+            # steps on the hand-written GEMM family (cd360_ms), then the same with every Linear on torch / hipBLASLt (library_ms)
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import bench_train
+                del smp
+                torch.cuda.empty_cache()
+                mine_ = bench_train.measure(steps=3, warmup=1, batch=4, views=4, latent=64, profile=False, library=False)
+                lib_ = bench_train.measure(steps=3, warmup=1, batch=4, views=4, latent=64, profile=False, library=True)
+                out["train_step"] = {"ms": mine_["ms_per_step"], "bs": 4, "n_ref": 4, "latent": 64, "cd360_ms": mine_["ms_per_step"],
+                                     "library_ms": lib_["ms_per_step"], "losses": mine_["losses"], "peak_mem_gb": mine_["peak_mem_gb"],
+                                     "what": "tools/bench_train.py shapes: main.py fine-tune step (train_co3d_concept.yaml), random-init SDXL UNet, "
+                                             "1 warm + 3 timed steps, eager launches; cd360_ms = every Linear on cd360_gemm_bf16 / cd360_gemm_tn_bf16 "
+                                             "(forward, dgrad, wgrad), library_ms = the same step with the Linears on torch (hipBLASLt)"}
+            except Exception as e:  # noqa: BLE001
+                out["train_step"] = {"ms": None, "error": repr(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 # 32 threads: PyTorch's CPU kernels stop scaling (and regress badly) beyond one socket's worth of cores

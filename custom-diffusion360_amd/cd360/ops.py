@@ -810,7 +810,7 @@ def qproj_attention_ok(a: torch.Tensor, nk: int) -> bool:
 
 
 def qproj_attention(a: torch.Tensor, w: torch.Tensor, k: torch.Tensor, v: torch.Tensor, nk: int, heads: int,
-                    bias: Optional[torch.Tensor] = None, ln=None, dup: int = 0) -> torch.Tensor:
+                    bias: Optional[torch.Tensor] = None, ln=None, dup: int = 0, tag: str = "qproj_attn") -> torch.Tensor:
     """softmax((a w^T [+ LayerNorm fold, + bias]) k^T / 8) v per head with the query projection and the attention in ONE kernel
     (cd360_qproj_attn_bf16): a [b, Nq, K] bf16, w [heads*64, K] bf16, k / v [b, >= nk, heads*64] (last dim contiguous, e.g. the two
     halves of the merged k|v projection), nk <= 96 -> [b, Nq, heads*64].  bias / ln as gemm().  Forward only.
@@ -835,7 +835,7 @@ def qproj_attention(a: torch.Tensor, w: torch.Tensor, k: torch.Tensor, v: torch.
         parts, ln_dim = stats_in.shape[1], K
     out = torch.empty(b + dup, nq, N, dtype=torch.bfloat16, device=a.device)
     flops = 2.0 * M * N * K + 4.0 * (M + dup * nq) * nk * N
-    with _timed("qproj_attn", flops, 2.0 * (M * K + N * K + M * N + 2 * b * nk * N)):
+    with _timed(tag, flops, 2.0 * (M * K + N * K + M * N + 2 * b * nk * N)):  # per-kernel timing name: A3 "qproj_attn", A2 "qproj_attn_text"
         check(_lib.load().cd360_qproj_attn_dedup_bf16(_ptr(a), _ptr(w), _ptr(out), M, N, K, lda, w.stride(0), N, _ptr(bias), _ptr(stats_in), parts,
                                                      ln_dim, float(eps), _ptr(wsum), _ptr(k), _ptr(v), k.stride(0), k.stride(1), v.stride(0),
                                                      v.stride(1), nq, nk, 64 ** -0.5, dup, _stream()), "cd360_qproj_attn_dedup_bf16")

@@ -511,7 +511,7 @@ class BasicTransformerBlock(nn.Module):
         k, v, nk = a2.project_context(context)
         if ops.qproj_attention_ok(x, nk) and k.shape[0] == x.shape[0] and not os.environ.get("CD360_NO_A2_FUSE"):
             # text cross-attention (attention.py:620-625): LayerNorm fold + q projection + softmax(q K^T) V in ONE kernel, q never in HBM
-            o = ops.qproj_attention(x, w, k, v, nk, a2.heads, bias=cb, ln=(stats, ws, self.norm2.eps))
+            o = ops.qproj_attention(x, w, k, v, nk, a2.heads, bias=cb, ln=(stats, ws, self.norm2.eps), tag="qproj_attn_text")
         else:
             o = ops.attention(ops.gemm(x, w, bias=cb, ln=(stats, ws, self.norm2.eps)), k, v, a2.heads, nk)
         if context_ref is None:

@@ -403,11 +403,34 @@ def test_full_sdxl_unet_configA_matches_cpu_oracle():
             taught.append(dict(x=xin, ctx=context, cref=context_ref, fg=res[1], alphas=res[2], rgb=res[3], xref=res[4]))
         return res
 
-    O.transformer_block = recording_block
+    # ... and what the PLAIN transformer blocks and the ResBlocks of the target stream were given / returned (first of each width), for
+    # the same judgement of the fused block (LayerNorm fold -> q|k|v -> attention -> out + statistics -> fused text cross-attention ->
+    # GEGLU feed-forward: 62 % of a denoise step) and of the GroupNorm / convolution path at full width
+    plain, resb, counters, orig_res = {}, {}, {"blk": 0, "res": 0}, O.res_block
+    inner_block = recording_block
+
+    def counting_block(w, xin, context, heads, context_ref=None, cams=None, rendered_feat=None, **kw):
+        res = inner_block(w, xin, context, heads, context_ref=context_ref, cams=cams, rendered_feat=rendered_feat, **kw)
+        if xin.shape[0] == b:  # the target stream walks the 70 blocks in module order (the reference stream has b * n rows)
+            if context_ref is None and xin.shape[-1] not in plain:
+                plain[xin.shape[-1]] = dict(index=counters["blk"], x=xin, ctx=context, out=res[0])
+            counters["blk"] += 1
+        return res
+
+    def counting_res(w, xin, emb):
+        out = orig_res(w, xin, emb)
+        if xin.shape[0] == b:
+            key = (xin.shape[1], out.shape[1])
+            if key in ((640, 640), (1280, 1280), (2560, 1280)) and key not in resb:
+                resb[key] = dict(index=counters["res"], x=xin, emb=emb, out=out)
+            counters["res"] += 1
+        return out
+
+    O.transformer_block, O.res_block = counting_block, counting_res
     try:
         want, wfg, wal, wrgb = O.unet_forward(sd, x, t, ctx, y, cams=cams, input_ref=xr, sigmas_ref=tr, model_channels=320, num_samples=24, far=2.0)
     finally:
-        O.transformer_block = orig_block
+        O.transformer_block, O.res_block = orig_block, orig_res
     del sd
     got, fgs, als, rgbs = net(x.to(DEV), timesteps=t.to(DEV), context=ctx.to(DEV), y=y.to(DEV), pose=unpack_cameras(cams), input_ref=xr.to(DEV),
                               sigmas_ref=tr.to(DEV), mask_ref=None)
@@ -436,6 +459,33 @@ def test_full_sdxl_unet_configA_matches_cpu_oracle():
     print("teacher-forced render errors (xref, fg, alphas, rgb) per pose block:", {k: tuple(round(e, 4) for e in v) for k, v in tf.items()})
     # north_star tolerance: bf16 render outputs within 1e-2 of the reference's path on identical inputs
     assert max(max(v) for v in tf.values()) < 1e-2, tf
+    # ---- teacher-forced PLAIN blocks at full width (C = 640 and C = 1280): fused route and module route, each on the oracle's inputs ----
+    from sgm.modules.attention import BasicTransformerBlock
+    from sgm.modules.diffusionmodules.openaimodel import ResBlock
+    all_blocks = [m for m in net.modules() if isinstance(m, BasicTransformerBlock)]
+    assert counters["blk"] == len(all_blocks) == 70 and set(plain) == {640, 1280}
+    tb = {}
+    for C, rec in plain.items():
+        blk = all_blocks[rec["index"]]
+        assert not blk.image_cross and blk.norm1.weight.shape[0] == C
+        xin, cin = dev(rec["x"]).contiguous(), dev(rec["ctx"])
+        assert blk.fused_ready(xin)
+        fused = blk._forward_fused(xin, None, cin)[0]
+        module = blk._forward(xin, cin)[0]
+        tb[C] = (rel(fused, rec["out"]), rel(module, rec["out"]))
+    print("teacher-forced plain transformer blocks (fused route, module route) by width:", {k: tuple(round(e, 4) for e in v) for k, v in tb.items()})
+    assert max(max(v) for v in tb.values()) < 1e-2, tb
+    # ---- teacher-forced ResBlocks (GroupNorm + SiLU -> conv3x3 (+ emb) -> GroupNorm + SiLU -> conv3x3 + skip), same bar ----
+    all_res = [m for m in net.modules() if isinstance(m, ResBlock)]
+    assert counters["res"] == len(all_res) and len(resb) == 3
+    tr_ = {}
+    for key, rec in resb.items():
+        rb = all_res[rec["index"]]
+        assert (rb.channels, rb.out_channels) == key
+        got_r = rb(dev(rec["x"]).contiguous(memory_format=torch.channels_last), dev(rec["emb"]))
+        tr_[key] = rel(got_r, rec["out"])
+    print("teacher-forced ResBlocks by (in, out) channels:", {k: round(v, 4) for k, v in tr_.items()})
+    assert max(tr_.values()) < 1e-2, tr_
 
 
 # ------------------------------------------------------------------------------------------- BASELINE configs[1] / [3] at full size

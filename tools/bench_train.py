@@ -18,18 +18,28 @@ for p in (os.path.join(ROOT, "custom-diffusion360_amd"), os.path.join(ROOT, "tes
 import torch  # noqa: E402
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=4)
-    ap.add_argument("--views", type=int, default=4)
-    ap.add_argument("--latent", type=int, default=64)
-    ap.add_argument("--eval-mode", action="store_true", help="no stratified jitter")
-    a = ap.parse_args()
+def measure(steps=5, warmup=2, batch=4, views=4, latent=64, eval_mode=False, profile=True, library=False):
+    """One fine-tune configuration: build the SDXL UNet, run `warmup` + `steps` optimisation steps, return the result dict.
+    library=True: the round-1 path (CD360_LIBRARY_LINEAR=1: every Linear on torch / hipBLASLt) for an A/B on the same box."""
     from cd360 import finetune, ops, sampling, synth
     from make_golden_params import LOSS_CFG, SDXL_NETWORK_CONFIG
     from sgm.util import instantiate_from_config
+    prev = os.environ.get("CD360_LIBRARY_LINEAR")
+    if library:
+        os.environ["CD360_LIBRARY_LINEAR"] = "1"
+    else:
+        os.environ.pop("CD360_LIBRARY_LINEAR", None)
+    try:
+        return _measure(steps, warmup, batch, views, latent, eval_mode, profile, finetune, ops, sampling, synth, LOSS_CFG, SDXL_NETWORK_CONFIG,
+                        instantiate_from_config)
+    finally:
+        if prev is None:
+            os.environ.pop("CD360_LIBRARY_LINEAR", None)
+        else:
+            os.environ["CD360_LIBRARY_LINEAR"] = prev
+
+
+def _measure(steps, warmup, batch, views, latent, eval_mode, profile, finetune, ops, sampling, synth, LOSS_CFG, SDXL_NETWORK_CONFIG, instantiate_from_config):
     dev = "cuda"
     torch.manual_seed(0)
     with torch.device(dev):
@@ -44,35 +54,52 @@ def main():
         for m in net.modules():
             if m.__class__.__name__ == "SpatialTransformer":
                 m.proj_out.weight.copy_(torch.randn(m.proj_out.weight.shape, generator=g, device=dev).mul_(0.02))
-    net.eval() if a.eval_mode else net.train()
+    net.eval() if eval_mode else net.train()
     names = finetune.select_trainable(net, "pose")
     opt = finetune.MasterAdamW(finetune.optimizer_param_groups(net, "pose", lr=1e-4), lr=1e-4)  # configs/train_co3d_concept.yaml:2,7-8
     loss_fn = instantiate_from_config({"target": "sgm.modules.diffusionmodules.loss.StandardDiffusionLossImgRef", "params": LOSS_CFG})
-    b, n, L = a.batch, a.views, a.latent
+    b, n, L = batch, views, latent
     rn = lambda *s: torch.randn(*s, generator=g, device=dev)
-    batch = dict(noised=rn(b, 4, L, L), timesteps=torch.full((b,), 500.0, device=dev), context=rn(b + b * n, 77, 2048), y=rn(b + b * n, 2816),
-                 pose=synth.pose_batch(b, n, seed=3), input_ref=rn(b, n, 4, L, L), sigmas_ref=torch.full((b,), 3.0, device=dev),
-                 target=rn(b, 4, L, L), target_rgb=rn(b, 3, 8 * L, 8 * L).clamp(-1, 1), w=torch.full((b, 1, 1, 1), 0.7, device=dev),
-                 mask=torch.ones(b, 1, L, L, device=dev), opacity=torch.sigmoid(3 * rn(b, 1, 8 * L, 8 * L)))
+    bt = dict(noised=rn(b, 4, L, L), timesteps=torch.full((b,), 500.0, device=dev), context=rn(b + b * n, 77, 2048), y=rn(b + b * n, 2816),
+              pose=synth.pose_batch(b, n, seed=3), input_ref=rn(b, n, 4, L, L), sigmas_ref=torch.full((b,), 3.0, device=dev),
+              target=rn(b, 4, L, L), target_rgb=rn(b, 3, 8 * L, 8 * L).clamp(-1, 1), w=torch.full((b, 1, 1, 1), 0.7, device=dev),
+              mask=torch.ones(b, 1, L, L, device=dev), opacity=torch.sigmoid(3 * rn(b, 1, 8 * L, 8 * L)))
     losses = []
-    for _ in range(a.warmup):
-        losses.append(float(finetune.train_step(net, loss_fn, opt, **batch)[0]))
+    for _ in range(warmup):
+        losses.append(float(finetune.train_step(net, loss_fn, opt, **bt)[0]))
     torch.cuda.synchronize()
-    ops.profile_start()
+    if profile:
+        ops.profile_start()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        losses.append(float(finetune.train_step(net, loss_fn, opt, **batch)[0]))
+    for _ in range(steps):
+        losses.append(float(finetune.train_step(net, loss_fn, opt, **bt)[0]))
     torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / a.steps
-    prof = ops.profile_stop()
-    kern = {k: {"ms_per_step": round(v["ms"] / a.steps, 3), "launches_per_step": v["n"] // a.steps,
+    dt = (time.perf_counter() - t0) / steps
+    prof = ops.profile_stop() if profile else {}
+    kern = {k: {"ms_per_step": round(v["ms"] / steps, 3), "launches_per_step": v["n"] // steps,
                 **({"tflops": round(v["flops"] / v["ms"] / 1e9, 1)} if v.get("flops") else {}),
                 **({"gbs": round(v["bytes"] / v["ms"] / 1e6, 1)} if v.get("bytes") else {})} for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
-    print(json.dumps({"metric": "fine-tune optimisation steps/sec (config 4)", "value": round(1.0 / dt, 4), "unit": "steps/s", "ms_per_step": round(dt * 1e3, 2),
-                      "steps": a.steps, "warmup": a.warmup, "dtype": "bf16 (+fp32 master weights)", "data": "synthetic",
-                      "config": {"workload": f"SDXL UNet {8 * L}^2, batch {b}, {n} reference views, trainkeys=pose, {'eval' if a.eval_mode else 'train (stratified)'} mode",
-                                 "trainable_tensors": len(names), "trainable_params": int(sum(p.numel() for p in opt.params))},
-                      "losses": [round(x, 5) for x in losses], "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "hip_kernels": kern}))
+    out = {"metric": "fine-tune optimisation steps/sec (config 4)", "value": round(1.0 / dt, 4), "unit": "steps/s", "ms_per_step": round(dt * 1e3, 2),
+           "steps": steps, "warmup": warmup, "dtype": "bf16 (+fp32 master weights)", "data": "synthetic",
+           "config": {"workload": f"SDXL UNet {8 * L}^2, batch {b}, {n} reference views, trainkeys=pose, {'eval' if eval_mode else 'train (stratified)'} mode",
+                      "trainable_tensors": len(names), "trainable_params": int(sum(p.numel() for p in opt.params))},
+           "losses": [round(x, 5) for x in losses], "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "hip_kernels": kern}
+    del net, opt, loss_fn, bt
+    torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=4)
+    ap.add_argument("--views", type=int, default=4)
+    ap.add_argument("--latent", type=int, default=64)
+    ap.add_argument("--eval-mode", action="store_true", help="no stratified jitter")
+    ap.add_argument("--library", action="store_true", help="every Linear on torch / hipBLASLt (CD360_LIBRARY_LINEAR=1): the A/B partner")
+    a = ap.parse_args()
+    print(json.dumps(measure(a.steps, a.warmup, a.batch, a.views, a.latent, a.eval_mode, True, a.library)))
 
 
 if __name__ == "__main__":

@@ -7,8 +7,25 @@ import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 NAMES = {"conv_igemm_kernel": "conv_igemm", "attn_fwd_kernel": "attn_self", "attn_self_kernel": "attn_self", "attn_smallk_kernel": "attn_smallk", "nerf_fused_kernel": "nerf_mlp_aggregate",
+         "nerf_fused_line_kernel": "nerf_mlp_aggregate",
          "gemm_mfma_kernel": "gemm8p", "row_stats_kernel": "row_stats",
          "geglu_kernel": "geglu", "volrender_kernel": "volrender", "gn_partial_kernel": "gn_silu", "gn_apply_kernel": "gn_silu", "gn_finalize_kernel": "gn_silu"}
+
+
+def symbol_fragment(demangled: str) -> str:
+    """Itanium-mangled fragment (name + integer / bool template arguments) of a kernel name as rocprofv3 prints it, e.g.
+    `void (anonymous namespace)::gemm_mfma_kernel<2, 4, 1, 2, 4, 1, 4, 0>(...)` -> `16gemm_mfma_kernelILi2ELi4ELi1ELi2ELi4ELi1ELi4ELi0EE`:
+    bench.py looks for it in the library it is running before it quotes this file's traffic for the kernel."""
+    import re
+    m = re.search(r"(\w+_kernel)(?:<([^>]*)>)?", demangled)
+    name, targs = m.group(1), m.group(2)
+    frag = f"{len(name)}{name}"
+    if targs:
+        parts = []
+        for t in (x.strip() for x in targs.split(",")):
+            parts.append({"true": "Lb1E", "false": "Lb0E"}.get(t, f"Li{t}E" if not t.startswith("-") else f"Lin{t[1:]}E"))
+        frag += "I" + "".join(parts) + "E"
+    return frag
 
 
 def load(counter):
@@ -17,16 +34,18 @@ def load(counter):
         key = next((v for k, v in NAMES.items() if k in r["kernel"]), None)
         if key is None:
             continue
-        if key == "gemm8p":  # gemm_mfma_kernel<WM, WN, NCB, NMB, NBUF, KS, EPI>: EPI 2-4 = fused q-projection + attention, 5 = 3x3 convolution
-            import re
-            m = re.search(r"gemm_mfma_kernel<[^>]*?(\d+)>", r["kernel"])
-            if m and int(m.group(1)) == 5:
+        if key == "gemm8p":  # gemm_mfma_kernel<WM, WN, NCB, NMB, NBUF, KS, MV, EPI>: EPI 2-4 = fused q-projection + attention (256 x 256 tile: the
+            import re        # pose tokens A3; 128 x 128 tile = <4, 2, 2, 1, ...>: the text cross-attention A2), 5 = 3x3 convolution, 6 = Linear + GN statistics
+            m = re.search(r"gemm_mfma_kernel<([^>]*)>", r["kernel"])
+            targs = [int(t) for t in m.group(1).split(",")] if m else []
+            if targs and targs[-1] == 5:
                 key = "conv_igemm"
-            elif m and int(m.group(1)) >= 2:
-                key = "qproj_attn"
-        d = out.setdefault(key, {"n": 0, "kb": 0.0})
+            elif targs and 2 <= targs[-1] <= 4:
+                key = "qproj_attn_text" if targs[:4] == [4, 2, 2, 1] else "qproj_attn"
+        d = out.setdefault(key, {"n": 0, "kb": 0.0, "symbols": set()})
         d["n"] += int(r["dispatches"])
         d["kb"] += float(r["total"])
+        d["symbols"].add(symbol_fragment(r["kernel"]))
     return out
 
 
@@ -35,7 +54,8 @@ kern = {}
 for k in f:
     n = f[k]["n"]
     fetch, write = f[k]["kb"] / n, w.get(k, {"kb": 0.0})["kb"] / n
-    kern[k] = {"fetch_size_kb_raw": round(fetch, 1), "write_size_kb": round(write, 1), "hbm_bytes_per_launch": int((2 * fetch + write) * 1024), "dispatches": n}
+    kern[k] = {"fetch_size_kb_raw": round(fetch, 1), "write_size_kb": round(write, 1), "hbm_bytes_per_launch": int((2 * fetch + write) * 1024), "dispatches": n,
+               "symbols": sorted(f[k]["symbols"])}
 doc = {"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-profile "
                  "--no-graph` (tools/gpu_profile.sh), " + dst + "_pmc_*.csv",
        "correction": "gfx950: FETCH_SIZE reports 1/2 of the bytes of wide coalesced reads (MI355X_MICROARCH.md HBM section; confirmed on geglu_kernel: "
