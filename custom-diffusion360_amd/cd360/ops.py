@@ -544,9 +544,9 @@ def conv_igemm(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Ten
     lib = _lib.load()
     stats = None
     if want_stats:
-        if (ho * wo) % 128:
-            raise Cd360Error("conv_igemm(want_stats=True) needs Ho*Wo % 128 == 0")
         rows = lib.cd360_conv_stats_rows(N, H, W, cin, cout, taps, stride)  # pixels per slab: the kernel serving this shape decides
+        if rows <= 0 or (ho * wo) % rows or (rows < 64 and (ho * wo) % 128):  # slabs must not straddle images (register-staged kernel: 128-pixel tiles)
+            raise Cd360Error(f"conv_igemm(want_stats=True): Ho*Wo = {ho * wo} is not a whole number of the kernel's {rows}-pixel slabs")
         stats = torch.empty(N, (ho * wo) // rows, cout, 2, dtype=torch.float32, device=x.device)
     acin, acout = alg_channels or (cin, cout)  # un-padded channel counts for the algorithmic FLOP / byte accounting
     with _timed("conv_igemm", 2.0 * m * taps * acin * acout, 2.0 * (N * H * W * acin + m * acout + taps * acin * acout)):

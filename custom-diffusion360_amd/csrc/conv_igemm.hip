@@ -365,8 +365,12 @@ extern "C" int cd360_conv_stats_rows(int N, int H, int W, int Cin, int Cout, int
 extern "C" int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const void* bias, const void* emb, int64_t emb_stride, const void* res,
                                      void* out, int N, int H, int W, int Cin, int Cout, int taps, int stride, void* tile_stats, void* stream) {
   if (!x || !w_packed || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return CD360_ERR_ARG;
-  if (cd360_conv_dma_slab_rows(N, H, W, Cin, Cout, taps, stride) > 0)  // 3 x 3 / stride 1: the LDS-DMA core (gemm8p.hip, EPI 5)
-    return cd360_conv3x3_dma_bf16(x, w_packed, bias, emb, emb_stride, res, out, N, H, W, Cin, Cout, tile_stats, stream);
+  if (cd360_conv_dma_slab_rows(N, H, W, Cin, Cout, taps, stride) > 0) {  // 3 x 3 / stride 1: the LDS-DMA core (gemm8p.hip, EPI 5)
+    const int rc = cd360_conv3x3_dma_bf16(x, w_packed, bias, emb, emb_stride, res, out, N, H, W, Cin, Cout, tile_stats, stream);
+    // outside that entry's envelope (e.g. an emb row stride it cannot read): the register-staged kernel below serves the call -- unless
+    // statistics were asked for, whose slab size cd360_conv_stats_rows() has already promised from the DMA tiling
+    if (rc != CD360_ERR_SHAPE || tile_stats) return rc;
+  }
   // 1 x 1 (the ResBlock skip_connection convs, openaimodel.py:335-343): a plain Linear over the pixels -- the same core through its GEMM entry
   if (taps == 1 && stride == 1 && !emb && !tile_stats && Cin % 64 == 0 && Cout % 16 == 0 && cd360_tune().conv_dma != 0) {
     const int rc = cd360_gemm_bf16(x, w_packed, out, (int64_t)N * H * W, Cout, Cin, Cin, Cin, Cout, bias, res, Cout, nullptr, 0, 0, 0.f, nullptr, nullptr, 0, stream);

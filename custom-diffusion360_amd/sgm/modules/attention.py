@@ -151,7 +151,7 @@ class MemoryEfficientCrossAttention(nn.Module):
         wk, wv = self.to_k.weight, self.to_v.weight
         use_cache = self.cache_context_kv and not torch.is_grad_enabled()
         if use_cache:
-            key = (context.data_ptr(), context._version, tuple(context.shape), context.dtype, wk.data_ptr(), wk._version, wv._version)
+            key = (context.data_ptr(), context._version, tuple(context.shape), context.dtype, wk.data_ptr(), wk._version, wv.data_ptr(), wv._version)
             if self._kv_cache is not None and self._kv_cache[0] == key:
                 return self._kv_cache[1]
         inner = self.heads * self.dim_head

@@ -449,12 +449,13 @@ def test_gn_silu(N, P, C, silu):
 
 
 # ------------------------------------------------------------------------------------------------ fp8-MFMA cross-attention (configs[4])
-@pytest.mark.parametrize("B,H,Nq,Nk", [(1, 3, 200, 77), (2, 2, 96, 40), (3, 10, 4096, 77)])
+@pytest.mark.parametrize("B,H,Nq,Nk", [(1, 3, 200, 77), (2, 2, 96, 40), (3, 10, 4096, 77), (1, 10, 98304, 77)])
 def test_attention_fp8_mfma_variant_tolerance(B, H, Nq, Nk):
-    """BASELINE configs[4]: QK^T and PV on e4m3 MFMA, bf16 tensors in and out.  Stated tolerance on unit-normal q / k / v with
-    per-tensor amax / 448 scales (measured 5e-2 RMS, 6e-2 - 1e-1 max-norm at SDXL shapes, profiles/r01_fp8_tolerance.json): RMS
-    < 7e-2 and max-norm < 1.5e-1 against the fp32 oracle -- five times outside the 1e-2 bar the bf16 kernel meets, which is why
-    the variant is opt-in and not on the product path.  NaN padding beyond Nk must never leak; Nk > 96 is refused."""
+    """BASELINE configs[4]: QK^T and PV on e4m3 MFMA, bf16 tensors in and out, up to the shape the config is quoted for (the 98 304 pose
+    tokens of one batch element at 1024^2).  Stated tolerance on unit-normal q / k / v with per-tensor amax / 448 scales (measured 5e-2
+    RMS, 6e-2 - 1e-1 max-norm at SDXL shapes, profiles/r03_fp8_tolerance.json): RMS < 7e-2 and max-norm < 1.5e-1 against the fp32 oracle
+    -- six times outside the 1e-2 bar the bf16 kernel meets and 4 % slower at the pose-token shape, which is why the variant is retired
+    from the product path and kept as this measured record.  NaN padding beyond Nk must never leak; Nk > 96 is refused."""
     from cd360 import ops
     g = torch.Generator().manual_seed(B * 1000 + Nq + Nk)
     q = bf(torch.randn(B, Nq, H * 64, generator=g))
