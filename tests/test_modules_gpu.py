@@ -575,9 +575,10 @@ def test_cfgB_full_unet_sampling_step_properties():
 
 
 def test_config4_sdxl_size_train_step_reduces_the_loss():
-    """BASELINE configs[3] at SDXL width and depth (tools/bench_train.py's shapes, batch 2 to keep the test short): train mode
-    (stratified jitter), trainkeys = pose, forward + the four-term loss + backward through the HIP kernels + AdamW on fp32 masters.
-    The loss of the fixed synthetic batch must fall over four steps, every trainable gradient must be finite and non-zero."""
+    """BASELINE configs[3] at SDXL width and depth and at the config's own batch (tools/bench_train.py's shapes: bs = 4, 4 reference views,
+    512^2 images): train mode (stratified jitter), trainkeys = pose, forward + the four-term loss + backward through the HIP kernels
+    (every Linear on cd360_gemm_bf16 / cd360_gemm_tn_bf16: no library GEMM may be reached) + AdamW on fp32 masters.  The loss of the fixed
+    synthetic batch must fall over four steps, every trainable gradient must be finite and non-zero."""
     from cd360 import finetune, synth
     from make_golden_params import LOSS_CFG
     from sgm.util import instantiate_from_config
@@ -587,13 +588,15 @@ def test_config4_sdxl_size_train_step_reduces_the_loss():
     assert len(names) == 96
     opt = finetune.MasterAdamW(finetune.optimizer_param_groups(net, "pose", lr=1e-4), lr=1e-4)
     loss_fn = instantiate_from_config({"target": "sgm.modules.diffusionmodules.loss.StandardDiffusionLossImgRef", "params": LOSS_CFG})
-    b, n, L = 2, 4, 64
+    b, n, L = 4, 4, 64
     rn = lambda *s: torch.randn(*s, generator=g, device=DEV)
     batch = dict(noised=rn(b, 4, L, L), timesteps=torch.full((b,), 500.0, device=DEV), context=rn(b + b * n, 77, 2048), y=rn(b + b * n, 2816),
                  pose=synth.pose_batch(b, n, seed=3), input_ref=rn(b, n, 4, L, L), sigmas_ref=torch.full((b,), 3.0, device=DEV),
                  target=rn(b, 4, L, L), target_rgb=rn(b, 3, 8 * L, 8 * L).clamp(-1, 1), w=torch.full((b, 1, 1, 1), 0.7, device=DEV),
                  mask=torch.ones(b, 1, L, L, device=DEV), opacity=torch.sigmoid(3 * rn(b, 1, 8 * L, 8 * L)))
-    losses = [float(finetune.train_step(net, loss_fn, opt, **batch)[0]) for _ in range(4)]
+    from test_linear_gpu import no_library_gemm
+    with no_library_gemm():
+        losses = [float(finetune.train_step(net, loss_fn, opt, **batch)[0]) for _ in range(4)]
     print("config-4 losses:", [round(v, 4) for v in losses])
     assert all(torch.isfinite(torch.tensor(losses))) and losses[-1] < losses[0]
     params = dict(net.named_parameters())
