@@ -23,7 +23,7 @@ typedef struct cd360_tuning {
   int32_t attn_self;        // 0 | 1 | 2: self-attention kernel generation / tiling
   int32_t attn_fast;        // 0: guarded (masked) path of the first-generation kernel
   int32_t nerf_kernel;      // 0 | 1: render kernel with register gathers / full-line gathers through the wave's LDS block
-  int32_t qattn_cfg;        // 1 | 2: tile of cd360_qproj_attn_bf16 (256 x 256 / 128 x 128)
+  int32_t qattn_cfg;        // 1..4: tile of cd360_qproj_attn_bf16 (256 x 256 / 128 x 128 + movers / 128 x 128 x 2 WGs / 256 x 128)
   int32_t whatif;           // what-if timing bits of the GEMM core: honoured by -DCD360_WHATIF builds only (results are wrong when set)
   int32_t reserved[6];
 } cd360_tuning;

@@ -1074,12 +1074,16 @@ extern "C" int cd360_qproj_attn_dedup_bf16(const void* a, const void* w, void* o
                                            float scale, int dup, void* stream) {
   if (!a || !w || !out || !k || !v || M <= 0 || N <= 0 || K <= 0 || Nq <= 0 || Nk <= 0 || dup < 0 || (int64_t)dup * Nq > M) return CD360_ERR_ARG;
   if (K % 64 || N % 64 || lda % 8 || ldw % 8 || ldo % 8 || lda < K || ldw < K || Nk > 96 || Nq % 128 || M % Nq) return CD360_ERR_SHAPE;
-  // tile: 256 tokens x 256 channels (four heads, eight waves of 128 x 64: the FeatureNeRF pose tokens, 10^5 rows) or 128 x 128 (two
-  // heads, eight waves of 32 x 64 + four mover waves, four LDS buffers: the text cross-attention of every block, M = 3072 ... 12288, where
-  // 256 x 256 tiles would leave most of the 256 CUs idle)
+  // tile (cd360_tuning.qattn_cfg): 1 = 256 tokens x 256 channels (four heads, eight waves of 128 x 64: the FeatureNeRF pose tokens, 10^5
+  // rows), 2 = 128 x 128 (two heads, eight waves of 32 x 64 + four mover waves, four LDS buffers), 4 = 256 x 128 (eight waves of 64 x 64) --
+  // the text cross-attention of every block, M = 3072 ... 12288, where 256 x 256 tiles would leave most of the 256 CUs idle; 3 = 128 x 128
+  // as four waves of 64 x 64 with two buffers (two workgroups per CU: A/B only)
+  // measured (tools/bench_gemm.py qattn, b = 3): the largest tile that still gives every CU a workgroup wins -- pose tokens 256 x 256
+  // (479 / 297 us at the 640 / 1280 level; 128 x 128 with two workgroups per CU 474 / 345: one's attention epilogue under the other's K
+  // loop buys nothing), text tokens of the 640 level 256 x 128 (22 us against 28 on 128 x 128), of the 1280 level 128 x 128 (20 against 31)
   int qcfg = cd360_tune().qattn_cfg;
-  if (qcfg != 1 && qcfg != 2) qcfg = (M / 256) * ((N + 255) / 256) >= 200 ? 1 : 2;
-  if (Nq % 256) qcfg = 2;
+  if (qcfg < 1 || qcfg > 4) qcfg = (M / 256) * ((N + 255) / 256) >= 200 ? 1 : ((M / 256) * ((N + 127) / 128) >= 200 ? 4 : 2);
+  if (Nq % 256 && (qcfg == 1 || qcfg == 4)) qcfg = 2;
   if (k_sb % 8 || k_sn % 8 || v_sb % 8 || v_sn % 8) return CD360_ERR_SHAPE;
   if (((uintptr_t)a | (uintptr_t)w | (uintptr_t)out | (uintptr_t)k | (uintptr_t)v) % 16) return CD360_ERR_ARG;
   if (((uintptr_t)bias | (uintptr_t)ln_stats | (uintptr_t)wsum) % 8) return CD360_ERR_ARG;
@@ -1095,6 +1099,16 @@ extern "C" int cd360_qproj_attn_dedup_bf16(const void* a, const void* w, void* o
   p.a_nq = Nq; p.a_nk = Nk; p.a_scale_log2e = scale * 1.4426950408889634f;
   p.a_dup = dup; p.a_dup_from = (int)(M / Nq) - dup;
   p.cv_H = p.cv_W = p.cv_kg = p.cv_up = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = nullptr;
+  if (qcfg == 3) {  // 128 x 128, four waves of 64 x 64, two buffers: two workgroups per CU (one's attention epilogue under the other's K loop)
+    if (Nk <= 32) return launch_epi<2, 2, 2, 2, 2, 2>(p, (hipStream_t)stream);
+    if (Nk <= 64) return launch_epi<2, 2, 2, 2, 2, 3>(p, (hipStream_t)stream);
+    return launch_epi<2, 2, 2, 2, 2, 4>(p, (hipStream_t)stream);
+  }
+  if (qcfg == 4) {  // 256 x 128, eight waves of 64 x 64, two buffers (96 KB: one workgroup per CU, half the K-loop operand bytes per flop of 128 x 128)
+    if (Nk <= 32) return launch_epi<4, 2, 2, 2, 2, 2>(p, (hipStream_t)stream);
+    if (Nk <= 64) return launch_epi<4, 2, 2, 2, 2, 3>(p, (hipStream_t)stream);
+    return launch_epi<4, 2, 2, 2, 2, 4>(p, (hipStream_t)stream);
+  }
   if (qcfg == 2) {
     if (Nk <= 32) return launch_epi<4, 2, 2, 1, 4, 2>(p, (hipStream_t)stream);
     if (Nk <= 64) return launch_epi<4, 2, 2, 1, 4, 3>(p, (hipStream_t)stream);

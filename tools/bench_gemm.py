@@ -128,12 +128,13 @@ def check():
     ok &= check_qattn(2, 256, 1280, 1280, 50)
     ok &= check_qattn(1, 768, 256, 320, 96)
     ok &= check_qattn(2, 256, 128, 192, 20)
-    for qcfg in (1, 2):  # both tiles on the same shapes; 128-token multiples only on the 128 x 128 tile
+    for qcfg in (1, 2, 3, 4):  # every tile on the same shapes; 128-token multiples only on the 128-row tiles
         ok &= check_qattn(3, 1024, 1280, 1280, 77, qcfg=qcfg)
         ok &= check_qattn(2, 512, 640, 640, 77, qcfg=qcfg)
         ok &= check_qattn(1, 256, 192, 128, 33, qcfg=qcfg)
-    ok &= check_qattn(2, 384, 320, 320, 77, qcfg=2)
-    ok &= check_qattn(3, 128, 128, 64, 20, ln=False, qcfg=2)
+    for qcfg in (2, 3):
+        ok &= check_qattn(2, 384, 320, 320, 77, qcfg=qcfg)
+        ok &= check_qattn(3, 128, 128, 64, 20, ln=False, qcfg=qcfg)
     for cfg in (1, 2, 3, 4, 5, 6, 7):
         for (M, N, K) in [(256, 256, 64), (256, 256, 128), (512, 512, 192), (300, 272, 320), (128, 128, 64), (1000, 640, 640), (3072, 1280, 1280)]:
             ok &= check_case(M, N, K, cfg=cfg)
@@ -219,7 +220,7 @@ def time_qattn():
         st = ops.row_stats(a)
         n = 10 if nq > 50000 else 30
         t_f = {}
-        for qcfg in (1, 2):
+        for qcfg in (1, 2, 3, 4):
             ENV["CD360_QATTN_CFG"] = str(qcfg)
             t_f[qcfg] = timeit_graph(lambda: ops.qproj_attention(a, w, k, v, 77, heads, bias=cb, ln=(st, ws, 1e-5)), n=n)
         ENV.pop("CD360_QATTN_CFG", None)
@@ -228,6 +229,7 @@ def time_qattn():
         t_a = timeit_graph(lambda: ops.attention(q, k, v, heads, 77), n=n)
         flops = b * nq * (2.0 * C * C + 4.0 * 77 * C)
         print(f"{name}: fused 256x256 {t_f[1]:7.1f} us ({flops / t_f[1] * 1e-6:5.0f} TF/s) | fused 128x128 {t_f[2]:7.1f} us ({flops / t_f[2] * 1e-6:5.0f} TF/s) | "
+              f"128x128 4 waves x2 WG {t_f[3]:7.1f} | 256x128 {t_f[4]:7.1f} | "
               f"q GEMM {t_g:7.1f} + attention {t_a:7.1f} = {t_g + t_a:7.1f}", flush=True)
 
 
