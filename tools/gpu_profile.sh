@@ -6,7 +6,7 @@ TAG=${1:-r1}
 STEPS=${2:-6}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
-BENCH="python $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --no-profile --no-graph"
+BENCH="python $GRAFT_REPO_ROOT/bench.py --steps $STEPS --warmup 2 --no-cpu-baseline --no-train-step --no-profile --no-graph"
 cd /tmp
 rm -rf /tmp/prof_$TAG
 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$TAG/kt -o bench -- $BENCH > $OUT/bench_kt.log 2>&1; echo "kt exit $?"

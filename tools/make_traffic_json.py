@@ -41,7 +41,7 @@ def load(counter):
             if targs and targs[-1] == 5:
                 key = "conv_igemm"
             elif targs and 2 <= targs[-1] <= 4:
-                key = "qproj_attn_text" if targs[:4] == [4, 2, 2, 1] else "qproj_attn"
+                key = "qproj_attn" if targs[:4] == [2, 4, 2, 4] else "qproj_attn_text"  # only the pose tokens take the 256 x 256 tile
         d = out.setdefault(key, {"n": 0, "kb": 0.0, "symbols": set()})
         d["n"] += int(r["dispatches"])
         d["kb"] += float(r["total"])
