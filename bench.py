@@ -241,6 +241,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying the steady-state step from a hipGraph")
+    ap.add_argument("--route", choices=["fused", "module"], default="fused", help="module: a no-op forward hook on every transformer block, so the "
+                    "blocks take the strict module route a patched sample.py (sample.py:247-262) or a hooked run takes -- same kernels, un-fused")
     ap.add_argument("--no-train-step", action="store_true", help="skip the fine-tuning step measurement appended after the timed region (BASELINE configs[3])")
     args = ap.parse_args()
 
@@ -260,6 +262,11 @@ def main():
     mine = shard.assign_poses(n_poses, world, rank)  # indices of the target poses this rank samples (independent trajectories)
     assert len(mine) >= 1, "--poses must be >= --gpus"
     net = build_model(args.latent, args.refs, 50, dev)
+    if args.route == "module":
+        from sgm.modules.attention import BasicTransformerBlock
+        for m in net.modules():
+            if isinstance(m, BasicTransformerBlock):
+                m.register_forward_hook(lambda mod, inp, out: None)
     jobs = []
     for pi in mine:  # one target pose = one CFG-3 batch with its own latent; the 50 reference cameras are shared
         pose = synth.pose_batch(1, args.refs, seed=100 + pi, n_train=50) * 3
@@ -404,7 +411,7 @@ def main():
                        "render_step_ms": round(render_ms, 2), "steady_step_ms": round(steady_ms, 2), "cfg_batch": 3, "latent": args.latent,
                        "n_ref": args.refs, "poses": n_poses, "poses_per_gpu": len(mine), "world_size": world,
                        "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1, "parallelism": "pose-dp%d" % world,
-                       "hipgraph": not args.no_graph, "hipgraph_render_step": smp.rgraph is not None,
+                       "hipgraph": not args.no_graph, "hipgraph_render_step": smp.rgraph is not None, "route": args.route,
                        "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)},
                        "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
                        "kernel_ms_per_step_source": "a separate EAGER replay of the same K steps after the timed region, HIP events around every launch "

@@ -582,7 +582,7 @@ if __name__ == "__main__":
     if "group_m" in what:
         group_m_sweep()
     if "qattn_one" in what:  # a few launches of the fused pose-token attention (A3) at both pose levels for rocprofv3 --pmc passes
-        for b, nq, C in ((3, 98304, 640), (3, 24576, 1280)):
+        for b, nq, C in ((3, 98304, 640), (3, 24576, 1280), (3, 4096, 640), (3, 1024, 1280)):  # A3 at both pose levels, then A2 at both levels
             a = rnd(b, nq, C, seed=1).to(torch.bfloat16)
             w = rnd(C, C, seed=2, scale=C ** -0.5).to(torch.bfloat16)
             kv = rnd(b, 80, 2 * C, seed=4).to(torch.bfloat16)
