@@ -89,21 +89,27 @@ def optimizer_param_groups(unet: torch.nn.Module, trainkeys: str = "pose", lr: f
 
 # ---------------------------------------------------------------- loss weighting
 def combine_losses(loss, loss_fg, loss_bg, loss_rgb, drop_im, *, rgb: bool = True, rgb_predict: bool = True, global_step: int = 1,
-                   loss_fg_lambda: float = 10.0, loss_bg_lambda: float = 10.0, loss_rgb_lambda: float = 5.0):
+                   loss_fg_lambda: float = 10.0, loss_bg_lambda: float = 10.0, loss_rgb_lambda: float = 5.0, as_tensors: bool = False):
     """DiffusionEngine.forward (diffusion.py:226-241).  `drop_im` [b] is 1 where the sample kept its reference images; the
-    render losses only count those samples.  Defaults are configs/train_co3d_concept.yaml:9-11."""
+    render losses only count those samples.  Defaults are configs/train_co3d_concept.yaml:9-11.
+    as_tensors=True: the logged terms stay 0-d device tensors and the `loss_rgb.mean() > 0` test of the reference becomes arithmetic
+    (the rgb term is a masked mean of squared errors: > 0, or exactly 0 with every error 0 -- adding lambda * 0 leaves the total unchanged
+    and sends a zero gradient through those errors, as skipping the term does) -- no host synchronisation between the forward and the
+    backward pass, and the step can be captured into a hipGraph."""
     total = loss.mean()
-    out = {"loss": float(total.detach())}
+    out = {"loss": total.detach()}
     den = drop_im.sum() + 1e-12
     if rgb and global_step > 0:
         fg = (loss_fg.mean(1) * drop_im.reshape(-1)).sum() / den
         bg = (loss_bg.mean(1) * drop_im.reshape(-1)).sum() / den
         total = total + loss_fg_lambda * fg + loss_bg_lambda * bg
-        out["loss_fg"], out["loss_bg"] = float(fg.detach()), float(bg.detach())
-    if rgb_predict and loss_rgb.mean() > 0:
+        out["loss_fg"], out["loss_bg"] = fg.detach(), bg.detach()
+    if rgb_predict and (as_tensors or loss_rgb.mean() > 0):
         lr = (loss_rgb.mean(1) * drop_im.reshape(-1)).sum() / den
         total = total + loss_rgb_lambda * lr
-        out["loss_rgb"] = float(lr.detach())
+        out["loss_rgb"] = lr.detach()
+    if not as_tensors:
+        out = {k: float(v) for k, v in out.items()}
     return total, out
 
 
@@ -240,17 +246,66 @@ class MasterAdamW:
 
 
 def train_step(unet: torch.nn.Module, loss_fn, optimizer, *, noised, timesteps, context, y, pose, input_ref, sigmas_ref, target, target_rgb,
-               w, mask, opacity, drop_im=None, mask_ref=None, **loss_kw):
+               w, mask, opacity, drop_im=None, mask_ref=None, as_tensors: bool = False, **loss_kw):
     """One step of the fine-tuning loop on already-noised inputs (the engine's denoiser / conditioner / data loading stay outside
     the path): forward, StandardDiffusionLossImgRef.get_loss (loss.py:177-209), the lambda-weighted total
-    (diffusion.py:226-241), backward, optimiser step.  Returns (total loss tensor, dict of logged terms)."""
+    (diffusion.py:226-241), backward, optimiser step.  Returns (total loss tensor, dict of logged terms).
+    The logged terms are read back AFTER the optimiser step has been queued (one host synchronisation per step, at its end, instead of
+    four between the forward and the backward pass); as_tensors=True leaves them on the device (no synchronisation at all)."""
     optimizer.zero_grad()
     out, fgs, alphas, rgbs = unet(noised, timesteps=timesteps, context=context, y=y, pose=pose, input_ref=input_ref, sigmas_ref=sigmas_ref,
                                   mask_ref=mask_ref)
     l2, lfg, lbg, lrgb = loss_fn.get_loss(out, fgs, rgbs, target, target_rgb, w, mask, mask_ref, opacity, alphas)
     if drop_im is None:
         drop_im = torch.ones(noised.shape[0], device=noised.device)
-    total, logged = combine_losses(l2, lfg, lbg, lrgb, drop_im, **loss_kw)
+    total, logged = combine_losses(l2, lfg, lbg, lrgb, drop_im, as_tensors=True, **loss_kw)
     total.backward()
     optimizer.step()
+    if not as_tensors:
+        logged = {k: float(v) for k, v in logged.items()}
     return total.detach(), logged
+
+
+class GraphedTrainStep:
+    """train_step captured ONCE into a hipGraph and replayed: forward, loss, backward and the optimiser step of BASELINE config 4 are
+    ~6400 kernel launches and ~16000 torch operator calls per step -- host work that takes longer than the kernels run (DESIGN.md section 6b);
+    a replay costs one launch.  Conditions: fixed shapes (the batch is copied into static buffers), a MasterAdamW built with
+    capturable=True, the raymarchers on device_rng=True (the stratified jitter of patch x / y is then drawn by the device generator, which
+    a graph advances on every replay; the reference draws those two on the CPU generator), a single process (no gradient all-reduce
+    inside the graph).  The returned loss terms are 0-d device tensors that the next replay overwrites."""
+
+    def __init__(self, unet: torch.nn.Module, loss_fn, optimizer: "MasterAdamW", batch: dict, warmup: int = 3, **loss_kw):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            raise NotImplementedError("GraphedTrainStep: single process only (the gradient all-reduce is not captured)")
+        if not all(g.get("capturable") for g in optimizer.opt.param_groups):
+            raise ValueError("GraphedTrainStep: build the optimiser with MasterAdamW(..., capturable=True)")
+        self.unet, self.loss_fn, self.optimizer, self.loss_kw = unet, loss_fn, optimizer, loss_kw
+        for m in unet.modules():
+            if hasattr(m, "device_rng"):
+                m.device_rng = True
+        clone = lambda v: v.clone() if torch.is_tensor(v) else ({k: clone(x) for k, x in v.items()} if isinstance(v, dict) else v)
+        self.static = {k: clone(v) for k, v in batch.items()}
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):  # allocator, library workspaces, weight packs, optimiser state: all settled before the capture
+            for _ in range(warmup):
+                train_step(unet, loss_fn, optimizer, as_tensors=True, **self.static, **loss_kw)
+        torch.cuda.current_stream().wait_stream(side)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.total, self.logged = train_step(unet, loss_fn, optimizer, as_tensors=True, **self.static, **loss_kw)
+
+    @staticmethod
+    def _load(dst, src):
+        if torch.is_tensor(dst):
+            dst.copy_(src)
+        elif isinstance(dst, dict):
+            for k in dst:
+                GraphedTrainStep._load(dst[k], src[k])
+
+    def __call__(self, **batch):
+        """Copies `batch` (same keys and shapes as at construction; omitted keys keep their values) into the static buffers, replays."""
+        for k, v in batch.items():
+            self._load(self.static[k], v)
+        self.graph.replay()
+        return self.total, self.logged

@@ -51,7 +51,18 @@ def positional_encoding(x: torch.Tensor, n_freqs: int) -> torch.Tensor:
     """utils_cameraray.py:222-242 (only used here for the per-view constants: O(b*n) values)."""
     start = -1 * (n_freqs / 2)
     freqs = 2.0 ** torch.arange(start, start + n_freqs, device=x.device) * np.pi
-    return torch.cat([torch.sin(x * f) for f in freqs] + [torch.cos(x * f) for f in freqs], dim=-1)
+    xf = (x[..., None, :] * freqs[:, None]).flatten(-2)  # [..., n_freqs * D], frequency-major as the reference's concatenation
+    return torch.cat([torch.sin(xf), torch.cos(xf)], dim=-1)
+
+
+_grid_cache = {}
+
+
+def _const(key, make):
+    """Host-built constants, uploaded once per (what, device): a training step then issues no host-to-device copy for them."""
+    if key not in _grid_cache:
+        _grid_cache[key] = make()
+    return _grid_cache[key]
 
 
 class FusedNerfWeights:
@@ -69,8 +80,8 @@ class FusedNerfWeights:
         self.Wf_t = W1f[:, :C].t().contiguous().to(dtype)  # [C, C]: Y = xref @ Wf_t
         cols = xyz_k_columns(C)
         Wk = torch.zeros(C, len(cols), dtype=torch.float32, device=dev)
-        idx = torch.tensor([c for c in cols if c >= 0], device=dev)
-        pos = torch.tensor([i for i, c in enumerate(cols) if c >= 0], device=dev)
+        idx, pos = _const(("xyz_k", C, str(dev)), lambda: (torch.tensor([c for c in cols if c >= 0], device=dev),
+                                                           torch.tensor([i for i, c in enumerate(cols) if c >= 0], device=dev)))
         Wk[:, pos] = W1f[:, idx]
         self.Wk_f32 = Wk  # [C, 112] fp32 (kept for tests / re-quantisation)
         self.Wk = Wk.to(torch.bfloat16).contiguous()
@@ -95,26 +106,24 @@ class FusedNerfWeights:
         self.live = live
 
 
-_grid_cache = {}
-
-
 def patch_positions(r: int, device, jitter: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """utils_cameraray.py:106-147 on the host (r floats), then uploaded; cached in eval mode."""
+    """utils_cameraray.py:106-147: r patch centres in [1, -1]; with `jitter` (r + 1 uniforms, stratified training) a uniform point of
+    each patch.  Eval: computed on the host once and cached.  A host `jitter` (the reference's CPU generator) is combined on the host and
+    uploaded; a device `jitter` is combined on the device against cached bounds (no host tensor: graph capture)."""
     key = (r, str(device))
-    if jitter is None and key in _grid_cache:
-        return _grid_cache[key]
-    edges = torch.linspace(1, -1, r + 1)
     if jitter is None:
-        pos = (edges[:-1] + edges[1:]) / 2
-    else:
+        return _const(key, lambda: ((lambda e: (e[:-1] + e[1:]) / 2)(torch.linspace(1, -1, r + 1))).to(device))
+
+    def bounds():
+        edges = torch.linspace(1, -1, r + 1)
         center = (edges[1:] + edges[:-1]) / 2.0
-        upper = torch.cat([center, edges[-1:]], -1)
-        lower = torch.cat([edges[:1], center], -1)
-        pos = (lower + (upper - lower) * jitter.cpu())[:-1]
-    out = pos.to(device)
-    if jitter is None:
-        _grid_cache[key] = out
-    return out
+        return torch.cat([edges[:1], center], -1), torch.cat([center, edges[-1:]], -1)
+
+    if jitter.is_cuda:
+        lower, upper = _const(("bounds",) + key, lambda: tuple(t.to(device) for t in bounds()))
+        return (lower + (upper - lower) * jitter)[:-1].contiguous()
+    lower, upper = bounds()
+    return (lower + (upper - lower) * jitter)[:-1].to(device)
 
 
 _depth_cache = {}
@@ -126,14 +135,18 @@ def depth_samples(num_samples: int, far: float, near: float, device, num_rays: i
     key = (int(num_samples), float(far), float(near), str(device))
     if jitter is None and key in _depth_cache:  # eval mode: constants -- no host-to-device copy per call (hipGraph-capturable)
         return _depth_cache[key]
-    l = torch.linspace(near, near + (near + far), num_samples + 1)
     if jitter is None:
+        l = torch.linspace(near, near + (near + far), num_samples + 1)
         _depth_cache[key] = (((l[1:] + l[:-1]) / 2.0).to(device), (l[1:] - l[:-1]).to(device))
         return _depth_cache[key]
-    center = (l[1:] + l[:-1]) / 2.0
-    upper = torch.cat([center, l[-1:]], -1).to(device)
-    lower = torch.cat([l[:1], center], -1).to(device)
-    j = lower[None] + (upper[None] - lower[None]) * jitter.to(device)
+
+    def bounds():
+        l = torch.linspace(near, near + (near + far), num_samples + 1)
+        center = (l[1:] + l[:-1]) / 2.0
+        return torch.cat([l[:1], center], -1).to(device)[None], torch.cat([center, l[-1:]], -1).to(device)[None]
+
+    lower, upper = _const(("depth_bounds",) + key, bounds)
+    j = lower + (upper - lower) * jitter.to(device)
     return ((j[..., :-1] + j[..., 1:]) / 2.0).contiguous(), (j[..., 1:] - j[..., :-1]).contiguous()
 
 

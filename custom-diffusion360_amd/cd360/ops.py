@@ -18,11 +18,17 @@ _I64x3 = ctypes.c_int64 * 3
 # bench.py brackets every C-ABI launch with HIP events ON THE LAUNCH STREAM (torch's current stream is the stream every
 # kernel here is enqueued on) and reads them back after the timed region; off by default (zero overhead).
 _PROF = None
+_PROF_SHAPES = False
 
 
-def profile_start() -> None:
-    global _PROF
-    _PROF = []
+def profile_start(shapes: bool = False) -> None:
+    """shapes=True: the GEMM entries are keyed per problem shape ("gemm8p[MxNxK]", "gemm_tn[MxNxK]") instead of per kernel."""
+    global _PROF, _PROF_SHAPES
+    _PROF, _PROF_SHAPES = [], bool(shapes)
+
+
+def _shape_tag(name: str, M: int, N: int, K: int) -> str:
+    return f"{name}[{M}x{N}x{K}]" if _PROF_SHAPES else name
 
 
 def profile_stop() -> dict:
@@ -676,7 +682,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     if want_stats:
         tn = lib.cd360_gemm_tile_n(M, N)
         stats_out = torch.empty(M, (N + tn - 1) // tn, 2, dtype=torch.float32, device=a.device)
-    with _timed("gemm8p", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * nout + (M * N if res is not None else 0))):
+    with _timed(_shape_tag("gemm8p", M, N, K), 2.0 * M * N * K, 2.0 * (M * K + N * K + M * nout + (M * N if res is not None else 0))):
         check(lib.cd360_gemm_bf16(_ptr(a), _ptr(w), _ptr(out), M, N, K, lda, w.stride(0), ldo, _ptr(bias), _ptr(res), ldr, _ptr(stats_in), parts,
                                   ln_dim, float(eps), _ptr(wsum), _ptr(stats_out), 1 if geglu else 0, _stream()), "cd360_gemm_bf16")
     return (out, stats_out) if want_stats else out
@@ -760,7 +766,7 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.bfloat16) -> torch
     lib = _lib.load()
     out = torch.empty(N, K, dtype=out_dtype, device=a.device)
     ws = torch.empty(max(16, lib.cd360_gemm_tn_workspace_bytes(M, N, K)), dtype=torch.uint8, device=a.device)
-    with _timed("gemm_tn", 2.0 * M * N * K, 2.0 * (M * N + M * K) + out.element_size() * N * K):
+    with _timed(_shape_tag("gemm_tn", M, N, K), 2.0 * M * N * K, 2.0 * (M * N + M * K) + out.element_size() * N * K):
         check(lib.cd360_gemm_tn_bf16(_ptr(a), _ptr(b), _ptr(out), M, N, K, lda, ldb, 1 if out_dtype == torch.bfloat16 else 0, _ptr(ws), _stream()),
               "cd360_gemm_tn_bf16")
     return out
@@ -780,14 +786,16 @@ def gemm_tn_ok(a: torch.Tensor, b: torch.Tensor) -> bool:
 
 
 def gemm_cstats(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None):
-    """gemm(a, w, bias, res) for an output a GroupNorm reads next: -> (out, cstats) with cstats fp32 [rows / 64, N, 2] = per slab of 64
-    rows and channel the (sum, sum of squares) of the stored outputs (gn_silu's tile_stats after a reshape to [images, slabs, N, 2]);
-    cstats is None when the tiling chosen for this shape has no 64-row slabs or rows % 64 != 0 (plain gemm then)."""
+    """gemm(a, w, bias, res) for an output a GroupNorm reads next: -> (out, cstats) with cstats fp32 [rows / S, N, 2] = per slab of S = 64
+    or 32 rows (cd360_gemm_cstats_rows: the tiling decides) and channel the (sum, sum of squares) of the stored outputs (gn_silu's
+    tile_stats after a reshape to [images, slabs, N, 2]); cstats is None when the tiling chosen for this shape writes no slabs or
+    rows % 64 != 0 (plain gemm then)."""
     _need_gpu(a, w, bias, res)
     M, lda = _rows2d(a)
     K, N = a.shape[-1], w.shape[0]
     lib = _lib.load()
-    if M % 64 or lib.cd360_gemm_cstats_rows(M, N) != 64:
+    slab = lib.cd360_gemm_cstats_rows(M, N)
+    if M % 64 or slab <= 0:
         return gemm(a, w, bias=bias, res=res), None
     assert w.dtype == torch.bfloat16 and w.dim() == 2 and w.shape[1] == K and w.stride(1) == 1
     assert bias is None or (bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == N)
@@ -796,8 +804,8 @@ def gemm_cstats(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     if res is not None:
         mr, ldr = _rows2d(res)
         assert mr == M and res.shape[-1] == N
-    cstats = torch.empty(M // 64, N, 2, dtype=torch.float32, device=a.device)
-    with _timed("gemm8p", 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N + (M * N if res is not None else 0))):
+    cstats = torch.empty(M // slab, N, 2, dtype=torch.float32, device=a.device)
+    with _timed(_shape_tag("gemm8p", M, N, K), 2.0 * M * N * K, 2.0 * (M * K + N * K + M * N + (M * N if res is not None else 0))):
         check(lib.cd360_gemm_cstats_bf16(_ptr(a), _ptr(w), _ptr(out), M, N, K, lda, w.stride(0), N, _ptr(bias), _ptr(res), ldr, _ptr(cstats), _stream()),
               "cd360_gemm_cstats_bf16")
     return out, cstats

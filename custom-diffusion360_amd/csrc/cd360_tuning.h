@@ -25,7 +25,8 @@ typedef struct cd360_tuning {
   int32_t nerf_kernel;      // 0 | 1: render kernel with register gathers / full-line gathers through the wave's LDS block
   int32_t qattn_cfg;        // 1..4: tile of cd360_qproj_attn_bf16 (256 x 256 / 128 x 128 + movers / 128 x 128 x 2 WGs / 256 x 128)
   int32_t whatif;           // what-if timing bits of the GEMM core: honoured by -DCD360_WHATIF builds only (results are wrong when set)
-  int32_t reserved[6];
+  int32_t gemm_small;       // 0: pick_cfg without its small-batch rules (64 x 128 tiles; 128-wide tiles for wide outputs of <= 512 tiles)
+  int32_t reserved[5];
 } cd360_tuning;
 
 int cd360_set_tuning(const cd360_tuning* t);

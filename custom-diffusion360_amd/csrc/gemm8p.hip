@@ -958,6 +958,17 @@ int launch_128x4(const GemmParams& p, hipStream_t stream) {
   return launch_ks<2, 4, 1, 2, 4, 1, EPI>(p, stream);
 }
 
+// 64 x 128 tiles for launches whose 128 x 128 tiling would leave more than half of the 256 CUs without a workgroup (the 1280-wide
+// projections of a 1024-token batch: 80 tiles -> 160): eight waves of 32 x 32 on all four k-steps, or -- K >= 3072 -- eight waves of
+// 32 x 64 in two k-step groups; four LDS buffers + mover waves as the 128 x 128 arrangement.
+template <int EPI>
+int launch_64x4(const GemmParams& p, hipStream_t stream) {
+  const int forced = cd360_tune().gemm_ksplit;
+  const int mode = forced >= 0 ? forced : (p.K >= 3072 ? 1 : 0);
+  if (mode == 1) return launch_ks<2, 2, 2, 1, 4, 2, EPI>(p, stream);
+  return launch_ks<2, 4, 1, 1, 4, 1, EPI>(p, stream);
+}
+
 template <int WM, int WN, int NCB, int NMB, int NBUF>
 int launch(const GemmParams& p, hipStream_t stream) {
   return p.geglu ? launch_epi<WM, WN, NCB, NMB, NBUF, 1>(p, stream) : launch_epi<WM, WN, NCB, NMB, NBUF, 0>(p, stream);
@@ -966,22 +977,31 @@ int launch(const GemmParams& p, hipStream_t stream) {
 // Tilings (tokens x channels, waves, LDS buffers): 1 = 128 x 128, 4 waves of 64 x 64, 2 buffers (two workgroups per CU);
 // 2 = 128 x 128, 8 waves of 64 x 32, 2 buffers; 3 = 256 x 256, 8 waves of 128 x 64, 2 buffers; 4 = as 2 with 4 buffers (3 tiles in
 // flight: long K loops of launches with one workgroup per CU); 5 = 256 x 128, 8 waves of 64 x 64, 3 buffers; 6 = 256 x 192, 8 waves of
-// 64 x 96, 2 buffers; 7 = 256 x 256, SIXTEEN waves of 64 x 64 (four per SIMD), 2 buffers
-constexpr int NCFG = 7;
-constexpr int CFG_BM[NCFG + 1] = {0, 128, 128, 256, 128, 256, 256, 256}, CFG_BN[NCFG + 1] = {0, 128, 128, 256, 128, 128, 192, 256};
+// 64 x 96, 2 buffers; 7 = 256 x 256, SIXTEEN waves of 64 x 64 (four per SIMD), 2 buffers; 8 = 64 x 128, 8 waves, 4 buffers (launch_64x4)
+constexpr int NCFG = 8;
+constexpr int CFG_BM[NCFG + 1] = {0, 128, 128, 256, 128, 256, 256, 256, 64}, CFG_BN[NCFG + 1] = {0, 128, 128, 256, 128, 128, 192, 256, 128};
 int pick_cfg(int64_t M, int N, bool geglu) {
   const int cfg = cd360_tune().gemm_cfg;  // tuning / A-B override
-  if (cfg >= 1 && cfg <= NCFG && !(geglu && (cfg == 2 || cfg == 4 || cfg == 6))) return cfg;
+  if (cfg >= 1 && cfg <= NCFG && !(geglu && (cfg == 2 || cfg == 4 || cfg == 6 || cfg == 8))) return cfg;
   if (geglu) return 7;  // FF1 + GEGLU: sixteen waves of 64 x 64 on the 256 x 256 tile, -3 % against eight of 128 x 64 (bit-identical results)
   // Measured on the SDXL shapes (tools/bench_gemm.py, profiles/r02_gemm_shapes.txt).  Narrow outputs (the C -> C projections and the
   // feed-forward's second Linear): 128 x 128 tiles -- with four LDS buffers when the launch has at most one workgroup per CU (the
   // 1280-wide level: 240 tiles), two otherwise (two workgroups per CU overlap each other's prologue / epilogue) -- except for very
   // tall problems (the FeatureNeRF pose tokens) where 256 x 256 tiles amortise the weights better.
+  // Small batches (the fine-tune step's target stream, context / embedding projections; tools/bench_gemm.py small_m, mid_m): with at most
+  // 128 tiles of 128 x 128, 64 x 128 tiles double the busy CUs (M = 1024, N = 1280: 14.0 -> 11.7 us at K = 1280, 63.5 -> 50.8 at K = 10240;
+  // M = 320, N = 2560: 16.5 -> 14.1 where the wide rule below took 32.9)
+  const long nwg = ((M + 127) / 128) * ((N + 127) / 128);
+  const bool small = cd360_tune().gemm_small != 0;
+  if (small && nwg <= 128) return 8;
   if (N <= 1536) {
     if (M >= 65536) return 3;
-    const long nwg = ((M + 127) / 128) * ((N + 127) / 128);
     return nwg <= 256 ? 4 : 2;
   }
+  // wide outputs that 256-wide tiles cannot spread over the chip: 128 x 128 up to one workgroup per CU (M = 1024, N = 3840: 15.2 us
+  // against 25.9 on 256 x 192), 256 x 128 with three buffers up to two (M = 1024, N = 5120: 20.5 against 27.8; M = 4096, N = 1920: 16.2 / 19.7)
+  if (small && nwg <= 256) return 4;
+  if (small && nwg <= 512) return 5;
   // Wide outputs: 256 x 256 tiles unless 256 x 192 fills the 256 CUs better (q|k|v: 12 x 15 = 180 tiles against 12 x 20 = 240)
   auto eff = [&](int bm, int bn) {
     const long tm = (M + bm - 1) / bm, tn = (N + bn - 1) / bn, nwg = tm * tn, rounds = (nwg + 255) / 256;
@@ -997,7 +1017,10 @@ int pick_cfg(int64_t M, int N, bool geglu) {
 extern "C" int cd360_gemm_tile_n(int64_t M, int N) { return CFG_BN[pick_cfg(M, N, false)]; }
 
 // Rows per slab of the channel statistics cd360_gemm_cstats_bf16 writes for an [M, N] output (the launch's wave tiling decides)
-extern "C" int cd360_gemm_cstats_rows(int64_t M, int N) { return pick_cfg(M, N, false) == 2 || pick_cfg(M, N, false) == 4 ? 64 : 0; }
+extern "C" int cd360_gemm_cstats_rows(int64_t M, int N) {
+  const int cfg = pick_cfg(M, N, false);
+  return cfg == 2 || cfg == 4 ? 64 : (cfg == 8 ? 32 : 0);
+}
 
 // out[M, N] (bf16, row stride ldo) = epilogue(A[M, K] @ W[N, K]^T); A, W bf16 with row strides lda, ldw (elements, multiples of 8),
 // K % 64 == 0, N % 16 == 0, all base pointers 16-byte aligned.
@@ -1031,6 +1054,7 @@ extern "C" int cd360_gemm_bf16(const void* a, const void* w, void* out, int64_t 
     case 1: return launch<2, 2, 2, 2, 2>(p, (hipStream_t)stream);
     case 2: return geglu ? CD360_ERR_SHAPE : launch_epi<2, 4, 1, 2, 2, 0>(p, (hipStream_t)stream);
     case 4: return geglu ? CD360_ERR_SHAPE : launch_128x4<0>(p, (hipStream_t)stream);
+    case 8: return geglu ? CD360_ERR_SHAPE : launch_64x4<0>(p, (hipStream_t)stream);
     case 5: return launch<4, 2, 2, 2, 3>(p, (hipStream_t)stream);
     case 7: return launch<4, 4, 2, 2, 2>(p, (hipStream_t)stream);  // 256 x 256 as sixteen waves of 64 x 64 (four per SIMD): A/B only
     case 6: return geglu ? CD360_ERR_SHAPE : launch_epi<4, 2, 3, 2, 2, 0>(p, (hipStream_t)stream);
@@ -1040,8 +1064,8 @@ extern "C" int cd360_gemm_bf16(const void* a, const void* w, void* out, int64_t 
 
 // cd360_gemm_bf16(a, w, out, ..., bias, res) for an output that a GroupNorm reads next (SpatialTransformer.proj_out + its residual,
 // attention.py:880-886, followed by the next ResBlock's in_layers): additionally writes cstats fp32 [M / cd360_gemm_cstats_rows(M, N), N, 2]
-// = per slab of 64 rows and channel, (sum, sum of squares) of the stored bf16 outputs -- the `tile_stats` of cd360_gn_silu_bf16, like
-// the convolution epilogue's.  CD360_ERR_SHAPE when the tiling chosen for (M, N) has no 64-row slabs (cd360_gemm_cstats_rows == 0).
+// = per slab of cd360_gemm_cstats_rows(M, N) = 64 | 32 rows and channel, (sum, sum of squares) of the stored bf16 outputs -- the `tile_stats`
+// of cd360_gn_silu_bf16, like the convolution epilogue's.  CD360_ERR_SHAPE when the tiling chosen for (M, N) writes none (rows == 0).
 extern "C" int cd360_gemm_cstats_bf16(const void* a, const void* w, void* out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldo,
                                       const void* bias, const void* res, int64_t ldr, void* cstats, void* stream) {
   if (!a || !w || !out || !cstats || M <= 0 || N <= 0 || K <= 0) return CD360_ERR_ARG;
@@ -1049,7 +1073,7 @@ extern "C" int cd360_gemm_cstats_bf16(const void* a, const void* w, void* out, i
   if (((uintptr_t)a | (uintptr_t)w | (uintptr_t)out | (uintptr_t)res | (uintptr_t)cstats) % 16 || (uintptr_t)bias % 8) return CD360_ERR_ARG;
   if (M > 0x7fffffffL || (M + 256) * lda * 2 >= (1L << 32) || ((long)N + 256) * ldw * 2 >= (1L << 32)) return CD360_ERR_SHAPE;
   const int cfg = pick_cfg(M, N, false);
-  if (cfg != 2 && cfg != 4) return CD360_ERR_SHAPE;
+  if (cfg != 2 && cfg != 4 && cfg != 8) return CD360_ERR_SHAPE;
   GemmParams p;
   p.a = (const uint16_t*)a; p.w = (const uint16_t*)w; p.out = (uint16_t*)out; p.bias = (const float*)bias; p.res = (const uint16_t*)res;
   p.ln_stats = nullptr; p.wsum = nullptr; p.stats_out = nullptr;
@@ -1058,6 +1082,7 @@ extern "C" int cd360_gemm_cstats_bf16(const void* a, const void* w, void* out, i
   p.tiles_m = p.tiles_n = p.group_m = 0;
   p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f; p.a_dup = p.a_dup_from = 0;
   p.cv_H = p.cv_W = p.cv_kg = p.cv_up = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = (float*)cstats;
+  if (cfg == 8) return launch_64x4<6>(p, (hipStream_t)stream);
   return cfg == 2 ? launch_epi<2, 4, 1, 2, 2, 6>(p, (hipStream_t)stream) : launch_128x4<6>(p, (hipStream_t)stream);
 }
 

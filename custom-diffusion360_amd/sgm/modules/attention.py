@@ -450,11 +450,16 @@ class BasicTransformerBlock(nn.Module):
                a1.to_q.weight, a1.to_k.weight, a1.to_v.weight, a1.to_out[0].weight, a1.to_out[0].bias,
                a2.to_q.weight, a2.to_out[0].weight, a2.to_out[0].bias,
                ff.net[0].proj.weight, ff.net[0].proj.bias, ff.net[2].weight, ff.net[2].bias]
-        if self.image_cross:
-            src.append(self.pose_emb_layers.weight)
         key = tuple((t.data_ptr(), t._version) for t in src)
         if self._pack is not None and self._pack[0] == key:
-            return self._pack[1]
+            P = self._pack[1]
+            if self.image_cross:  # the one trainable source ("pose" keys): re-packed alone, the frozen entries stay (fine-tune step)
+                pw = self.pose_emb_layers.weight
+                pkey = (pw.data_ptr(), pw._version)
+                if self._pack[2] != pkey:
+                    P["pose"] = self._pack_pose()
+                    self._pack = (key, P, pkey)
+            return P
         P = {}
         # the q rows carry the softmax scale and log2(e) (ops.attention(prescaled=True)): q is rounded to bf16 once, as in the reference
         P["qkv"] = ops.pack_ln_linear(torch.cat([a1.to_q.weight.detach().float() * ops.ATTN_PRESCALE, a1.to_k.weight.detach().float(),
@@ -466,12 +471,17 @@ class BasicTransformerBlock(nn.Module):
         perm = ops.geglu_row_order(w.shape[0] // 2, w.device)
         P["ff1"] = (w[perm].contiguous(), ws[perm].contiguous(), cb[perm].contiguous())
         P["ff2"] = (ff.net[2].weight.detach().to(torch.bfloat16).contiguous(), ff.net[2].bias.detach().float().contiguous())
+        pkey = None
         if self.image_cross:
-            c = self.pose_emb_layers.weight.shape[0]
-            wp = self.pose_emb_layers.weight.detach().to(torch.bfloat16)
-            P["pose"] = (wp[:, :c].contiguous(), wp[:, c:].contiguous())  # Linear layout [out, in] of the x half and the xref half
-        self._pack = (key, P)
+            pw = self.pose_emb_layers.weight
+            P["pose"], pkey = self._pack_pose(), (pw.data_ptr(), pw._version)
+        self._pack = (key, P, pkey)
         return P
+
+    def _pack_pose(self):
+        c = self.pose_emb_layers.weight.shape[0]
+        wp = self.pose_emb_layers.weight.detach().to(torch.bfloat16)
+        return (wp[:, :c].contiguous(), wp[:, c:].contiguous())  # Linear layout [out, in] of the x half and the xref half
 
     def _pose_tokens_attn(self, tok: torch.Tensor, context, project: bool = True, dup: int = 0) -> torch.Tensor:
         """attn2(norm2(tok), context) + tok on the FeatureNeRF samples (attention.py:578-588) through the fused GEMMs; project=False
@@ -713,7 +723,8 @@ class SpatialTransformer(nn.Module):
             return tokens_to_image(ops.gemm(t, wo, bias=bo, res=r), H, W)
         out, cst = ops.gemm_cstats(t, wo, bias=bo, res=r)
         image = tokens_to_image(out, H, W)
-        return image if cst is None else tag_gn_stats(image, cst.reshape(out.shape[0], (H * W) // 64, out.shape[-1], 2))
+        # slabs of 64 or 32 rows (the GEMM tiling decides): H * W % 64 == 0 keeps either inside one image
+        return image if cst is None else tag_gn_stats(image, cst.reshape(out.shape[0], cst.shape[0] // out.shape[0], out.shape[-1], 2))
 
     def _forward_fused(self, x, xr, context, contextr, pose, mask_ref):
         """forward() on the fused GEMM path: proj_in writes the first block's LayerNorm statistics, every block hands its output's

@@ -78,8 +78,10 @@ class StandardDiffusionLossImgRef(nn.Module):
         if len(fg_mask_list) > 0 and len(alphas_list) > 0:
             for fg_mask, alphas in zip(fg_mask_list, alphas_list):
                 size = int(math.sqrt(fg_mask.size(1)))
-                # as in the reference, `opacity` is re-assigned: every block resizes the PREVIOUS block's resized map
-                opacity = F.interpolate(opacity, size=size, antialias=True, mode="bilinear").detach()
+                # as in the reference, `opacity` is re-assigned: every block resizes the PREVIOUS block's resized map.  A resize to the
+                # size the map already has is the identity (the antialias filter at scale 1 has the weights 1, 0): not launched
+                if opacity.shape[-2:] != (size, size):
+                    opacity = F.interpolate(opacity, size=size, antialias=True, mode="bilinear").detach()
                 op = opacity.reshape(-1, size * size)
                 fg = torch.clamp(fg_mask.float().reshape(-1, size * size), 0.0, 1.0)
                 loss_fg.append(((fg - op) ** 2).mean(1))
@@ -88,10 +90,13 @@ class StandardDiffusionLossImgRef(nn.Module):
                 loss_bg.append((bg * ((op4 < 0.1) * 1)).mean([1, 2, 3]))
             loss_fg, loss_bg = torch.stack(loss_fg, 1), torch.stack(loss_bg, 1)
         if len(predicted_rgb_list) > 0:
+            resized = {}  # per feature-grid size: the blocks of one resolution share the resized mask / rgb target
             for rgb in predicted_rgb_list:
                 size = int(math.sqrt(rgb.size(1)))
-                mask_ = F.interpolate(mask, size=size, antialias=True, mode="bilinear").detach()
-                want = F.interpolate(target_rgb * 0.5 + 0.5, size=size, antialias=True, mode="bilinear").detach()
+                if size not in resized:
+                    resized[size] = (F.interpolate(mask, size=size, antialias=True, mode="bilinear").detach(),
+                                     F.interpolate(target_rgb * 0.5 + 0.5, size=size, antialias=True, mode="bilinear").detach())
+                mask_, want = resized[size]
                 err = (want - rgb.float().reshape(-1, size, size, 3).permute(0, 3, 1, 2)) ** 2
                 loss_rgb.append((err * mask_).sum([1, 2, 3]) / (mask.sum([1, 2, 3]) + 1e-6))
             loss_rgb = torch.stack(loss_rgb, 1)

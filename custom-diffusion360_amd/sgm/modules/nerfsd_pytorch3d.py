@@ -107,13 +107,17 @@ class Raymarcher(nn.Module):
         self.stratified = stratified
         self.training = training
         self.imp_sampling_percent = imp_sampling_percent
+        self.device_rng = False  # True: patch x / y jitter drawn on the device generator too (no host tensor in the step: hipGraph capture)
 
     def jitter(self, resolution: int, device):
         """The three uniform draws of a stratified training step, in the reference's order and on the reference's
         generators: patch x then y on the CPU RNG (utils_cameraray.py:121-140), depths on the device RNG (:317-325)."""
         if not (self.stratified and self.training):
             return None, None
-        jx, jy = torch.rand(resolution + 1), torch.rand(resolution + 1)
+        if self.device_rng:
+            jx, jy = torch.rand(resolution + 1, device=device), torch.rand(resolution + 1, device=device)
+        else:
+            jx, jy = torch.rand(resolution + 1), torch.rand(resolution + 1)
         jd = torch.rand((resolution ** 2, self.num_samples + 1), dtype=torch.float32, device=device)
         return (jx, jy), jd
 

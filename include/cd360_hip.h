@@ -53,7 +53,8 @@ typedef struct cd360_tuning {
   int32_t nerf_kernel;      /* 0 | 1: FeatureNeRF render kernel with register gathers / full-line gathers */
   int32_t qattn_cfg;        /* 1..4: tile of cd360_qproj_attn_bf16 (256 x 256 / 128 x 128 + movers / 128 x 128 x 2 WGs / 256 x 128) */
   int32_t whatif;           /* -DCD360_WHATIF builds only */
-  int32_t reserved[6];
+  int32_t gemm_small;       /* 0: no small-batch tilings (64 x 128 tiles, 128-wide tiles for wide outputs): the A/B partner */
+  int32_t reserved[5];
 } cd360_tuning;
 int cd360_set_tuning(const cd360_tuning* t);
 int cd360_get_tuning(cd360_tuning* t);
@@ -321,9 +322,10 @@ int cd360_qproj_attn_dedup_bf16(const void* a, const void* w, void* out, int64_t
 /* N-tile width (256 | 192 | 128) cd360_gemm_bf16 uses for an [M, N] output: stats_out holds ceil(N / that) partials per row. */
 int cd360_gemm_tile_n(int64_t M, int N);
 /* cd360_gemm_bf16(a, w, out, ..., bias, res) for an output that a GroupNorm reads next -- SpatialTransformer.proj_out plus its residual
- * (attention.py:880-886) feeding the next ResBlock's in_layers: also writes cstats fp32 [M / 64, N, 2] = per slab of 64 rows and channel
+ * (attention.py:880-886) feeding the next ResBlock's in_layers: also writes cstats fp32 [M / S, N, 2] = per slab of S rows and channel
  * the (sum, sum of squares) of the stored bf16 outputs, i.e. the `tile_stats` of cd360_gn_silu_bf16 (as the convolution epilogue does).
- * Needs M % 64 == 0 and cd360_gemm_cstats_rows(M, N) == 64 (the 128 x 128 tilings); CD360_ERR_SHAPE otherwise. */
+ * S = cd360_gemm_cstats_rows(M, N): 64 on the 128 x 128 tilings, 32 on the 64 x 128 tiling of small batches, 0 = this shape's tiling
+ * writes none (CD360_ERR_SHAPE); needs M % 64 == 0. */
 int cd360_gemm_cstats_rows(int64_t M, int N);
 int cd360_gemm_cstats_bf16(const void* a, const void* w, void* out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldo,
                            const void* bias, const void* res, int64_t ldr, void* cstats, void* stream);

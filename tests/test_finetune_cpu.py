@@ -208,3 +208,41 @@ def test_optimizer_param_groups_follow_configure_optimizers():
     opt = finetune.MasterAdamW(finetune.optimizer_param_groups(net, "poseattn", lr=1e-4), lr=1e-4)
     assert [pg["lr"] for pg in opt.opt.param_groups] == [1e-4, 1e-4 * 0.05]
     assert len(opt.params) == len(finetune.select_trainable(net, "poseattn")) == sum(len(pg["params"]) for pg in opt.opt.param_groups)
+
+
+def test_combine_losses_as_tensors_is_the_same_total_without_host_reads():
+    """as_tensors=True (graph capture / no mid-step synchronisation): logged terms are 0-d tensors, the `loss_rgb.mean() > 0` test of
+    diffusion.py:238 becomes arithmetic -- identical totals and gradients, including the all-zero rgb case the reference skips."""
+    l2 = torch.tensor([1.0, 2.0, 3.0], requires_grad=True)
+    lfg, lbg = torch.tensor([[0.1, 0.3], [9.0, 9.0], [0.2, 0.2]]), torch.ones(3, 2) * 0.01
+    drop = torch.tensor([1.0, 0.0, 1.0])
+    for e0 in (torch.tensor([[0.7, 0.7], [2.6, 2.6], [0.3, 0.55]]), torch.zeros(3, 2)):  # loss_rgb is a (masked) mean of squared errors (loss.py)
+        e = e0.clone().requires_grad_(True)
+        t0, p0 = finetune.combine_losses(l2, lfg, lbg, e * e, drop)
+        t1, p1 = finetune.combine_losses(l2, lfg, lbg, e * e, drop, as_tensors=True)
+        assert torch.equal(t0.detach(), t1.detach()) and all(torch.is_tensor(v) and v.dim() == 0 and not v.requires_grad for v in p1.values())
+        assert all(abs(float(p1[k]) - v) < 1e-7 for k, v in p0.items()) and float(p1["loss_rgb"]) == p0.get("loss_rgb", 0.0)
+        g0 = torch.autograd.grad(t0, e, allow_unused=True)[0]  # None when the reference's branch skipped the term
+        g1 = torch.autograd.grad(t1, e)[0]
+        assert torch.equal(g1, torch.zeros_like(g1) if g0 is None else g0)
+
+
+def test_patch_and_depth_jitter_bounds_are_cached_and_device_side_form_equals_host_form():
+    """cd360.nerf.patch_positions / depth_samples with jitter: the host form (jitter drawn on the CPU generator, as the reference) and the
+    device form (bounds cached per device, jitter combined where it lives: no host tensor inside a captured step) are the same numbers."""
+    from cd360 import nerf
+    g = torch.Generator().manual_seed(5)
+    for r in (8, 16, 32):
+        j = torch.rand(r + 1, generator=g)
+        edges = torch.linspace(1, -1, r + 1)
+        center = (edges[1:] + edges[:-1]) / 2.0
+        upper, lower = torch.cat([center, edges[-1:]], -1), torch.cat([edges[:1], center], -1)
+        want = (lower + (upper - lower) * j)[:-1]  # utils_cameraray.py:121-140
+        got = nerf.patch_positions(r, "cpu", j)
+        assert torch.equal(got, want) and got.shape == (r,)
+        assert torch.equal(nerf.patch_positions(r, "cpu"), (edges[:-1] + edges[1:]) / 2)
+    jd = torch.rand(64, 25, generator=g)
+    t, d = nerf.depth_samples(24, 2.0, 0.0, "cpu", 64, jd)
+    t2, d2 = nerf.depth_samples(24, 2.0, 0.0, "cpu", 64, jd)
+    assert t.shape == (64, 24) and torch.equal(t, t2) and torch.equal(d, d2) and (d > 0).all() and (t[:, 1:] > t[:, :-1]).all()
+    assert ("depth_bounds", 24, 2.0, 0.0, "cpu") in nerf._grid_cache

@@ -602,3 +602,52 @@ def test_config4_sdxl_size_train_step_reduces_the_loss():
     params = dict(net.named_parameters())
     assert all(params[k].grad is not None and torch.isfinite(params[k].grad.float()).all() for k in names)
     assert sum(float(params[k].grad.float().abs().sum()) > 0 for k in names) >= len(names) - 12  # nviews.bias has a zero gradient
+
+
+def test_config4_train_step_replayed_from_a_hipgraph_follows_the_eager_steps():
+    """finetune.GraphedTrainStep: the whole optimisation step (forward, loss, backward, AdamW on fp32 masters) captured once and replayed.
+    Without jitter (eval-mode raymarchers: every kernel is deterministic) the replayed steps must follow the eagerly launched ones --
+    same losses step for step (capturable AdamW orders its scalar arithmetic differently: 1e-4 relative) and the same trained weights
+    to bf16 resolution; new inputs copied into the static buffers must change the result; with the stratified jitter on the device
+    generator (train mode) successive replays must draw fresh jitter (losses differ from the no-jitter run) and still descend."""
+    import copy
+    from cd360 import finetune, synth
+    from make_golden_params import LOSS_CFG
+    from sgm.util import instantiate_from_config
+    net, g = _sdxl_net(seed=43)
+    net.eval()
+    names = finetune.select_trainable(net, "pose")
+    loss_fn = instantiate_from_config({"target": "sgm.modules.diffusionmodules.loss.StandardDiffusionLossImgRef", "params": LOSS_CFG})
+    b, n, L = 2, 2, 32
+    rn = lambda *s: torch.randn(*s, generator=g, device=DEV)
+    batch = dict(noised=rn(b, 4, L, L), timesteps=torch.full((b,), 500.0, device=DEV), context=rn(b + b * n, 77, 2048), y=rn(b + b * n, 2816),
+                 pose=synth.pose_batch(b, n, seed=3), input_ref=rn(b, n, 4, L, L), sigmas_ref=torch.full((b,), 3.0, device=DEV),
+                 target=rn(b, 4, L, L), target_rgb=rn(b, 3, 8 * L, 8 * L).clamp(-1, 1), w=torch.full((b, 1, 1, 1), 0.7, device=DEV),
+                 mask=torch.ones(b, 1, L, L, device=DEV), opacity=torch.sigmoid(3 * rn(b, 1, 8 * L, 8 * L)))
+    start = copy.deepcopy({k: v for k, v in net.state_dict().items() if "pose" in k})
+    opt = finetune.MasterAdamW(finetune.optimizer_param_groups(net, "pose", lr=1e-4), lr=1e-4)
+    eager = [float(finetune.train_step(net, loss_fn, opt, **batch)[0]) for _ in range(6)]
+    w_eager = {k: dict(net.named_parameters())[k].detach().clone() for k in names}
+    net.load_state_dict(start, strict=False)
+    opt = finetune.MasterAdamW(finetune.optimizer_param_groups(net, "pose", lr=1e-4), lr=1e-4, capturable=True)
+    with pytest.raises(ValueError):
+        finetune.GraphedTrainStep(net, loss_fn, finetune.MasterAdamW(finetune.optimizer_param_groups(net, "pose", lr=1e-4), lr=1e-4), batch)
+    step = finetune.GraphedTrainStep(net, loss_fn, opt, batch, warmup=2)  # steps 1-2 run eagerly inside; the capture itself executes nothing
+    graphed = [float(step()[0]) for _ in range(4)]
+    print("eager:", [round(v, 5) for v in eager], "graph (steps 3-6):", [round(v, 5) for v in graphed])
+    assert all(abs(a - e) <= 1e-4 * abs(e) for a, e in zip(graphed, eager[2:]))
+    params = dict(net.named_parameters())
+    worst = max(float((params[k].float() - w_eager[k].float()).abs().max() / w_eager[k].float().abs().max().clamp_min(1e-6)) for k in names)
+    assert worst < 2e-2, worst  # bf16 copies of fp32 masters that differ in their last bits
+    same = float(step()[0])
+    other = float(step(target=batch["target"] * 0.5, noised=batch["noised"] + 0.1)[0])
+    assert torch.isfinite(torch.tensor(other)) and abs(other - same) > 1e-3 * abs(same)
+    # stratified jitter inside the graph: the device generator advances on every replay
+    net.load_state_dict(start, strict=False)
+    net.train()
+    opt = finetune.MasterAdamW(finetune.optimizer_param_groups(net, "pose", lr=1e-4), lr=1e-4, capturable=True)
+    step = finetune.GraphedTrainStep(net, loss_fn, opt, batch, warmup=2)
+    jit = [float(step()[0]) for _ in range(6)]
+    print("graph, stratified:", [round(v, 5) for v in jit])
+    assert all(torch.isfinite(torch.tensor(jit))) and jit[-1] < jit[0] and any(abs(a - e) > 1e-6 * abs(e) for a, e in zip(jit, eager[2:]))
+    assert all(m.device_rng for m in net.modules() if hasattr(m, "device_rng"))

@@ -135,7 +135,7 @@ def check():
     for qcfg in (2, 3):
         ok &= check_qattn(2, 384, 320, 320, 77, qcfg=qcfg)
         ok &= check_qattn(3, 128, 128, 64, 20, ln=False, qcfg=qcfg)
-    for cfg in (1, 2, 3, 4, 5, 6, 7):
+    for cfg in (1, 2, 3, 4, 5, 6, 7, 8):
         for (M, N, K) in [(256, 256, 64), (256, 256, 128), (512, 512, 192), (300, 272, 320), (128, 128, 64), (1000, 640, 640), (3072, 1280, 1280)]:
             ok &= check_case(M, N, K, cfg=cfg)
         ok &= check_case(520, 640, 320, bias=True, res=True, stats=True, cfg=cfg)
@@ -149,6 +149,9 @@ def check():
     ok &= check_case(12288, 1920, 640, bias=True, ln=True)
     ok &= check_case(12288, 640, 2560, bias=True, res=True, stats=True)
     ok &= check_case(3072, 1280, 5120, bias=True, res=True, stats=True)
+    for (M, N, K) in ((1024, 1280, 5120), (1000, 1280, 10240), (320, 2560, 2048), (1024, 5120, 1280)):  # small batches: 64 x 128 tiles (both wave
+        ok &= check_case(M, N, K, bias=True, res=True, stats=True)                                    # arrangements), 256 x 128 with three buffers
+        ok &= check_case(M, N, K, bias=True, ln=True)
     print("CHECK", "PASSED" if ok else "FAILED", flush=True)
     return ok
 
@@ -399,6 +402,48 @@ def narrow():
     print(" | ".join(line), flush=True)
 
 
+def small_m():
+    """The fine-tune step's target stream at the 1280 level (batch 4 x 256 tokens = 1024 rows; backward dX shapes included): 128 x 128 tiles
+    (tiling 4: 80 workgroups) against 64 x 128 tiles (tiling 8: 160), bias + residual epilogue; parity of tiling 8 against fp32 first."""
+    for (M, N, K) in ((1024, 1280, 1280), (1024, 1280, 3840), (1024, 1280, 5120), (1024, 1280, 10240), (1024, 3840, 1280), (1024, 5120, 1280),
+                      (1024, 10240, 1280), (768, 1280, 1280), (320, 2560, 2048), (1280, 2560, 2048), (4096, 640, 640), (4096, 1280, 1280), (1000, 1280, 1280)):
+        a = rnd(M, K, seed=1).to(torch.bfloat16)
+        w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
+        b32, r = rnd(N, seed=3), rnd(M, N, seed=4).to(torch.bfloat16)
+        want = F.linear(a.float(), w.float(), b32) + r.float()
+        line = f"M={M:5d} N={N:5d} K={K:5d}:"
+        for cfg in (0, 4, 8):
+            if cfg:
+                ENV["CD360_GEMM_CFG"] = str(cfg)
+            else:
+                ENV.pop("CD360_GEMM_CFG", None)
+            got, st = ops.gemm(a, w, bias=b32, res=r, want_stats=True)
+            err = relerr(got, want)
+            serr = (st.sum(1)[:, 0] - got.float().sum(1)).abs().max().item()
+            assert err < 2e-2 and serr < 0.5, (cfg, M, N, K, err, serr)
+            line += f"  cfg{cfg} {timeit_graph(lambda: ops.gemm(a, w, bias=b32, res=r, want_stats=True)):6.1f} us (err {err:.1e})"
+        ENV.pop("CD360_GEMM_CFG", None)
+        print(line, flush=True)
+
+
+def mid_m():
+    """Wide outputs of a small batch (fine-tune step: merged q|k|v, context k|v, GEGLU backward): every linear tiling."""
+    for (M, N, K) in ((1024, 3840, 1280), (1024, 5120, 1280), (1024, 10240, 1280), (1280, 2560, 2048), (320, 2560, 2048), (320, 1280, 2048),
+                      (4096, 3840, 1280), (4096, 5120, 640), (4096, 1920, 640), (2048, 1280, 1280), (1536, 1280, 1280), (3072, 3840, 1280)):
+        a = rnd(M, K, seed=1).to(torch.bfloat16)
+        w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
+        b32 = rnd(N, seed=3)
+        line = f"M={M:5d} N={N:5d} K={K:5d}:"
+        for cfg in (0, 1, 2, 3, 4, 5, 6, 8):
+            if cfg:
+                ENV["CD360_GEMM_CFG"] = str(cfg)
+            else:
+                ENV.pop("CD360_GEMM_CFG", None)
+            line += f"  cfg{cfg} {timeit_graph(lambda: ops.gemm(a, w, bias=b32)):6.1f}"
+        ENV.pop("CD360_GEMM_CFG", None)
+        print(line, flush=True)
+
+
 def fixed_cost():
     """Launch time against K on the 1280-level C -> C shape (M = 3072, N = 1280): the intercept is what a launch costs besides its K loop."""
     M, N = 3072, 1280
@@ -563,6 +608,10 @@ if __name__ == "__main__":
         stride_sweep()
     if "whatif" in what:
         whatif()
+    if "mid_m" in what:
+        mid_m()
+    if "small_m" in what:
+        small_m()
     if "fixed" in what:
         fixed_cost()
     if "narrow" in what:

@@ -18,8 +18,9 @@ for p in (os.path.join(ROOT, "custom-diffusion360_amd"), os.path.join(ROOT, "tes
 import torch  # noqa: E402
 
 
-def measure(steps=5, warmup=2, batch=4, views=4, latent=64, eval_mode=False, profile=True, library=False):
+def measure(steps=5, warmup=2, batch=4, views=4, latent=64, eval_mode=False, profile=True, library=False, graph=False):
     """One fine-tune configuration: build the SDXL UNet, run `warmup` + `steps` optimisation steps, return the result dict.
+    graph=True: the step captured into a hipGraph (finetune.GraphedTrainStep) and replayed -- no per-kernel breakdown then.
     library=True: the round-1 path (CD360_LIBRARY_LINEAR=1: every Linear on torch / hipBLASLt) for an A/B on the same box."""
     from cd360 import finetune, ops, sampling, synth
     from make_golden_params import LOSS_CFG, SDXL_NETWORK_CONFIG
@@ -30,8 +31,8 @@ def measure(steps=5, warmup=2, batch=4, views=4, latent=64, eval_mode=False, pro
     else:
         os.environ.pop("CD360_LIBRARY_LINEAR", None)
     try:
-        return _measure(steps, warmup, batch, views, latent, eval_mode, profile, finetune, ops, sampling, synth, LOSS_CFG, SDXL_NETWORK_CONFIG,
-                        instantiate_from_config)
+        return _measure(steps, warmup, batch, views, latent, eval_mode, profile and not graph, finetune, ops, sampling, synth, LOSS_CFG,
+                        SDXL_NETWORK_CONFIG, instantiate_from_config, graph)
     finally:
         if prev is None:
             os.environ.pop("CD360_LIBRARY_LINEAR", None)
@@ -39,7 +40,8 @@ def measure(steps=5, warmup=2, batch=4, views=4, latent=64, eval_mode=False, pro
             os.environ["CD360_LIBRARY_LINEAR"] = prev
 
 
-def _measure(steps, warmup, batch, views, latent, eval_mode, profile, finetune, ops, sampling, synth, LOSS_CFG, SDXL_NETWORK_CONFIG, instantiate_from_config):
+def _measure(steps, warmup, batch, views, latent, eval_mode, profile, finetune, ops, sampling, synth, LOSS_CFG, SDXL_NETWORK_CONFIG, instantiate_from_config,
+             graph=False):
     dev = "cuda"
     torch.manual_seed(0)
     with torch.device(dev):
@@ -56,7 +58,8 @@ def _measure(steps, warmup, batch, views, latent, eval_mode, profile, finetune, 
                 m.proj_out.weight.copy_(torch.randn(m.proj_out.weight.shape, generator=g, device=dev).mul_(0.02))
     net.eval() if eval_mode else net.train()
     names = finetune.select_trainable(net, "pose")
-    opt = finetune.MasterAdamW(finetune.optimizer_param_groups(net, "pose", lr=1e-4), lr=1e-4)  # configs/train_co3d_concept.yaml:2,7-8
+    opt = finetune.MasterAdamW(finetune.optimizer_param_groups(net, "pose", lr=1e-4), lr=1e-4,  # configs/train_co3d_concept.yaml:2,7-8
+                               **({"capturable": True} if graph else {}))
     loss_fn = instantiate_from_config({"target": "sgm.modules.diffusionmodules.loss.StandardDiffusionLossImgRef", "params": LOSS_CFG})
     b, n, L = batch, views, latent
     rn = lambda *s: torch.randn(*s, generator=g, device=dev)
@@ -65,14 +68,17 @@ def _measure(steps, warmup, batch, views, latent, eval_mode, profile, finetune, 
               target=rn(b, 4, L, L), target_rgb=rn(b, 3, 8 * L, 8 * L).clamp(-1, 1), w=torch.full((b, 1, 1, 1), 0.7, device=dev),
               mask=torch.ones(b, 1, L, L, device=dev), opacity=torch.sigmoid(3 * rn(b, 1, 8 * L, 8 * L)))
     losses = []
+    step = lambda: finetune.train_step(net, loss_fn, opt, **bt)
+    if graph:
+        step = finetune.GraphedTrainStep(net, loss_fn, opt, bt, warmup=max(warmup, 1))
     for _ in range(warmup):
-        losses.append(float(finetune.train_step(net, loss_fn, opt, **bt)[0]))
+        losses.append(float(step()[0]))
     torch.cuda.synchronize()
     if profile:
-        ops.profile_start()
+        ops.profile_start(shapes=bool(os.environ.get("CD360_PROFILE_SHAPES")))  # per-shape GEMM rows for the shape table of DESIGN.md
     t0 = time.perf_counter()
     for _ in range(steps):
-        losses.append(float(finetune.train_step(net, loss_fn, opt, **bt)[0]))
+        losses.append(float(step()[0]))
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / steps
     prof = ops.profile_stop() if profile else {}
@@ -80,11 +86,11 @@ def _measure(steps, warmup, batch, views, latent, eval_mode, profile, finetune, 
                 **({"tflops": round(v["flops"] / v["ms"] / 1e9, 1)} if v.get("flops") else {}),
                 **({"gbs": round(v["bytes"] / v["ms"] / 1e6, 1)} if v.get("bytes") else {})} for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])}
     out = {"metric": "fine-tune optimisation steps/sec (config 4)", "value": round(1.0 / dt, 4), "unit": "steps/s", "ms_per_step": round(dt * 1e3, 2),
-           "steps": steps, "warmup": warmup, "dtype": "bf16 (+fp32 master weights)", "data": "synthetic",
+           "steps": steps, "warmup": warmup, "launch": "hipGraph replay" if graph else "eager", "dtype": "bf16 (+fp32 master weights)", "data": "synthetic",
            "config": {"workload": f"SDXL UNet {8 * L}^2, batch {b}, {n} reference views, trainkeys=pose, {'eval' if eval_mode else 'train (stratified)'} mode",
                       "trainable_tensors": len(names), "trainable_params": int(sum(p.numel() for p in opt.params))},
            "losses": [round(x, 5) for x in losses], "peak_mem_gb": round(torch.cuda.max_memory_allocated() / 2 ** 30, 2), "hip_kernels": kern}
-    del net, opt, loss_fn, bt
+    del net, opt, loss_fn, bt, step
     torch.cuda.empty_cache()
     return out
 
@@ -98,8 +104,9 @@ def main():
     ap.add_argument("--latent", type=int, default=64)
     ap.add_argument("--eval-mode", action="store_true", help="no stratified jitter")
     ap.add_argument("--library", action="store_true", help="every Linear on torch / hipBLASLt (CD360_LIBRARY_LINEAR=1): the A/B partner")
+    ap.add_argument("--graph", action="store_true", help="capture the step into a hipGraph and replay it (finetune.GraphedTrainStep)")
     a = ap.parse_args()
-    print(json.dumps(measure(a.steps, a.warmup, a.batch, a.views, a.latent, a.eval_mode, True, a.library)))
+    print(json.dumps(measure(a.steps, a.warmup, a.batch, a.views, a.latent, a.eval_mode, True, a.library, a.graph)))
 
 
 if __name__ == "__main__":

@@ -18,7 +18,7 @@ def load(path):
     agg = defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(path)):
         name = re.sub(r"\(anonymous namespace\)::", "", r["Kernel_Name"])[:120]
-        key = (name, r.get("Grid_Size", "?"))
+        key = (name, r.get("Grid_Size_X", "?") + "x" + r.get("Grid_Size_Y", "?"))
         a = agg[key]; a[0] += 1; a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3
     return agg
 a, b, n = load(sys.argv[1]), load(sys.argv[2]), int(sys.argv[3])
