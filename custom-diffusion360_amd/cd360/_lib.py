@@ -66,6 +66,8 @@ SIGNATURES = {
     "cd360_rowdot4_bwd_bf16": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P]),
     "cd360_gemm_tn_workspace_bytes": (c_int64, [c_int64, c_int, c_int]),
     "cd360_gemm_tn_bf16": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int64, c_int64, c_int, _P, _P]),
+    "cd360_adamw_tick": (c_int, [_P, _P]),
+    "cd360_adamw_bf16": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, _P]),
     "cd360_set_tuning": (c_int, [_P]),
     "cd360_get_tuning": (c_int, [_P]),
     "cd360_whatif_build": (c_int, []),

@@ -197,9 +197,12 @@ def load_delta_state_dict(unet: torch.nn.Module, sd_delta: Dict[str, object], pr
 class MasterAdamW:
     """AdamW (configs/train_co3d_concept.yaml: optimizer_config AdamW) on fp32 master copies of the trainable parameters: the HIP
     path keeps the UNet in bf16, and a bf16 parameter cannot absorb updates of lr ~ 1e-5 (its spacing near 1 is 8e-3), so the
-    optimiser state and the accumulated weights live in fp32 and the bf16 parameters are refreshed from them after every step."""
+    optimiser state and the accumulated weights live in fp32 and the bf16 parameters are refreshed from them after every step.
+    bf16 parameters on the GPU take the fused path: masters and both moments in three flat fp32 buffers, the whole update (gradient
+    read, decay, moments, bias-corrected step, bf16 write-back) in one pass of cd360_adamw_bf16 with the step count on the device
+    (graph-capturable as it is).  Anything else (CPU, fp32 parameters, amsgrad / maximize) runs torch.optim.AdamW on the masters."""
 
-    def __init__(self, params, lr: float = 1e-5, **kw):
+    def __init__(self, params, lr: float = 1e-5, fused: Optional[bool] = None, **kw):
         """`params`: an iterable of parameters, or optimiser groups as returned by optimizer_param_groups (per-group `lr`)."""
         params = list(params)
         if params and isinstance(params[0], dict):
@@ -208,9 +211,37 @@ class MasterAdamW:
         else:
             groups = [{"params": [p for p in params if p.requires_grad]}]
         self.params = [p for g in groups for p in g["params"]]
+        can_fuse = (bool(self.params) and all(p.is_cuda and p.dtype == torch.bfloat16 for p in self.params)
+                    and not kw.get("amsgrad") and not kw.get("maximize") and not (set(kw) - {"betas", "eps", "weight_decay", "capturable", "amsgrad",
+                                                                                            "maximize", "foreach"}))
+        if fused and not can_fuse:
+            raise ValueError("MasterAdamW(fused=True) needs bf16 parameters on the GPU and plain AdamW options")
+        self.fused = can_fuse if fused is None else bool(fused)
+        if self.fused:
+            from . import ops
+            dev = self.params[0].device
+            begin, total = [], 0
+            for p in self.params:
+                begin.append(total)
+                total += (p.numel() + 7) // 8 * 8  # every tensor starts on a 32-byte boundary of the flat buffers
+            self._master = torch.zeros(total, dtype=torch.float32, device=dev)
+            self.exp_avg, self.exp_avg_sq = torch.zeros_like(self._master), torch.zeros_like(self._master)
+            self.steps = torch.zeros((), dtype=torch.float32, device=dev)  # steps taken; on the device so that graph replays advance it
+            self.master = [self._master[b:b + p.numel()].view(p.shape) for b, p in zip(begin, self.params)]
+            for m, p in zip(self.master, self.params):
+                m.copy_(p.detach())
+            self.betas, self.eps = tuple(kw.get("betas", (0.9, 0.999))), float(kw.get("eps", 1e-8))
+            self.param_groups = [{"lr": g.get("lr", lr), "weight_decay": g.get("weight_decay", kw.get("weight_decay", 1e-2)), "n": len(g["params"])}
+                                 for g in groups]  # edit lr / weight_decay here (a captured graph keeps the values it was captured with)
+            self._begin, self._plan, self._plan_key, self.opt, self.capturable = begin, None, None, None, True
+            self._ops = ops
+            return
         self.master = [p.detach().float().clone() for p in self.params]
         it = iter(self.master)
+        kw.pop("foreach", None)
         self.opt = torch.optim.AdamW([{**g, "params": [next(it) for _ in g["params"]]} for g in groups], lr=lr, **kw)
+        self.param_groups = self.opt.param_groups
+        self.capturable = all(g.get("capturable") for g in self.opt.param_groups)
 
     def zero_grad(self) -> None:
         for p in self.params:
@@ -235,9 +266,27 @@ class MasterAdamW:
             p.grad = flat[off:off + n].reshape(g.shape).to(g.dtype)
             off += n
 
+    def _fused_plan(self, active):
+        lrs = [g["lr"] for g in self.param_groups for _ in range(g["n"])]
+        wds = [g["weight_decay"] for g in self.param_groups for _ in range(g["n"])]
+        key = (tuple(active), tuple(lrs), tuple(wds))
+        if self._plan_key != key:
+            self._plan = self._ops.AdamwPlan([self.params[i] for i in active], [self._begin[i] for i in active], [lrs[i] for i in active],
+                                             [wds[i] for i in active])
+            self._plan_key = key
+        return self._plan
+
     @torch.no_grad()
     def step(self, group: Optional[dist.ProcessGroup] = None) -> None:
         self.allreduce_grads(group)
+        if self.fused:
+            # parameters without a gradient are skipped as torch does; the step count is one per optimiser, not one per tensor
+            active = [i for i, p in enumerate(self.params) if p.grad is not None]
+            if active:
+                grads = [self.params[i].grad if self.params[i].grad.is_contiguous() else self.params[i].grad.contiguous() for i in active]
+                self._ops.adamw_step(self._fused_plan(active), grads, self._master, self.exp_avg, self.exp_avg_sq, self.steps, self.betas[0],
+                                     self.betas[1], self.eps)
+            return
         for m, p in zip(self.master, self.params):
             m.grad = None if p.grad is None else p.grad.float()
         self.opt.step()
@@ -269,16 +318,16 @@ def train_step(unet: torch.nn.Module, loss_fn, optimizer, *, noised, timesteps, 
 class GraphedTrainStep:
     """train_step captured ONCE into a hipGraph and replayed: forward, loss, backward and the optimiser step of BASELINE config 4 are
     ~6400 kernel launches and ~16000 torch operator calls per step -- host work that takes longer than the kernels run (DESIGN.md section 6b);
-    a replay costs one launch.  Conditions: fixed shapes (the batch is copied into static buffers), a MasterAdamW built with
-    capturable=True, the raymarchers on device_rng=True (the stratified jitter of patch x / y is then drawn by the device generator, which
+    a replay costs one launch.  Conditions: fixed shapes (the batch is copied into static buffers), a MasterAdamW on its fused
+    path (or built with capturable=True), the raymarchers on device_rng=True (the stratified jitter of patch x / y is then drawn by the device generator, which
     a graph advances on every replay; the reference draws those two on the CPU generator), a single process (no gradient all-reduce
     inside the graph).  The returned loss terms are 0-d device tensors that the next replay overwrites."""
 
     def __init__(self, unet: torch.nn.Module, loss_fn, optimizer: "MasterAdamW", batch: dict, warmup: int = 3, **loss_kw):
         if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
             raise NotImplementedError("GraphedTrainStep: single process only (the gradient all-reduce is not captured)")
-        if not all(g.get("capturable") for g in optimizer.opt.param_groups):
-            raise ValueError("GraphedTrainStep: build the optimiser with MasterAdamW(..., capturable=True)")
+        if not optimizer.capturable:
+            raise ValueError("GraphedTrainStep: the torch fall-back of MasterAdamW must be built with capturable=True (the fused path is as it is)")
         self.unet, self.loss_fn, self.optimizer, self.loss_kw = unet, loss_fn, optimizer, loss_kw
         for m in unet.modules():
             if hasattr(m, "device_rng"):

@@ -772,6 +772,43 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, out_dtype=torch.bfloat16) -> torch
     return out
 
 
+ADAMW_MAX_TENSORS = 64  # CD360_ADAMW_MAX_TENSORS of include/cd360_hip.h
+
+
+class AdamwPlan:
+    """Host-side argument arrays of cd360_adamw_bf16 for a fixed list of bf16 parameters whose fp32 master / exp_avg / exp_avg_sq live
+    at offsets `begin` of three flat buffers: everything except the gradient pointers is built once."""
+
+    def __init__(self, params, begin, lr, wd):
+        self.n = len(params)
+        self.chunks = []
+        for c0 in range(0, self.n, ADAMW_MAX_TENSORS):
+            idx = list(range(c0, min(self.n, c0 + ADAMW_MAX_TENSORS)))
+            k = len(idx)
+            self.chunks.append(dict(
+                idx=idx, k=k, grads=(ctypes.c_void_p * k)(), params=(ctypes.c_void_p * k)(*[params[i].data_ptr() for i in idx]),
+                begin=(ctypes.c_int64 * k)(*[int(begin[i]) for i in idx]), numel=(ctypes.c_int64 * k)(*[params[i].numel() for i in idx]),
+                lr=(ctypes.c_float * k)(*[float(lr[i]) for i in idx]), wd=(ctypes.c_float * k)(*[float(wd[i]) for i in idx])))
+
+
+def adamw_step(plan: AdamwPlan, grads, master: torch.Tensor, exp_avg: torch.Tensor, exp_avg_sq: torch.Tensor, step: torch.Tensor,
+               beta1: float, beta2: float, eps: float) -> None:
+    """One AdamW step of every tensor of `plan` (cd360_adamw_tick + cd360_adamw_bf16): `grads` are the bf16 gradients in plan order
+    (contiguous), `step` the fp32 device scalar holding the number of steps taken so far."""
+    _need_gpu(master, exp_avg, exp_avg_sq, step, *grads)
+    lib = _lib.load()
+    assert len(grads) == plan.n and all(g.dtype == torch.bfloat16 and g.is_contiguous() for g in grads)
+    assert all(t.dtype == torch.float32 and t.is_contiguous() for t in (master, exp_avg, exp_avg_sq, step))
+    check(lib.cd360_adamw_tick(_ptr(step), _stream()), "cd360_adamw_tick")
+    total = sum(g.numel() for g in grads)
+    with _timed("adamw", 0.0, 28.0 * total):
+        for c in plan.chunks:
+            for j, i in enumerate(c["idx"]):
+                c["grads"][j] = grads[i].data_ptr()
+            check(lib.cd360_adamw_bf16(c["k"], c["grads"], c["params"], c["begin"], c["numel"], c["lr"], c["wd"], _ptr(master), _ptr(exp_avg),
+                                       _ptr(exp_avg_sq), _ptr(step), beta1, beta2, eps, _stream()), "cd360_adamw_bf16")
+
+
 def gemm_tn_ok(a: torch.Tensor, b: torch.Tensor) -> bool:
     if not (a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.stride(-1) == 1 and b.stride(-1) == 1):
         return False

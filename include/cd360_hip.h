@@ -329,6 +329,18 @@ int cd360_gemm_tile_n(int64_t M, int N);
 int cd360_gemm_cstats_rows(int64_t M, int N);
 int cd360_gemm_cstats_bf16(const void* a, const void* w, void* out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldo,
                            const void* bias, const void* res, int64_t ldr, void* cstats, void* stream);
+/* Fine-tuning optimiser (configs/train_co3d_concept.yaml optimizer_config: torch.optim.AdamW; the step the reference's Lightning loop
+ * takes after main.py's backward): AdamW on fp32 master weights of bf16 parameters in ONE pass -- for each of n <= CD360_ADAMW_MAX_TENSORS
+ * tensors reads the bf16 gradient grads[t] and the fp32 master / exp_avg / exp_avg_sq at offset begin[t] (multiple of 8) of the flat state
+ * buffers, applies torch's update (decoupled weight decay wd[t], learning rate lr[t], bias correction with the device-side step count
+ * *step, no amsgrad), writes the states back and OVERWRITES the bf16 parameter params[t] with the rounded master.  grads / params / begin /
+ * numel / lr / wd are host arrays of n entries.  cd360_adamw_tick(step) adds 1 to *step: once per optimisation step, before the update
+ * launches (the count lives on the device so that hipGraph replays advance it). */
+#define CD360_ADAMW_MAX_TENSORS 64
+int cd360_adamw_tick(void* step, void* stream);
+int cd360_adamw_bf16(int n, const void* const* grads, void* const* params, const int64_t* begin, const int64_t* numel, const float* lr,
+                     const float* wd, void* master, void* exp_avg, void* exp_avg_sq, const void* step, float beta1, float beta2, float eps,
+                     void* stream);
 /* (sum, sum of squares) of every row of a bf16 [rows, C] matrix (row stride ld) as one fp32 partial per row: the `ln_stats` input for a
  * tensor that did not come out of cd360_gemm_bf16 (C % 8 == 0). */
 int cd360_row_stats_bf16(const void* x, void* stats, int64_t rows, int C, int64_t ld, void* stream);

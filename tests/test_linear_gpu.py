@@ -197,3 +197,40 @@ def test_finetune_step_reaches_no_library_gemm():
     grads = {k: p.grad for k, p in net.named_parameters() if p.requires_grad}
     assert grads and all(v is not None and torch.isfinite(v.float()).all() for k, v in grads.items() if not k.endswith("nviews.bias"))
     assert any(v.float().abs().max() > 0 for v in grads.values())
+
+
+def test_fused_adamw_matches_torch_adamw_on_fp32_masters():
+    """cd360_adamw_bf16 (MasterAdamW's fused path) against torch.optim.AdamW on fp32 masters, step for step: ragged tensor sizes (tails
+    of fewer than 8 values, an unaligned view), two groups with their own lr / weight decay, a tensor without a gradient in one step;
+    masters and moments agree to fp32 rounding, the bf16 parameters are the rounded masters, more than 64 tensors take two launches."""
+    from cd360 import finetune
+    g = torch.Generator(device="cuda").manual_seed(7)
+    shapes = [(1280, 2560), (640,), (3, 5), (1,), (4, 1280), (77,), (640, 1280)] + [(9 + i,) for i in range(70)]
+    base = [torch.randn(*s, generator=g, device="cuda").mul_(0.1).to(torch.bfloat16) for s in shapes]
+    base[5] = torch.randn(78, generator=g, device="cuda").to(torch.bfloat16)[1:]  # a 2-byte-aligned view: the kernel's scalar path
+    mk = lambda: [torch.nn.Parameter(b.clone() if b.is_contiguous() and b.storage_offset() == 0 else b) for b in base]
+    pa, pb = mk(), mk()
+    pb[5] = torch.nn.Parameter(torch.cat([base[5][:1], base[5]])[1:])  # same values, own storage, same misalignment
+    groups = lambda ps: [{"params": ps[:4], "lr": 1e-3, "weight_decay": 0.1}, {"params": ps[4:], "lr": 3e-4}]
+    fused = finetune.MasterAdamW(groups(pa), lr=1e-4, betas=(0.9, 0.95), eps=1e-6)
+    plain = finetune.MasterAdamW(groups(pb), lr=1e-4, betas=(0.9, 0.95), eps=1e-6, fused=False)
+    assert fused.fused and not plain.fused and fused.capturable and len(fused._fused_plan(list(range(len(pa)))).chunks) == 2
+    for it in range(6):
+        for i, (a, b) in enumerate(zip(pa, pb)):
+            if it == 3 and i == 2:
+                a.grad = b.grad = None
+                continue
+            gr = torch.randn(a.shape, generator=g, device="cuda").to(torch.bfloat16)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        fused.step()
+        plain.step()
+    assert float(fused.steps) == 6
+    rel = lambda x, y: float((x.float() - y.float()).abs().max() / y.float().abs().max().clamp_min(1e-12))
+    for i, (ma, mb, a, b) in enumerate(zip(fused.master, plain.master, pa, pb)):
+        if i == 2:
+            continue  # skipped once: torch's per-tensor step count differs from the one-per-optimiser count by design
+        assert rel(ma, mb) < 2e-6, (i, rel(ma, mb))
+        assert torch.equal(a.detach(), ma.to(torch.bfloat16)) and rel(a, b) < 1e-2
+    st = plain.opt.state[plain.master[0]]
+    n0 = pa[0].numel()
+    assert rel(fused.exp_avg[:n0].view_as(st["exp_avg"]), st["exp_avg"]) < 2e-6 and rel(fused.exp_avg_sq[:n0].view_as(st["exp_avg_sq"]), st["exp_avg_sq"]) < 2e-6

@@ -607,8 +607,7 @@ def test_config4_sdxl_size_train_step_reduces_the_loss():
 def test_config4_train_step_replayed_from_a_hipgraph_follows_the_eager_steps():
     """finetune.GraphedTrainStep: the whole optimisation step (forward, loss, backward, AdamW on fp32 masters) captured once and replayed.
     Without jitter (eval-mode raymarchers: every kernel is deterministic) the replayed steps must follow the eagerly launched ones --
-    same losses step for step (capturable AdamW orders its scalar arithmetic differently: 1e-4 relative) and the same trained weights
-    to bf16 resolution; new inputs copied into the static buffers must change the result; with the stratified jitter on the device
+    same losses step for step (1e-4 relative) and the same trained weights to bf16 resolution; new inputs copied into the static buffers must change the result; with the stratified jitter on the device
     generator (train mode) successive replays must draw fresh jitter (losses differ from the no-jitter run) and still descend."""
     import copy
     from cd360 import finetune, synth
@@ -629,9 +628,10 @@ def test_config4_train_step_replayed_from_a_hipgraph_follows_the_eager_steps():
     eager = [float(finetune.train_step(net, loss_fn, opt, **batch)[0]) for _ in range(6)]
     w_eager = {k: dict(net.named_parameters())[k].detach().clone() for k in names}
     net.load_state_dict(start, strict=False)
-    opt = finetune.MasterAdamW(finetune.optimizer_param_groups(net, "pose", lr=1e-4), lr=1e-4, capturable=True)
-    with pytest.raises(ValueError):
-        finetune.GraphedTrainStep(net, loss_fn, finetune.MasterAdamW(finetune.optimizer_param_groups(net, "pose", lr=1e-4), lr=1e-4), batch)
+    opt = finetune.MasterAdamW(finetune.optimizer_param_groups(net, "pose", lr=1e-4), lr=1e-4)
+    assert opt.fused and opt.capturable
+    with pytest.raises(ValueError):  # the torch fall-back keeps its step counts on the host unless built capturable
+        finetune.GraphedTrainStep(net, loss_fn, finetune.MasterAdamW(finetune.optimizer_param_groups(net, "pose", lr=1e-4), lr=1e-4, fused=False), batch)
     step = finetune.GraphedTrainStep(net, loss_fn, opt, batch, warmup=2)  # steps 1-2 run eagerly inside; the capture itself executes nothing
     graphed = [float(step()[0]) for _ in range(4)]
     print("eager:", [round(v, 5) for v in eager], "graph (steps 3-6):", [round(v, 5) for v in graphed])
@@ -645,7 +645,7 @@ def test_config4_train_step_replayed_from_a_hipgraph_follows_the_eager_steps():
     # stratified jitter inside the graph: the device generator advances on every replay
     net.load_state_dict(start, strict=False)
     net.train()
-    opt = finetune.MasterAdamW(finetune.optimizer_param_groups(net, "pose", lr=1e-4), lr=1e-4, capturable=True)
+    opt = finetune.MasterAdamW(finetune.optimizer_param_groups(net, "pose", lr=1e-4), lr=1e-4)
     step = finetune.GraphedTrainStep(net, loss_fn, opt, batch, warmup=2)
     jit = [float(step()[0]) for _ in range(6)]
     print("graph, stratified:", [round(v, 5) for v in jit])

@@ -58,8 +58,7 @@ def _measure(steps, warmup, batch, views, latent, eval_mode, profile, finetune, 
                 m.proj_out.weight.copy_(torch.randn(m.proj_out.weight.shape, generator=g, device=dev).mul_(0.02))
     net.eval() if eval_mode else net.train()
     names = finetune.select_trainable(net, "pose")
-    opt = finetune.MasterAdamW(finetune.optimizer_param_groups(net, "pose", lr=1e-4), lr=1e-4,  # configs/train_co3d_concept.yaml:2,7-8
-                               **({"capturable": True} if graph else {}))
+    opt = finetune.MasterAdamW(finetune.optimizer_param_groups(net, "pose", lr=1e-4), lr=1e-4)  # configs/train_co3d_concept.yaml:2,7-8
     loss_fn = instantiate_from_config({"target": "sgm.modules.diffusionmodules.loss.StandardDiffusionLossImgRef", "params": LOSS_CFG})
     b, n, L = batch, views, latent
     rn = lambda *s: torch.randn(*s, generator=g, device=dev)

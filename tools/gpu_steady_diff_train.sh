@@ -1,6 +1,6 @@
 #!/bin/bash
 # Per-kernel time of ONE fine-tune step (tools/bench_train.py, BASELINE config 4): kernel traces of runs with K1 and K2 timed steps are
-# differenced, so model construction / random init / warmup cancel.  tools/gpu_steady_diff_train.sh TAG [K1 K2]
+# differenced, so model construction / random init / warmup cancel.  [TRAIN_ARGS=--graph] tools/gpu_steady_diff_train.sh TAG [K1 K2 [rows]]
 export TMPDIR=/tmp HSA_ENABLE_IPC_MODE_LEGACY=0
 TAG=${1:-t}; K1=${2:-1}; K2=${3:-4}
 OUT=$GRAFT_REPO_ROOT/gpurun_out/steady_train_$TAG
@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp
 for K in $K1 $K2; do
   rm -rf /tmp/sdt_$K
-  timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/sdt_$K -o b -- python $GRAFT_REPO_ROOT/tools/bench_train.py --steps $K --warmup 1 > $OUT/log_$K.txt 2>&1
+  timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/sdt_$K -o b -- python $GRAFT_REPO_ROOT/tools/bench_train.py --steps $K --warmup 1 $TRAIN_ARGS > $OUT/log_$K.txt 2>&1
   echo "K=$K exit $?"
 done
 python - $(find /tmp/sdt_$K1 -name "*kernel_trace.csv" | head -1) $(find /tmp/sdt_$K2 -name "*kernel_trace.csv" | head -1) $((K2-K1)) > $OUT/steady_train_step.csv <<'PY'
