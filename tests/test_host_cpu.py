@@ -130,8 +130,9 @@ def test_library_exports_every_declared_symbol():
 
 def test_gemm_dispatch_contract_of_the_sdxl_shapes():
     """The host side sizes two buffers from what the GEMM dispatcher will choose (no GPU needed to ask): the row-statistics partials of a
-    residual-stream GEMM (one per `cd360_gemm_tile_n` columns, consumed by the next LayerNorm fold) and the 64-row channel statistics
-    of `proj_out` (consumed by the next GroupNorm).  Pin both for the shapes of the SDXL UNet at cfg-A / cfg-B batch sizes."""
+    residual-stream GEMM (one per `cd360_gemm_tile_n` columns, consumed by the next LayerNorm fold) and the 64- or 32-row channel
+    statistics of `proj_out` (consumed by the next GroupNorm).  Pin both for the shapes of the SDXL UNet at cfg-A / cfg-B batch sizes, and
+    the small-batch tilings (64 x 128 tiles up to 128 tiles of 128 x 128; `gemm_small` = 0 switches the rule off)."""
     from cd360 import _lib
     lib = _lib.load()
     for b in (1, 2, 3):
@@ -139,9 +140,14 @@ def test_gemm_dispatch_contract_of_the_sdxl_shapes():
             M = b * tokens
             assert lib.cd360_gemm_tile_n(M, C) in (128, 256), (M, C)           # C -> C, FF2: narrow outputs
             assert lib.cd360_gemm_tile_n(M, 3 * C) in (128, 192, 256), (M, C)   # q|k|v
-            assert lib.cd360_gemm_cstats_rows(M, C) in (0, 64)                 # proj_out: 64-row slabs or the plain path
+            slab = lib.cd360_gemm_cstats_rows(M, C)                              # proj_out: 64-row slabs, 32 on the 64 x 128 tiling
+            assert slab == (32 if -(-M // 128) * (C // 128) <= 128 else 64), (M, C, slab)
     assert lib.cd360_gemm_cstats_rows(3072, 1280) == 64 and lib.cd360_gemm_cstats_rows(12288, 640) == 64
     assert lib.cd360_gemm_tile_n(3072, 1280) == 128 and lib.cd360_gemm_tile_n(3072, 3840) == 192
+    assert lib.cd360_gemm_tile_n(1024, 3840) == 128 and lib.cd360_gemm_tile_n(1024, 5120) == 128 and lib.cd360_gemm_tile_n(1024, 10240) in (192, 256)
+    with _lib.tuning(gemm_small=0):  # the A/B partner: the rules before the small-batch tilings
+        assert lib.cd360_gemm_cstats_rows(1024, 1280) == 64 and lib.cd360_gemm_tile_n(1024, 3840) in (192, 256)
+    assert lib.cd360_gemm_cstats_rows(1024, 1280) == 32
 
 
 @pytest.mark.parametrize("cin", [64, 320, 640, 960, 1280, 1920, 2560])
