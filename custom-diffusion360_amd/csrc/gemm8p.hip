@@ -1050,7 +1050,12 @@ extern "C" int cd360_gemm_bf16(const void* a, const void* w, void* out, int64_t 
   p.tiles_m = p.tiles_n = p.group_m = 0;
   p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f; p.a_dup = p.a_dup_from = 0;
   p.cv_H = p.cv_W = p.cv_kg = p.cv_up = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = nullptr;
-  switch (pick_cfg(M, N, geglu)) {
+  int cfg = pick_cfg(M, N, geglu);
+  // narrow outputs of 257 .. 512 tiles with a long K loop: 256 x 128 tiles with three buffers instead of two 128 x 128 workgroups per CU
+  // (same 128-column statistics partials; tools/bench_gemm.py mid_m "narrow": 4096 x 1280 x 5120 64.7 -> 58.5 us, 12288 x 640 x 2560 44.8 -> 40.9,
+  // K = 1280 22.1 -> 21.2, K = 640 equal).  Decided here, not in pick_cfg: the tile width the host sizes buffers from does not change.
+  if (cfg == 2 && K >= 1280 && cd360_tune().gemm_cfg < 1 && cd360_tune().gemm_small != 0 && ((M + 127) / 128) * ((N + 127) / 128) <= 512) cfg = 5;
+  switch (cfg) {
     case 1: return launch<2, 2, 2, 2, 2>(p, (hipStream_t)stream);
     case 2: return geglu ? CD360_ERR_SHAPE : launch_epi<2, 4, 1, 2, 2, 0>(p, (hipStream_t)stream);
     case 4: return geglu ? CD360_ERR_SHAPE : launch_128x4<0>(p, (hipStream_t)stream);

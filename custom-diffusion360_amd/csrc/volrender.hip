@@ -291,7 +291,7 @@ extern "C" int cd360_rowdot4_bf16(const void* h, const void* w, void* out, int64
 // Backward of cd360_rowdot4_bf16 (the FeatureNeRF decoder is trained: trainkeys = pose, diffusion.py:139-144):
 //   dh[row, c] = sum_j d[row, j] w[j, c]   (bf16, the layout of h)          dw[j, c] = sum_row d[row, j] h[row, c]   (fp32)
 // dh is one pass (reads 16 B of d per row, writes the row); dw is a column reduction over all rows: each workgroup reduces a slab of
-// rows for 256 channels into a partial [slab, 4, C], summed by the caller in slab order (deterministic, no atomics).
+// rows for 512 channels into a partial [slab, 4, C], summed by the caller in slab order (deterministic, no atomics).
 namespace {
 __global__ __launch_bounds__(256) void rowdot4_bwd_dh_kernel(const float* __restrict__ d, const float* __restrict__ w, uint16_t* __restrict__ dh,
                                                              long rows, int C) {
@@ -316,21 +316,53 @@ __global__ __launch_bounds__(256) void rowdot4_bwd_dh_kernel(const float* __rest
   }
 }
 
-constexpr int DW_SLAB_ROWS = 512;
+constexpr int DW_SLAB_ROWS = 256;
+// One workgroup: 256 rows x 512 channels.  A wave owns every fourth row and reads it as one 1-KB access (16 bytes = 8 channels per
+// lane), 32 fp32 accumulators per lane; the four waves meet once in the LDS.  (The first version gave a thread ONE channel and 512 rows:
+// 2-byte loads, 0.4-0.6 TB/s.)
 __global__ __launch_bounds__(256) void rowdot4_bwd_dw_kernel(const float* __restrict__ d, const uint16_t* __restrict__ h, float* __restrict__ part,
                                                              long rows, int C) {
-  const int c = blockIdx.x * 256 + threadIdx.x;
+  __shared__ float red[3][64][33];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  const int c = (blockIdx.x * 64 + lane) * 8;
+  const bool live = c < C;
   const long r0 = (long)blockIdx.y * DW_SLAB_ROWS, r1 = r0 + DW_SLAB_ROWS < rows ? r0 + DW_SLAB_ROWS : rows;
-  float a[4] = {0.f, 0.f, 0.f, 0.f};
-  if (c < C) {
-    for (long r = r0; r < r1; ++r) {
-      const float hv = bf16_to_f32(h[r * C + c]);
-      const f32x4 dv = *reinterpret_cast<const f32x4*>(d + r * 4);  // wave-uniform address: one broadcast load
+  float a[4][8];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) a[j] = fmaf(dv[j], hv, a[j]);
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) a[j][e] = 0.f;
+#pragma unroll 4
+  for (long r = r0 + wv; r < r1; r += 4) {
+    u32x4 hv = {0u, 0u, 0u, 0u};
+    if (live) hv = *reinterpret_cast<const u32x4*>(h + r * C + c);
+    const f32x4 dv = *reinterpret_cast<const f32x4*>(d + r * 4);  // wave-uniform address
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const float lo = bf16lo_to_f32(hv[e]), hi = bf16hi_to_f32(hv[e]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        a[j][2 * e] = fmaf(dv[j], lo, a[j][2 * e]);
+        a[j][2 * e + 1] = fmaf(dv[j], hi, a[j][2 * e + 1]);
+      }
     }
+  }
+  if (wv) {
 #pragma unroll
-    for (int j = 0; j < 4; ++j) part[((long)blockIdx.y * 4 + j) * C + c] = a[j];
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) red[wv - 1][lane][j * 8 + e] = a[j][e];
+  }
+  __syncthreads();
+  if (wv == 0 && live) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) a[j][e] = ((a[j][e] + red[0][lane][j * 8 + e]) + red[1][lane][j * 8 + e]) + red[2][lane][j * 8 + e];
+      float* dst = part + ((long)blockIdx.y * 4 + j) * C + c;
+      *reinterpret_cast<f32x4*>(dst) = f32x4{a[j][0], a[j][1], a[j][2], a[j][3]};
+      *reinterpret_cast<f32x4*>(dst + 4) = f32x4{a[j][4], a[j][5], a[j][6], a[j][7]};
+    }
   }
 }
 }  // namespace
@@ -351,7 +383,8 @@ extern "C" int cd360_rowdot4_bwd_bf16(const void* d, const void* h, const void* 
   if (dw_part) {
     const long slabs = (rows + DW_SLAB_ROWS - 1) / DW_SLAB_ROWS;
     if (slabs > 65535) return CD360_ERR_SHAPE;
-    hipLaunchKernelGGL(rowdot4_bwd_dw_kernel, dim3((unsigned)((C + 255) / 256), (unsigned)slabs), dim3(256), 0, (hipStream_t)stream,
+    if ((uintptr_t)dw_part % 16) return CD360_ERR_ARG;
+    hipLaunchKernelGGL(rowdot4_bwd_dw_kernel, dim3((unsigned)((C + 511) / 512), (unsigned)slabs), dim3(256), 0, (hipStream_t)stream,
                        (const float*)d, (const uint16_t*)h, (float*)dw_part, (long)rows, C);
     CD360_LAUNCH_CHECK();
   }

@@ -265,6 +265,18 @@ def test_rowdot4():
     assert rel(ops.rowdot4(h.to(DEV, torch.bfloat16), w.to(DEV)), h @ w.t()) < 1e-5
 
 
+@pytest.mark.parametrize("rows,C", [(111, 64), (1000, 640), (24576, 1280), (257, 520)])
+def test_rowdot4_backward(rows, C):
+    """cd360_rowdot4_bwd_bf16 (decoder head of the FeatureNeRF samples, nerfsd_pytorch3d.py decoder Linear): dh = d w per row, dw = d^T h
+    reduced per 256-row slab (ragged last slab, channel counts that leave lanes of the last 512-channel group idle), deterministic."""
+    from cd360 import ops
+    g = torch.Generator().manual_seed(19)
+    h, w, d = bf(torch.randn(rows, C, generator=g)), torch.randn(4, C, generator=g), torch.randn(rows, 4, generator=g)
+    dh, dw = ops.rowdot4_bwd(d.to(DEV), h.to(DEV, torch.bfloat16), w.to(DEV))
+    assert rel(dh, d @ w) < 1e-2 and rel(dw, d.t() @ h) < 1e-5
+    assert torch.equal(dw, ops.rowdot4_bwd(d.to(DEV), h.to(DEV, torch.bfloat16), w.to(DEV), need_dh=False)[1])
+
+
 def test_geglu_and_concat():
     from cd360 import ops
     g = torch.Generator().manual_seed(10)

@@ -428,8 +428,15 @@ def small_m():
 
 def mid_m():
     """Wide outputs of a small batch (fine-tune step: merged q|k|v, context k|v, GEGLU backward): every linear tiling."""
-    for (M, N, K) in ((1024, 3840, 1280), (1024, 5120, 1280), (1024, 10240, 1280), (1280, 2560, 2048), (320, 2560, 2048), (320, 1280, 2048),
-                      (4096, 3840, 1280), (4096, 5120, 640), (4096, 1920, 640), (2048, 1280, 1280), (1536, 1280, 1280), (3072, 3840, 1280)):
+    shapes = ((1024, 3840, 1280), (1024, 5120, 1280), (1024, 10240, 1280), (1280, 2560, 2048), (320, 2560, 2048), (320, 1280, 2048),
+              (4096, 3840, 1280), (4096, 5120, 640), (4096, 1920, 640), (2048, 1280, 1280), (1536, 1280, 1280), (3072, 3840, 1280))
+    if os.environ.get("CD360_BENCH_SHAPES") == "cfgB":  # the linear launches of the sampling step (b = 3 at 1024^2)
+        shapes = ((12288, 640, 640), (12288, 640, 2560), (12288, 1920, 640), (3072, 1280, 1280), (3072, 1280, 5120), (3072, 3840, 1280),
+                  (231, 2560, 2048), (231, 1280, 2048), (3072, 1280, 2560), (12288, 640, 1280), (49152, 320, 320))
+    if os.environ.get("CD360_BENCH_SHAPES") == "narrow":  # narrow outputs with 257 .. 640 tiles of 128 x 128: two-buffer 128 x 128 or 256 x 128?
+        shapes = ((4096, 1280, 1280), (4096, 1280, 5120), (4096, 1280, 3840), (16384, 640, 640), (12288, 640, 640), (12288, 640, 2560), (5120, 1280, 1280),
+                  (6144, 1280, 1280), (8192, 640, 640), (8192, 640, 2560))
+    for (M, N, K) in shapes:
         a = rnd(M, K, seed=1).to(torch.bfloat16)
         w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
         b32 = rnd(N, seed=3)
