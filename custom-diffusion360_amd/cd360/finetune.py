@@ -243,6 +243,8 @@ class MasterAdamW:
         self.param_groups = self.opt.param_groups
         self.capturable = all(g.get("capturable") for g in self.opt.param_groups)
 
+    allreduce_single = False  # True: run the gradient all-reduce even in a group of one (tests of the collective path on a 1-GPU box)
+
     def zero_grad(self) -> None:
         for p in self.params:
             p.grad = None
@@ -252,7 +254,7 @@ class MasterAdamW:
         """Data-parallel fine-tuning (the reference trains under Lightning DDP, main.py): average the gradients of the trainable
         parameters over the ranks as ONE flat fp32 all-reduce (66.7 M values = 267 MB at SDXL size: a single RCCL ring over xGMI,
         per-link bound, instead of 96 small collectives).  No-op without an initialised process group."""
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        if not (dist.is_available() and dist.is_initialized()) or (dist.get_world_size(group) == 1 and not self.allreduce_single):
             return
         grads = [p.grad for p in self.params]
         if any(g is None for g in grads):
@@ -320,12 +322,10 @@ class GraphedTrainStep:
     ~6400 kernel launches and ~16000 torch operator calls per step -- host work that takes longer than the kernels run (DESIGN.md section 6b);
     a replay costs one launch.  Conditions: fixed shapes (the batch is copied into static buffers), a MasterAdamW on its fused
     path (or built with capturable=True), the raymarchers on device_rng=True (the stratified jitter of patch x / y is then drawn by the device generator, which
-    a graph advances on every replay; the reference draws those two on the CPU generator), a single process (no gradient all-reduce
-    inside the graph).  The returned loss terms are 0-d device tensors that the next replay overwrites."""
+    a graph advances on every replay; the reference draws those two on the CPU generator).  Under an initialised process group the
+    gradient all-reduce is part of the graph (RCCL collectives capture; tools/probe/rccl_graph_probe.py).  The returned loss terms are 0-d device tensors that the next replay overwrites."""
 
     def __init__(self, unet: torch.nn.Module, loss_fn, optimizer: "MasterAdamW", batch: dict, warmup: int = 3, **loss_kw):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            raise NotImplementedError("GraphedTrainStep: single process only (the gradient all-reduce is not captured)")
         if not optimizer.capturable:
             raise ValueError("GraphedTrainStep: the torch fall-back of MasterAdamW must be built with capturable=True (the fused path is as it is)")
         self.unet, self.loss_fn, self.optimizer, self.loss_kw = unet, loss_fn, optimizer, loss_kw
@@ -341,7 +341,11 @@ class GraphedTrainStep:
                 train_step(unet, loss_fn, optimizer, as_tensors=True, **self.static, **loss_kw)
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        # with a process group the gradient all-reduce (one flat RCCL all-reduce, MasterAdamW.allreduce_grads) is captured with the step; the
+        # group's watchdog thread polls events meanwhile, which only the thread-local capture mode tolerates.  Every rank captures the same
+        # sequence and must replay in lock-step, as with any collective.
+        mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
+        with torch.cuda.graph(self.graph, capture_error_mode=mode):
             self.total, self.logged = train_step(unet, loss_fn, optimizer, as_tensors=True, **self.static, **loss_kw)
 
     @staticmethod

@@ -31,6 +31,7 @@ from ...modules.diffusionmodules.util import (
     linear,
     normalization,
     tag_gn_stats,
+    _tagged_gn_stats,
     timestep_embedding,
     tokens_to_image,
     zero_module,
@@ -42,7 +43,19 @@ def _cat_channels(a, b):
     """th.cat([a, b], dim=1) (openaimodel.py:1074-1076); channels-last bf16 goes through cd360_concat_channels_bf16."""
     if a.is_cuda and a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16 and a.shape[1] % 8 == 0 and b.shape[1] % 8 == 0:
         cl = torch.channels_last
-        return ops.concat_channels(a.contiguous(memory_format=cl), b.contiguous(memory_format=cl))
+        out = ops.concat_channels(a.contiguous(memory_format=cl), b.contiguous(memory_format=cl))
+        # GroupNorm statistics of a concatenation are the concatenated per-channel statistics: when both inputs still carry the slab sums
+        # their producers' epilogues took (tag_gn_stats), the in_layers GroupNorm of the ResBlock that reads `out` needs no pass over it
+        sa, sb = _tagged_gn_stats(a), _tagged_gn_stats(b)
+        if sa is not None and sb is not None and not torch.is_grad_enabled() and not (os.environ.get("CD360_NO_GN_STATS") or os.environ.get("CD360_NO_CONCAT_STATS")):
+            na, nb = sa.shape[1], sb.shape[1]  # [N, slabs, C, 2]: bring both to the coarser slab count (slabs are consecutive pixel runs)
+            if na > nb and na % nb == 0:
+                sa = sa.reshape(sa.shape[0], nb, na // nb, sa.shape[2], 2).sum(2)
+            elif nb > na and nb % na == 0:
+                sb = sb.reshape(sb.shape[0], na, nb // na, sb.shape[2], 2).sum(2)
+            if sa.shape[1] == sb.shape[1]:
+                tag_gn_stats(out, torch.cat([sa, sb], dim=2))
+        return out
     return th.cat([a, b], dim=1)
 
 

@@ -651,3 +651,77 @@ def test_config4_train_step_replayed_from_a_hipgraph_follows_the_eager_steps():
     print("graph, stratified:", [round(v, 5) for v in jit])
     assert all(torch.isfinite(torch.tensor(jit))) and jit[-1] < jit[0] and any(abs(a - e) > 1e-6 * abs(e) for a, e in zip(jit, eager[2:]))
     assert all(m.device_rng for m in net.modules() if hasattr(m, "device_rng"))
+
+
+@torch.no_grad()
+def test_groupnorm_statistics_ride_through_the_skip_concat():
+    """openaimodel.py:1074-1076 (th.cat([h, hs.pop()], dim=1)) in front of a ResBlock's in_layers GroupNorm: when both inputs carry the
+    per-slab channel sums of their producers' epilogues, the concatenation carries their concatenation (slab counts brought to the coarser
+    one) and the GroupNorm skips its statistics pass -- same result as statistics taken from the concatenated tensor itself."""
+    from sgm.modules.diffusionmodules import openaimodel as om
+    from sgm.modules.diffusionmodules.util import _tagged_gn_stats, group_norm_tokens, normalization, tag_gn_stats
+    g = torch.Generator(device=DEV).manual_seed(77)
+    N, H, W, ca, cb = 3, 32, 32, 1280, 640
+    mk = lambda c: (torch.randn(N, c, H, W, generator=g, device=DEV) * 1.5 + 0.3).to(BF).contiguous(memory_format=torch.channels_last)
+    a, b = mk(ca), mk(cb)
+
+    def slab_stats(x, slabs):
+        t = x.permute(0, 2, 3, 1).reshape(N, slabs, H * W // slabs, x.shape[1]).float()
+        return torch.stack([t.sum(2), (t * t).sum(2)], -1).contiguous()
+
+    tag_gn_stats(a, slab_stats(a, 16))
+    tag_gn_stats(b, slab_stats(b, 8))
+    out = om._cat_channels(a, b)
+    st = _tagged_gn_stats(out)
+    assert st is not None and st.shape == (N, 8, ca + cb, 2)
+    assert torch.equal(out, torch.cat([a, b], 1))
+    norm = normalization(ca + cb).to(DEV, BF)
+    norm.weight.copy_(1 + 0.2 * torch.randn(ca + cb, generator=g, device=DEV))
+    norm.bias.copy_(0.1 * torch.randn(ca + cb, generator=g, device=DEV))
+    with_tag = group_norm_tokens(norm, out, silu=True)
+    fresh = group_norm_tokens(norm, out.clone(memory_format=torch.channels_last), silu=True)  # a clone has no tag: statistics pass over the data
+    want = torch.nn.functional.silu(torch.nn.functional.group_norm(out.float(), norm.num_groups, norm.weight.float(), norm.bias.float(), norm.eps))
+    want = want.permute(0, 2, 3, 1).reshape(N, H * W, ca + cb)
+    assert rel(with_tag, want) < 1e-2 and rel(fresh, want) < 1e-2 and rel(with_tag, fresh) < 4e-3
+    assert _tagged_gn_stats(om._cat_channels(a, mk(cb))) is None  # an untagged input: no tag on the result
+
+
+def test_graphed_train_step_captures_the_gradient_allreduce():
+    """Data-parallel fine-tuning replayed from a hipGraph: under an initialised process group (RCCL, a group of ONE here -- all a 1-GPU box
+    offers; `allreduce_single` forces the collective path that a larger group takes) MasterAdamW's flat gradient all-reduce is captured
+    with the step.  The replayed steps must equal the eager steps of the same optimiser, which in a group of one are the plain steps."""
+    import copy
+    import torch.distributed as dist
+    from cd360 import finetune, synth
+    from make_golden_params import LOSS_CFG
+    from sgm.util import instantiate_from_config
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29547")
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        net, g = _sdxl_net(seed=47)
+        net.eval()
+        names = finetune.select_trainable(net, "pose")
+        loss_fn = instantiate_from_config({"target": "sgm.modules.diffusionmodules.loss.StandardDiffusionLossImgRef", "params": LOSS_CFG})
+        b, n, L = 1, 2, 32
+        rn = lambda *s: torch.randn(*s, generator=g, device=DEV)
+        batch = dict(noised=rn(b, 4, L, L), timesteps=torch.full((b,), 500.0, device=DEV), context=rn(b + b * n, 77, 2048), y=rn(b + b * n, 2816),
+                     pose=synth.pose_batch(b, n, seed=3), input_ref=rn(b, n, 4, L, L), sigmas_ref=torch.full((b,), 3.0, device=DEV),
+                     target=rn(b, 4, L, L), target_rgb=rn(b, 3, 8 * L, 8 * L).clamp(-1, 1), w=torch.full((b, 1, 1, 1), 0.7, device=DEV),
+                     mask=torch.ones(b, 1, L, L, device=DEV), opacity=torch.sigmoid(3 * rn(b, 1, 8 * L, 8 * L)))
+        start = copy.deepcopy({k: v for k, v in net.state_dict().items() if "pose" in k})
+        opt = finetune.MasterAdamW(finetune.optimizer_param_groups(net, "pose", lr=1e-4), lr=1e-4)
+        eager = [float(finetune.train_step(net, loss_fn, opt, **batch)[0]) for _ in range(5)]  # group of one: no collective
+        net.load_state_dict(start, strict=False)
+        opt = finetune.MasterAdamW(finetune.optimizer_param_groups(net, "pose", lr=1e-4), lr=1e-4)
+        opt.allreduce_single = True
+        dist.all_reduce(torch.ones(8, device=DEV))  # communicator set-up outside the capture
+        step = finetune.GraphedTrainStep(net, loss_fn, opt, batch, warmup=2)
+        graphed = [float(step()[0]) for _ in range(3)]
+        print("eager:", [round(v, 5) for v in eager], "graph + all-reduce (steps 3-5):", [round(v, 5) for v in graphed])
+        # the all-reduce path rounds the gradients through one fp32 flat buffer and back to bf16: same values
+        assert all(abs(a - e) <= 1e-4 * abs(e) for a, e in zip(graphed, eager[2:]))
+    finally:
+        dist.destroy_process_group()
