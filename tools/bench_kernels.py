@@ -119,6 +119,13 @@ def gemm(tag, M, K, N):
 if __name__ == "__main__":
     which = sys.argv[1:] or ["attn", "nerf", "gn", "conv"]
     print("env CD360_ATTN_FAST =", os.environ.get("CD360_ATTN_FAST"))
+    if "gemm_tn" in which:  # weight-gradient shapes of the config-4 step
+        for (M, N, K) in ((98304, 1280, 1280), (393216, 640, 640), (24576, 1280, 1280), (98304, 1280, 112), (98304, 8, 1280), (1024, 1280, 1280), (4096, 1280, 128)):
+            a, b = torch.randn(M, N, device=dev).to(torch.bfloat16), torch.randn(M, K, device=dev).to(torch.bfloat16)
+            line = f"gemm_tn M={M:6d} N={N:4d} K={K:4d}:"
+            us = timeit(lambda: ops.gemm_tn(a, b), iters=20)
+            line += f" {us:7.1f} us ({2.0 * M * N * K / us / 1e6:5.0f} TF/s)"
+            print(line, flush=True)
     if "attn" in which:
         attn("L1 self", 3, 10, 4096, 4096)
         attn("L2 self", 3, 20, 1024, 1024)
