@@ -134,7 +134,11 @@ class Sampler:
             fn()
         torch.cuda.current_stream().wait_stream(side)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # under torch.distributed the process group's watchdog thread may still poll the events of finished collectives (the launch
+        # barrier) while this thread captures: only the thread-local capture mode tolerates that (tools/probe/rccl_graph_probe.py)
+        import torch.distributed as dist
+        mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
+        with torch.cuda.graph(graph, capture_error_mode=mode):
             out = fn()
         return graph, out
 
