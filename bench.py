@@ -434,14 +434,17 @@ def main():
                 del smp
                 torch.cuda.empty_cache()
                 graph_ = bench_train.measure(steps=5, warmup=1, batch=4, views=4, latent=64, profile=False, library=False, graph=True)
+                libg_ = bench_train.measure(steps=5, warmup=1, batch=4, views=4, latent=64, profile=False, library=True, graph=True)
                 mine_ = bench_train.measure(steps=3, warmup=1, batch=4, views=4, latent=64, profile=False, library=False)
                 lib_ = bench_train.measure(steps=3, warmup=1, batch=4, views=4, latent=64, profile=False, library=True)
                 out["train_step"] = {"ms": graph_["ms_per_step"], "bs": 4, "n_ref": 4, "latent": 64, "graph_ms": graph_["ms_per_step"],
-                                     "cd360_ms": mine_["ms_per_step"], "library_ms": lib_["ms_per_step"], "losses": graph_["losses"],
+                                     "library_graph_ms": libg_["ms_per_step"], "cd360_ms": mine_["ms_per_step"], "library_ms": lib_["ms_per_step"],
+                                     "losses": graph_["losses"],
                                      "eager_losses": mine_["losses"], "peak_mem_gb": graph_["peak_mem_gb"],
                                      "what": "tools/bench_train.py shapes: main.py fine-tune step (train_co3d_concept.yaml), random-init SDXL UNet; "
                                              "graph_ms (= ms) = the whole step (forward, four-term loss, backward, AdamW on fp32 masters) captured once into "
-                                             "a hipGraph and replayed (cd360.finetune.GraphedTrainStep), 1 warm + 5 timed replays; cd360_ms = the same "
+                                             "a hipGraph and replayed (cd360.finetune.GraphedTrainStep), 1 warm + 5 timed replays; library_graph_ms = the same replay with "
+                                             "every Linear on torch (hipBLASLt) -- the GPU-side comparison of the two GEMM families; cd360_ms = the same "
                                              "step launched eagerly (1 warm + 3 timed; host-bound: ~6400 launches), every Linear on cd360_gemm_bf16 / "
                                              "cd360_gemm_tn_bf16 (forward, dgrad, wgrad); library_ms = eager with the Linears on torch (hipBLASLt)"}
             except Exception as e:  # noqa: BLE001
