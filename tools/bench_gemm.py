@@ -571,6 +571,24 @@ def ff1_tilings():
         ENV.pop(k, None)
 
 
+def geglu_cost():
+    """What the GEGLU epilogue (erf GELU of the gate, product with the value) costs on FF1: the same launch with and without it
+    (same tiling, same LayerNorm fold and bias)."""
+    for name, M, N, K in (("L2 ff1", 3072, 10240, 1280), ("L1 ff1", 12288, 5120, 640)):
+        a = rnd(M, K, seed=1).to(torch.bfloat16)
+        w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
+        b32 = rnd(N, seed=3)
+        st, ws = ops.row_stats(a), w.float().sum(1).contiguous()
+        line = f"{name}:"
+        for cfg in ("7", "3"):
+            ENV["CD360_GEMM_CFG"] = cfg
+            g = timeit_graph(lambda: ops.gemm(a, w, bias=b32, ln=(st, ws, 1e-5), geglu=True), n=20)
+            p_ = timeit_graph(lambda: ops.gemm(a, w, bias=b32, ln=(st, ws, 1e-5)), n=20)
+            line += f"  cfg{cfg}: GEGLU {g:6.1f} us, plain (2x the output bytes) {p_:6.1f} us"
+        ENV.pop("CD360_GEMM_CFG", None)
+        print(line, flush=True)
+
+
 def whatif():
     """hipGraph-timed what-if builds of the 128 x 128 four-buffer tiling on the long-K shape (results invalid by construction)."""
     M, N = 3072, 1280
@@ -617,6 +635,8 @@ if __name__ == "__main__":
         whatif()
     if "mid_m" in what:
         mid_m()
+    if "geglu_cost" in what:
+        geglu_cost()
     if "small_m" in what:
         small_m()
     if "fixed" in what:
