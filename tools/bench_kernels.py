@@ -133,6 +133,17 @@ if __name__ == "__main__":
         attn("L2 cross", 3, 20, 1024, 77)
         attn("L1 pose", 3, 10, 98304, 77)
         attn("L2 pose", 3, 20, 24576, 77)
+    if "gn_graph" in which:  # GroupNorm + SiLU timed inside a hipGraph (the eager loop above measures the host): own statistics pass / producer's slab sums
+        sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+        from bench_gemm import timeit_graph
+        for tag, N, P, C in (("L0", 3, 16384, 320), ("L1", 3, 4096, 640), ("L2", 3, 1024, 1280), ("up", 3, 1024, 2560), ("up0", 3, 16384, 960)):
+            x = torch.randn(N, P, C, device=dev).to(BF)
+            g, bta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
+            t = x.float().reshape(N, P // 64, 64, C)
+            st = torch.stack([t.sum(2), (t * t).sum(2)], -1).contiguous()
+            us = timeit_graph(lambda: ops.gn_silu(x, g, bta, 32, 1e-5, True), n=20)
+            us2 = timeit_graph(lambda: ops.gn_silu(x, g, bta, 32, 1e-5, True, tile_stats=st), n=20)
+            print(f"gn_silu {tag}: N{N} P{P} C{C}: partial+finalize+apply {us:6.1f} us | finalize+apply {us2:6.1f} us ({2.0 * 2 * N * P * C / us2 / 1e3:6.0f} GB/s)", flush=True)
     if "gn" in which:
         gn("L0", 3, 16384, 320); gn("L1", 3, 4096, 640); gn("L2", 3, 1024, 1280); gn("up", 3, 1024, 2560); gn("up0", 3, 16384, 960)
     if "conv" in which:
