@@ -232,6 +232,16 @@ def cpu_baseline(net, latent: int, threads: int):
                       f"{dt:.1f} s measured, value = 1/(3*t)"}
 
 
+
+def _baseline_metric() -> str:
+    """BASELINE.json's metric string, verbatim (the file travels with the repository); the literal is the fall-back."""
+    try:
+        with open(os.path.join(ROOT, "BASELINE.json")) as f:
+            return json.load(f)["metric"]
+    except Exception:  # noqa: BLE001
+        return "UNet denoise steps/sec @ SDXL 1024\u00b2, 50 ref views, 1/2/4/8 MI355X"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -403,7 +413,7 @@ def main():
                                         "unit": "TFLOP/s", "frac": round(2.03e13 / (steady_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4),
                                         "what": "2.03e13 algorithmic FLOP of one CFG-3 UNet step / steady_step_ms (hipGraph replay wall time)"}
         out = {
-            "metric": "UNet denoise steps/sec @ SDXL 1024^2, 50 ref views", "value": round(sum_steps / elapsed, 4), "unit": "steps/s",
+            "metric": _baseline_metric(), "value": round(sum_steps / elapsed, 4), "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / steps_done * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "sample.py 50-step sampling, SDXL UNet (random init), latent %d^2, CFG x3, %d ref views (synthetic ring cameras), "

@@ -22,8 +22,10 @@ def test_bench_line_has_the_contract_keys_and_baseline_metric():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
                 "config", "roofline", "cpu_baseline"):
         assert key in line, key
-    norm = lambda m: m.replace("\u00b2", "^2").split(", 1/2/4/8")[0]  # BASELINE.json writes 1024² and appends the GPU counts of the scaling run
+    norm = lambda m: m.replace("\u00b2", "^2").split(", 1/2/4/8")[0]  # lines committed before bench.py quoted BASELINE.json verbatim wrote 1024^2
     assert norm(line["metric"]) == norm(base["metric"]) and line["unit"] == "steps/s"
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert '"metric": _baseline_metric()' in src and 'json.load(f)["metric"]' in src  # the line quotes BASELINE.json's metric verbatim
     assert line["n_gpus"] == 1 and line["steps"] == 20 and line["warmup"] == 5 and line["higher_is_better"] is True
     assert line["scaling"] == "weak" and line["vs_baseline"] is None and line["dtype"] == "bf16" and "synthetic" in line["data"]
     assert abs(line["value"] - 1e3 / line["ms_per_step"]) < 1e-2 * line["value"]
