@@ -264,10 +264,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 through torch.distributed.run)"
+    # CD360_BENCH_ONE_GPU=1: every rank on GPU 0 over gloo -- a SANITY run of the N > 1 control path (sharding, barriers, captures under a
+    # process group, per-rank times, the final all-gather) on a 1-GPU box; RCCL refuses two ranks on one device.  Never a measurement.
+    one_gpu = bool(os.environ.get("CD360_BENCH_ONE_GPU"))
+    if one_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1 or "RANK" in os.environ:  # launched through torch.distributed.run (also with a single rank)
-        dist.init_process_group("nccl", device_id=dev)
+        if one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
 
     from cd360 import ops, synth
 
@@ -424,7 +432,9 @@ def main():
                                    % (args.latent, args.refs, n_poses, world, args.traj),
                        "render_step_ms": round(render_ms, 2), "steady_step_ms": round(steady_ms, 2), "cfg_batch": 3, "latent": args.latent,
                        "n_ref": args.refs, "poses": n_poses, "poses_per_gpu": len(mine), "world_size": world,
-                       "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1, "parallelism": "pose-dp%d" % world,
+                       "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
+                       **({"sanity_run": "CD360_BENCH_ONE_GPU: all ranks on GPU 0 over gloo -- not a measurement"} if one_gpu else {}),
+                       "parallelism": "pose-dp%d" % world,
                        "hipgraph": not args.no_graph, "hipgraph_render_step": smp.rgraph is not None, "route": args.route,
                        "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)},
                        "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
