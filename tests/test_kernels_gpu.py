@@ -258,11 +258,14 @@ def test_volrender(dtype):
     assert rel(got2[0], want2[0]) < tol and rel(got2[4], want2[4]) < 1e-5
 
 
-def test_rowdot4():
+@pytest.mark.parametrize("C", [64, 520, 640, 1280, 2048])
+def test_rowdot4(C):
+    """decoder head (nerfsd_pytorch3d.py:49-51,160): every number of 512-channel chunks a lane can own, a ragged last chunk"""
     from cd360 import ops
     g = torch.Generator().manual_seed(9)
-    h, w = bf(torch.randn(3, 37, 640, generator=g)), torch.randn(4, 640, generator=g)
-    assert rel(ops.rowdot4(h.to(DEV, torch.bfloat16), w.to(DEV)), h @ w.t()) < 1e-5
+    h, w = bf(torch.randn(3, 37, C, generator=g)), torch.randn(4, C, generator=g)
+    got = ops.rowdot4(h.to(DEV, torch.bfloat16), w.to(DEV))
+    assert rel(got, h @ w.t()) < 1e-5 and torch.equal(got, ops.rowdot4(h.to(DEV, torch.bfloat16), w.to(DEV)))
 
 
 @pytest.mark.parametrize("rows,C", [(111, 64), (1000, 640), (24576, 1280), (257, 520)])
