@@ -777,10 +777,14 @@ ADAMW_MAX_TENSORS = 64  # CD360_ADAMW_MAX_TENSORS of include/cd360_hip.h
 
 class AdamwPlan:
     """Host-side argument arrays of cd360_adamw_bf16 for a fixed list of bf16 parameters whose fp32 master / exp_avg / exp_avg_sq live
-    at offsets `begin` of three flat buffers: everything except the gradient pointers is built once."""
+    at offsets `begin` of three flat buffers: offsets, sizes, learning rates and decays are built once; the gradient AND parameter
+    pointers are refreshed on every step (a parameter whose storage was replaced -- `p.data = ...` -- must not be written through a
+    stale address)."""
 
     def __init__(self, params, begin, lr, wd):
         self.n = len(params)
+        self.params = list(params)
+        assert all(p.dtype == torch.bfloat16 and p.is_contiguous() for p in self.params)
         self.chunks = []
         for c0 in range(0, self.n, ADAMW_MAX_TENSORS):
             idx = list(range(c0, min(self.n, c0 + ADAMW_MAX_TENSORS)))
@@ -805,6 +809,8 @@ def adamw_step(plan: AdamwPlan, grads, master: torch.Tensor, exp_avg: torch.Tens
         for c in plan.chunks:
             for j, i in enumerate(c["idx"]):
                 c["grads"][j] = grads[i].data_ptr()
+                c["params"][j] = plan.params[i].data_ptr()
+                assert grads[i].numel() == c["numel"][j] == plan.params[i].numel()
             check(lib.cd360_adamw_bf16(c["k"], c["grads"], c["params"], c["begin"], c["numel"], c["lr"], c["wd"], _ptr(master), _ptr(exp_avg),
                                        _ptr(exp_avg_sq), _ptr(step), beta1, beta2, eps, _stream()), "cd360_adamw_bf16")
 
