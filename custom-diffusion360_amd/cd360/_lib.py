@@ -74,12 +74,13 @@ SIGNATURES = {
 }
 
 TUNING_FIELDS = ("gemm_cfg", "gemm_group_m", "gemm_movers", "gemm_ksplit", "conv_cfg", "conv_dma", "conv_kgroup", "conv_wide", "conv_wmajor",
-                 "conv_split", "attn_smallk", "attn_smallk_wgs", "attn_self", "attn_fast", "nerf_kernel", "qattn_cfg", "whatif", "gemm_small")
+                 "conv_split", "attn_smallk", "attn_smallk_wgs", "attn_self", "attn_fast", "nerf_kernel", "qattn_cfg", "whatif", "gemm_small", "qattn_keys16",
+                 "qattn_split", "qattn_fp8")
 
 
 class Tuning(ctypes.Structure):
     """struct cd360_tuning of include/cd360_hip.h: -1 = choose by shape (the default of every field)."""
-    _fields_ = [("size", ctypes.c_int32)] + [(f, ctypes.c_int32) for f in TUNING_FIELDS] + [("reserved", ctypes.c_int32 * 5)]
+    _fields_ = [("size", ctypes.c_int32)] + [(f, ctypes.c_int32) for f in TUNING_FIELDS] + [("reserved", ctypes.c_int32 * 2)]
 
 
 # environment variable -> tuning field: read ONCE, when the library is loaded (the C side never reads the environment)
@@ -88,7 +89,8 @@ TUNING_ENV = {
     "CD360_CONV_CFG": "conv_cfg", "CD360_CONV_DMA": "conv_dma", "CD360_CONV_KGROUP": "conv_kgroup", "CD360_CONV_WIDE": "conv_wide",
     "CD360_CONV_WMAJOR": "conv_wmajor", "CD360_CONV_SPLIT": "conv_split", "CD360_ATTN_SMALLK": "attn_smallk", "CD360_SMALLK_WGS": "attn_smallk_wgs",
     "CD360_ATTN_SELF": "attn_self", "CD360_ATTN_FAST": "attn_fast", "CD360_NERF_KERNEL": "nerf_kernel", "CD360_QATTN_CFG": "qattn_cfg",
-    "CD360_GEMM_ABL": "whatif", "CD360_GEMM_SMALL": "gemm_small",
+    "CD360_GEMM_ABL": "whatif", "CD360_GEMM_SMALL": "gemm_small", "CD360_QATTN_KEYS16": "qattn_keys16", "CD360_QATTN_SPLIT": "qattn_split",
+    "CD360_QATTN_FP8": "qattn_fp8",
 }
 
 _lib = None
@@ -118,7 +120,15 @@ def load(check_symbols: bool = True):
             continue
         fn.restype, fn.argtypes = res, args
     _lib = lib
-    env = {field: int(os.environ[name]) for name, field in TUNING_ENV.items() if os.environ.get(name, "") != ""}
+    env = {}
+    for name, field in TUNING_ENV.items():
+        raw = os.environ.get(name, "")
+        if raw != "":
+            try:
+                env[field] = int(raw)
+            except ValueError:
+                raise Cd360Error(f"{name}={raw!r}: tuning variables are integers (include/cd360_hip.h: cd360_tuning.{field}); read once, when "
+                                 "the library loads -- later changes of os.environ have no effect, use cd360._lib.set_tuning()") from None
     if env:
         set_tuning(**env)
     return lib

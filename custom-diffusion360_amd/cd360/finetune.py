@@ -92,10 +92,9 @@ def combine_losses(loss, loss_fg, loss_bg, loss_rgb, drop_im, *, rgb: bool = Tru
                    loss_fg_lambda: float = 10.0, loss_bg_lambda: float = 10.0, loss_rgb_lambda: float = 5.0, as_tensors: bool = False):
     """DiffusionEngine.forward (diffusion.py:226-241).  `drop_im` [b] is 1 where the sample kept its reference images; the
     render losses only count those samples.  Defaults are configs/train_co3d_concept.yaml:9-11.
-    as_tensors=True: the logged terms stay 0-d device tensors and the `loss_rgb.mean() > 0` test of the reference becomes arithmetic
-    (the rgb term is a masked mean of squared errors: > 0, or exactly 0 with every error 0 -- adding lambda * 0 leaves the total unchanged
-    and sends a zero gradient through those errors, as skipping the term does) -- no host synchronisation between the forward and the
-    backward pass, and the step can be captured into a hipGraph."""
+    as_tensors=True: the logged terms stay 0-d device tensors and the `loss_rgb.mean() > 0` test of the reference becomes a device-side
+    select (torch.where: a zero or NaN rgb term contributes nothing to the total, as skipping it does) -- no host synchronisation between
+    the forward and the backward pass, and the step can be captured into a hipGraph."""
     total = loss.mean()
     out = {"loss": total.detach()}
     den = drop_im.sum() + 1e-12
@@ -106,6 +105,8 @@ def combine_losses(loss, loss_fg, loss_bg, loss_rgb, drop_im, *, rgb: bool = Tru
         out["loss_fg"], out["loss_bg"] = fg.detach(), bg.detach()
     if rgb_predict and (as_tensors or loss_rgb.mean() > 0):
         lr = (loss_rgb.mean(1) * drop_im.reshape(-1)).sum() / den
+        if as_tensors:  # the reference's `if loss_rgb.mean() > 0` without a host read: a NaN (or zero) rgb term is skipped, not added
+            lr = torch.where(loss_rgb.mean() > 0, lr, torch.zeros_like(lr))
         total = total + loss_rgb_lambda * lr
         out["loss_rgb"] = lr.detach()
     if not as_tensors:
@@ -211,7 +212,7 @@ class MasterAdamW:
         else:
             groups = [{"params": [p for p in params if p.requires_grad]}]
         self.params = [p for g in groups for p in g["params"]]
-        can_fuse = (bool(self.params) and all(p.is_cuda and p.dtype == torch.bfloat16 for p in self.params)
+        can_fuse = (bool(self.params) and all(p.is_cuda and p.dtype == torch.bfloat16 and p.is_contiguous() for p in self.params)
                     and not kw.get("amsgrad") and not kw.get("maximize") and not (set(kw) - {"betas", "eps", "weight_decay", "capturable", "amsgrad",
                                                                                             "maximize", "foreach"}))
         if fused and not can_fuse:
@@ -242,6 +243,13 @@ class MasterAdamW:
         self.opt = torch.optim.AdamW([{**g, "params": [next(it) for _ in g["params"]]} for g in groups], lr=lr, **kw)
         self.param_groups = self.opt.param_groups
         self.capturable = all(g.get("capturable") for g in self.opt.param_groups)
+
+    def bump_versions(self, active=None) -> None:
+        """The fused kernel (and a hipGraph replay of it) writes the bf16 parameters through raw pointers, which torch's version counter
+        does not see.  Every derived-weight cache of the package (LayerNorm-folded packs, W^T copies, fp32 biases, the FeatureNeRF's fused
+        weights, the pose-projection split) is keyed on `_version`, so the update is made visible here -- no kernel is launched."""
+        for i in (range(len(self.params)) if active is None else active):
+            torch.autograd.graph.increment_version(self.params[i])
 
     allreduce_single = False  # True: run the gradient all-reduce even in a group of one (tests of the collective path on a 1-GPU box)
 
@@ -288,6 +296,7 @@ class MasterAdamW:
                 grads = [self.params[i].grad if self.params[i].grad.is_contiguous() else self.params[i].grad.contiguous() for i in active]
                 self._ops.adamw_step(self._fused_plan(active), grads, self._master, self.exp_avg, self.exp_avg_sq, self.steps, self.betas[0],
                                      self.betas[1], self.eps)
+                self.bump_versions(active)
             return
         for m, p in zip(self.master, self.params):
             m.grad = None if p.grad is None else p.grad.float()
@@ -323,9 +332,15 @@ class GraphedTrainStep:
     a replay costs one launch.  Conditions: fixed shapes (the batch is copied into static buffers), a MasterAdamW on its fused
     path (or built with capturable=True), the raymarchers on device_rng=True (the stratified jitter of patch x / y is then drawn by the device generator, which
     a graph advances on every replay; the reference draws those two on the CPU generator).  Under an initialised process group the
-    gradient all-reduce is part of the graph (RCCL collectives capture; tools/probe/rccl_graph_probe.py).  The returned loss terms are 0-d device tensors that the next replay overwrites."""
+    gradient all-reduce is part of the graph (RCCL collectives capture; tools/probe/rccl_graph_probe.py).  The returned loss terms are 0-d device tensors that the next replay overwrites.
+    Side effects of construction, all deliberate: (1) `warmup` REAL optimisation steps run on the construction batch before the capture
+    (weights, moments and the device step counter advance by `warmup`; pass warmup_restore=True to snapshot and restore parameters,
+    masters, moments and the step counter around them); (2) `device_rng = True` stays set on every raymarcher, so later eager steps draw
+    their patch jitter from the device generator too; (3) lr and weight_decay are frozen into the graph at capture time -- an LR scheduler
+    that edits `optimizer.param_groups` has no effect on replays (re-capture to change them)."""
 
-    def __init__(self, unet: torch.nn.Module, loss_fn, optimizer: "MasterAdamW", batch: dict, warmup: int = 3, **loss_kw):
+    def __init__(self, unet: torch.nn.Module, loss_fn, optimizer: "MasterAdamW", batch: dict, warmup: int = 3, warmup_restore: bool = False,
+                 **loss_kw):
         if not optimizer.capturable:
             raise ValueError("GraphedTrainStep: the torch fall-back of MasterAdamW must be built with capturable=True (the fused path is as it is)")
         self.unet, self.loss_fn, self.optimizer, self.loss_kw = unet, loss_fn, optimizer, loss_kw
@@ -337,8 +352,17 @@ class GraphedTrainStep:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):  # allocator, library workspaces, weight packs, optimiser state: all settled before the capture
+            saved = None
+            if warmup_restore and optimizer.fused:
+                saved = ([p.detach().clone() for p in optimizer.params], optimizer._master.clone(), optimizer.exp_avg.clone(),
+                         optimizer.exp_avg_sq.clone(), optimizer.steps.clone())
             for _ in range(warmup):
                 train_step(unet, loss_fn, optimizer, as_tensors=True, **self.static, **loss_kw)
+            if saved is not None:
+                with torch.no_grad():
+                    for p, q in zip(optimizer.params, saved[0]):
+                        p.copy_(q)
+                    optimizer._master.copy_(saved[1]); optimizer.exp_avg.copy_(saved[2]); optimizer.exp_avg_sq.copy_(saved[3]); optimizer.steps.copy_(saved[4])
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
         # with a process group the gradient all-reduce (one flat RCCL all-reduce, MasterAdamW.allreduce_grads) is captured with the step; the
@@ -361,4 +385,5 @@ class GraphedTrainStep:
         for k, v in batch.items():
             self._load(self.static[k], v)
         self.graph.replay()
+        self.optimizer.bump_versions()  # the replay rewrote the parameters behind torch's back: invalidate every cache keyed on their version
         return self.total, self.logged

@@ -701,6 +701,10 @@ _WT_CACHE = {}   # id(weight) -> (weakref, version, weight^T contiguous): the da
 
 def _cached(cache: dict, t: torch.Tensor, make):
     import weakref
+    # a view (`w[:, :c]` of pose_emb_layers is a fresh tensor object on every call) or a trainable tensor gains nothing from an id-keyed
+    # cache and would leave one dead entry per call behind: compute directly
+    if t.requires_grad or t._base is not None:
+        return make(t)
     ent = cache.get(id(t))
     if ent is not None and ent[0]() is t and ent[1] == t._version:
         return ent[2]

@@ -118,17 +118,23 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   constexpr int NWC = NWT * KS;                    // waves that multiply
   constexpr int NW = NWC + MV;                     // waves
   constexpr int NWD = MV ? MV : NW;                // waves that move data
-  static_assert(MV == 0 || (EPI >= 0 && EPI <= 6), "mover waves: every epilogue (in the attention epilogues they only help stage K / V)");
+  static_assert(MV == 0 || (EPI >= 0 && EPI <= 9), "mover waves: every epilogue (in the attention epilogues they also fetch K / V)");
   constexpr int KPW = 4 / KS;                      // k-steps of a K-tile that one wave multiplies
   constexpr int BM = WM * NMB * 32, BN = WN * NCB * 32;
   constexpr uint32_t XB = BM * 128, WB = BN * 128;  // bytes of one buffer of each operand (64-deep K-tile, 128-byte rows)
-  constexpr uint32_t XREG = 0, WREG = NBUF * XB;   // LDS map: NBUF token buffers, then NBUF channel buffers
+  // epilogue: 0 linear, 1 GEGLU, 2 / 3 / 4 small-Nk attention on the projected tile with 2 / 4 / 6 groups of 16 keys, 7 / 8 / 9 the same
+  // with 5 / 3 / 1 groups (the last 32-key block of scores is half used: 77 text keys are 5 groups, not 6)
+  // EPI 6 = linear epilogue + the per-slab channel statistics of EPI 5 (a Linear whose output feeds a GroupNorm: SpatialTransformer.proj_out)
+  constexpr bool GEGLU = EPI == 1, ATTN = (EPI >= 2 && EPI <= 4) || (EPI >= 7 && EPI <= 9), CONV = EPI == 5, CSTATS = EPI == 5 || EPI == 6;
+  // LDS map: NBUF token buffers, then NBUF channel buffers.  The attention epilogues interleave them instead (buffer b = tokens, then
+  // channels, at b * (XB + WB)) and rotate the ring so that the LAST K-tile sits in buffer 0: everything behind buffer 0 is then free
+  // one tile before the loop ends, and the K / V rows of the tile's heads are fetched into it under the last K-tile's MFMAs.
+  constexpr uint32_t BB = XB + WB;
+  constexpr uint32_t XSTR = ATTN ? BB : XB, WSTR = ATTN ? BB : WB;  // byte distance between consecutive buffers of one operand
+  constexpr uint32_t XREG = 0, WREG = ATTN ? XB : NBUF * XB;
   constexpr int PR = 8 * NWD;                      // rows one DMA piece of all moving waves covers (8 per wave)
   constexpr int XP = BM / PR, WP = BN / PR;        // pieces per wave per K-tile
   constexpr int NP = XP + WP, NMMA = NCB * NMB;
-  // epilogue: 0 linear, 1 GEGLU, 2 / 3 / 4 small-Nk attention on the projected tile with 1 / 2 / 3 blocks of 32 keys
-  // EPI 6 = linear epilogue + the per-slab channel statistics of EPI 5 (a Linear whose output feeds a GroupNorm: SpatialTransformer.proj_out)
-  constexpr bool GEGLU = EPI == 1, ATTN = EPI >= 2 && EPI <= 4, CONV = EPI == 5, CSTATS = EPI == 5 || EPI == 6;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
 
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
@@ -248,6 +254,15 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
       for (int i = 0; i < 16; ++i) acc[nb][mb][i] = 0.f;
 
   const int nk = p.K >> 6;
+  // attention epilogues: K-tile t lives in buffer (t + rot) % NBUF, so that the last one lands in buffer 0
+  const int rot = ATTN ? (NBUF - ((nk - 1) % NBUF)) % NBUF : 0;
+  if constexpr (ATTN) {
+#pragma unroll
+    for (int i = 0; i < KPW; ++i) {
+      xo[i] += rot * XSTR;
+      wo[i] += rot * WSTR;
+    }
+  }
 #ifdef CD360_WHATIF
   const int abl = p.abl;
 #else
@@ -255,6 +270,41 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
 #endif
   // a wave whose channels are all beyond N (last channel tile of N = 640 = 2.5 tiles) moves data and synchronises but does not multiply
   const bool has_ch = n0 + wc * (NCB * 32) < p.N && !(abl & 512) && !mover;  // (what-if bit 512: every wave only moves data)
+
+  // ---- attention epilogues: K and V rows of the tile's WN heads -> LDS by LDS-DMA, no staging registers ----------------------------
+  // Per head KROWS rows of K then KROWS rows of V, 128 bytes each (K with the 16-byte XOR swizzle of its fragment reads, V with the 32-byte
+  // one of the transposing reads, both applied on the per-lane SOURCE address), starting at the second ring buffer.  Rows >= Nk lie past
+  // the end of the buffer descriptor and arrive as zeros.  A piece is 8 rows (1 KiB); the moving waves take pieces round-robin.
+  constexpr int NK16 = EPI == 2 ? 2 : EPI == 3 ? 4 : EPI == 4 ? 6 : EPI == 7 ? 5 : EPI == 8 ? 3 : 1;
+  constexpr int NKB = (NK16 + 1) / 2, KROWS = NK16 * 16, HEAD_LDS = 2 * KROWS * 128;
+  constexpr bool HALF = (NK16 & 1) != 0;  // the last 32-key block of scores is used in its first 16 keys only
+  constexpr uint32_t KVBASE = BB;
+  static_assert(!ATTN || (NWC * 4096 <= (int)BB), "attention epilogue: the waves' output blocks alias ring buffer 0");
+  const int a_bidx = ATTN ? (int)(m0 / p.a_nq) : 0;  // batch element of this token tile
+  auto kv_issue = [&](int kvb) {
+    if constexpr (ATTN) {
+      const int kbytes = (int)((((long)p.a_nk - 1) * p.ak_sn + p.N) * 2), vbytes = (int)((((long)p.a_nk - 1) * p.av_sn + p.N) * 2);
+      const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ak + (long)kvb * p.ak_sb), 0, kbytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.av + (long)kvb * p.av_sb), 0, vbytes, 0x00020000);
+      constexpr int PPH = 2 * KROWS / 8, NPKV = WN * PPH;  // pieces per head (K, then V), pieces in all
+      const int lrow8 = lane >> 3, lch = lane & 7;
+#pragma unroll
+      for (int i = 0; i < (NPKV + NWD - 1) / NWD; ++i) {
+        const int q = i * NWD + dwave;  // wave-uniform
+        if (q < NPKV) {
+          const int hl = q / PPH, rem = q - hl * PPH;
+          const bool isv = rem >= KROWS / 8;
+          const int key = (isv ? rem - KROWS / 8 : rem) * 8 + lrow8;
+          const int sch = isv ? (lch ^ (((key >> 1) & 3) << 1)) : (lch ^ ((key >> 1) & 7));
+          const int col = n0 + hl * 64;
+          uint32_t off = (uint32_t)key * (uint32_t)(isv ? p.av_sn : p.ak_sn) * 2u + (uint32_t)(col * 2 + sch * 16);
+          if (col >= p.N) off = 0x80000000u;
+          if (isv) __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, LDS_AS3(lds + KVBASE + q * 1024), 16, off, 0, 0, 0);
+          else __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, LDS_AS3(lds + KVBASE + q * 1024), 16, off, 0, 0, 0);
+        }
+      }
+    }
+  };
 
   // ---- prologue: tiles 0 .. NBUF-1 in flight (one per buffer), tile 0 landed ----
   // counted wait: everything but the `later` most recently issued tiles has landed (s_waitcnt takes an immediate)
@@ -272,8 +322,11 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
       if (b < nk) {
         if constexpr (CONV) conv_next();
 #pragma unroll
-        for (int i = 0; i < NP; ++i) piece(b, i, b * XB, b * WB);
+        for (int i = 0; i < NP; ++i) piece(b, i, ((b + rot) % NBUF) * XSTR, ((b + rot) % NBUF) * WSTR);
       }
+    if constexpr (ATTN) {
+      if (nk == 1) kv_issue(a_bidx);  // (a one-tile loop never reaches the issue point below; buffers 1 .. are idle from the start)
+    }
     wait_tiles_in_flight((nk < NBUF ? nk : NBUF) - 1);
   }
   BARRIER();
@@ -301,9 +354,9 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
       for (int q = 0; q < NP; ++q)
         if ((q * NSLOT / NP) / NMMA == j && (q * NSLOT / NP) % NMMA == i) piece(tile, q, obx, obw);
     };
-    uint32_t bx = 0, bw = 0;    // buffers of tile t
+    uint32_t bx = rot * XSTR, bw = rot * WSTR;  // buffers of tile t
     uint32_t pbx = 0, pbw = 0;  // buffers of tile t-1 (being refilled with tile t-1+NBUF while tile t is multiplied)
-    int bnext = 1;              // index of the buffer of tile t+1
+    int bnext = (rot + 1) % NBUF;  // index of the buffer of tile t+1
     for (int t = 0; t < nk; ++t) {
       // fences pin the order "reads of k-step ks+1, then the MFMAs of ks": the compiler otherwise sinks the reads to the end of the
       // MFMA run (exposing the LDS latency) or hoists later k-steps' reads (spilling)
@@ -347,7 +400,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
 #ifdef CD360_GEMM_STAMP
         stD = __builtin_amdgcn_s_memtime();
 #endif
-        const uint32_t ax = bnext == 0 ? 0u - (NBUF - 1) * XB : XB, aw = bnext == 0 ? 0u - (NBUF - 1) * WB : WB;
+        const uint32_t ax = bnext == 0 ? 0u - (NBUF - 1) * XSTR : XSTR, aw = bnext == 0 ? 0u - (NBUF - 1) * WSTR : WSTR;
 #pragma unroll
         for (int ks = 0; ks < KPW; ++ks) {
           xo[ks] += ax;
@@ -376,6 +429,11 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
           }
         }
       }
+      if constexpr (ATTN && MOVE) {
+        // the barrier of this iteration released every buffer but the last tile's (buffer 0): K / V of the tile's heads travel under
+        // the last K-tile's MFMAs (no operand piece is issued any more, the address path is idle)
+        if (t == nk - 2) kv_issue(a_bidx);
+      }
       FENCE();
 #ifdef CD360_GEMM_STAMP
       if (p.stamp && t < 64 && wave < NWC) {  // stamps parked in the LDS behind the ring (a global store would count in vmcnt); lane 0 of each wave
@@ -388,8 +446,8 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
 #endif
       pbx = bx;
       pbw = bw;
-      bx = bnext * XB;
-      bw = bnext * WB;
+      bx = bnext * XSTR;
+      bw = bnext * WSTR;
       bnext = bnext + 1 == NBUF ? 0 : bnext + 1;
     }
   };
@@ -545,29 +603,32 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
 
   };
 
-  // ---- EPI 2: softmax(q k^T * scale) v per head on the projected tile (sgm/modules/attention.py:368-372,406-408 for a 77-token
-  // context: the text cross-attention attn2 of every block and the pose-token attention :578-588) -------------------------------------
-  // A wave's 128 x 64 accumulator IS the query block of one head (WN = 4 waves = 4 heads per 256-column tile).  The LayerNorm fold and
-  // the bias are applied in registers and the rows are packed to bf16 MFMA B fragments without moving: the contraction over the 64
-  // channels runs in the order the accumulator holds them (k-step j <-> channels 32 (j >> 1) + 16 hh + 8 (j & 1) + 0..7), which the K
-  // fragments follow by reading chunk 4 (j >> 1) + 2 hh + (j & 1) of their rows.  S^T for all keys at once (keys >= Nk masked through
-  // the accumulator's initial value), one max / exp2 / sum per token, P from the accumulator registers straight into the P V MFMAs with
-  // V^T taken from the row-major V rows by ds_read_b64_tr_b16 (attn_fwd.hip's small-Nk kernel, minus its Q round trip through HBM).
-  constexpr int NKB = ATTN ? EPI - 1 : 1, NKEYS = NKB * 32, HEAD_LDS = 2 * NKEYS * 128;  // per head: K rows then V rows, 128 B each
+  // ---- attention epilogues: softmax(q k^T * scale) v per head on the projected tile (sgm/modules/attention.py:368-372,406-408 for a
+  // 77-token context: the text cross-attention attn2 of every block and the pose-token attention :578-588) -----------------------------
+  // A wave's NMB x 32 tokens x 64 channels accumulator IS the query block of one head (WN waves = WN heads per tile).  The LayerNorm
+  // fold and the bias are applied in registers (two FMAs per value) and the rows are packed to bf16 MFMA B fragments without moving: the
+  // contraction over the 64 channels runs in the order the accumulator holds them (k-step j <-> channels 32 (j >> 1) + 16 hh + 8 (j & 1)
+  // + 0..7), which the K fragments follow by reading chunk 4 (j >> 1) + 2 hh + (j & 1) of their rows.  S^T for all keys at once (keys
+  // >= Nk masked through the accumulator's initial value; of a half-used last block only registers 0..7 = its first 16 keys are looked
+  // at), one max / exp2 / sum per token, P from the accumulator registers straight into the P V MFMAs (one per 16 keys and 32 channels)
+  // with V^T taken from the row-major V rows by ds_read_b64_tr_b16 (attn_fwd.hip's small-Nk kernel, minus its Q round trip through HBM).
+  // K / V are already in the LDS when the loop ends (kv_issue); the second key / value set of a de-duplicated tile is fetched between
+  // the two passes.
   auto attn_tile = [&]() {
     if constexpr (ATTN) {
       static_assert(!ATTN || NCB == 2, "one head (64 channels) per wave; any number of 32-token blocks and of heads per tile");
-      unsigned char* const Ks = lds + wc * HEAD_LDS;
-      unsigned char* const Vs = Ks + NKEYS * 128;
-      unsigned char* const Os = lds + WN * HEAD_LDS + wave * (32 * 128);  // this wave's 32-token output block
-      // LayerNorm fold + bias, pack to B fragments (has_ch waves only; the others hold zeros and are skipped below)
+      unsigned char* const Ks = lds + KVBASE + wc * HEAD_LDS;
+      unsigned char* const Vs = Ks + KROWS * 128;
+      unsigned char* const Os = lds + wave * (32 * 128);  // this wave's 32-token output block (ring buffer 0 is idle now)
+      // LayerNorm fold + bias, pack to B fragments (has_ch waves only; the others hold zeros and are skipped below):
+      // q = rstd (acc - mu wsum) + bias = acc * rstd + (bias - rstd mu wsum)
       bf16x8 qf[NMB][4];
       if (has_ch) {
-        float mu[NMB], rs[NMB];
+        float c1[NMB], c2[NMB];
 #pragma unroll
         for (int mb = 0; mb < NMB; ++mb) {
-          mu[mb] = 0.f;
-          rs[mb] = 1.f;
+          c1[mb] = 1.f;
+          c2[mb] = 0.f;
         }
         if (p.ln_stats) {
           const float inv = 1.f / (float)p.ln_dim;
@@ -575,17 +636,16 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
           for (int mb = 0; mb < NMB; ++mb) {
             const long m = m0 + mrow0 + mb * 32;
             float s = 0.f, ss = 0.f;
-            if (m < p.M) {
-              const f32x2* st = reinterpret_cast<const f32x2*>(p.ln_stats) + m * p.ln_parts;
-              for (int q = 0; q < p.ln_parts; ++q) {
-                const f32x2 v = st[q];
-                s += v[0];
-                ss += v[1];
-              }
+            const f32x2* st = reinterpret_cast<const f32x2*>(p.ln_stats) + m * p.ln_parts;
+            for (int q = 0; q < p.ln_parts; ++q) {
+              const f32x2 v = st[q];
+              s += v[0];
+              ss += v[1];
             }
             const float mean = s * inv;
-            mu[mb] = mean;
-            rs[mb] = rsqrtf(fmaxf(ss * inv - mean * mean, 0.f) + p.ln_eps);
+            const float rstd = rsqrtf(fmaxf(ss * inv - mean * mean, 0.f) + p.ln_eps);
+            c1[mb] = rstd;
+            c2[mb] = -rstd * mean;
           }
         }
 #pragma unroll
@@ -593,55 +653,41 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
           FENCE();
           const int nb = j >> 1, c8 = j & 1;
           const int n = n0 + wc * 64 + nb * 32 + 16 * hh + 8 * c8;
-          float bv[8], sv[8];
-#pragma unroll
-          for (int r = 0; r < 8; ++r) {
-            bv[r] = p.bias ? p.bias[n + r] : 0.f;
-            sv[r] = p.ln_stats ? p.wsum[n + r] : 0.f;
-          }
+          const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+          const f32x4 b0 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : z4, b1 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n + 4) : z4;
+          const f32x4 s0 = p.ln_stats ? *reinterpret_cast<const f32x4*>(p.wsum + n) : z4, s1 = p.ln_stats ? *reinterpret_cast<const f32x4*>(p.wsum + n + 4) : z4;
+          const float bv[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+          const float sv[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
 #pragma unroll
           for (int mb = 0; mb < NMB; ++mb) {
             u32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              float t0 = acc[nb][mb][8 * c8 + 2 * e], t1 = acc[nb][mb][8 * c8 + 2 * e + 1];
-              if (p.ln_stats) {
-                t0 = rs[mb] * (t0 - mu[mb] * sv[2 * e]);
-                t1 = rs[mb] * (t1 - mu[mb] * sv[2 * e + 1]);
-              }
-              o[e] = pack_bf16x2(t0 + bv[2 * e], t1 + bv[2 * e + 1]);
+              const float t0 = fmaf(acc[nb][mb][8 * c8 + 2 * e], c1[mb], fmaf(c2[mb], sv[2 * e], bv[2 * e]));
+              const float t1 = fmaf(acc[nb][mb][8 * c8 + 2 * e + 1], c1[mb], fmaf(c2[mb], sv[2 * e + 1], bv[2 * e + 1]));
+              o[e] = pack_bf16x2(t0, t1);
             }
             qf[mb][j] = __builtin_bit_cast(bf16x8, o);
           }
         }
       }
-      const int bidx = (int)(m0 / p.a_nq);
-      const int nrep = (p.a_dup > 0 && bidx >= p.a_dup_from) ? 2 : 1;
+      const int nrep = (p.a_dup > 0 && a_bidx >= p.a_dup_from) ? 2 : 1;
       for (int rep = 0; rep < nrep; ++rep) {
-      if (rep) __syncthreads();  // the first pass has consumed its K / V
-      const int kvb = bidx + rep * p.a_dup;
       const long orow = (long)rep * p.a_dup * p.a_nq;
-      // K and V rows of the tile's four heads -> LDS (rows >= Nk zero), all waves
-      for (int i = tid; i < WN * NKEYS * 8; i += 64 * NW) {
-        const int hl = i / (NKEYS * 8), rem = i - hl * (NKEYS * 8), row = rem >> 3, chunk = rem & 7;
-        const int col = n0 + hl * 64 + chunk * 8;
-        u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-        if (row < p.a_nk && col < p.N) {
-          kv = *reinterpret_cast<const u32x4*>(p.ak + kvb * p.ak_sb + (long)row * p.ak_sn + col);
-          vv = *reinterpret_cast<const u32x4*>(p.av + kvb * p.av_sb + (long)row * p.av_sn + col);
-        }
-        unsigned char* hb = lds + hl * HEAD_LDS;
-        *reinterpret_cast<u32x4*>(hb + row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4)) = kv;
-        *reinterpret_cast<u32x4*>(hb + NKEYS * 128 + row * 128 + ((chunk ^ (((row >> 1) & 3) << 1)) << 4)) = vv;
+      if (rep) {  // the first pass has consumed its K / V: fetch the second set into the same rows
+        __syncthreads();
+        if (!MV || mover) kv_issue(a_bidx + p.a_dup);
+        WAIT_VM0();
+        __syncthreads();
       }
-      __syncthreads();
       if (!has_ch) continue;
       f32x16 init_last;  // accumulator start of the last key block: 0 for real keys, -1e30 for padding
 #pragma unroll
       for (int r = 0; r < 16; ++r) init_last[r] = ((NKB - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh < p.a_nk) ? 0.f : -1e30f;
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const float c = p.a_scale_log2e;
-      // per-lane offsets: K fragment of k-step j = chunk 4 (j >> 1) + 2 hh + (j & 1) of row kb * 32 + l31 (16-B XOR swizzle);
+      // per-lane offsets: K fragment of k-step j = chunk 4 (j >> 1) + 2 hh + (j & 1) of row kb * 32 + l31 (16-B XOR swizzle; the rows
+      // 16 .. 31 of a half-used last block are the head's first V rows: finite values whose scores nobody reads);
       // V^T fragments as attn_fwd.hip's v_frag_offset / v_frag (32-B swizzle, transposing reads)
       int koff[4], voff[2];
 #pragma unroll
@@ -671,15 +717,15 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-          for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sT[kb][r]);
+          for (int r = 0; r < ((HALF && kb == NKB - 1) ? 8 : 16); ++r) mx = fmaxf(mx, sT[kb][r]);
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float mc = -mx * c;
         float rsum_p = 0.f;
-        uint32_t pk[NKB * 8];
+        uint32_t pk[NK16 * 4];
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-          for (int r = 0; r < 16; r += 2) {
+          for (int r = 0; r < ((HALF && kb == NKB - 1) ? 8 : 16); r += 2) {
             const float p0 = __builtin_amdgcn_exp2f(fmaf(sT[kb][r], c, mc)), p1 = __builtin_amdgcn_exp2f(fmaf(sT[kb][r + 1], c, mc));
             rsum_p += p0 + p1;
             pk[kb * 8 + (r >> 1)] = pack_bf16x2(p0, p1);
@@ -687,7 +733,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
         rsum_p += __shfl_xor(rsum_p, 32);
         f32x16 oT[2];
 #pragma unroll
-        for (int kk = 0; kk < 2 * NKB; ++kk) {
+        for (int kk = 0; kk < NK16; ++kk) {
           const u32x4 pw = {pk[kk * 4 + 0], pk[kk * 4 + 1], pk[kk * 4 + 2], pk[kk * 4 + 3]};
 #pragma unroll
           for (int db = 0; db < 2; ++db) {
@@ -698,7 +744,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
           }
         }
         // O^T registers (lane = token, 4 consecutive channels per group) -> this wave's LDS block -> full 128-byte rows
-        const float inv = 1.f / rsum_p;
+        const float inv = __builtin_amdgcn_rcpf(rsum_p);
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -707,12 +753,13 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
             const u32x2 wv = {pack_bf16x2(oT[db][4 * g + 0] * inv, oT[db][4 * g + 1] * inv), pack_bf16x2(oT[db][4 * g + 2] * inv, oT[db][4 * g + 3] * inv)};
             *reinterpret_cast<u32x2*>(Os + l31 * 128 + (((dbyte >> 4) ^ ((l31 >> 1) & 7)) << 4) + (dbyte & 8)) = wv;
           }
+        // (token tiles never straddle the end of the matrix: M = B Nq with Nq a multiple of the tile height)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int row = 8 * i + lrow;
           const long m = m0 + wr * (NMB * 32) + mb * 32 + row;
           const u32x4 v = *reinterpret_cast<const u32x4*>(Os + row * 128 + ((lchunk ^ ((row >> 1) & 7)) << 4));
-          if (m < p.M) *reinterpret_cast<u32x4*>(p.out + (m + orow) * p.ldo + ocol) = v;
+          *reinterpret_cast<u32x4*>(p.out + (m + orow) * p.ldo + ocol) = v;
         }
       }
       }  // rep
@@ -726,6 +773,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
     if (has_ch) k_loop(std::true_type{}, std::true_type{});
     else k_loop(std::false_type{}, std::true_type{});
   }
+  if constexpr (ATTN) WAIT_VM0();  // this wave's K / V pieces have landed (visible to the others behind the barrier)
   __syncthreads();  // every wave is past its last fragment read: the K-loop buffers become the output staging area
 #ifdef CD360_GEMM_STAMP
   if (p.stamp) {
@@ -886,9 +934,12 @@ int launch_mv(const GemmParams& p0, hipStream_t stream) {
   GemmParams p = p0;
   constexpr int BM = WM * NMB * 32, BN = WN * NCB * 32;
   // K-loop buffers, reused as the output staging image (+ the fp32 partial tile of the second k-step group)
-  // (the attention epilogues stage K / V rows of the tile's WN heads, 2 x NKB x 32 rows of 128 bytes each, plus a 4-KB output block per wave)
-  constexpr int ATTN_BYTES = (EPI >= 2 && EPI <= 4) ? WN * 2 * (EPI - 1) * 32 * 128 + (WM * WN * KS + MV) * 4096 : 0;
-  constexpr int RING_BYTES = NBUF * (BM + BN) * 128, STAGE_BYTES0 = BM * BN * 2 + (KS == 2 ? BM * BN * 4 : 0);
+  // (the attention epilogues keep the K / V rows of the tile's WN heads, 2 x NK16 x 16 rows of 128 bytes each, behind ring buffer 0; the
+  // waves' 4-KB output blocks alias buffer 0 and the projected tile never leaves the registers)
+  constexpr bool ATTN = (EPI >= 2 && EPI <= 4) || (EPI >= 7 && EPI <= 9);
+  constexpr int NK16 = EPI == 2 ? 2 : EPI == 3 ? 4 : EPI == 4 ? 6 : EPI == 7 ? 5 : EPI == 8 ? 3 : 1;
+  constexpr int ATTN_BYTES = ATTN ? (BM + BN) * 128 + WN * 2 * NK16 * 16 * 128 : 0;
+  constexpr int RING_BYTES = NBUF * (BM + BN) * 128, STAGE_BYTES0 = ATTN ? 0 : BM * BN * 2 + (KS == 2 ? BM * BN * 4 : 0);
   constexpr int STAGE_BYTES = STAGE_BYTES0 > ATTN_BYTES ? STAGE_BYTES0 : ATTN_BYTES;
 #ifdef CD360_GEMM_STAMP
   constexpr int BASE_BYTES = RING_BYTES > STAGE_BYTES ? RING_BYTES : STAGE_BYTES;
@@ -1091,6 +1142,35 @@ extern "C" int cd360_gemm_cstats_bf16(const void* a, const void* w, void* out, i
   return cfg == 2 ? launch_epi<2, 4, 1, 2, 2, 6>(p, (hipStream_t)stream) : launch_128x4<6>(p, (hipStream_t)stream);
 }
 
+namespace {
+// tile dispatch of the fused query projection + attention (qcfg as cd360_tuning.qattn_cfg); the key count picks the epilogue: 2 / 4 / 6
+// groups of 16 keys (EPI 2 / 3 / 4), or five (EPI 7: 65 .. 80 keys -- SDXL's 77 text tokens) unless cd360_tuning.qattn_keys16 = 0
+int qattn_launch(const GemmParams& p, int qcfg, int Nk, bool keys16, hipStream_t stream) {
+  if (qcfg == 3) {  // 128 x 128, four waves of 64 x 64, two buffers: two workgroups per CU (one's attention epilogue under the other's K loop)
+    if (Nk <= 32) return launch_epi<2, 2, 2, 2, 2, 2>(p, stream);
+    if (Nk <= 64) return launch_epi<2, 2, 2, 2, 2, 3>(p, stream);
+    if (Nk <= 80 && keys16) return launch_epi<2, 2, 2, 2, 2, 7>(p, stream);
+    return launch_epi<2, 2, 2, 2, 2, 4>(p, stream);
+  }
+  if (qcfg == 4) {  // 256 x 128, eight waves of 64 x 64, two buffers (96 KB: one workgroup per CU, half the K-loop operand bytes per flop of 128 x 128)
+    if (Nk <= 32) return launch_epi<4, 2, 2, 2, 2, 2>(p, stream);
+    if (Nk <= 64) return launch_epi<4, 2, 2, 2, 2, 3>(p, stream);
+    if (Nk <= 80 && keys16) return launch_epi<4, 2, 2, 2, 2, 7>(p, stream);
+    return launch_epi<4, 2, 2, 2, 2, 4>(p, stream);
+  }
+  if (qcfg == 2) {
+    if (Nk <= 32) return launch_epi<4, 2, 2, 1, 4, 2>(p, stream);
+    if (Nk <= 64) return launch_epi<4, 2, 2, 1, 4, 3>(p, stream);
+    if (Nk <= 80 && keys16) return launch_epi<4, 2, 2, 1, 4, 7>(p, stream);
+    return launch_epi<4, 2, 2, 1, 4, 4>(p, stream);
+  }
+  if (Nk <= 32) return launch_epi<2, 4, 2, 4, 2, 2>(p, stream);
+  if (Nk <= 64) return launch_epi<2, 4, 2, 4, 2, 3>(p, stream);
+  if (Nk <= 80 && keys16) return launch_epi<2, 4, 2, 4, 2, 7>(p, stream);
+  return launch_epi<2, 4, 2, 4, 2, 4>(p, stream);
+}
+}  // namespace
+
 // out[M, N] = softmax_keys((A W^T [LayerNorm-folded] + bias) K_h^T * scale) V_h per head h (N = heads * 64): the query projection of a
 // cross-attention over Nk <= 96 keys fused with the attention itself -- Q never exists in memory.  A, W, bias, ln_stats, wsum as in
 // cd360_gemm_bf16; k, v bf16 [B, >= Nk, N] (element strides k_sb / k_sn, v_sb / v_sn: batch, key; head h at columns 64 h .. 64 h + 63),
@@ -1114,7 +1194,8 @@ extern "C" int cd360_qproj_attn_dedup_bf16(const void* a, const void* w, void* o
   int qcfg = cd360_tune().qattn_cfg;
   if (qcfg < 1 || qcfg > 4) qcfg = (M / 256) * ((N + 255) / 256) >= 200 ? 1 : ((M / 256) * ((N + 127) / 128) >= 200 ? 4 : 2);
   if (Nq % 256 && (qcfg == 1 || qcfg == 4)) qcfg = 2;
-  if (k_sb % 8 || k_sn % 8 || v_sb % 8 || v_sn % 8) return CD360_ERR_SHAPE;
+  if (k_sb % 8 || k_sn % 8 || v_sb % 8 || v_sn % 8 || k_sn < N || v_sn < N) return CD360_ERR_SHAPE;
+  if ((96 * k_sn + N) * 2 >= (1L << 31) || (96 * v_sn + N) * 2 >= (1L << 31)) return CD360_ERR_SHAPE;  // 32-bit offsets inside one batch element's K / V
   if (((uintptr_t)a | (uintptr_t)w | (uintptr_t)out | (uintptr_t)k | (uintptr_t)v) % 16) return CD360_ERR_ARG;
   if (((uintptr_t)bias | (uintptr_t)ln_stats | (uintptr_t)wsum) % 8) return CD360_ERR_ARG;
   if (M > 0x7fffffffL || (M + 256) * lda * 2 >= (1L << 32) || ((long)N + 256) * ldw * 2 >= (1L << 32)) return CD360_ERR_SHAPE;
@@ -1129,24 +1210,25 @@ extern "C" int cd360_qproj_attn_dedup_bf16(const void* a, const void* w, void* o
   p.a_nq = Nq; p.a_nk = Nk; p.a_scale_log2e = scale * 1.4426950408889634f;
   p.a_dup = dup; p.a_dup_from = (int)(M / Nq) - dup;
   p.cv_H = p.cv_W = p.cv_kg = p.cv_up = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = nullptr;
-  if (qcfg == 3) {  // 128 x 128, four waves of 64 x 64, two buffers: two workgroups per CU (one's attention epilogue under the other's K loop)
-    if (Nk <= 32) return launch_epi<2, 2, 2, 2, 2, 2>(p, (hipStream_t)stream);
-    if (Nk <= 64) return launch_epi<2, 2, 2, 2, 2, 3>(p, (hipStream_t)stream);
-    return launch_epi<2, 2, 2, 2, 2, 4>(p, (hipStream_t)stream);
+  const bool keys16 = cd360_tune().qattn_keys16 != 0;
+  // A width that is 128 short of a multiple of 256 (SDXL's 640 = 2.5 tiles) leaves half of the last 256-column tile's waves without
+  // channels while the workgroup still holds its CU.  Sending the last 128 columns (two heads) to the 256 x 128 tile in a second launch
+  // was measured and LOSES (pose tokens of the 640 level, b = 3: 428 us in one launch, 450-464 split; de-duplicated 350 / 356): two
+  // launches have two ragged last rounds and the narrow tile is slower per column.  cd360_tuning.qattn_split = 1 keeps the A/B.
+  if (qcfg == 1 && N > 256 && N % 256 == 128 && cd360_tune().qattn_split > 0) {
+    GemmParams p1 = p;
+    p1.N = N - 128;
+    const int r1 = qattn_launch(p1, 1, Nk, keys16, (hipStream_t)stream);
+    if (r1 != CD360_OK) return r1;
+    GemmParams p2 = p;
+    const long c0 = N - 128;
+    p2.N = 128;
+    p2.w += c0 * ldw; p2.out += c0; p2.ak += c0; p2.av += c0;
+    if (p2.bias) p2.bias += c0;
+    if (p2.wsum) p2.wsum += c0;
+    return qattn_launch(p2, 4, Nk, keys16, (hipStream_t)stream);
   }
-  if (qcfg == 4) {  // 256 x 128, eight waves of 64 x 64, two buffers (96 KB: one workgroup per CU, half the K-loop operand bytes per flop of 128 x 128)
-    if (Nk <= 32) return launch_epi<4, 2, 2, 2, 2, 2>(p, (hipStream_t)stream);
-    if (Nk <= 64) return launch_epi<4, 2, 2, 2, 2, 3>(p, (hipStream_t)stream);
-    return launch_epi<4, 2, 2, 2, 2, 4>(p, (hipStream_t)stream);
-  }
-  if (qcfg == 2) {
-    if (Nk <= 32) return launch_epi<4, 2, 2, 1, 4, 2>(p, (hipStream_t)stream);
-    if (Nk <= 64) return launch_epi<4, 2, 2, 1, 4, 3>(p, (hipStream_t)stream);
-    return launch_epi<4, 2, 2, 1, 4, 4>(p, (hipStream_t)stream);
-  }
-  if (Nk <= 32) return launch_epi<2, 4, 2, 4, 2, 2>(p, (hipStream_t)stream);
-  if (Nk <= 64) return launch_epi<2, 4, 2, 4, 2, 3>(p, (hipStream_t)stream);
-  return launch_epi<2, 4, 2, 4, 2, 4>(p, (hipStream_t)stream);
+  return qattn_launch(p, qcfg, Nk, keys16, (hipStream_t)stream);
 }
 
 extern "C" int cd360_qproj_attn_bf16(const void* a, const void* w, void* out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldo,

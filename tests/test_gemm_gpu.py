@@ -67,6 +67,37 @@ def test_qproj_attention_dedup_equals_the_expanded_batch(b, dup, nq, C, nk):
     assert got.shape == (b + dup, nq, C) and torch.equal(got, want)
 
 
+@pytest.mark.parametrize("C,nq", [(640, 98304), (1280, 24576)])
+def test_qproj_attention_dedup_at_the_headline_size_matches_fp32_on_row_slices(C, nq):
+    """cd360_qproj_attn_dedup_bf16 at the pose-token count of BASELINE configs[1] (1024^2 image: 4096 x 24 = 98 304 tokens per CFG branch at
+    the 640 level, 1024 x 24 at the 1280 level; b = 2 + 1 de-duplicated, 77 text keys, LayerNorm fold): 4096-row slices from the start,
+    the middle and the end of every output batch element against fp32 torch (attention.py:578-588 = LayerNorm -> to_q -> softmax(q k^T / 8) v)."""
+    import torch.nn.functional as F
+    from bench_gemm import rnd
+    from cd360 import ops
+    b, dup, nk, heads, K = 2, 1, 77, C // 64, C
+    a = (rnd(b, nq, K, seed=41) * (0.5 + rnd(b, nq, 1, seed=42).abs()) + 0.5 * rnd(b, nq, 1, seed=43)).to(torch.bfloat16)
+    gamma, beta = 1 + 0.2 * rnd(K, seed=5), 0.1 * rnd(K, seed=6)
+    w = rnd(C, K, seed=44, scale=K ** -0.5)
+    wp, wsum, cb = ops.pack_ln_linear(w, None, gamma, beta)
+    kv = rnd(b + dup, 80, 2 * C, seed=45).to(torch.bfloat16)
+    k, v = kv[..., :C], kv[..., C:]
+    got = ops.qproj_attention(a, wp, k, v, nk, heads, bias=cb, ln=(ops.row_stats(a), wsum, 1e-5), dup=dup)
+    assert got.shape == (b + dup, nq, C) and bool(torch.isfinite(got).all())
+    worst = 0.0
+    for ob in range(b + dup):
+        qb = ob if ob < b else ob - dup  # query element of output batch ob
+        for r0 in (0, nq // 2 - 2048, nq - 4096):
+            x = a[qb, r0:r0 + 4096].float()
+            q = F.linear(F.layer_norm(x, (K,), gamma, beta, 1e-5), w).reshape(4096, heads, 64).transpose(0, 1)
+            kh = k[ob, :nk].float().reshape(nk, heads, 64).transpose(0, 1)
+            vh = v[ob, :nk].float().reshape(nk, heads, 64).transpose(0, 1)
+            want = (torch.softmax(q @ kh.transpose(-1, -2) / 8.0, -1) @ vh).transpose(0, 1).reshape(4096, C)
+            worst = max(worst, ((got[ob, r0:r0 + 4096].float() - want).abs().max() / want.abs().max()).item())
+    print(f"qproj_attn_dedup C={C} nq={nq}: worst slice error {worst:.2e}")
+    assert worst < 1e-2
+
+
 @pytest.mark.parametrize("M,N,K", [(3072, 1280, 1280), (12288, 640, 640), (192, 64, 128), (1024, 1280, 1280), (1024, 1280, 5120)])
 def test_gemm_with_groupnorm_channel_statistics(M, N, K):
     """cd360_gemm_cstats_bf16 (SpatialTransformer.proj_out + residual feeding a GroupNorm): same output as cd360_gemm_bf16, per-slab

@@ -121,20 +121,7 @@ def _check_qattn(b, nq, C, K, nk, ln, qcfg):
 
 
 def check():
-    ok = True
-    ok &= check_qattn(2, 256, 128, 128, 77)
-    ok &= check_qattn(1, 512, 64, 64, 77, ln=False)
-    ok &= check_qattn(3, 1024, 640, 640, 77)
-    ok &= check_qattn(2, 256, 1280, 1280, 50)
-    ok &= check_qattn(1, 768, 256, 320, 96)
-    ok &= check_qattn(2, 256, 128, 192, 20)
-    for qcfg in (1, 2, 3, 4):  # every tile on the same shapes; 128-token multiples only on the 128-row tiles
-        ok &= check_qattn(3, 1024, 1280, 1280, 77, qcfg=qcfg)
-        ok &= check_qattn(2, 512, 640, 640, 77, qcfg=qcfg)
-        ok &= check_qattn(1, 256, 192, 128, 33, qcfg=qcfg)
-    for qcfg in (2, 3):
-        ok &= check_qattn(2, 384, 320, 320, 77, qcfg=qcfg)
-        ok &= check_qattn(3, 128, 128, 64, 20, ln=False, qcfg=qcfg)
+    ok = check_qattn_all()
     for cfg in (1, 2, 3, 4, 5, 6, 7, 8):
         for (M, N, K) in [(256, 256, 64), (256, 256, 128), (512, 512, 192), (300, 272, 320), (128, 128, 64), (1000, 640, 640), (3072, 1280, 1280)]:
             ok &= check_case(M, N, K, cfg=cfg)
@@ -210,30 +197,71 @@ VARIANTS = [(0, 0)]  # 0 = the tiling pick_cfg chooses (the product path); CD360
 
 
 def time_qattn():
-    """The pose-token attention (A3) and the text cross-attention (A2) at cfg-B: fused kernel (both tiles) against q GEMM + small-Nk
-    attention; hipGraph-timed."""
-    for name, b, nq, C in (("A3 L1", 3, 98304, 640), ("A3 L2", 3, 24576, 1280), ("A2 L1", 3, 4096, 640), ("A2 L2", 3, 1024, 1280)):
+    """The pose-token attention (A3; plain b = 3 and the de-duplicated CFG form the render step runs) and the text cross-attention (A2) at
+    cfg-B: fused kernel (auto tile, every forced tile, and the A/B partners of the round-4 epilogue: keys padded to 96, no column split)
+    against q GEMM + small-Nk attention; hipGraph-timed.  Run it under CD360_LIB=<another build> for a same-box A/B of two libraries."""
+    from cd360 import _lib
+    print("library:", _lib.LIB_PATH, flush=True)
+    for name, b, nq, C, dup in (("A3 L1", 3, 98304, 640, 0), ("A3 L2", 3, 24576, 1280, 0), ("A3 L1 dedup", 2, 98304, 640, 1), ("A3 L2 dedup", 2, 24576, 1280, 1),
+                                ("A2 L1", 3, 4096, 640, 0), ("A2 L2", 3, 1024, 1280, 0)):
         heads = C // 64
         a = rnd(b, nq, C, seed=1).to(torch.bfloat16)
         w = rnd(C, C, seed=2, scale=C ** -0.5).to(torch.bfloat16)
         ws = w.float().sum(1).contiguous()
         cb = rnd(C, seed=3)
-        kv = rnd(b, 80, 2 * C, seed=4).to(torch.bfloat16)
+        kv = rnd(b + dup, 80, 2 * C, seed=4).to(torch.bfloat16)
         k, v = kv[..., :C], kv[..., C:]
         st = ops.row_stats(a)
         n = 10 if nq > 50000 else 30
-        t_f = {}
+        run = lambda: ops.qproj_attention(a, w, k, v, 77, heads, bias=cb, ln=(st, ws, 1e-5), dup=dup)
+        flops = (b * nq * 2.0 * C * C + (b + dup) * nq * 4.0 * 77 * C)
+        line = [f"{name}: auto {timeit_graph(run, n=n):7.1f} us"]
+        line[0] += f" ({flops / float(line[0].split()[-2]) * 1e-6:5.0f} TF/s)"
+        for field in ("qattn_keys16", "qattn_split"):
+            try:
+                with _lib.tuning(**{field: 0}):
+                    line.append(f"{field}=0 {timeit_graph(run, n=n):7.1f}")
+            except Exception as e:  # an older library build
+                line.append(f"{field}=0 n/a")
         for qcfg in (1, 2, 3, 4):
-            ENV["CD360_QATTN_CFG"] = str(qcfg)
-            t_f[qcfg] = timeit_graph(lambda: ops.qproj_attention(a, w, k, v, 77, heads, bias=cb, ln=(st, ws, 1e-5)), n=n)
-        ENV.pop("CD360_QATTN_CFG", None)
-        t_g = timeit_graph(lambda: ops.gemm(a, w, bias=cb, ln=(st, ws, 1e-5)), n=n)
-        q = ops.gemm(a, w, bias=cb, ln=(st, ws, 1e-5))
-        t_a = timeit_graph(lambda: ops.attention(q, k, v, heads, 77), n=n)
-        flops = b * nq * (2.0 * C * C + 4.0 * 77 * C)
-        print(f"{name}: fused 256x256 {t_f[1]:7.1f} us ({flops / t_f[1] * 1e-6:5.0f} TF/s) | fused 128x128 {t_f[2]:7.1f} us ({flops / t_f[2] * 1e-6:5.0f} TF/s) | "
-              f"128x128 4 waves x2 WG {t_f[3]:7.1f} | 256x128 {t_f[4]:7.1f} | "
-              f"q GEMM {t_g:7.1f} + attention {t_a:7.1f} = {t_g + t_a:7.1f}", flush=True)
+            with _lib.tuning(qattn_cfg=qcfg):
+                line.append(f"tile{qcfg} {timeit_graph(run, n=n):7.1f}")
+        if not dup:
+            t_g = timeit_graph(lambda: ops.gemm(a, w, bias=cb, ln=(st, ws, 1e-5)), n=n)
+            q = ops.gemm(a, w, bias=cb, ln=(st, ws, 1e-5))
+            t_a = timeit_graph(lambda: ops.attention(q, k, v, heads, 77), n=n)
+            line.append(f"q GEMM {t_g:7.1f} + attention {t_a:7.1f}")
+        print(" | ".join(line), flush=True)
+
+
+def check_qattn_all():
+    """Parity list of the fused query projection + attention alone (every tile, every key-count epilogue, one-tile K loops, the column split)."""
+    ok = True
+    ok &= check_qattn(2, 256, 128, 128, 77)
+    ok &= check_qattn(1, 512, 64, 64, 77, ln=False)
+    ok &= check_qattn(3, 1024, 640, 640, 77)
+    ok &= check_qattn(2, 256, 1280, 1280, 50)
+    ok &= check_qattn(1, 768, 256, 320, 96)
+    ok &= check_qattn(2, 256, 128, 192, 20)
+    ok &= check_qattn(1, 256, 384, 256, 77)   # 384 = 256 + 128 columns: the split launch
+    ok &= check_qattn(1, 512, 640, 64, 80)    # one K-tile
+    ok &= check_qattn(1, 256, 640, 128, 65)   # two K-tiles
+    ok &= check_qattn(1, 256, 320, 192, 81)   # three K-tiles, 96-key epilogue
+    for qcfg in (1, 2, 3, 4):  # every tile on the same shapes; 128-token multiples only on the 128-row tiles
+        ok &= check_qattn(3, 1024, 1280, 1280, 77, qcfg=qcfg)
+        ok &= check_qattn(2, 512, 640, 640, 77, qcfg=qcfg)
+        ok &= check_qattn(1, 256, 192, 128, 33, qcfg=qcfg)
+        ok &= check_qattn(1, 256, 128, 64, 77, qcfg=qcfg)
+        ok &= check_qattn(1, 256, 256, 320, 16, qcfg=qcfg)
+    for qcfg in (2, 3):
+        ok &= check_qattn(2, 384, 320, 320, 77, qcfg=qcfg)
+        ok &= check_qattn(3, 128, 128, 64, 20, ln=False, qcfg=qcfg)
+    from cd360 import _lib
+    with _lib.tuning(qattn_keys16=0, qattn_split=0):
+        ok &= check_qattn(3, 1024, 640, 640, 77)
+        ok &= check_qattn(2, 256, 1280, 1280, 77, qcfg=2)
+    print("QATTN CHECK", "PASSED" if ok else "FAILED", flush=True)
+    return ok
 
 
 def time_all():
@@ -647,6 +675,8 @@ if __name__ == "__main__":
         good = ksplit()
     if "check" in what:
         good = check()
+    if "qcheck" in what:
+        good = check_qattn_all() and good
     if "time" in what:
         time_all()
     if "qattn" in what:
