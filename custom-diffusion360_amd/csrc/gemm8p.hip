@@ -136,6 +136,9 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   constexpr int XP = BM / PR, WP = BN / PR;        // pieces per wave per K-tile
   constexpr int NP = XP + WP, NMMA = NCB * NMB;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  // (LDS-DMA destinations of the attention epilogues are formed in address space 3 from here: a generic pointer that reaches the cast
+  // through a select makes hipcc 7.2 emit an illegal "V_CMP_NE_U32 0, src_shared_base")
+  __attribute__((address_space(3))) unsigned char* const lds3 = (__attribute__((address_space(3))) unsigned char*)lds;
 
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -279,6 +282,10 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   constexpr int NKB = (NK16 + 1) / 2, KROWS = NK16 * 16, HEAD_LDS = 2 * KROWS * 128;
   constexpr bool HALF = (NK16 & 1) != 0;  // the last 32-key block of scores is used in its first 16 keys only
   constexpr uint32_t KVBASE = BB;
+  // the tile's slices of bias and wsum (BN floats each) travel with K / V when the LDS has the 2 KiB left: the LayerNorm fold then
+  // reads them with two ds_read_b128 per 8 channels instead of four dependent L2 round trips in front of the first attention MFMA
+  constexpr uint32_t BWBASE = KVBASE + WN * HEAD_LDS;
+  constexpr bool BW_LDS = ATTN && BN * 4 <= 1024 && BWBASE + 2048 <= 160 * 1024;
   static_assert(!ATTN || (NWC * 4096 <= (int)BB), "attention epilogue: the waves' output blocks alias ring buffer 0");
   const int a_bidx = ATTN ? (int)(m0 / p.a_nq) : 0;  // batch element of this token tile
   auto kv_issue = [&](int kvb) {
@@ -299,12 +306,41 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
           const int col = n0 + hl * 64;
           uint32_t off = (uint32_t)key * (uint32_t)(isv ? p.av_sn : p.ak_sn) * 2u + (uint32_t)(col * 2 + sch * 16);
           if (col >= p.N) off = 0x80000000u;
-          if (isv) __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, LDS_AS3(lds + KVBASE + q * 1024), 16, off, 0, 0, 0);
-          else __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, LDS_AS3(lds + KVBASE + q * 1024), 16, off, 0, 0, 0);
+          if (isv) __builtin_amdgcn_raw_ptr_buffer_load_lds(vrs, lds3 + (KVBASE + q * 1024), 16, off, 0, 0, 0);
+          else __builtin_amdgcn_raw_ptr_buffer_load_lds(krs, lds3 + (KVBASE + q * 1024), 16, off, 0, 0, 0);
         }
       }
     }
   };
+  auto bw_issue = [&]() {  // once per tile, by the first two moving waves
+    if constexpr (BW_LDS) {
+      const uint32_t off = (lane * 4 < BN && n0 + lane * 4 < p.N) ? (uint32_t)((n0 + lane * 4) * 4) : 0x80000000u;
+      if (p.bias && dwave == 0) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, p.N * 4, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds3 + BWBASE, 16, off, 0, 0, 0);
+      }
+      if (p.ln_stats && dwave == (NWD > 1 ? 1 : 0)) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wsum, 0, p.N * 4, 0x00020000);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds3 + (BWBASE + 1024), 16, off, 0, 0, 0);
+      }
+    }
+  };
+
+  // attention epilogues: the rows' LayerNorm constants (q = acc * c1 + (c2 * wsum + bias), c1 = rstd, c2 = -rstd * mean) are requested
+  // here, ahead of the first operand pieces (older than every piece: the counted waits below still count pieces only), so that their
+  // L2 round trip is over long before the epilogue wants them
+  float a_c1[ATTN ? NMB : 1], a_c2[ATTN ? NMB : 1];
+  f32x2 a_st[ATTN ? NMB : 1];
+  if constexpr (ATTN) {
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) {
+      a_st[mb] = f32x2{0.f, 0.f};
+      if (p.ln_stats && !mover) {
+        const f32x2* st = reinterpret_cast<const f32x2*>(p.ln_stats) + (m0 + wr * (NMB * 32) + l31 + mb * 32) * p.ln_parts;
+        for (int q = 0; q < p.ln_parts; ++q) a_st[mb] += st[q];
+      }
+    }
+  }
 
   // ---- prologue: tiles 0 .. NBUF-1 in flight (one per buffer), tile 0 landed ----
   // counted wait: everything but the `later` most recently issued tiles has landed (s_waitcnt takes an immediate)
@@ -325,12 +361,25 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
         for (int i = 0; i < NP; ++i) piece(b, i, ((b + rot) % NBUF) * XSTR, ((b + rot) % NBUF) * WSTR);
       }
     if constexpr (ATTN) {
-      if (nk == 1) kv_issue(a_bidx);  // (a one-tile loop never reaches the issue point below; buffers 1 .. are idle from the start)
+      if (nk == 1) {  // (a one-tile loop never reaches the issue point below; buffers 1 .. are idle from the start)
+        kv_issue(a_bidx);
+        bw_issue();
+      }
     }
     wait_tiles_in_flight((nk < NBUF ? nk : NBUF) - 1);
   }
   BARRIER();
   read_ks(0, 0);
+  if constexpr (ATTN) {
+    const float inv = p.ln_stats ? 1.f / (float)p.ln_dim : 0.f;
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) {
+      const float mean = a_st[mb][0] * inv;
+      const float rstd = p.ln_stats ? rsqrtf(fmaxf(a_st[mb][1] * inv - mean * mean, 0.f) + p.ln_eps) : 1.f;
+      a_c1[mb] = rstd;
+      a_c2[mb] = -rstd * mean;
+    }
+  }
 
   // the loop exists twice: waves with output channels multiply, the others only move data
   auto k_loop = [&](auto mul_tag, auto move_tag) {
@@ -432,7 +481,10 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
       if constexpr (ATTN && MOVE) {
         // the barrier of this iteration released every buffer but the last tile's (buffer 0): K / V of the tile's heads travel under
         // the last K-tile's MFMAs (no operand piece is issued any more, the address path is idle)
-        if (t == nk - 2) kv_issue(a_bidx);
+        if (t == nk - 2) {
+          kv_issue(a_bidx);
+          bw_issue();
+        }
       }
       FENCE();
 #ifdef CD360_GEMM_STAMP
@@ -624,38 +676,33 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
       // q = rstd (acc - mu wsum) + bias = acc * rstd + (bias - rstd mu wsum)
       bf16x8 qf[NMB][4];
       if (has_ch) {
-        float c1[NMB], c2[NMB];
-#pragma unroll
-        for (int mb = 0; mb < NMB; ++mb) {
-          c1[mb] = 1.f;
-          c2[mb] = 0.f;
-        }
-        if (p.ln_stats) {
-          const float inv = 1.f / (float)p.ln_dim;
-#pragma unroll
-          for (int mb = 0; mb < NMB; ++mb) {
-            const long m = m0 + mrow0 + mb * 32;
-            float s = 0.f, ss = 0.f;
-            const f32x2* st = reinterpret_cast<const f32x2*>(p.ln_stats) + m * p.ln_parts;
-            for (int q = 0; q < p.ln_parts; ++q) {
-              const f32x2 v = st[q];
-              s += v[0];
-              ss += v[1];
-            }
-            const float mean = s * inv;
-            const float rstd = rsqrtf(fmaxf(ss * inv - mean * mean, 0.f) + p.ln_eps);
-            c1[mb] = rstd;
-            c2[mb] = -rstd * mean;
-          }
-        }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           FENCE();
           const int nb = j >> 1, c8 = j & 1;
           const int n = n0 + wc * 64 + nb * 32 + 16 * hh + 8 * c8;
           const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-          const f32x4 b0 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n) : z4, b1 = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + n + 4) : z4;
-          const f32x4 s0 = p.ln_stats ? *reinterpret_cast<const f32x4*>(p.wsum + n) : z4, s1 = p.ln_stats ? *reinterpret_cast<const f32x4*>(p.wsum + n + 4) : z4;
+          f32x4 b0 = z4, b1 = z4, s0 = z4, s1 = z4;
+          if constexpr (BW_LDS) {  // (slices that were not fetched -- no bias, no fold -- are never read)
+            const uint32_t bo = BWBASE + (uint32_t)(n - n0) * 4;
+            if (p.bias) {
+              b0 = *reinterpret_cast<const f32x4*>(lds + bo);
+              b1 = *reinterpret_cast<const f32x4*>(lds + bo + 16);
+            }
+            if (p.ln_stats) {
+              s0 = *reinterpret_cast<const f32x4*>(lds + bo + 1024);
+              s1 = *reinterpret_cast<const f32x4*>(lds + bo + 1040);
+            }
+          } else {
+            if (p.bias) {
+              b0 = *reinterpret_cast<const f32x4*>(p.bias + n);
+              b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+            }
+            if (p.ln_stats) {
+              s0 = *reinterpret_cast<const f32x4*>(p.wsum + n);
+              s1 = *reinterpret_cast<const f32x4*>(p.wsum + n + 4);
+            }
+          }
           const float bv[8] = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
           const float sv[8] = {s0[0], s0[1], s0[2], s0[3], s1[0], s1[1], s1[2], s1[3]};
 #pragma unroll
@@ -663,8 +710,8 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
             u32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-              const float t0 = fmaf(acc[nb][mb][8 * c8 + 2 * e], c1[mb], fmaf(c2[mb], sv[2 * e], bv[2 * e]));
-              const float t1 = fmaf(acc[nb][mb][8 * c8 + 2 * e + 1], c1[mb], fmaf(c2[mb], sv[2 * e + 1], bv[2 * e + 1]));
+              const float t0 = fmaf(acc[nb][mb][8 * c8 + 2 * e], a_c1[mb], fmaf(a_c2[mb], sv[2 * e], bv[2 * e]));
+              const float t1 = fmaf(acc[nb][mb][8 * c8 + 2 * e + 1], a_c1[mb], fmaf(a_c2[mb], sv[2 * e + 1], bv[2 * e + 1]));
               o[e] = pack_bf16x2(t0, t1);
             }
             qf[mb][j] = __builtin_bit_cast(bf16x8, o);
@@ -938,7 +985,8 @@ int launch_mv(const GemmParams& p0, hipStream_t stream) {
   // waves' 4-KB output blocks alias buffer 0 and the projected tile never leaves the registers)
   constexpr bool ATTN = (EPI >= 2 && EPI <= 4) || (EPI >= 7 && EPI <= 9);
   constexpr int NK16 = EPI == 2 ? 2 : EPI == 3 ? 4 : EPI == 4 ? 6 : EPI == 7 ? 5 : EPI == 8 ? 3 : 1;
-  constexpr int ATTN_BYTES = ATTN ? (BM + BN) * 128 + WN * 2 * NK16 * 16 * 128 : 0;
+  constexpr int ATTN_KV_END = (BM + BN) * 128 + WN * 2 * NK16 * 16 * 128;
+  constexpr int ATTN_BYTES = ATTN ? ATTN_KV_END + ((BN * 4 <= 1024 && ATTN_KV_END + 2048 <= 160 * 1024) ? 2048 : 0) : 0;  // + bias / wsum slices (BW_LDS)
   constexpr int RING_BYTES = NBUF * (BM + BN) * 128, STAGE_BYTES0 = ATTN ? 0 : BM * BN * 2 + (KS == 2 ? BM * BN * 4 : 0);
   constexpr int STAGE_BYTES = STAGE_BYTES0 > ATTN_BYTES ? STAGE_BYTES0 : ATTN_BYTES;
 #ifdef CD360_GEMM_STAMP
