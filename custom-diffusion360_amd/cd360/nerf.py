@@ -15,13 +15,12 @@ Linear) on cd360_gemm_bf16 (ops.linear, forward and backward) and the rest happe
 from __future__ import annotations
 
 import math
-import os
 from typing import Optional
 
 import numpy as np
 import torch
 
-from . import ops
+from . import ops, routes
 
 NUM_FREQS = 16
 
@@ -173,7 +172,7 @@ def fused_feature_nerf(fw: FusedNerfWeights, cams: torch.Tensor, xref: Optional[
     # the three table GEMMs run on cd360_gemm_bf16 in every mode (ops.linear: recorded by autograd when the weights are live) -- Plucker
     # features written as bf16 rows of 128 by their kernel (no fp32 intermediate, no cast pass), bias fused; CD360_LIBRARY_LINEAR=1 = the
     # round-1 torch GEMMs (A/B)
-    fused = cams.is_cuda and C % 64 == 0 and fw.Wp.dtype == torch.bfloat16 and not os.environ.get("CD360_LIBRARY_LINEAR")
+    fused = cams.is_cuda and C % 64 == 0 and fw.Wp.dtype == torch.bfloat16 and not routes.library_linear
     if fused:
         zP = ops.linear(ops.plucker_features_bf16(cams, xs, ys).reshape(b * n * hw, 128), fw.Wp, fw.b1).reshape(b * n, hw, C)
     else:
@@ -206,7 +205,7 @@ def reference_tables(fw: FusedNerfWeights, xref: torch.Tensor):
     Y = xref @ Wf^T (bf16) and lv = xref @ vf (fp32)."""
     b, n, hw, C = xref.shape
     x2 = xref.reshape(b * n * hw, C)
-    if x2.is_cuda and x2.dtype == torch.bfloat16 and C % 64 == 0 and not os.environ.get("CD360_LIBRARY_LINEAR"):
+    if x2.is_cuda and x2.dtype == torch.bfloat16 and C % 64 == 0 and not routes.library_linear:
         Y = ops.linear(x2, fw.Wf).reshape(b * n, hw, C)
     else:
         Y = torch.mm(x2.to(fw.Wf_t.dtype), fw.Wf_t).reshape(b * n, hw, C)

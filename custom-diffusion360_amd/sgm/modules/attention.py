@@ -19,7 +19,6 @@ LoRA branches, `additional_tokens`, `n_times_crossframe_attn_in_self`, `disable_
 """
 from __future__ import annotations
 
-import os
 
 import logging
 import math
@@ -29,7 +28,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from cd360 import ops
+from cd360 import ops, routes
 from ..modules.diffusionmodules.util import HipLayerNorm, HipLinear, checkpoint, group_norm_tokens, tag_gn_stats, tokens_to_image, zero_module  # noqa: F401
 from ..modules.nerfsd_pytorch3d import NerfSDModule, VolRender
 from ..util import default, exists
@@ -83,7 +82,7 @@ class FeedForward(nn.Module):
 
 def _linear(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
     """F.linear on the hand-written GEMM whenever it can serve the call (bf16, GPU, K % 64 == 0), in every grad mode."""
-    if ops.linear_ok(x, weight) and not os.environ.get("CD360_LIBRARY_LINEAR"):
+    if ops.linear_ok(x, weight) and not routes.library_linear:
         return ops.linear(x, weight, bias)
     return F.linear(x, weight, bias)
 
@@ -255,7 +254,7 @@ class BasicTransformerBlock(nn.Module):
         stride 2C).  Under autograd both go through grad.LinearFn: the halves' weight gradients land in the two halves of the parameter's."""
         w = self.pose_emb_layers.weight
         c = w.shape[0]
-        if ops.linear_ok(x, w[:, :c]) and xref.is_cuda and not os.environ.get("CD360_LIBRARY_LINEAR"):
+        if ops.linear_ok(x, w[:, :c]) and xref.is_cuda and not routes.library_linear:
             half = ops.linear(xref.to(x.dtype), w[:, c:])
             return ops.linear(x, w[:, :c], None, res=half)
         wa, wb = self._pose_weights()
@@ -273,9 +272,9 @@ class BasicTransformerBlock(nn.Module):
         b, n, c = x.shape
         tag = self._rendered_proj
         w = self.pose_emb_layers.weight
-        hip = ops.linear_ok(x, w[:, :c]) and not torch.is_grad_enabled() and not os.environ.get("CD360_LIBRARY_LINEAR")
+        hip = ops.linear_ok(x, w[:, :c]) and not torch.is_grad_enabled() and not routes.library_linear
         wb = self._packed()["pose"][1] if (hip and self.fused_ready(x)) else self._pose_weights()[1]
-        if tag is None or tag[0] is not rf or tag[1] != rf._version or tag[2] is not wb or os.environ.get("CD360_NO_POSE_PROJ_CACHE"):
+        if tag is None or tag[0] is not rf or tag[1] != rf._version or tag[2] is not wb or routes.no_pose_proj_cache:
             if hip:
                 half = ops.linear(rf.reshape(-1, c).to(x.dtype), w.detach()[:, c:])
             else:
@@ -326,7 +325,7 @@ class BasicTransformerBlock(nn.Module):
             h, dec, dists, _ = self.pose_featurenerf.render_inputs(list(pose[:2 * dup]), None, None, tables=t2, dims=d2)
             b2, hw, S, C = h.shape
             tok = h.reshape(b2, hw * S, C)
-            if (tok.dtype == x.dtype and self.fused_ready(tok) and not os.environ.get("CD360_NO_RENDER_COMMUTE") and not os.environ.get("CD360_NO_QPROJ_ATTN")
+            if (tok.dtype == x.dtype and self.fused_ready(tok) and not routes.no_render_commute and not routes.no_qproj_attn
                     and ops.qproj_attention_ok(tok, 96)):
                 # ... and keep the pose tokens de-duplicated through their cross-attention: the shared third's queries are projected
                 # once and meet both text contexts inside cd360_qproj_attn_dedup_bf16; the render commutes with the out projection
@@ -348,7 +347,7 @@ class BasicTransformerBlock(nn.Module):
         tok = h.reshape(b, hw * S, C)
         if tok.dtype != x.dtype:
             tok = tok.to(x.dtype)
-        if self.fused_ready(tok) and not os.environ.get("CD360_NO_RENDER_COMMUTE"):
+        if self.fused_ready(tok) and not routes.no_render_commute:
             # The volume render is linear in the features and its weights depend on `dec` only, so it commutes with the out projection
             # of the pose-token attention: sum_s w_s (tok_s + o_s Wo^T + b) = R(tok) + R(o) Wo^T + fg b.  The [b hw S, C] x [C, C]
             # GEMM (attention.py:586 applied per sample) becomes a [b hw, C] one, S = 24 times smaller; fp32 sums, fewer bf16 roundings.
@@ -376,7 +375,7 @@ class BasicTransformerBlock(nn.Module):
     def _duplicate_cfg_branch(pose, dims) -> int:
         """bs > 0 when `pose` is a list of 3*bs camera batches whose last two thirds are the SAME objects (what the guider's
         `[pose] * 3` / torch.cat of one conditioning produces); decided on object identity only -- no device comparison."""
-        if os.environ.get("CD360_NO_CFG_DEDUP") or not isinstance(pose, (list, tuple)) or dims is None:
+        if routes.no_cfg_dedup or not isinstance(pose, (list, tuple)) or dims is None:
             return 0
         b = len(pose)
         if b != dims[0] or b % 3:
@@ -437,7 +436,7 @@ class BasicTransformerBlock(nn.Module):
 
     def _fused_ready(self, is_cuda: bool, dtype, rows: int, c: int) -> bool:
         return (is_cuda and dtype == torch.bfloat16 and not torch.is_grad_enabled() and self.norm1.weight.dtype == torch.bfloat16
-                and c % 64 == 0 and isinstance(self.ff.net[0], GEGLU) and not os.environ.get("CD360_LIBRARY_LINEAR")
+                and c % 64 == 0 and isinstance(self.ff.net[0], GEGLU) and not routes.library_linear
                 and ops.gemm_ok(rows, c, c)  # 32-bit buffer offsets of the GEMM core: a larger batch takes the module route
                 and not (self.training and any(isinstance(m, nn.Dropout) and m.p > 0 for m in (self.attn1.to_out[1], self.attn2.to_out[1], self.ff.net[1]))))
 
@@ -495,7 +494,7 @@ class BasicTransformerBlock(nn.Module):
             if not (ops.qproj_attention_ok(tok, nk) and k.shape[0] == tok.shape[0] + dup):
                 return None
             return ops.qproj_attention(tok, w, k, v, nk, a2.heads, bias=cb, ln=ln, dup=dup)
-        if ops.qproj_attention_ok(tok, nk) and not os.environ.get("CD360_NO_QPROJ_ATTN"):
+        if ops.qproj_attention_ok(tok, nk) and not routes.no_qproj_attn:
             o = ops.qproj_attention(tok, w, k, v, nk, a2.heads, bias=cb, ln=ln)  # q never leaves the registers (cd360_qproj_attn_bf16)
         else:
             o = ops.attention(ops.gemm(tok, w, bias=cb, ln=ln), k, v, a2.heads, nk)
@@ -519,7 +518,7 @@ class BasicTransformerBlock(nn.Module):
         x, stats = ops.gemm(o, P["o1"][0], bias=P["o1"][1], res=x, want_stats=True)
         w, ws, cb = P["q2"]
         k, v, nk = a2.project_context(context)
-        if ops.qproj_attention_ok(x, nk) and k.shape[0] == x.shape[0] and not os.environ.get("CD360_NO_A2_FUSE"):
+        if ops.qproj_attention_ok(x, nk) and k.shape[0] == x.shape[0] and not routes.no_a2_fuse:
             # text cross-attention (attention.py:620-625): LayerNorm fold + q projection + softmax(q K^T) V in ONE kernel, q never in HBM
             o = ops.qproj_attention(x, w, k, v, nk, a2.heads, bias=cb, ln=(stats, ws, self.norm2.eps), tag="qproj_attn_text")
         else:
@@ -541,7 +540,7 @@ class BasicTransformerBlock(nn.Module):
                     self.rendered_feat = xref
                 rf = self.rendered_feat
                 tag = self._rendered_proj  # rendered_feat @ Wb^T stays constant while the render is cached (49 of 50 steps)
-                if tag is None or tag[0] is not rf or tag[1] != rf._version or tag[2] is not wb or os.environ.get("CD360_NO_POSE_PROJ_CACHE"):
+                if tag is None or tag[0] is not rf or tag[1] != rf._version or tag[2] is not wb or routes.no_pose_proj_cache:
                     tag = (rf, rf._version, wb, ops.gemm(rf.to(torch.bfloat16).contiguous(), wb))
                     self._rendered_proj = tag
                 half = tag[3]
@@ -719,7 +718,7 @@ class SpatialTransformer(nn.Module):
         H, W = img.shape[2], img.shape[3]
         r = img.permute(0, 2, 3, 1)
         r = (r if r.is_contiguous() else r.contiguous()).reshape(img.shape[0], H * W, img.shape[1])
-        if os.environ.get("CD360_NO_GN_STATS") or (H * W) % 64:
+        if routes.no_gn_stats or (H * W) % 64:
             return tokens_to_image(ops.gemm(t, wo, bias=bo, res=r), H, W)
         out, cst = ops.gemm_cstats(t, wo, bias=bo, res=r)
         image = tokens_to_image(out, H, W)

@@ -11,7 +11,6 @@ integer / "continuous" / "timestep" class embeddings) raise NotImplementedError.
 """
 from __future__ import annotations
 
-import os
 
 from abc import abstractmethod
 from typing import List, Optional, Tuple, Union
@@ -21,7 +20,7 @@ import torch as th
 import torch.nn as nn
 import torch.nn.functional as F
 
-from cd360 import ops
+from cd360 import ops, routes
 from ...modules.attention import SpatialTransformer
 from ...modules.diffusionmodules.util import (
     conv_image,
@@ -47,7 +46,7 @@ def _cat_channels(a, b):
         # GroupNorm statistics of a concatenation are the concatenated per-channel statistics: when both inputs still carry the slab sums
         # their producers' epilogues took (tag_gn_stats), the in_layers GroupNorm of the ResBlock that reads `out` needs no pass over it
         sa, sb = _tagged_gn_stats(a), _tagged_gn_stats(b)
-        if sa is not None and sb is not None and not torch.is_grad_enabled() and not (os.environ.get("CD360_NO_GN_STATS") or os.environ.get("CD360_NO_CONCAT_STATS")):
+        if sa is not None and sb is not None and not torch.is_grad_enabled() and not (routes.no_gn_stats or routes.no_concat_stats):
             na, nb = sa.shape[1], sb.shape[1]  # [N, slabs, C, 2]: bring both to the coarser slab count (slabs are consecutive pixel runs)
             if na > nb and na % nb == 0:
                 sa = sa.reshape(sa.shape[0], nb, na // nb, sa.shape[2], 2).sum(2)
@@ -109,7 +108,7 @@ class Upsample(nn.Module):
         conv = self.conv if self.use_conv else None
         if (conv is not None and x.is_cuda and x.dtype == torch.bfloat16 and self.scale_factor == 2 and conv.kernel_size == (3, 3) and conv.padding == (1, 1)
                 and conv.stride == (1, 1) and conv.weight.dtype == torch.bfloat16 and self.channels % 64 == 0 and self.out_channels % 16 == 0
-                and not torch.is_grad_enabled() and not os.environ.get("CD360_NO_UPSAMPLE_FOLD")):
+                and not torch.is_grad_enabled() and not routes.no_upsample_fold):
             # nearest 2x + conv3x3 as four 2 x 2-tap phase convolutions of the source image: no upsampled intermediate, 4 / 9 of the MACs
             N, _, H, W = x.shape
             xt = x.permute(0, 2, 3, 1)
@@ -295,7 +294,7 @@ class UNetModel(nn.Module):
         same `emb` as ONE GEMM against the concatenated weights: 17 SiLU launches and 17 GEMMs with M = batch (3) rows -- 17 us
         each on hipBLASLt -- become one of each.  The result rides on the `emb` tensor object as column slices keyed by block;
         a ResBlock that does not find its slice computes its own projection as before."""
-        if not (emb.is_cuda and emb.dtype == torch.bfloat16) or torch.is_grad_enabled() or os.environ.get("CD360_NO_EMB_MERGE"):
+        if not (emb.is_cuda and emb.dtype == torch.bfloat16) or torch.is_grad_enabled() or routes.no_emb_merge:
             return emb
         blocks = [m for m in self.modules() if isinstance(m, ResBlock)]
         key = tuple((b.emb_layers[1].weight.data_ptr(), b.emb_layers[1].weight._version, b.emb_layers[1].bias._version) for b in blocks)
@@ -304,7 +303,7 @@ class UNetModel(nn.Module):
             bias = torch.cat([b.emb_layers[1].bias.detach() for b in blocks], 0).contiguous()
             self._emb_cat = (key, w, bias)
         act = torch.nn.functional.silu(emb)
-        if ops.linear_ok(act, self._emb_cat[1]) and not os.environ.get("CD360_LIBRARY_LINEAR"):
+        if ops.linear_ok(act, self._emb_cat[1]) and not routes.library_linear:
             allp = ops.linear(act, self._emb_cat[1], self._emb_cat[2])  # [b, sum(out_channels)] on the hand-written GEMM (M = batch rows)
         else:
             allp = torch.nn.functional.linear(act, self._emb_cat[1], self._emb_cat[2])

@@ -6,12 +6,11 @@ import them by name."""
 from __future__ import annotations
 
 import math
-import os
 
 import torch
 import torch.nn as nn
 
-from cd360 import ops
+from cd360 import ops, routes
 
 
 def checkpoint(func, inputs, params, flag):
@@ -184,7 +183,7 @@ def conv_tokens(conv: nn.Conv2d, tokens: torch.Tensor, N: int, H: int, W: int, e
     padded_out = cout_p != cout
     if padded_out and (emb is not None or res is not None):
         raise NotImplementedError("emb / res epilogue with a padded channel count")
-    stats_ok = want_stats and not padded_out and ((H // stride) * (W // stride)) % 128 == 0 and not os.environ.get("CD360_NO_GN_STATS")
+    stats_ok = want_stats and not padded_out and ((H // stride) * (W // stride)) % 128 == 0 and not routes.no_gn_stats
     out = ops.conv_igemm(tokens, pk[0], pk[1], N, H, W, taps, emb, res, want_stats=stats_ok, stride=stride, alg_channels=(cin, cout),
                          w_dgrad=lambda: packed_conv_dgrad(conv))
     y, stats = out if stats_ok else (out, None)
@@ -196,7 +195,7 @@ def conv_tokens(conv: nn.Conv2d, tokens: torch.Tensor, N: int, H: int, W: int, e
 def conv_image(conv: nn.Conv2d, x: torch.Tensor) -> torch.Tensor:
     """A plain nn.Conv2d call site (the UNet's input conv, Downsample.op, the output conv) on the implicit-GEMM kernel: image in,
     image out, channels-last in between; CPU / non-bf16 tensors go through the module itself."""
-    if not (x.is_cuda and x.dtype == torch.bfloat16) or os.environ.get("CD360_EDGE_CONVS_MIOPEN") or not _frozen(conv) or packed_conv(conv) is None:
+    if not (x.is_cuda and x.dtype == torch.bfloat16) or routes.edge_convs_miopen or not _frozen(conv) or packed_conv(conv) is None:
         return conv(x)  # (the environment knob keeps these four convs on MIOpen, for A/B runs)
     N, _, H, W = x.shape
     xt = x.permute(0, 2, 3, 1)
@@ -235,7 +234,7 @@ class HipLinear(nn.Linear):
     same kernel.  Other dtypes / devices / shapes outside the kernel's envelope (K % 64, N % 16) take torch's F.linear."""
 
     def forward(self, x):
-        if ops.linear_ok(x, self.weight) and not os.environ.get("CD360_LIBRARY_LINEAR"):
+        if ops.linear_ok(x, self.weight) and not routes.library_linear:
             return ops.linear(x, self.weight, self.bias)
         return torch.nn.functional.linear(x, self.weight, self.bias)
 
@@ -246,7 +245,7 @@ class HipLayerNorm(nn.LayerNorm):
 
     def forward(self, x):
         if (x.is_cuda and x.dtype == torch.bfloat16 and self.weight is not None and self.weight.dtype == torch.bfloat16 and self.bias is not None
-                and len(self.normalized_shape) == 1 and x.shape[-1] <= 2048 and x.shape[-1] % 8 == 0 and not os.environ.get("CD360_LIBRARY_LINEAR")):
+                and len(self.normalized_shape) == 1 and x.shape[-1] <= 2048 and x.shape[-1] % 8 == 0 and not routes.library_linear):
             return ops.add_layernorm(x.contiguous(), None, self.weight, self.bias, self.eps)[1]
         return super().forward(x)
 

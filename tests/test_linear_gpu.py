@@ -234,3 +234,54 @@ def test_fused_adamw_matches_torch_adamw_on_fp32_masters():
     st = plain.opt.state[plain.master[0]]
     n0 = pa[0].numel()
     assert rel(fused.exp_avg[:n0].view_as(st["exp_avg"]), st["exp_avg"]) < 2e-6 and rel(fused.exp_avg_sq[:n0].view_as(st["exp_avg_sq"]), st["exp_avg_sq"]) < 2e-6
+
+
+def test_fused_adamw_updates_are_seen_by_every_weight_cache():
+    """The fused optimiser (and a hipGraph replay of it) writes the bf16 parameters through raw pointers; MasterAdamW.bump_versions makes
+    the update visible to the caches keyed on `_version` (LayerNorm-folded packs, W^T copies, fp32 biases, the FeatureNeRF's fused weights,
+    the pose-projection split).  The reference's periodic image logging is exactly this sequence: train, sample under no_grad, train,
+    sample.  One pose block, trainable set `poseattn` (pose parameters + attn1 / attn2, diffusion.py:121-138): after every burst of fused
+    optimiser steps the no_grad (fused-route) forward must equal, bit for bit, the forward of a freshly built block that holds the
+    current parameter values -- and must differ from the forward before the burst."""
+    import weights as W
+    from cd360 import finetune, synth
+    from sgm.modules.attention import BasicTransformerBlock
+    dev, bf = "cuda", torch.bfloat16
+
+    def build():
+        return BasicTransformerBlock(128, 2, 64, context_dim=64, checkpoint=False, attn_mode="softmax-xformers", image_cross=True, far=2, num_samples=6,
+                                     rgb_predict=True, mode="feature-nerf", stratified=True).eval()
+
+    blk = build()
+    W.load_into(blk, seed=51)
+    blk = blk.to(dev, bf)
+    train = lambda k: "pose" in k or k.startswith(("attn1.", "attn2."))
+    for k, p in blk.named_parameters():
+        p.requires_grad = train(k)
+    b, n, hw = 2, 3, 64
+    x, ctx = W.tensor("x", (b, hw, 128), seed=51).to(dev, bf), W.tensor("ctx", (b, 77, 64), seed=51).to(dev, bf)
+    cref = W.tensor("cref", (b * n, hw, 128), seed=51).to(dev, bf)
+    pose = synth.pose_batch(b, n, seed=4)
+    opt = finetune.MasterAdamW([p for p in blk.parameters() if p.requires_grad], lr=2e-2)
+    assert opt.fused
+
+    def sample(m):
+        with torch.no_grad():
+            out = m(x, context=ctx, context_ref=cref, pose=pose)
+        return out[0].clone(), out[1].clone(), out[4].clone()
+
+    prev = sample(blk)
+    for burst in range(2):
+        for _ in range(2):
+            opt.zero_grad()
+            out, fg, _, _, rgb = blk(x, context=ctx, context_ref=cref, pose=pose)
+            (out.float().pow(2).mean() + fg.float().mean() + rgb.float().mean()).backward()
+            opt.step()
+        now = sample(blk)
+        fresh = build()
+        fresh.load_state_dict({k: v.detach().float().cpu() for k, v in blk.state_dict().items()}, strict=False)
+        want = sample(fresh.to(dev, bf))
+        for a, w_, p_ in zip(now, want, prev):
+            assert torch.equal(a, w_), f"burst {burst}: a cache survived the fused optimiser step"
+        assert not torch.equal(now[0], prev[0]) and not torch.equal(now[1], prev[1])
+        prev = now

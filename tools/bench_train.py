@@ -21,23 +21,14 @@ import torch  # noqa: E402
 def measure(steps=5, warmup=2, batch=4, views=4, latent=64, eval_mode=False, profile=True, library=False, graph=False):
     """One fine-tune configuration: build the SDXL UNet, run `warmup` + `steps` optimisation steps, return the result dict.
     graph=True: the step captured into a hipGraph (finetune.GraphedTrainStep) and replayed -- no per-kernel breakdown then.
-    library=True: the round-1 path (CD360_LIBRARY_LINEAR=1: every Linear on torch / hipBLASLt) for an A/B on the same box."""
+    library=True: the round-1 path (cd360.routes.library_linear: every Linear on torch / hipBLASLt) for an A/B on the same box."""
     from cd360 import finetune, ops, sampling, synth
     from make_golden_params import LOSS_CFG, SDXL_NETWORK_CONFIG
     from sgm.util import instantiate_from_config
-    prev = os.environ.get("CD360_LIBRARY_LINEAR")
-    if library:
-        os.environ["CD360_LIBRARY_LINEAR"] = "1"
-    else:
-        os.environ.pop("CD360_LIBRARY_LINEAR", None)
-    try:
+    from cd360 import routes
+    with routes.override(library_linear=bool(library)):
         return _measure(steps, warmup, batch, views, latent, eval_mode, profile and not graph, finetune, ops, sampling, synth, LOSS_CFG,
                         SDXL_NETWORK_CONFIG, instantiate_from_config, graph)
-    finally:
-        if prev is None:
-            os.environ.pop("CD360_LIBRARY_LINEAR", None)
-        else:
-            os.environ["CD360_LIBRARY_LINEAR"] = prev
 
 
 def _measure(steps, warmup, batch, views, latent, eval_mode, profile, finetune, ops, sampling, synth, LOSS_CFG, SDXL_NETWORK_CONFIG, instantiate_from_config,
