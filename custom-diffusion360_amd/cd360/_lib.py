@@ -56,6 +56,10 @@ SIGNATURES = {
                                       c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_float, _P]),
     "cd360_qproj_attn_dedup_bf16": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int64, c_int64, c_int64, _P, _P, c_int, c_int, c_float, _P, _P, _P,
                                             c_int64, c_int64, c_int64, c_int64, c_int, c_int, c_float, c_int, _P]),
+    "cd360_kv_fp8_bytes": (c_int64, [c_int, c_int]),
+    "cd360_kv_pack_fp8": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int64, c_int64, c_int64, c_int64, _P]),
+    "cd360_qproj_attn_fp8_bf16": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int64, c_int64, c_int64, _P, _P, c_int, c_int, c_float, _P, _P, _P,
+                                          c_int, c_int, c_float, c_int, _P]),
     "cd360_gemm_tile_n": (c_int, [c_int64, c_int]),
     "cd360_gemm_cstats_rows": (c_int, [c_int64, c_int]),
     "cd360_gemm_cstats_bf16": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int64, c_int64, c_int64, _P, _P, c_int64, _P, _P]),

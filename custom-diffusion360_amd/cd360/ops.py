@@ -864,21 +864,44 @@ def qproj_attention_ok(a: torch.Tensor, nk: int) -> bool:
     return a.dim() == 3 and a.shape[1] % 128 == 0 and a.shape[2] % 64 == 0 and nk <= 96
 
 
+def kv_pack_fp8(k: torch.Tensor, v: torch.Tensor, nk: int, heads: int):
+    """k, v bf16 [B, >= nk, heads*64] (last dim contiguous) -> (kv8 uint8 [B, heads, 14336], scales fp32 [B, heads, 2]): the OCP e4m3
+    image of K and V^T that cd360_qproj_attn_fp8_bf16 copies into its LDS (cd360_kv_pack_fp8; BASELINE configs[4]).  Once per image:
+    the text context is constant over a trajectory."""
+    _need_gpu(k, v)
+    B = k.shape[0]
+    assert k.dtype == torch.bfloat16 and v.dtype == torch.bfloat16 and k.shape[-1] == heads * 64 and v.shape[-1] == heads * 64
+    assert k.stride(2) == 1 and v.stride(2) == 1 and k.shape[1] >= nk and v.shape[1] >= nk and v.shape[0] == B and nk <= 96
+    kv8 = torch.empty(B, heads, 96 * 64 + 64 * 128, dtype=torch.uint8, device=k.device)
+    assert kv8.numel() == _lib.load().cd360_kv_fp8_bytes(B, heads)
+    scales = torch.empty(B, heads, 2, dtype=torch.float32, device=k.device)
+    check(_lib.load().cd360_kv_pack_fp8(_ptr(k), _ptr(v), _ptr(kv8), _ptr(scales), B, heads, nk, k.stride(0), k.stride(1), v.stride(0), v.stride(1),
+                                        _stream()), "cd360_kv_pack_fp8")
+    return kv8, scales
+
+
 def qproj_attention(a: torch.Tensor, w: torch.Tensor, k: torch.Tensor, v: torch.Tensor, nk: int, heads: int,
-                    bias: Optional[torch.Tensor] = None, ln=None, dup: int = 0, tag: str = "qproj_attn") -> torch.Tensor:
+                    bias: Optional[torch.Tensor] = None, ln=None, dup: int = 0, tag: str = "qproj_attn", fp8=None) -> torch.Tensor:
     """softmax((a w^T [+ LayerNorm fold, + bias]) k^T / 8) v per head with the query projection and the attention in ONE kernel
     (cd360_qproj_attn_bf16): a [b, Nq, K] bf16, w [heads*64, K] bf16, k / v [b, >= nk, heads*64] (last dim contiguous, e.g. the two
     halves of the merged k|v projection), nk <= 96 -> [b, Nq, heads*64].  bias / ln as gemm().  Forward only.
     dup > 0 (cd360_qproj_attn_dedup_bf16): k / v hold b + dup batch elements; the last `dup` query elements attend to the keys of their own
     batch index AND of index + dup -> [b + dup, Nq, heads*64] (the de-duplicated third of a 3-way CFG batch: q projected once)."""
-    _need_gpu(a, w, k, v, bias)
+    _need_gpu(a, w, bias)
     b, nq, K = a.shape
     N = heads * 64
     M, lda = _rows2d(a)
     assert w.dtype == torch.bfloat16 and w.shape == (N, K) and w.stride(1) == 1
-    assert 0 <= dup <= b
-    assert k.dtype == torch.bfloat16 and v.dtype == torch.bfloat16 and k.shape[0] == b + dup and v.shape[0] == b + dup and k.shape[-1] == N and v.shape[-1] == N
-    assert k.stride(2) == 1 and v.stride(2) == 1 and k.shape[1] >= nk and v.shape[1] >= nk and qproj_attention_ok(a, nk)
+    assert 0 <= dup <= b and qproj_attention_ok(a, nk)
+    if fp8 is None:
+        _need_gpu(k, v)
+        assert k.dtype == torch.bfloat16 and v.dtype == torch.bfloat16 and k.shape[0] == b + dup and v.shape[0] == b + dup and k.shape[-1] == N and v.shape[-1] == N
+        assert k.stride(2) == 1 and v.stride(2) == 1 and k.shape[1] >= nk and v.shape[1] >= nk
+    else:  # (kv8, scales) of kv_pack_fp8: both attention contractions on fp8 MFMA (cd360_qproj_attn_fp8_bf16); k, v are not read
+        kv8, kvs = fp8
+        _need_gpu(kv8, kvs)
+        assert kv8.dtype == torch.uint8 and kv8.is_contiguous() and kv8.shape == (b + dup, heads, 96 * 64 + 64 * 128)
+        assert kvs.dtype == torch.float32 and kvs.is_contiguous() and kvs.shape == (b + dup, heads, 2)
     assert bias is None or (bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == N)
     stats_in = wsum = None
     parts = ln_dim = 0
@@ -890,6 +913,12 @@ def qproj_attention(a: torch.Tensor, w: torch.Tensor, k: torch.Tensor, v: torch.
         parts, ln_dim = stats_in.shape[1], K
     out = torch.empty(b + dup, nq, N, dtype=torch.bfloat16, device=a.device)
     flops = 2.0 * M * N * K + 4.0 * (M + dup * nq) * nk * N
+    if fp8 is not None:
+        with _timed(tag, flops, 2.0 * (M * K + N * K + M * N) + 2.0 * b * nk * N):
+            check(_lib.load().cd360_qproj_attn_fp8_bf16(_ptr(a), _ptr(w), _ptr(out), M, N, K, lda, w.stride(0), N, _ptr(bias), _ptr(stats_in), parts,
+                                                       ln_dim, float(eps), _ptr(wsum), _ptr(fp8[0]), _ptr(fp8[1]), nq, nk, 64 ** -0.5, dup,
+                                                       _stream()), "cd360_qproj_attn_fp8_bf16")
+        return out
     with _timed(tag, flops, 2.0 * (M * K + N * K + M * N + 2 * b * nk * N)):  # per-kernel timing name: A3 "qproj_attn", A2 "qproj_attn_text"
         check(_lib.load().cd360_qproj_attn_dedup_bf16(_ptr(a), _ptr(w), _ptr(out), M, N, K, lda, w.stride(0), N, _ptr(bias), _ptr(stats_in), parts,
                                                      ln_dim, float(eps), _ptr(wsum), _ptr(k), _ptr(v), k.stride(0), k.stride(1), v.stride(0),

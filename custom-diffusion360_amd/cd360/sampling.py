@@ -50,6 +50,7 @@ def enable_reference_sampling(model: torch.nn.Module, choices: Iterable[int], ca
     for att in _cross_attentions(model):
         att.cache_context_kv = bool(cache_context)
         att._kv_cache = None
+        att._kv8_cache = None
     return names
 
 
@@ -60,6 +61,7 @@ def disable_reference_sampling(model: torch.nn.Module) -> None:
     for att in _cross_attentions(model):
         att.cache_context_kv = False
         att._kv_cache = None
+        att._kv8_cache = None
 
 
 def clear_rendered_feat(model: torch.nn.Module) -> None:
@@ -71,3 +73,4 @@ def clear_rendered_feat(model: torch.nn.Module) -> None:
             blk._rendered_proj = None  # rendered_feat @ Wb^T kept beside the cached render
     for att in _cross_attentions(model):
         att._kv_cache = None
+        att._kv8_cache = None

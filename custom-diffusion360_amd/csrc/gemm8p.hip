@@ -53,6 +53,12 @@ struct GemmParams {
   long ak_sb, ak_sn, av_sb, av_sn;
   int a_nq, a_nk;      // queries per batch element (M = B * a_nq, a_nq % 256 == 0), keys
   float a_scale_log2e;
+  // EPI 10 (BASELINE configs[4]): the two attention contractions on fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, unit block scales) --
+  // a_kv8 = the packed e4m3 image of K and V^T per (batch, head) (cd360_kv_pack_fp8: 14336 bytes each), a_kvs [B, heads, 2] fp32 =
+  // the (K, V) tensor scales of that head; ak / av unused
+  const unsigned char* a_kv8;
+  const float* a_kvs;
+  int a_heads;
   int a_dup_from, a_dup;  // query batch elements >= a_dup_from attend to TWO key / value sets (batch i and i + a_dup; output rows of
                           // batch i and i + a_dup): the de-duplicated CFG branch, whose q is projected once
   int abl;  // what-if timing knob (cd360_tuning.whatif, -DCD360_WHATIF probe builds only; results are wrong when set): 8 no DMA wait,
@@ -118,14 +124,16 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   constexpr int NWC = NWT * KS;                    // waves that multiply
   constexpr int NW = NWC + MV;                     // waves
   constexpr int NWD = MV ? MV : NW;                // waves that move data
-  static_assert(MV == 0 || (EPI >= 0 && EPI <= 9), "mover waves: every epilogue (in the attention epilogues they also fetch K / V)");
+  static_assert(MV == 0 || (EPI >= 0 && EPI <= 10), "mover waves: every epilogue (in the attention epilogues they also fetch K / V)");
   constexpr int KPW = 4 / KS;                      // k-steps of a K-tile that one wave multiplies
   constexpr int BM = WM * NMB * 32, BN = WN * NCB * 32;
   constexpr uint32_t XB = BM * 128, WB = BN * 128;  // bytes of one buffer of each operand (64-deep K-tile, 128-byte rows)
   // epilogue: 0 linear, 1 GEGLU, 2 / 3 / 4 small-Nk attention on the projected tile with 2 / 4 / 6 groups of 16 keys, 7 / 8 / 9 the same
   // with 5 / 3 / 1 groups (the last 32-key block of scores is half used: 77 text keys are 5 groups, not 6)
   // EPI 6 = linear epilogue + the per-slab channel statistics of EPI 5 (a Linear whose output feeds a GroupNorm: SpatialTransformer.proj_out)
-  constexpr bool GEGLU = EPI == 1, ATTN = (EPI >= 2 && EPI <= 4) || (EPI >= 7 && EPI <= 9), CONV = EPI == 5, CSTATS = EPI == 5 || EPI == 6;
+  // 10 = the 6-group attention epilogue with both contractions on fp8 MFMA (K / V pre-packed by cd360_kv_pack_fp8)
+  constexpr bool F8 = EPI == 10;
+  constexpr bool GEGLU = EPI == 1, ATTN = (EPI >= 2 && EPI <= 4) || (EPI >= 7 && EPI <= 10), CONV = EPI == 5, CSTATS = EPI == 5 || EPI == 6;
   // LDS map: NBUF token buffers, then NBUF channel buffers.  The attention epilogues interleave them instead (buffer b = tokens, then
   // channels, at b * (XB + WB)) and rotate the ring so that the LAST K-tile sits in buffer 0: everything behind buffer 0 is then free
   // one tile before the loop ends, and the K / V rows of the tile's heads are fetched into it under the last K-tile's MFMAs.
@@ -278,8 +286,9 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   // Per head KROWS rows of K then KROWS rows of V, 128 bytes each (K with the 16-byte XOR swizzle of its fragment reads, V with the 32-byte
   // one of the transposing reads, both applied on the per-lane SOURCE address), starting at the second ring buffer.  Rows >= Nk lie past
   // the end of the buffer descriptor and arrive as zeros.  A piece is 8 rows (1 KiB); the moving waves take pieces round-robin.
-  constexpr int NK16 = EPI == 2 ? 2 : EPI == 3 ? 4 : EPI == 4 ? 6 : EPI == 7 ? 5 : EPI == 8 ? 3 : 1;
-  constexpr int NKB = (NK16 + 1) / 2, KROWS = NK16 * 16, HEAD_LDS = 2 * KROWS * 128;
+  constexpr int NK16 = (EPI == 4 || EPI == 10) ? 6 : EPI == 2 ? 2 : EPI == 3 ? 4 : EPI == 7 ? 5 : EPI == 8 ? 3 : 1;
+  constexpr int F8_HEAD = 96 * 64 + 64 * 128;  // fp8: 96 key rows of 64 bytes, then V^T as 64 channel rows of 128 key slots
+  constexpr int NKB = (NK16 + 1) / 2, KROWS = NK16 * 16, HEAD_LDS = F8 ? F8_HEAD : 2 * KROWS * 128;
   constexpr bool HALF = (NK16 & 1) != 0;  // the last 32-key block of scores is used in its first 16 keys only
   constexpr uint32_t KVBASE = BB;
   // the tile's slices of bias and wsum (BN floats each) travel with K / V when the LDS has the 2 KiB left: the LayerNorm fold then
@@ -289,7 +298,17 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   static_assert(!ATTN || (NWC * 4096 <= (int)BB), "attention epilogue: the waves' output blocks alias ring buffer 0");
   const int a_bidx = ATTN ? (int)(m0 / p.a_nq) : 0;  // batch element of this token tile
   auto kv_issue = [&](int kvb) {
-    if constexpr (ATTN) {
+    if constexpr (F8) {  // the packed image is copied as it lies: 14 pieces per head; heads past the last one are out of range (zeros)
+      const int h0 = n0 >> 6, nh = p.a_heads - h0 < WN ? p.a_heads - h0 : WN;
+      const __amdgpu_buffer_rsrc_t rs =
+          __builtin_amdgcn_make_buffer_rsrc((void*)(p.a_kv8 + ((long)kvb * p.a_heads + h0) * F8_HEAD), 0, nh * F8_HEAD, 0x00020000);
+      constexpr int NPKV = WN * (F8_HEAD / 1024);
+#pragma unroll
+      for (int i = 0; i < (NPKV + NWD - 1) / NWD; ++i) {
+        const int q = i * NWD + dwave;
+        if (q < NPKV) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds3 + (KVBASE + q * 1024), 16, (uint32_t)(q * 1024 + lane * 16), 0, 0, 0);
+      }
+    } else if constexpr (ATTN) {
       const int kbytes = (int)((((long)p.a_nk - 1) * p.ak_sn + p.N) * 2), vbytes = (int)((((long)p.a_nk - 1) * p.av_sn + p.N) * 2);
       const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.ak + (long)kvb * p.ak_sb), 0, kbytes, 0x00020000);
       const __amdgpu_buffer_rsrc_t vrs = __builtin_amdgcn_make_buffer_rsrc((void*)(p.av + (long)kvb * p.av_sb), 0, vbytes, 0x00020000);
@@ -670,8 +689,17 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
     if constexpr (ATTN) {
       static_assert(!ATTN || NCB == 2, "one head (64 channels) per wave; any number of 32-token blocks and of heads per tile");
       unsigned char* const Ks = lds + KVBASE + wc * HEAD_LDS;
-      unsigned char* const Vs = Ks + KROWS * 128;
+      unsigned char* const Vs = Ks + (F8 ? 96 * 64 : KROWS * 128);
       unsigned char* const Os = lds + wave * (32 * 128);  // this wave's 32-token output block (ring buffer 0 is idle now)
+      typedef __attribute__((ext_vector_type(8))) int i32x8;
+      // fp8 form: the LayerNorm-folded q stays fp32 in the accumulator registers until every channel of the token has been seen (the
+      // e4m3 scale is per token: max |q| over its 64 channels / 448), then becomes ONE B operand of the K = 64 MFMA per 32-token block
+      i32x8 q8[F8 ? NMB : 1];
+      float qs[F8 ? NMB : 1], qmax[F8 ? NMB : 1];
+      if constexpr (F8) {
+#pragma unroll
+        for (int mb = 0; mb < NMB; ++mb) qmax[mb] = 0.f;
+      }
       // LayerNorm fold + bias, pack to B fragments (has_ch waves only; the others hold zeros and are skipped below):
       // q = rstd (acc - mu wsum) + bias = acc * rstd + (bias - rstd mu wsum)
       bf16x8 qf[NMB][4];
@@ -712,9 +740,33 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
             for (int e = 0; e < 4; ++e) {
               const float t0 = fmaf(acc[nb][mb][8 * c8 + 2 * e], a_c1[mb], fmaf(a_c2[mb], sv[2 * e], bv[2 * e]));
               const float t1 = fmaf(acc[nb][mb][8 * c8 + 2 * e + 1], a_c1[mb], fmaf(a_c2[mb], sv[2 * e + 1], bv[2 * e + 1]));
-              o[e] = pack_bf16x2(t0, t1);
+              if constexpr (F8) {
+                acc[nb][mb][8 * c8 + 2 * e] = t0;
+                acc[nb][mb][8 * c8 + 2 * e + 1] = t1;
+                qmax[mb] = fmaxf(qmax[mb], fmaxf(fabsf(t0), fabsf(t1)));
+              } else {
+                o[e] = pack_bf16x2(t0, t1);
+              }
             }
-            qf[mb][j] = __builtin_bit_cast(bf16x8, o);
+            if constexpr (!F8) qf[mb][j] = __builtin_bit_cast(bf16x8, o);
+          }
+        }
+        if constexpr (F8) {
+          // B operand of v_mfma_scale_f32_32x32x64_f8f6f4: lane (token, hh) supplies k-slots 32 hh + e, e = 0 .. 31 -- here channel
+          // 16 hh + e (e < 16) or 32 + 16 hh + (e - 16): the order the accumulator holds them; cd360_kv_pack_fp8 lays K out the same way
+#pragma unroll
+          for (int mb = 0; mb < NMB; ++mb) {
+            float am = fmaxf(qmax[mb], __shfl_xor(qmax[mb], 32));
+            am = fmaxf(am, 1e-20f);
+            qs[mb] = am * (1.f / 448.f);
+            const float inv = 448.f * __builtin_amdgcn_rcpf(am);
+#pragma unroll
+            for (int jd = 0; jd < 8; ++jd) {
+              const int nb = jd >> 2, r0 = 4 * (jd & 3);
+              int w8 = __builtin_amdgcn_cvt_pk_fp8_f32(acc[nb][mb][r0] * inv, acc[nb][mb][r0 + 1] * inv, 0, false);
+              w8 = __builtin_amdgcn_cvt_pk_fp8_f32(acc[nb][mb][r0 + 2] * inv, acc[nb][mb][r0 + 3] * inv, w8, true);
+              q8[mb][jd] = w8;
+            }
           }
         }
       }
@@ -733,6 +785,21 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
       for (int r = 0; r < 16; ++r) init_last[r] = ((NKB - 1) * 32 + (r & 3) + 8 * (r >> 2) + 4 * hh < p.a_nk) ? 0.f : -1e30f;
       const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       const float c = p.a_scale_log2e;
+      float ksc = 1.f, vsc = 1.f;  // fp8: the head's K and V tensor scales (amax / 448, cd360_kv_pack_fp8)
+      int koff8[2], voff8[2][2];
+      if constexpr (F8) {
+        const float* sc = p.a_kvs + ((long)(a_bidx + rep * p.a_dup) * p.a_heads + (n0 >> 6) + wc) * 2;
+        ksc = sc[0];
+        vsc = sc[1];
+        // K row = 64 bytes (four 16-byte chunks, chunk ^ ((row >> 2) & 3)): the lane's 32 bytes are chunks 2 hh, 2 hh + 1;
+        // V^T row = 128 bytes (eight chunks, chunk ^ ((row >> 1) & 7)): chunks 4 m + 2 hh, + 1 for the m-th 64-key MFMA
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          koff8[u] = l31 * 64 + (((2 * hh + u) ^ ((l31 >> 2) & 3)) << 4);
+#pragma unroll
+          for (int m = 0; m < 2; ++m) voff8[m][u] = l31 * 128 + (((4 * m + 2 * hh + u) ^ ((l31 >> 1) & 7)) << 4);
+        }
+      }
       // per-lane offsets: K fragment of k-step j = chunk 4 (j >> 1) + 2 hh + (j & 1) of row kb * 32 + l31 (16-B XOR swizzle; the rows
       // 16 .. 31 of a half-used last block are the head's first V rows: finite values whose scores nobody reads);
       // V^T fragments as attn_fwd.hip's v_frag_offset / v_frag (32-B swizzle, transposing reads)
@@ -753,6 +820,51 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
       for (int mb = 0; mb < NMB; ++mb) {
         FENCE();
         f32x16 sT[NKB];
+        f32x16 oT[2];
+        float inv;
+        if constexpr (F8) {
+          static_assert(!F8 || NKB == 3, "fp8 epilogue: 96 key slots");
+#pragma unroll
+          for (int kb = 0; kb < 3; ++kb) {
+            const u32x4 lo = *reinterpret_cast<const u32x4*>(Ks + kb * 2048 + koff8[0]), hi = *reinterpret_cast<const u32x4*>(Ks + kb * 2048 + koff8[1]);
+            const i32x8 kf = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+            sT[kb] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(kf, q8[mb], kb == 2 ? init_last : zero, 0, 0, 0, 0x7f, 0, 0x7f);
+          }
+          float mx = sT[0][0];
+#pragma unroll
+          for (int kb = 0; kb < 3; ++kb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sT[kb][r]);
+          mx = fmaxf(mx, __shfl_xor(mx, 32));
+          // scores = raw * (q scale of the token * K scale of the head); P leaves as p * 2^8 (e4m3 keeps three mantissa bits down to 2^-6:
+          // the shift puts the probabilities that matter there) -- the row sum carries the same factor, so O / sum is unchanged
+          const float cs = c * qs[mb] * ksc;
+          const float mc = fmaf(-mx, cs, 8.f);
+          float rsum_p = 0.f;
+          i32x8 pb[2];
+#pragma unroll
+          for (int jd = 0; jd < 12; ++jd) {
+            const int kb = jd >> 2, r0 = 4 * (jd & 3);
+            const float p0 = __builtin_amdgcn_exp2f(fmaf(sT[kb][r0], cs, mc)), p1 = __builtin_amdgcn_exp2f(fmaf(sT[kb][r0 + 1], cs, mc));
+            const float p2 = __builtin_amdgcn_exp2f(fmaf(sT[kb][r0 + 2], cs, mc)), p3 = __builtin_amdgcn_exp2f(fmaf(sT[kb][r0 + 3], cs, mc));
+            rsum_p += (p0 + p1) + (p2 + p3);
+            int w8 = __builtin_amdgcn_cvt_pk_fp8_f32(p0, p1, 0, false);
+            w8 = __builtin_amdgcn_cvt_pk_fp8_f32(p2, p3, w8, true);
+            pb[jd >> 3][jd & 7] = w8;
+          }
+#pragma unroll
+          for (int jd = 4; jd < 8; ++jd) pb[1][jd] = 0;  // key slots 96 .. 127 of the second 64-key MFMA
+          rsum_p += __shfl_xor(rsum_p, 32);
+#pragma unroll
+          for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int db = 0; db < 2; ++db) {
+              const u32x4 lo = *reinterpret_cast<const u32x4*>(Vs + db * 4096 + voff8[m][0]), hi = *reinterpret_cast<const u32x4*>(Vs + db * 4096 + voff8[m][1]);
+              const i32x8 vf = {(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+              oT[db] = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(vf, pb[m], m == 0 ? zero : oT[db], 0, 0, 0, 0x7f, 0, 0x7f);
+            }
+          inv = __builtin_amdgcn_rcpf(rsum_p) * vsc;
+        } else {
 #pragma unroll
         for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
@@ -778,7 +890,6 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
             pk[kb * 8 + (r >> 1)] = pack_bf16x2(p0, p1);
           }
         rsum_p += __shfl_xor(rsum_p, 32);
-        f32x16 oT[2];
 #pragma unroll
         for (int kk = 0; kk < NK16; ++kk) {
           const u32x4 pw = {pk[kk * 4 + 0], pk[kk * 4 + 1], pk[kk * 4 + 2], pk[kk * 4 + 3]};
@@ -790,8 +901,9 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
             oT[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, vfr), __builtin_bit_cast(bf16x8, pw), kk == 0 ? zero : oT[db], 0, 0, 0);
           }
         }
+        inv = __builtin_amdgcn_rcpf(rsum_p);
+        }
         // O^T registers (lane = token, 4 consecutive channels per group) -> this wave's LDS block -> full 128-byte rows
-        const float inv = __builtin_amdgcn_rcpf(rsum_p);
 #pragma unroll
         for (int db = 0; db < 2; ++db)
 #pragma unroll
@@ -983,9 +1095,9 @@ int launch_mv(const GemmParams& p0, hipStream_t stream) {
   // K-loop buffers, reused as the output staging image (+ the fp32 partial tile of the second k-step group)
   // (the attention epilogues keep the K / V rows of the tile's WN heads, 2 x NK16 x 16 rows of 128 bytes each, behind ring buffer 0; the
   // waves' 4-KB output blocks alias buffer 0 and the projected tile never leaves the registers)
-  constexpr bool ATTN = (EPI >= 2 && EPI <= 4) || (EPI >= 7 && EPI <= 9);
-  constexpr int NK16 = EPI == 2 ? 2 : EPI == 3 ? 4 : EPI == 4 ? 6 : EPI == 7 ? 5 : EPI == 8 ? 3 : 1;
-  constexpr int ATTN_KV_END = (BM + BN) * 128 + WN * 2 * NK16 * 16 * 128;
+  constexpr bool ATTN = (EPI >= 2 && EPI <= 4) || (EPI >= 7 && EPI <= 10);
+  constexpr int NK16 = (EPI == 4 || EPI == 10) ? 6 : EPI == 2 ? 2 : EPI == 3 ? 4 : EPI == 7 ? 5 : EPI == 8 ? 3 : 1;
+  constexpr int ATTN_KV_END = (BM + BN) * 128 + WN * (EPI == 10 ? 96 * 64 + 64 * 128 : 2 * NK16 * 16 * 128);  // (EPI 10: the packed fp8 image)
   constexpr int ATTN_BYTES = ATTN ? ATTN_KV_END + ((BN * 4 <= 1024 && ATTN_KV_END + 2048 <= 160 * 1024) ? 2048 : 0) : 0;  // + bias / wsum slices (BW_LDS)
   constexpr int RING_BYTES = NBUF * (BM + BN) * 128, STAGE_BYTES0 = ATTN ? 0 : BM * BN * 2 + (KS == 2 ? BM * BN * 4 : 0);
   constexpr int STAGE_BYTES = STAGE_BYTES0 > ATTN_BYTES ? STAGE_BYTES0 : ATTN_BYTES;
@@ -1147,7 +1259,7 @@ extern "C" int cd360_gemm_bf16(const void* a, const void* w, void* out, int64_t 
   p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.ldr = res ? ldr : 0;
   p.M = (int)M; p.N = N; p.K = K; p.ln_parts = ln_parts; p.ln_dim = ln_dim; p.ln_eps = ln_eps; p.geglu = geglu ? 1 : 0;
   p.tiles_m = p.tiles_n = p.group_m = 0;
-  p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f; p.a_dup = p.a_dup_from = 0;
+  p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f; p.a_dup = p.a_dup_from = 0; p.a_kv8 = nullptr; p.a_kvs = nullptr; p.a_heads = 0;
   p.cv_H = p.cv_W = p.cv_kg = p.cv_up = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = nullptr;
   int cfg = pick_cfg(M, N, geglu);
   // narrow outputs of 257 .. 512 tiles with a long K loop: 256 x 128 tiles with three buffers instead of two 128 x 128 workgroups per CU
@@ -1184,7 +1296,7 @@ extern "C" int cd360_gemm_cstats_bf16(const void* a, const void* w, void* out, i
   p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.ldr = res ? ldr : 0;
   p.M = (int)M; p.N = N; p.K = K; p.ln_parts = 0; p.ln_dim = 0; p.ln_eps = 0.f; p.geglu = 0;
   p.tiles_m = p.tiles_n = p.group_m = 0;
-  p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f; p.a_dup = p.a_dup_from = 0;
+  p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f; p.a_dup = p.a_dup_from = 0; p.a_kv8 = nullptr; p.a_kvs = nullptr; p.a_heads = 0;
   p.cv_H = p.cv_W = p.cv_kg = p.cv_up = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = (float*)cstats;
   if (cfg == 8) return launch_64x4<6>(p, (hipStream_t)stream);
   return cfg == 2 ? launch_epi<2, 4, 1, 2, 2, 6>(p, (hipStream_t)stream) : launch_128x4<6>(p, (hipStream_t)stream);
@@ -1192,26 +1304,31 @@ extern "C" int cd360_gemm_cstats_bf16(const void* a, const void* w, void* out, i
 
 namespace {
 // tile dispatch of the fused query projection + attention (qcfg as cd360_tuning.qattn_cfg); the key count picks the epilogue: 2 / 4 / 6
-// groups of 16 keys (EPI 2 / 3 / 4), or five (EPI 7: 65 .. 80 keys -- SDXL's 77 text tokens) unless cd360_tuning.qattn_keys16 = 0
+// groups of 16 keys (EPI 2 / 3 / 4), or five (EPI 7: 65 .. 80 keys -- SDXL's 77 text tokens) unless cd360_tuning.qattn_keys16 = 0;
+// a packed fp8 K / V image (p.a_kv8, cd360_qproj_attn_fp8_bf16) selects the fp8-MFMA epilogue (EPI 10, 96 key slots)
 int qattn_launch(const GemmParams& p, int qcfg, int Nk, bool keys16, hipStream_t stream) {
   if (qcfg == 3) {  // 128 x 128, four waves of 64 x 64, two buffers: two workgroups per CU (one's attention epilogue under the other's K loop)
+    if (p.a_kv8) return launch_epi<2, 2, 2, 2, 2, 10>(p, stream);
     if (Nk <= 32) return launch_epi<2, 2, 2, 2, 2, 2>(p, stream);
     if (Nk <= 64) return launch_epi<2, 2, 2, 2, 2, 3>(p, stream);
     if (Nk <= 80 && keys16) return launch_epi<2, 2, 2, 2, 2, 7>(p, stream);
     return launch_epi<2, 2, 2, 2, 2, 4>(p, stream);
   }
   if (qcfg == 4) {  // 256 x 128, eight waves of 64 x 64, two buffers (96 KB: one workgroup per CU, half the K-loop operand bytes per flop of 128 x 128)
+    if (p.a_kv8) return launch_epi<4, 2, 2, 2, 2, 10>(p, stream);
     if (Nk <= 32) return launch_epi<4, 2, 2, 2, 2, 2>(p, stream);
     if (Nk <= 64) return launch_epi<4, 2, 2, 2, 2, 3>(p, stream);
     if (Nk <= 80 && keys16) return launch_epi<4, 2, 2, 2, 2, 7>(p, stream);
     return launch_epi<4, 2, 2, 2, 2, 4>(p, stream);
   }
   if (qcfg == 2) {
+    if (p.a_kv8) return launch_epi<4, 2, 2, 1, 4, 10>(p, stream);
     if (Nk <= 32) return launch_epi<4, 2, 2, 1, 4, 2>(p, stream);
     if (Nk <= 64) return launch_epi<4, 2, 2, 1, 4, 3>(p, stream);
     if (Nk <= 80 && keys16) return launch_epi<4, 2, 2, 1, 4, 7>(p, stream);
     return launch_epi<4, 2, 2, 1, 4, 4>(p, stream);
   }
+  if (p.a_kv8) return launch_epi<2, 4, 2, 4, 2, 10>(p, stream);
   if (Nk <= 32) return launch_epi<2, 4, 2, 4, 2, 2>(p, stream);
   if (Nk <= 64) return launch_epi<2, 4, 2, 4, 2, 3>(p, stream);
   if (Nk <= 80 && keys16) return launch_epi<2, 4, 2, 4, 2, 7>(p, stream);
@@ -1256,7 +1373,7 @@ extern "C" int cd360_qproj_attn_dedup_bf16(const void* a, const void* w, void* o
   p.tiles_m = p.tiles_n = p.group_m = 0;
   p.ak = (const uint16_t*)k; p.av = (const uint16_t*)v; p.ak_sb = k_sb; p.ak_sn = k_sn; p.av_sb = v_sb; p.av_sn = v_sn;
   p.a_nq = Nq; p.a_nk = Nk; p.a_scale_log2e = scale * 1.4426950408889634f;
-  p.a_dup = dup; p.a_dup_from = (int)(M / Nq) - dup;
+  p.a_dup = dup; p.a_dup_from = (int)(M / Nq) - dup; p.a_kv8 = nullptr; p.a_kvs = nullptr; p.a_heads = N / 64;
   p.cv_H = p.cv_W = p.cv_kg = p.cv_up = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = nullptr;
   const bool keys16 = cd360_tune().qattn_keys16 != 0;
   // A width that is 128 short of a multiple of 256 (SDXL's 640 = 2.5 tiles) leaves half of the last 256-column tile's waves without
@@ -1277,6 +1394,118 @@ extern "C" int cd360_qproj_attn_dedup_bf16(const void* a, const void* w, void* o
     return qattn_launch(p2, 4, Nk, keys16, (hipStream_t)stream);
   }
   return qattn_launch(p, qcfg, Nk, keys16, (hipStream_t)stream);
+}
+
+// ---- BASELINE configs[4]: the fused cross-attention with its two contractions (q K^T and P V) on fp8 MFMA --------------------------
+// K and V of a cross-attention over <= 96 keys are constant for a whole trajectory (the text context), so they are quantised ONCE per
+// image by cd360_kv_pack_fp8 into the image the kernel's LDS wants (OCP e4m3, one scale per tensor and head = amax / 448):
+//   per (batch, head) 14336 bytes = K as 96 key rows of 64 bytes (rows >= Nk zero; byte 32 hh + e of a row = channel 16 hh + e for
+//   e < 16, 32 + 16 hh + (e - 16) otherwise -- the order in which a lane of the projection's accumulator holds its 32 channels, i.e. the
+//   k-slot order of the B operand; 16-byte chunks XOR (row >> 2) & 3) followed by V^T as 64 channel rows of 128 key slots (slot
+//   64 m + 32 hh + e of row d = V[key][d] with key = 32 (2 m + (e >> 4)) + (e & 3) + 8 ((e & 15) >> 2) + 4 hh, the key a lane's score
+//   register holds; keys >= Nk zero; chunks XOR (d >> 1) & 7): both are the A operands of v_mfma_scale_f32_32x32x64_f8f6f4 read with
+//   two conflict-free ds_read_b128 per fragment, and the LDS-DMA copies the image as it lies.
+// In the kernel (EPI 10) the projected q is scaled per TOKEN (max |q| over the 64 channels of the head / 448), P is written as
+// p * 2^8, and the scales are applied to the fp32 scores / outputs -- see attn_tile.  Same envelope as cd360_qproj_attn_dedup_bf16.
+namespace {
+__global__ __launch_bounds__(256) void kv_pack_fp8_kernel(const uint16_t* __restrict__ k, const uint16_t* __restrict__ v, unsigned char* __restrict__ kv8,
+                                                          float* __restrict__ scales, int H, int Nk, long k_sb, long k_sn, long v_sb, long v_sn) {
+  const int b = blockIdx.x / H, h = blockIdx.x % H, tid = threadIdx.x;
+  const uint16_t* kb = k + b * k_sb + h * 64;
+  const uint16_t* vb = v + b * v_sb + h * 64;
+  __shared__ float red[2][4];
+  float ak = 0.f, av = 0.f;
+  for (int i = tid; i < Nk * 64; i += 256) {
+    const int key = i >> 6, c = i & 63;
+    ak = fmaxf(ak, fabsf(bf16_to_f32(kb[key * k_sn + c])));
+    av = fmaxf(av, fabsf(bf16_to_f32(vb[key * v_sn + c])));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ak = fmaxf(ak, __shfl_xor(ak, o));
+    av = fmaxf(av, __shfl_xor(av, o));
+  }
+  if ((tid & 63) == 0) {
+    red[0][tid >> 6] = ak;
+    red[1][tid >> 6] = av;
+  }
+  __syncthreads();
+  ak = fmaxf(fmaxf(red[0][0], red[0][1]), fmaxf(red[0][2], red[0][3]));
+  av = fmaxf(fmaxf(red[1][0], red[1][1]), fmaxf(red[1][2], red[1][3]));
+  const float sk = ak > 0.f ? ak / 448.f : 1.f, sv = av > 0.f ? av / 448.f : 1.f;
+  const float ik = 1.f / sk, iv = 1.f / sv;
+  if (tid == 0) {
+    scales[(long)blockIdx.x * 2] = sk;
+    scales[(long)blockIdx.x * 2 + 1] = sv;
+  }
+  uint32_t* out = reinterpret_cast<uint32_t*>(kv8 + (long)blockIdx.x * (96 * 64 + 64 * 128));
+  for (int dw = tid; dw < 96 * 16; dw += 256) {  // K: physical dword dw of the image
+    const int row = dw >> 4, pd = dw & 15, lc = (pd >> 2) ^ ((row >> 2) & 3);
+    float x[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int pos = lc * 16 + (pd & 3) * 4 + t, hh = pos >> 5, e = pos & 31;
+      const int c = e < 16 ? 16 * hh + e : 32 + 16 * hh + (e - 16);
+      x[t] = row < Nk ? bf16_to_f32(kb[row * k_sn + c]) * ik : 0.f;
+    }
+    int w8 = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], 0, false);
+    out[dw] = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(x[2], x[3], w8, true);
+  }
+  for (int dw = tid; dw < 64 * 32; dw += 256) {  // V^T
+    const int d = dw >> 5, pd = dw & 31, lc = (pd >> 2) ^ ((d >> 1) & 7);
+    float x[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int pos = lc * 16 + (pd & 3) * 4 + t, m = pos >> 6, hh = (pos >> 5) & 1, e = pos & 31;
+      const int key = 32 * (2 * m + (e >> 4)) + (e & 3) + 8 * ((e & 15) >> 2) + 4 * hh;
+      x[t] = key < Nk ? bf16_to_f32(vb[key * v_sn + d]) * iv : 0.f;
+    }
+    int w8 = __builtin_amdgcn_cvt_pk_fp8_f32(x[0], x[1], 0, false);
+    out[96 * 16 + dw] = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(x[2], x[3], w8, true);
+  }
+}
+}  // namespace
+
+extern "C" int64_t cd360_kv_fp8_bytes(int B, int H) { return (int64_t)B * H * (96 * 64 + 64 * 128); }
+
+// k, v bf16 [B, >= Nk, H * 64] (element strides k_sb / k_sn, v_sb / v_sn) -> kv8 (cd360_kv_fp8_bytes(B, H) bytes, 16-byte aligned),
+// scales fp32 [B, H, 2] = (K scale, V scale) per head; Nk <= 96
+extern "C" int cd360_kv_pack_fp8(const void* k, const void* v, void* kv8, void* scales, int B, int H, int Nk, int64_t k_sb, int64_t k_sn,
+                                 int64_t v_sb, int64_t v_sn, void* stream) {
+  if (!k || !v || !kv8 || !scales || B <= 0 || H <= 0 || Nk <= 0) return CD360_ERR_ARG;
+  if (Nk > 96 || (uintptr_t)kv8 % 16 || (uintptr_t)scales % 4) return CD360_ERR_SHAPE;
+  hipLaunchKernelGGL(kv_pack_fp8_kernel, dim3((unsigned)(B * H)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)k, (const uint16_t*)v,
+                     (unsigned char*)kv8, (float*)scales, H, Nk, (long)k_sb, (long)k_sn, (long)v_sb, (long)v_sn);
+  CD360_LAUNCH_CHECK();
+  return CD360_OK;
+}
+
+// cd360_qproj_attn_dedup_bf16 with K / V given as the packed fp8 image of cd360_kv_pack_fp8 (kv8, scales: B + dup batch elements,
+// N / 64 heads): out[M, N] = softmax_keys(q K_h^T * scale) V_h with both contractions on fp8 MFMA, fp32 accumulation, bf16 output.
+extern "C" int cd360_qproj_attn_fp8_bf16(const void* a, const void* w, void* out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldo,
+                                         const void* bias, const void* ln_stats, int ln_parts, int ln_dim, float ln_eps, const void* wsum,
+                                         const void* kv8, const void* scales, int Nq, int Nk, float scale, int dup, void* stream) {
+  if (!a || !w || !out || !kv8 || !scales || M <= 0 || N <= 0 || K <= 0 || Nq <= 0 || Nk <= 0 || dup < 0 || (int64_t)dup * Nq > M) return CD360_ERR_ARG;
+  if (K % 64 || N % 64 || lda % 8 || ldw % 8 || ldo % 8 || lda < K || ldw < K || Nk > 96 || Nq % 128 || M % Nq) return CD360_ERR_SHAPE;
+  if (Nk <= 64) return CD360_ERR_SHAPE;  // the fp8 epilogue masks the padding keys of its LAST 32-key block only: 65 .. 96 keys (SDXL: 77)
+  int qcfg = cd360_tune().qattn_cfg;
+  if (qcfg < 1 || qcfg > 4) qcfg = (M / 256) * ((N + 255) / 256) >= 200 ? 1 : ((M / 256) * ((N + 127) / 128) >= 200 ? 4 : 2);
+  if (Nq % 256 && (qcfg == 1 || qcfg == 4)) qcfg = 2;
+  if (((uintptr_t)a | (uintptr_t)w | (uintptr_t)out | (uintptr_t)kv8) % 16 || (uintptr_t)scales % 4) return CD360_ERR_ARG;
+  if (((uintptr_t)bias | (uintptr_t)ln_stats | (uintptr_t)wsum) % 8) return CD360_ERR_ARG;
+  if (M > 0x7fffffffL || (M + 256) * lda * 2 >= (1L << 32) || ((long)N + 256) * ldw * 2 >= (1L << 32)) return CD360_ERR_SHAPE;
+  if (ln_stats && (!wsum || ln_parts <= 0 || ln_dim <= 0)) return CD360_ERR_ARG;
+  GemmParams p;
+  p.a = (const uint16_t*)a; p.w = (const uint16_t*)w; p.out = (uint16_t*)out; p.bias = (const float*)bias; p.res = nullptr;
+  p.ln_stats = (const float*)ln_stats; p.wsum = (const float*)wsum; p.stats_out = nullptr;
+  p.lda = lda; p.ldw = ldw; p.ldo = ldo; p.ldr = 0;
+  p.M = (int)M; p.N = N; p.K = K; p.ln_parts = ln_parts; p.ln_dim = ln_dim; p.ln_eps = ln_eps; p.geglu = 0;
+  p.tiles_m = p.tiles_n = p.group_m = 0;
+  p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0;
+  p.a_nq = Nq; p.a_nk = Nk; p.a_scale_log2e = scale * 1.4426950408889634f;
+  p.a_dup = dup; p.a_dup_from = (int)(M / Nq) - dup; p.a_kv8 = (const unsigned char*)kv8; p.a_kvs = (const float*)scales; p.a_heads = N / 64;
+  p.cv_H = p.cv_W = p.cv_kg = p.cv_up = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = nullptr;
+  return qattn_launch(p, qcfg, Nk, true, (hipStream_t)stream);
 }
 
 extern "C" int cd360_qproj_attn_bf16(const void* a, const void* w, void* out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldo,
@@ -1346,7 +1575,7 @@ extern "C" int cd360_conv3x3_dma_bf16(const void* x, const void* w_packed, const
   p.lda = Cin; p.ldw = 9L * Cin; p.ldo = Cout; p.ldr = res ? Cout : 0;
   p.M = (int)M; p.N = Cout; p.K = 9 * Cin; p.ln_parts = 0; p.ln_dim = 0; p.ln_eps = 0.f; p.geglu = 0;
   p.tiles_m = p.tiles_n = p.group_m = 0;
-  p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f; p.a_dup = p.a_dup_from = 0;
+  p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f; p.a_dup = p.a_dup_from = 0; p.a_kv8 = nullptr; p.a_kvs = nullptr; p.a_heads = 0;
   p.cv_H = H; p.cv_W = W; p.cv_kg = cd360_conv_k_order(Cin, 9); p.cv_up = 0;
   p.emb = (const uint16_t*)emb; p.emb_stride = emb ? emb_stride : 0; p.cstats = (float*)tile_stats;
   switch (cfg) {
@@ -1376,7 +1605,7 @@ extern "C" int cd360_conv_up2x_bf16(const void* x, const void* w_phases, const v
   p.lda = Cin; p.ldw = 4L * Cin; p.ldo = Cout; p.ldr = 0;
   p.M = (int)M; p.N = Cout; p.K = 4 * Cin; p.ln_parts = 0; p.ln_dim = 0; p.ln_eps = 0.f; p.geglu = 0;
   p.tiles_m = p.tiles_n = p.group_m = 0;
-  p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f; p.a_dup = p.a_dup_from = 0;
+  p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f; p.a_dup = p.a_dup_from = 0; p.a_kv8 = nullptr; p.a_kvs = nullptr; p.a_heads = 0;
   p.cv_H = H; p.cv_W = W; p.cv_kg = cd360_conv_k_order(Cin, 9); p.cv_up = 1;
   p.emb = nullptr; p.emb_stride = 0; p.cstats = nullptr;
   switch (pick_conv_cfg(4 * M, Cout)) {  // the four phases share the launch: tile count of the full-resolution output

@@ -126,6 +126,7 @@ class MemoryEfficientCrossAttention(nn.Module):
         self.attention_op = None
         self._merged = {}
         self._kv_cache = None
+        self._kv8_cache = None  # fp8 image of the cached K / V (context_fp8)
         self.cache_context_kv = False
 
     def _merged_weight(self, which: str):
@@ -161,6 +162,17 @@ class MemoryEfficientCrossAttention(nn.Module):
         # the keyed tensors are held by the entry: their addresses cannot be recycled for other content while the entry is alive
         self._kv_cache = (key, out, (context, wk, wv)) if use_cache else None
         return out
+
+    def context_fp8(self, kv):
+        """(kv8, scales) of ops.kv_pack_fp8 for the (K, V, nk) of project_context -- the e4m3 image the fp8 form of the fused
+        cross-attention reads (cd360.routes.fp8_attn, BASELINE configs[4]); kept beside the cached K / V of the image."""
+        k, v, nk = kv
+        ent = getattr(self, "_kv8_cache", None)
+        if ent is not None and ent[0] is k and ent[1] == k._version:
+            return ent[2]
+        packed = ops.kv_pack_fp8(k, v, nk, self.heads)
+        self._kv8_cache = (k, k._version, packed) if (self.cache_context_kv and not torch.is_grad_enabled()) else None
+        return packed
 
     def attend(self, x: torch.Tensor, kv) -> torch.Tensor:
         """softmax(q k^T / sqrt(d)) v and the output projection for precomputed (k, v, nk)."""
@@ -490,12 +502,13 @@ class BasicTransformerBlock(nn.Module):
         k, v, nk = a2.project_context(context)
         w, ws, cb = P["q2"]
         ln = (ops.row_stats(tok), ws, self.norm2.eps)
+        fp8 = a2.context_fp8((k, v, nk)) if routes.fp8_attn and 64 < nk <= 96 and ops.qproj_attention_ok(tok, nk) else None  # BASELINE configs[4]
         if dup:  # de-duplicated CFG batch: tok holds 2 dup elements, the context 3 dup (only the fused kernel serves this)
             if not (ops.qproj_attention_ok(tok, nk) and k.shape[0] == tok.shape[0] + dup):
                 return None
-            return ops.qproj_attention(tok, w, k, v, nk, a2.heads, bias=cb, ln=ln, dup=dup)
+            return ops.qproj_attention(tok, w, k, v, nk, a2.heads, bias=cb, ln=ln, dup=dup, fp8=fp8)
         if ops.qproj_attention_ok(tok, nk) and not routes.no_qproj_attn:
-            o = ops.qproj_attention(tok, w, k, v, nk, a2.heads, bias=cb, ln=ln)  # q never leaves the registers (cd360_qproj_attn_bf16)
+            o = ops.qproj_attention(tok, w, k, v, nk, a2.heads, bias=cb, ln=ln, fp8=fp8)  # q never leaves the registers (cd360_qproj_attn_bf16)
         else:
             o = ops.attention(ops.gemm(tok, w, bias=cb, ln=ln), k, v, a2.heads, nk)
         if not project:
@@ -520,7 +533,8 @@ class BasicTransformerBlock(nn.Module):
         k, v, nk = a2.project_context(context)
         if ops.qproj_attention_ok(x, nk) and k.shape[0] == x.shape[0] and not routes.no_a2_fuse:
             # text cross-attention (attention.py:620-625): LayerNorm fold + q projection + softmax(q K^T) V in ONE kernel, q never in HBM
-            o = ops.qproj_attention(x, w, k, v, nk, a2.heads, bias=cb, ln=(stats, ws, self.norm2.eps), tag="qproj_attn_text")
+            o = ops.qproj_attention(x, w, k, v, nk, a2.heads, bias=cb, ln=(stats, ws, self.norm2.eps), tag="qproj_attn_text",
+                                    fp8=a2.context_fp8((k, v, nk)) if routes.fp8_attn and 64 < nk <= 96 else None)
         else:
             o = ops.attention(ops.gemm(x, w, bias=cb, ln=(stats, ws, self.norm2.eps)), k, v, a2.heads, nk)
         if context_ref is None:

@@ -322,6 +322,21 @@ int cd360_qproj_attn_dedup_bf16(const void* a, const void* w, void* out, int64_t
                                 const void* bias, const void* ln_stats, int ln_parts, int ln_dim, float ln_eps, const void* wsum,
                                 const void* k, const void* v, int64_t k_sb, int64_t k_sn, int64_t v_sb, int64_t v_sn, int Nq, int Nk,
                                 float scale, int dup, void* stream);
+/* BASELINE.json configs[4] -- the same fused cross-attention with q K^T and P V on fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, the only
+ * fp8 form above the bf16 rate on gfx950; unit block scales, real scales applied to the fp32 scores / outputs).  The keys and values of
+ * attention.py:578-588,620-625 are the text context's: constant over a trajectory, so they are quantised once per image:
+ *   cd360_kv_pack_fp8: k, v bf16 [B, >= Nk, H * 64] (element strides batch / key), Nk <= 96 -> kv8 (cd360_kv_fp8_bytes(B, H) bytes, 16-byte
+ *   aligned: per (batch, head) OCP e4m3 K rows and V^T rows in the layout the kernel's LDS reads want) + scales fp32 [B, H, 2] (amax / 448
+ *   of that head's K and V);
+ *   cd360_qproj_attn_fp8_bf16: arguments of cd360_qproj_attn_dedup_bf16 with (kv8, scales) -- B + dup batch elements -- in place of k, v
+ *   and their strides; 65 <= Nk <= 96 (CD360_ERR_SHAPE otherwise: the caller keeps the bf16 kernel).  The projected query is scaled per
+ *   token in registers; accumulation fp32, output bf16. */
+int64_t cd360_kv_fp8_bytes(int B, int H);
+int cd360_kv_pack_fp8(const void* k, const void* v, void* kv8, void* scales, int B, int H, int Nk, int64_t k_sb, int64_t k_sn, int64_t v_sb,
+                      int64_t v_sn, void* stream);
+int cd360_qproj_attn_fp8_bf16(const void* a, const void* w, void* out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldo,
+                              const void* bias, const void* ln_stats, int ln_parts, int ln_dim, float ln_eps, const void* wsum,
+                              const void* kv8, const void* scales, int Nq, int Nk, float scale, int dup, void* stream);
 /* N-tile width (256 | 192 | 128) cd360_gemm_bf16 uses for an [M, N] output: stats_out holds ceil(N / that) partials per row. */
 int cd360_gemm_tile_n(int64_t M, int N);
 /* cd360_gemm_bf16(a, w, out, ..., bias, res) for an output that a GroupNorm reads next -- SpatialTransformer.proj_out plus its residual

@@ -19,6 +19,15 @@ def test_gemm_family_and_fused_qproj_attention_against_fp32_torch(tune):
     assert bench_gemm.check()
 
 
+def test_fused_qproj_attention_fp8_mfma_variant_against_fp32_torch(tune):
+    """BASELINE configs[4] inside the product kernel: cd360_kv_pack_fp8 + cd360_qproj_attn_fp8_bf16 (q K^T and P V on
+    v_mfma_scale_f32_32x32x64_f8f6f4) on every tile, with and without the de-duplicated CFG form, against fp32 torch (layout / scale guard at 1.2e-1 of the
+    output's max magnitude: e4m3 logits measure 6e-2 ... 1e-1 on unit-scale inputs, the bf16 kernel 4e-3 -- printed side by side), and the
+    de-duplicated CFG form bit-identical to the expanded batch."""
+    import bench_gemm
+    assert bench_gemm.check_qattn_fp8_all()
+
+
 def test_gemm_k_step_groups_of_the_128x128_tiling(tune):
     """The in-workgroup split of K (two groups of waves on alternate k-step pairs, partial sums exchanged through the LDS): parity of
     every epilogue it serves against fp32 torch, the convolution form against the unsplit kernel, repeat-equal launches."""

@@ -234,6 +234,64 @@ def time_qattn():
         print(" | ".join(line), flush=True)
 
 
+def check_qattn_fp8(b, nq, C, K, nk, qcfg=None, dup=0):
+    """cd360_qproj_attn_fp8_bf16 (BASELINE configs[4]: q K^T and P V on fp8 MFMA) against fp32 torch and against the bf16 kernel on the same
+    inputs.  e4m3 carries three mantissa bits (2^-4 per value, and the logits feel it: measured 6e-2 ... 1e-1 of the output's max magnitude on
+    unit-scale inputs, against 4e-3 for bf16): the bar here only guards against layout / scale bugs (1.2e-1), the tolerance REPORT is
+    bench.py --fp8-attn's; returns
+    (ok, error vs fp32, error of the bf16 kernel vs fp32)."""
+    from cd360 import _lib
+    heads = C // 64
+    a = (rnd(b, nq, K, seed=11) * (0.5 + rnd(b, nq, 1, seed=12).abs()) + 0.5 * rnd(b, nq, 1, seed=13)).to(torch.bfloat16)
+    w = rnd(C, K, seed=14, scale=K ** -0.5)
+    kv = rnd(b + dup, max(80, nk), 2 * C, seed=15).to(torch.bfloat16)
+    k, v = kv[..., :C], kv[..., C:]
+    gamma, beta = 1 + 0.2 * rnd(K, seed=5), 0.1 * rnd(K, seed=6)
+    wp, wsum, cb = ops.pack_ln_linear(w, None, gamma, beta)
+    packed = ops.kv_pack_fp8(k, v, nk, heads)
+    with _lib.tuning(qattn_cfg=qcfg or -1):
+        got = [ops.qproj_attention(a, wp, k, v, nk, heads, bias=cb, ln=(ops.row_stats(a), wsum, 1e-5), dup=dup, fp8=packed) for _ in range(3)]
+        ref16 = ops.qproj_attention(a, wp, k, v, nk, heads, bias=cb, ln=(ops.row_stats(a), wsum, 1e-5), dup=dup)
+    a3 = torch.cat([a, a[b - dup:]], 0) if dup else a
+    q = F.linear(F.layer_norm(a3.float(), (K,), gamma, beta, 1e-5), w)
+    qh = q.reshape(b + dup, nq, heads, 64).transpose(1, 2)
+    kh = k[:, :nk].float().reshape(b + dup, nk, heads, 64).transpose(1, 2)
+    vh = v[:, :nk].float().reshape(b + dup, nk, heads, 64).transpose(1, 2)
+    want = (torch.softmax(qh @ kh.transpose(-1, -2) / 8.0, -1) @ vh).transpose(1, 2).reshape(b + dup, nq, C)
+    torch.cuda.synchronize()
+    e8, e16 = relerr(got[0], want), relerr(ref16, want)
+    same = all(torch.equal(got[0], g) for g in got[1:])
+    ok = same and e8 < 1.2e-1 and bool(torch.isfinite(got[0]).all())
+    print(("ok   " if ok else "FAIL ") + f"qproj_attention fp8 b={b} nq={nq} C={C} K={K} nk={nk} dup={dup} tile={qcfg or 'auto'}: err {e8:.2e} "
+          f"(bf16 kernel {e16:.2e}) repeat-equal {same}", flush=True)
+    return ok, e8, e16
+
+
+def check_qattn_fp8_all():
+    ok = True
+    for qcfg in (1, 2, 3, 4):
+        ok &= check_qattn_fp8(2, 512, 640, 640, 77, qcfg=qcfg)[0]
+        ok &= check_qattn_fp8(1, 256, 192, 128, 65, qcfg=qcfg)[0]
+    ok &= check_qattn_fp8(3, 1024, 1280, 1280, 77)[0]
+    ok &= check_qattn_fp8(1, 256, 128, 64, 96)[0]
+    ok &= check_qattn_fp8(2, 256, 128, 128, 80, dup=1)[0]
+    ok &= check_qattn_fp8(2, 1024, 640, 640, 77, dup=1, qcfg=1)[0]
+    # the de-duplicated form equals the expanded batch bit for bit, as the bf16 kernel's does
+    b, dup, nq, C, nk = 2, 1, 512, 640, 77
+    a = (rnd(b, nq, C, seed=21) * (0.5 + rnd(b, nq, 1, seed=22).abs())).to(torch.bfloat16)
+    w = rnd(C, C, seed=24, scale=C ** -0.5).to(torch.bfloat16)
+    kv = rnd(b + dup, 80, 2 * C, seed=25).to(torch.bfloat16)
+    packed = ops.kv_pack_fp8(kv[..., :C], kv[..., C:], nk, C // 64)
+    got = ops.qproj_attention(a, w, kv[..., :C], kv[..., C:], nk, C // 64, dup=dup, fp8=packed)
+    a3 = torch.cat([a, a[b - dup:]], 0).contiguous()
+    want = ops.qproj_attention(a3, w, kv[..., :C], kv[..., C:], nk, C // 64, fp8=packed)
+    same = torch.equal(got, want)
+    print(("ok   " if same else "FAIL ") + "fp8 de-duplicated == expanded batch", flush=True)
+    ok &= same
+    print("QATTN FP8 CHECK", "PASSED" if ok else "FAILED", flush=True)
+    return ok
+
+
 def check_qattn_all():
     """Parity list of the fused query projection + attention alone (every tile, every key-count epilogue, one-tile K loops, the column split)."""
     ok = True
@@ -677,6 +735,8 @@ if __name__ == "__main__":
         good = check()
     if "qcheck" in what:
         good = check_qattn_all() and good
+    if "qcheck8" in what:
+        good = check_qattn_fp8_all() and good
     if "time" in what:
         time_all()
     if "qattn" in what:
