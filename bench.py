@@ -51,6 +51,8 @@ def build_model(latent: int, n_ref: int, n_train: int, device, seed: int = 0):
         for m in net.modules():
             if m.__class__.__name__ == "SpatialTransformer":
                 m.proj_out.weight.copy_(torch.randn(m.proj_out.weight.shape, generator=g, device=device).mul_(0.02))
+        # (the 320 -> 4 output convolution is zero-initialised too, openaimodel.py:967-971: eps would be exactly 0 and every comparison of it vacuous)
+        net.out[2].weight.copy_(torch.randn(net.out[2].weight.shape, generator=g, device=device).mul_(0.02))
         refs = {}
         for name, blk in sampling.pose_blocks(net):
             c = blk.pose_emb_layers.weight.shape[0]
@@ -109,6 +111,13 @@ class Sampler:
         eps = self.net(x_in, timesteps=c_noise, context=self.ctx, y=self.y, pose=self.pose)[0]
         return cfg_euler_update(x, eps.contiguous(), s.reshape(1), s_next.reshape(1), self.scale, self.scale_im)
 
+    @torch.no_grad()
+    def eps(self, x, i):
+        """The UNet's output for step i of the schedule (the three CFG branches), launched eagerly: what --fp8-attn's tolerance report compares."""
+        x3 = x.expand(3, -1, -1, -1)
+        x_in, c_noise, _, _, _ = self.denoiser.network_inputs(x3, self.sigmas[i].expand(3), {})
+        return self.net(x_in, timesteps=c_noise, context=self.ctx, y=self.y, pose=self.pose)[0].float()
+
     def _pin_rendered(self):
         """Keep every block's cached render in a fixed buffer so a captured graph keeps reading the current image's render."""
         from cd360 import sampling
@@ -125,6 +134,14 @@ class Sampler:
                 st[0].copy_(k)
                 st[1].copy_(vt)
             att._kv_cache = (key, (att._static_kv[0], att._static_kv[1], nk)) + tuple(att._kv_cache[2:])
+            from cd360 import routes
+            if routes.fp8_attn and 64 < nk <= 96:  # --fp8-attn: the e4m3 image of the pinned K / V, re-packed by every (captured) render step
+                sk = att._static_kv[0]
+                if getattr(att, "_static_kv8", None) is None or att._static_kv8[0].shape[0] != sk.shape[0]:
+                    att._static_kv8 = ops_kv8_buffers(sk, att.heads)
+                from cd360 import ops
+                ops.kv_pack_fp8(sk, att._static_kv[1], nk, att.heads, out=att._static_kv8)
+                att._kv8_cache = (sk, sk._version, att._static_kv8)
 
     def _capture(self, fn):
         """Warm `fn` on a side stream (allocator / library workspaces), then capture it into a hipGraph."""
@@ -204,6 +221,11 @@ class Sampler:
         return self.gout.clone()
 
 
+def ops_kv8_buffers(k, heads):
+    return (torch.empty(k.shape[0], heads, 96 * 64 + 64 * 128, dtype=torch.uint8, device=k.device),
+            torch.empty(k.shape[0], heads, 2, dtype=torch.float32, device=k.device))
+
+
 def cpu_baseline(net, latent: int, threads: int):
     """CPU oracle (fp32 restatement of the reference) on a bounded sample of the same workload: ONE of the three CFG branches of
     ONE steady-state denoise step (cached render) at the bench's latent size; scaled by 1/3 to the metric's unit."""
@@ -258,6 +280,8 @@ def main():
     ap.add_argument("--route", choices=["fused", "module"], default="fused", help="module: a no-op forward hook on every transformer block, so the "
                     "blocks take the strict module route a patched sample.py (sample.py:247-262) or a hooked run takes -- same kernels, un-fused")
     ap.add_argument("--no-train-step", action="store_true", help="skip the fine-tuning step measurement appended after the timed region (BASELINE configs[3])")
+    ap.add_argument("--fp8-attn", action="store_true", help="BASELINE configs[4]: the text / pose-token cross-attention of every block with q K^T and P V on "
+                    "fp8 MFMA (cd360_qproj_attn_fp8_bf16) for the whole run; adds an `fp8_tolerance` object (rendered features and eps against the bf16 run)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", 0))
@@ -277,7 +301,9 @@ def main():
         else:
             dist.init_process_group("nccl", device_id=dev)
 
-    from cd360 import ops, synth
+    from cd360 import ops, routes, synth
+    if args.fp8_attn:
+        routes.set(fp8_attn=True)
 
     from cd360 import shard
     n_poses = args.poses or world
@@ -305,6 +331,8 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    # untimed set-up, reported: the FeatureNeRF reference tables (first eager render) and the two hipGraph captures
+    sync(); t0 = time.perf_counter(); smp.prepare(x); sync(); prepare_ms = (time.perf_counter() - t0) * 1e3
     xw = x.clone()
     for i in range(args.warmup):
         xw = smp.step(xw, i)
@@ -430,7 +458,12 @@ def main():
                                    "`references` buffers and weights only; the reference recomputes the equivalent inside every render) and hipGraph "
                                    "capture.  Inside the timed render step, once per image: the text K / V projections (reused by the 49 cached steps)"
                                    % (args.latent, args.refs, n_poses, world, args.traj),
-                       "render_step_ms": round(render_ms, 2), "steady_step_ms": round(steady_ms, 2), "cfg_batch": 3, "latent": args.latent,
+                       "render_step_ms": round(render_ms, 2), "steady_step_ms": round(steady_ms, 2), "prepare_ms": round(prepare_ms, 1),
+                       "prepare_ms_what": "Sampler.prepare(), once per job and outside every timed number: first eager render step (builds the reference "
+                                          "tables Y / lv of the 51 distinct reference images for the 12 pose blocks, packs every block's weights) + capture "
+                                          "of the steady-state and render hipGraphs; amortise it over the images of a job",
+                       "attention_arith": "fp8 MFMA (e4m3 q / K / P / V, fp32 accumulate) in the fused cross-attentions" if args.fp8_attn else "bf16 MFMA",
+                       "cfg_batch": 3, "latent": args.latent,
                        "n_ref": args.refs, "poses": n_poses, "poses_per_gpu": len(mine), "world_size": world,
                        "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
                        **({"sanity_run": "CD360_BENCH_ONE_GPU: all ranks on GPU 0 over gloo -- not a measurement"} if one_gpu else {}),
@@ -444,6 +477,30 @@ def main():
             "roofline": roof,
             "rooflines": roofs,
         }
+        if args.fp8_attn:
+            # BASELINE configs[4] tolerance report at workload level: the same render step (all 12 FeatureNeRF renders, pose-token attention
+            # over 98 304 / 24 576 tokens per branch) and one cached step, launched eagerly, with the attention contractions in bf16 and in fp8
+            from cd360 import sampling
+            smp.use_graph = False
+
+            def path_outputs(fp8):
+                with routes.override(fp8_attn=fp8):
+                    sampling.clear_rendered_feat(net)
+                    e0 = smp.eps(x, 0)
+                    rend = {n_: b_.rendered_feat.float().clone() for n_, b_ in sampling.pose_blocks(net)}
+                    return e0, smp.eps(x, 1), rend
+
+            relerr = lambda a_, b_: float((a_ - b_).abs().max() / b_.abs().max().clamp_min(1e-12))
+            e0b, e1b, rb = path_outputs(False)
+            e0f, e1f, rf = path_outputs(True)
+            per_block = {n_: round(relerr(rf[n_], rb[n_]), 5) for n_ in rb}
+            out["fp8_tolerance"] = {"rendered_feat_max_rel": max(per_block.values()), "rendered_feat_per_block": per_block,
+                                    "eps_render_step_max_rel": round(relerr(e0f, e0b), 5), "eps_cached_step_max_rel": round(relerr(e1f, e1b), 5),
+                                    "what": "max |fp8 - bf16| / max |bf16| of the 12 rendered feature maps (3 CFG branches each) and of the UNet output "
+                                            "eps on the render step and on a cached step; same weights, inputs and kernels, only the arithmetic of the "
+                                            "two attention contractions differs; against the fp32 oracle on a ray subset: "
+                                            "tests/test_modules_gpu.py::test_cfgB_pose_block_render_fp8_attention_tolerance_report"}
+            smp.use_graph = not args.no_graph
         if world == 1 and not args.no_train_step:
             # BASELINE configs[3] under the driver's eyes: one fine-tuning optimisation step at SDXL size (512^2 images, batch 4, 4 reference
             # views, trainkeys = pose: forward of both streams, four-term loss, backward, AdamW on fp32 masters) -- one warm + three timed

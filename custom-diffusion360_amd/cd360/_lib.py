@@ -115,6 +115,8 @@ def load(check_symbols: bool = True):
             "There is no CPU or PyTorch fallback for the cd360 operators."
         )
     lib = ctypes.CDLL(LIB_PATH)
+    if os.environ.get("CD360_LIB"):
+        check_symbols = False  # an explicitly named older / probe build (same-box A/B): entry points it predates stay unbound
     for name, (res, args) in SIGNATURES.items():
         try:
             fn = getattr(lib, name)

@@ -864,17 +864,21 @@ def qproj_attention_ok(a: torch.Tensor, nk: int) -> bool:
     return a.dim() == 3 and a.shape[1] % 128 == 0 and a.shape[2] % 64 == 0 and nk <= 96
 
 
-def kv_pack_fp8(k: torch.Tensor, v: torch.Tensor, nk: int, heads: int):
+def kv_pack_fp8(k: torch.Tensor, v: torch.Tensor, nk: int, heads: int, out=None):
     """k, v bf16 [B, >= nk, heads*64] (last dim contiguous) -> (kv8 uint8 [B, heads, 14336], scales fp32 [B, heads, 2]): the OCP e4m3
     image of K and V^T that cd360_qproj_attn_fp8_bf16 copies into its LDS (cd360_kv_pack_fp8; BASELINE configs[4]).  Once per image:
-    the text context is constant over a trajectory."""
+    the text context is constant over a trajectory.  `out` = (kv8, scales) buffers to write into."""
     _need_gpu(k, v)
     B = k.shape[0]
     assert k.dtype == torch.bfloat16 and v.dtype == torch.bfloat16 and k.shape[-1] == heads * 64 and v.shape[-1] == heads * 64
     assert k.stride(2) == 1 and v.stride(2) == 1 and k.shape[1] >= nk and v.shape[1] >= nk and v.shape[0] == B and nk <= 96
-    kv8 = torch.empty(B, heads, 96 * 64 + 64 * 128, dtype=torch.uint8, device=k.device)
+    if out is None:
+        kv8 = torch.empty(B, heads, 96 * 64 + 64 * 128, dtype=torch.uint8, device=k.device)
+        scales = torch.empty(B, heads, 2, dtype=torch.float32, device=k.device)
+    else:  # buffers that stay put (a captured graph re-packs into them on every replay of the render step)
+        kv8, scales = out
+        assert kv8.shape == (B, heads, 96 * 64 + 64 * 128) and kv8.dtype == torch.uint8 and scales.shape == (B, heads, 2) and scales.dtype == torch.float32
     assert kv8.numel() == _lib.load().cd360_kv_fp8_bytes(B, heads)
-    scales = torch.empty(B, heads, 2, dtype=torch.float32, device=k.device)
     check(_lib.load().cd360_kv_pack_fp8(_ptr(k), _ptr(v), _ptr(kv8), _ptr(scales), B, heads, nk, k.stride(0), k.stride(1), v.stride(0), v.stride(1),
                                         _stream()), "cd360_kv_pack_fp8")
     return kv8, scales

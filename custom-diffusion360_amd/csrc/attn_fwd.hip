@@ -519,22 +519,34 @@ __global__ __launch_bounds__(64 * NW, NW == 8 ? 1 : 2) void attn_self_kernel(Att
     }
   }
 
+  // O^T registers (lane = query, four consecutive channels per register group) -> a wave-private 4-KB block in a ring slot nobody reads
+  // any more (the last tile sits in slot (n_tiles - 1) % NB; waves 0-3 take the next slot, waves 4-7 the one after) -> FULL 128-byte rows,
+  // one dwordx4 per lane: the natural layout stores 8-byte pieces of 32 different rows per instruction, 16 instructions per query block
+  // (store-issue-bound tail of a 30 us kernel); through the LDS it is 4.
+  unsigned char* const Os = lds + ((n_tiles + (wave >> 2)) % NB) * TILE_BYTES + (wave & 3) * 4096;
+  const int lrow = lane >> 3, lchunk = lane & 7;
 #pragma unroll
   for (int qb = 0; qb < QB; ++qb) {
     const float l = l_run[qb] + __shfl_xor(l_run[qb], 32);
-    const float inv = 1.f / l;
+    const float inv = __builtin_amdgcn_rcpf(l);
     const int qrow = qrow0 + 32 * qb;
     if (p.lse && hh == 0) p.lse[(long)bh * p.Nq + qrow] = (__log2f(l) - negm[qb][0]) * 0.6931471805599453f;
-    uint16_t* orow = op + (long)qrow * p.o_sn;
 #pragma unroll
     for (int db = 0; db < 2; ++db)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int d = db * 32 + 8 * g + 4 * hh;
-        u32x2 wv = {pack_bf16x2(oT[qb][db][4 * g + 0] * inv, oT[qb][db][4 * g + 1] * inv),
-                    pack_bf16x2(oT[qb][db][4 * g + 2] * inv, oT[qb][db][4 * g + 3] * inv)};
-        *reinterpret_cast<u32x2*>(orow + d) = wv;
+        const int dbyte = (db * 32 + 8 * g + 4 * hh) * 2;
+        const u32x2 wv = {pack_bf16x2(oT[qb][db][4 * g + 0] * inv, oT[qb][db][4 * g + 1] * inv),
+                          pack_bf16x2(oT[qb][db][4 * g + 2] * inv, oT[qb][db][4 * g + 3] * inv)};
+        *reinterpret_cast<u32x2*>(Os + l31 * 128 + (((dbyte >> 4) ^ ((l31 >> 1) & 7)) << 4) + (dbyte & 8)) = wv;
       }
+    uint16_t* obase = op + (long)(qrow0 - l31 + 32 * qb) * p.o_sn;  // first row of this wave's query block
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = 8 * i + lrow;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(Os + row * 128 + ((lchunk ^ ((row >> 1) & 7)) << 4));
+      *reinterpret_cast<u32x4*>(obase + (long)row * p.o_sn + lchunk * 8) = v;
+    }
   }
 }
 
@@ -792,7 +804,9 @@ static int attn_launch(const void* q, const void* k, const void* v, void* o, int
   // Second-generation self-attention kernel (whole tiles).  Its q pre-scaling costs one more bf16 rounding of q unless the caller
   // folded the scale into the projection (cd360_attn_fwd_prescaled_bf16: exact), so plain calls keep the first generation unless
   // cd360_tuning.attn_self says otherwise: 0 = first generation, 1 = 4 waves x 32 queries, 2 = 8 waves x 64 queries, unset = by shape.
-  int gen2 = (Nk % 64 == 0 && Nq % 128 == 0 && (long)Nk * p.k_sn * 2 < (1L << 31) && (long)Nk * p.v_sn * 2 < (1L << 31)) ? 1 : 0;
+  int gen2 = (Nk % 64 == 0 && Nq % 128 == 0 && (long)Nk * p.k_sn * 2 < (1L << 31) && (long)Nk * p.v_sn * 2 < (1L << 31) &&
+              !(p.o_sb % 8 || p.o_sh % 8 || p.o_sn % 8 || (uintptr_t)o % 16))  // (its output leaves as 16-byte pieces of full rows)
+                 ? 1 : 0;
   int pick = prescaled ? -1 : 0;
   if (cd360_tune().attn_self >= 0) pick = cd360_tune().attn_self;
   if (gen2 && pick) {

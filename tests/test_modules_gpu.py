@@ -266,6 +266,21 @@ def _oracle_render_on_rays(w, cams, cref, ctx, heads, S, far, idx):
 @torch.no_grad()
 @pytest.mark.parametrize("level", [1, 2])
 def test_cfgB_pose_block_render_matches_the_oracle_on_a_ray_subset(level):
+    _cfgB_ray_subset(level, fp8=False)
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("level", [1, 2])
+def test_cfgB_pose_block_render_fp8_attention_tolerance_report(level):
+    """BASELINE configs[4] at workload level against the oracle: the same block, rays and inputs as the test above with the pose-token and
+    text cross-attention contractions on fp8 MFMA (cd360.routes.fp8_attn -> cd360_qproj_attn_fp8_bf16).  The rendered features are a
+    residual around the attention output (tok + attn2(norm2(tok))), so the e4m3 error of the attention (6e-2 ... 1e-1 of ITS max on
+    unit-scale inputs, tests/test_gemm_gpu.py) reaches them attenuated; printed per CFG branch and bounded at 5e-2 -- outside the bf16 bar,
+    which is why bf16 stays the default arithmetic."""
+    _cfgB_ray_subset(level, fp8=True)
+
+
+def _cfgB_ray_subset(level, fp8):
     """BASELINE configs[1] -- the headline configuration -- pinned on the oracle: one pose block at the 640 level (r = 64: 4096 rays) and
     one at the 1280 level (r = 32), n = 50 reference views, S = 24 depth samples, CFG batch 3 = [null image | image | image + text] through
     the product's sampling route (references buffer, de-duplicated render, fused pose-token attention with Nq = hw * 24 per branch, render
@@ -274,7 +289,7 @@ def test_cfgB_pose_block_render_matches_the_oracle_on_a_ray_subset(level):
     references and text context rounded to bf16 on both sides -- and compared with the block's rendered features, foreground mask,
     alphas and rgb at those rays: the north star's 1e-2 bar.  The integer corner indices / in-bounds masks / grid coordinates of the same
     rays at all 50 views are bit-exact (cd360_ray_project_index against oracle.bilinear_corners)."""
-    from cd360 import nerf, ops, sampling, synth
+    from cd360 import nerf, ops, routes, sampling, synth
     from cd360.cameras import pack_cameras
     from oracle import pose_path as O
     from sgm.modules.attention import BasicTransformerBlock
@@ -291,7 +306,8 @@ def test_cfgB_pose_block_render_matches_the_oracle_on_a_ray_subset(level):
     pose = synth.pose_batch(1, n, seed=9, n_train=n_train) * 3
     ctx = W.tensor("ctx", (3, 77, cd), seed=40 + level).to(BF)
     x = dev(W.tensor("x", (3, hw, C), seed=40 + level))
-    out, fg, _, alphas, rgb = blk(x, context=ctx.to(DEV), context_ref=x, pose=pose)
+    with routes.override(fp8_attn=fp8):
+        out, fg, _, alphas, rgb = blk(x, context=ctx.to(DEV), context_ref=x, pose=pose)
     rend = blk.rendered_feat
     assert rend.shape == (3, hw, C) and fg.shape[:2] == (3, hw) and alphas.shape[:3] == (3, hw, S)
     # 128 rays: the four corners, points on every border, the rest spread over the interior
@@ -309,9 +325,11 @@ def test_cfgB_pose_block_render_matches_the_oracle_on_a_ray_subset(level):
         dbg = want[4]
         errs[br] = (rel(rend[br:br + 1, idx.to(DEV)], want[0]), rel(fg[br:br + 1, idx.to(DEV)].reshape(want[1].shape), want[1]),
                     rel(alphas[br:br + 1, idx.to(DEV)].reshape(want[2].shape), want[2]), rel(rgb[br:br + 1, idx.to(DEV)].reshape(want[3].shape), want[3]))
-    print(f"cfg-B level-{level} pose block vs oracle on {len(idx)} rays (xref, fg, alphas, rgb) per CFG branch:",
+    print(f"cfg-B level-{level} pose block ({'fp8' if fp8 else 'bf16'} attention) vs oracle on {len(idx)} rays (xref, fg, alphas, rgb) per CFG branch:",
           {k: tuple(round(e, 4) for e in v) for k, v in errs.items()})
-    assert max(max(v) for v in errs.values()) < 1e-2, errs
+    assert max(max(v) for v in errs.values()) < (5e-2 if fp8 else 1e-2), errs
+    if fp8:
+        return
     # integer ray indices at the full camera set: bit-exact
     xs = nerf.patch_positions(r, DEV)
     t, _ = nerf.depth_samples(S, 2.0, 0.0, DEV, hw)
