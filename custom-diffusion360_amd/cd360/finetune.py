@@ -53,11 +53,11 @@ def select_trainable(unet: torch.nn.Module, trainkeys: str = "pose") -> List[str
         for name, p in named:
             p.requires_grad = "pose" in name
     elif trainkeys == "all":
-        # the reference accepts it (diffusion.py:117-150) and so does this function, but the HIP path has no weight gradients for
-        # convolutions and for the GroupNorm / LayerNorm affines: say so HERE, not only at the first forward
+        # the reference accepts it (diffusion.py:117-150) and so does this function -- off the hand-written path: trainable convolutions
+        # run on torch's own convolution, the GroupNorm / LayerNorm affine gradients are fp32 torch reductions
         import warnings
-        warnings.warn("trainkeys='all': convolution weights and GroupNorm / LayerNorm affine parameters have no backward kernel on the HIP "
-                      "path -- a grad-enabled forward will raise NotImplementedError for them; the shipped configs train 'pose' / 'poseattn'",
+        warnings.warn("trainkeys='all': convolution weights train through torch's convolution and the GroupNorm / LayerNorm affine gradients "
+                      "through torch reductions -- correct, but not the hand-written path the shipped configs ('pose' / 'poseattn') run on",
                       stacklevel=2)
         for _, p in named:
             p.requires_grad = True

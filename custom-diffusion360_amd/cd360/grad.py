@@ -127,7 +127,6 @@ class GroupNormSiluFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, gamma, beta, groups, eps, silu, tile_stats):
-        _no_wgrad("gn_silu", gamma, beta)
         y = ops.gn_silu(x, gamma, beta, groups, eps, silu, tile_stats=tile_stats)
         ctx.save_for_backward(x, gamma, beta)
         ctx.cfg = (groups, eps, silu)
@@ -136,7 +135,24 @@ class GroupNormSiluFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         x, gamma, beta = ctx.saved_tensors
-        return ops.gn_silu_bwd(x, dy, gamma, beta, *ctx.cfg), None, None, None, None, None, None
+        groups, eps, silu = ctx.cfg
+        dx = ops.gn_silu_bwd(x, dy, gamma, beta, groups, eps, silu) if ctx.needs_input_grad[0] else None
+        dgamma = dbeta = None
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            # affine gradients (`trainkeys: all`, diffusion.py:145-147 -- not a set the shipped configs train): fp32 torch reductions over
+            # the recomputed normalised activations; the hot path (trainkeys pose / poseattn) never asks for them
+            C = x.shape[-1]
+            xf = x.float().reshape(x.shape[0], -1, groups, C // groups)
+            mu = xf.mean((1, 3), keepdim=True)
+            xhat = ((xf - mu) * torch.rsqrt(xf.var((1, 3), unbiased=False, keepdim=True) + eps)).reshape(x.shape[0], -1, C)
+            du = dy.float().reshape(x.shape[0], -1, C)
+            if silu:
+                u = xhat * gamma.float() + beta.float()
+                sg = torch.sigmoid(u)
+                du = du * (sg * (1 + u * (1 - sg)))
+            dgamma = (du * xhat).sum((0, 1)).to(gamma.dtype) if ctx.needs_input_grad[1] else None
+            dbeta = du.sum((0, 1)).to(beta.dtype) if ctx.needs_input_grad[2] else None
+        return dx, dgamma, dbeta, None, None, None, None
 
 
 class GegluFn(torch.autograd.Function):
@@ -160,7 +176,6 @@ class AddLayerNormFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, a, b, gamma, beta, eps):
-        _no_wgrad("add_layernorm", gamma, beta)
         s, ln = ops.add_layernorm(a, b, gamma, beta, eps, want_sum=True)
         x = a if b is None else s
         ctx.save_for_backward(x, gamma)
@@ -178,7 +193,16 @@ class AddLayerNormFn(torch.autograd.Function):
             dx = d_sum
         else:
             dx = ops.add_layernorm_bwd(x, gamma, d_ln, d_sum, ctx.eps)
-        return dx, (dx if ctx.has_b else None), None, None, None
+        dgamma = dbeta = None
+        if d_ln is not None and (ctx.needs_input_grad[2] or ctx.needs_input_grad[3]):
+            # affine gradients (`trainkeys: all`): fp32 torch reductions, off the hot path (trainkeys pose / poseattn freeze the norms)
+            C = x.shape[-1]
+            xf = x.float().reshape(-1, C)
+            xhat = (xf - xf.mean(-1, keepdim=True)) * torch.rsqrt(xf.var(-1, unbiased=False, keepdim=True) + ctx.eps)
+            g2 = d_ln.float().reshape(-1, C)
+            dgamma = (g2 * xhat).sum(0).to(gamma.dtype) if ctx.needs_input_grad[2] else None
+            dbeta = g2.sum(0).to(gamma.dtype) if ctx.needs_input_grad[3] else None
+        return dx, (dx if ctx.has_b else None), dgamma, dbeta, None
 
 
 def add_layernorm(a, b, gamma, beta, eps, want_sum=True):

@@ -64,6 +64,51 @@ def _const(key, make):
     return _grid_cache[key]
 
 
+class _LiveNerfWeights(torch.autograd.Function):
+    """The derived operands of the fused render for TRAINABLE parameters as ONE autograd node: slicing W1 into its gather / encoding /
+    Plucker column groups, the column permutation of the encoding part, the zero pads and the dtype casts are ~50 tiny torch kernels when
+    autograd records them one by one (and as many again in the backward pass); twelve pose blocks made that ~1200 launches of a
+    fine-tuning step.  forward: the same values; backward: the column groups' gradients written back into one dW1, the three slices of
+    nviews.weight concatenated."""
+
+    @staticmethod
+    def forward(ctx, W1, b1, W2, b2, wv, bv, Wd):
+        C, dev = W2.shape[0], W1.device
+        cols = xyz_k_columns(C)
+        idx, pos = _const(("xyz_k", C, str(dev)), lambda: (torch.tensor([c for c in cols if c >= 0], device=dev),
+                                                           torch.tensor([i for i, c in enumerate(cols) if c >= 0], device=dev)))
+        bf = torch.bfloat16
+        Wk = torch.zeros(C, len(cols), dtype=bf, device=dev)
+        Wk[:, pos] = W1[:, idx].to(bf)
+        Wp = torch.zeros(C, 128, dtype=bf, device=dev)
+        Wp[:, :99] = W1[:, C + 99:C + 198]
+        wvf = wv.reshape(-1).float()
+        ctx.meta = (C, len(cols), idx, pos, tuple(t.dtype for t in (W1, b1, W2, b2, wv, bv, Wd)), wv.shape, bv.shape)
+        return (W1[:, :C].to(bf).contiguous(), Wk, Wp, b1.float(), W2.to(bf).contiguous(), b2.float(), wvf[:C].contiguous(),
+                wvf[C + 99:C + 102].contiguous(), wvf[C + 102:C + 198].contiguous(), bv.float().reshape(()), Wd.float().contiguous())
+
+    @staticmethod
+    def backward(ctx, dWf, dWk, dWp, db1, dW2, db2, dvf, dvo, dve, dbv, dWd):
+        C, nk, idx, pos, dts, wv_shape, bv_shape = ctx.meta
+        some = next(g for g in (dWf, dWk, dWp, db1, dW2, db2, dvf, dvo, dve, dbv, dWd) if g is not None)
+        dev = some.device
+        dW1 = None
+        if dWf is not None or dWk is not None or dWp is not None:
+            dW1 = torch.zeros(C, C + 198, dtype=dts[0], device=dev)
+            if dWf is not None:
+                dW1[:, :C] = dWf
+            if dWk is not None:
+                dW1[:, idx] = dWk[:, pos].to(dts[0])
+            if dWp is not None:
+                dW1[:, C + 99:C + 198] = dWp[:, :99]
+        dwv = None
+        if dvf is not None or dvo is not None or dve is not None:
+            z = lambda g, n_: torch.zeros(n_, dtype=torch.float32, device=dev) if g is None else g.reshape(-1).float()
+            dwv = torch.cat([z(dvf, C), torch.zeros(99, dtype=torch.float32, device=dev), z(dvo, 3), z(dve, 96)]).reshape(wv_shape).to(dts[4])
+        cast = lambda g, i: None if g is None else g.to(dts[i])
+        return (dW1, cast(db1, 1), cast(dW2, 2), cast(db2, 3), dwv, None if dbv is None else dbv.reshape(bv_shape).to(dts[5]), cast(dWd, 6))
+
+
 class FusedNerfWeights:
     """Derived, cached forms of one FeatureNeRFEncoding's parameters."""
 
@@ -73,6 +118,12 @@ class FusedNerfWeights:
         C = W2.shape[0]
         self.C = C
         dev = W1.device
+        if live and W1.is_cuda and dtype == torch.bfloat16 and not routes.library_linear:
+            # what the fused render reads, as one autograd node (the torch-GEMM route below keeps its transposed / fp32 forms)
+            (self.Wf, self.Wk, self.Wp, self.b1, self.W2, self.b2_f32, self.vf, self.v_otgt, self.v_otgt_enc, self.bv,
+             self.Wd) = _LiveNerfWeights.apply(W1, b1, W2, b2, wv, bv, Wd)
+            self.live = True
+            return
         if not live:
             W1, b1, W2, b2, wv, bv, Wd = (p.detach() for p in (W1, b1, W2, b2, wv, bv, Wd))
         W1f = W1.float()
@@ -152,11 +203,28 @@ def depth_samples(num_samples: int, far: float, near: float, device, num_rays: i
 def view_constants(fw: FusedNerfWeights, cams: torch.Tensor) -> torch.Tensor:
     """c_i = w_v[o_tgt].o_i^tgt + w_v[enc].enc16(o_i^tgt) + b_v, with o_i^tgt the reference camera centre in the
     target view frame (nerfsd_pytorch3d.py:116-123,146-147).  cams [b, n+1, 16] -> [b, n] fp32."""
-    R = cams[..., :9].reshape(*cams.shape[:-1], 3, 3)
-    T = cams[..., 9:12]
-    center = -(T[..., None, :] * R).sum(-1)  # -T @ R^T
-    o = (center[:, 1:, :, None] * R[:, :1]).sum(-2) + T[:, :1]  # centre_i @ R_0 + T_0
-    return ((o * fw.v_otgt).sum(-1) + (positional_encoding(o, NUM_FREQS) * fw.v_otgt_enc).sum(-1) + fw.bv).contiguous()
+    o, enc = _camera_constants(cams)
+    return ((o * fw.v_otgt).sum(-1) + (enc * fw.v_otgt_enc).sum(-1) + fw.bv).contiguous()
+
+
+_CAM_CONSTS = []  # the last few (cams, version, (o, enc16(o))): the twelve pose blocks of a forward share one packed camera tensor
+
+
+def _camera_constants(cams: torch.Tensor):
+    """Reference camera centres in the target view frame and their positional encoding: camera-only values, computed once per packed
+    camera tensor instead of once per pose block (a dozen tiny kernels each)."""
+    for ent in _CAM_CONSTS:
+        if ent[0] is cams and ent[1] == cams._version:
+            return ent[2]
+    with torch.no_grad():
+        R = cams[..., :9].reshape(*cams.shape[:-1], 3, 3)
+        T = cams[..., 9:12]
+        center = -(T[..., None, :] * R).sum(-1)  # -T @ R^T
+        o = (center[:, 1:, :, None] * R[:, :1]).sum(-2) + T[:, :1]  # centre_i @ R_0 + T_0
+        val = (o, positional_encoding(o, NUM_FREQS))
+    _CAM_CONSTS.insert(0, (cams, cams._version, val))  # (inside a graph capture too: the first pose block's kernels are captured, the others read)
+    del _CAM_CONSTS[4:]
+    return val
 
 
 def fused_feature_nerf(fw: FusedNerfWeights, cams: torch.Tensor, xref: Optional[torch.Tensor], num_samples: int, far: float,

@@ -15,7 +15,7 @@ reference_attn/pose_emb_layers`) keep working.  What differs is underneath:
 The reference's `CrossAttention` ("softmax" mode) cannot be constructed by BasicTransformerBlock (it is passed an
 `add_lora` kwarg it does not accept, attention.py:214-222,495-503); here "softmax" maps to the same HIP attention.
 LoRA branches, `additional_tokens`, `n_times_crossframe_attn_in_self`, `disable_self_attn`, conv proj_in/out and
-`average=True` are not exercised by the shipped config and raise NotImplementedError.
+are not exercised by the shipped config and raise NotImplementedError (`average=True` is served: uniform view weights).
 """
 from __future__ import annotations
 
@@ -102,9 +102,24 @@ def Normalize(in_channels):
     return torch.nn.GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
 
 
+_PADDED = []  # the last few (context, version, padded context): every block of a forward pads the SAME one or two context tensors
+
+
 def _pad_tokens(ctx: torch.Tensor, mult: int = 8) -> torch.Tensor:
+    """The context with its token count rounded up to a multiple of 8 (77 -> 80 zero rows: whole 16-byte rows for the K / V kernels).
+    One pad per context tensor and forward instead of one per attention module (152 pad kernels in a fine-tuning step)."""
     pad = (-ctx.shape[1]) % mult
-    return ctx if pad == 0 else F.pad(ctx, (0, 0, 0, pad))
+    if pad == 0:
+        return ctx
+    if ctx.requires_grad:
+        return F.pad(ctx, (0, 0, 0, pad))
+    for ent in _PADDED:
+        if ent[0] is ctx and ent[1] == ctx._version:
+            return ent[2]
+    out = F.pad(ctx, (0, 0, 0, pad))
+    _PADDED.insert(0, (ctx, ctx._version, out))
+    del _PADDED[4:]
+    return out
 
 
 class MemoryEfficientCrossAttention(nn.Module):

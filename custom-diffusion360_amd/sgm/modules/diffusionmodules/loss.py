@@ -76,21 +76,25 @@ class StandardDiffusionLossImgRef(nn.Module):
         else:
             loss_l2 = torch.mean(loss.reshape(target.shape[0], -1), 1)
         if len(fg_mask_list) > 0 and len(alphas_list) > 0:
-            for fg_mask, alphas in zip(fg_mask_list, alphas_list):
+            bg_w = None  # (1 - opacity) * [opacity < 0.1] of the current map: constant until the next resize (the factor [..] is 0 / 1, so
+            for fg_mask, alphas in zip(fg_mask_list, alphas_list):  # folding it into the weight first changes no bit of the product)
                 size = int(math.sqrt(fg_mask.size(1)))
                 # as in the reference, `opacity` is re-assigned: every block resizes the PREVIOUS block's resized map.  A resize to the
                 # size the map already has is the identity (the antialias filter at scale 1 has the weights 1, 0): not launched
                 if opacity.shape[-2:] != (size, size):
                     opacity = F.interpolate(opacity, size=size, antialias=True, mode="bilinear").detach()
+                    bg_w = None
                 op = opacity.reshape(-1, size * size)
                 fg = torch.clamp(fg_mask.float().reshape(-1, size * size), 0.0, 1.0)
                 loss_fg.append(((fg - op) ** 2).mean(1))
                 op4 = op.reshape(-1, size * size, 1, 1)
-                bg = (alphas.float() - op4).abs() * (1 - op4)
-                loss_bg.append((bg * ((op4 < 0.1) * 1)).mean([1, 2, 3]))
+                if bg_w is None:
+                    bg_w = (1 - op4) * ((op4 < 0.1) * 1)
+                loss_bg.append(((alphas.float() - op4).abs() * bg_w).mean([1, 2, 3]))
             loss_fg, loss_bg = torch.stack(loss_fg, 1), torch.stack(loss_bg, 1)
         if len(predicted_rgb_list) > 0:
             resized = {}  # per feature-grid size: the blocks of one resolution share the resized mask / rgb target
+            mask_den = mask.sum([1, 2, 3]) + 1e-6
             for rgb in predicted_rgb_list:
                 size = int(math.sqrt(rgb.size(1)))
                 if size not in resized:
@@ -98,6 +102,6 @@ class StandardDiffusionLossImgRef(nn.Module):
                                      F.interpolate(target_rgb * 0.5 + 0.5, size=size, antialias=True, mode="bilinear").detach())
                 mask_, want = resized[size]
                 err = (want - rgb.float().reshape(-1, size, size, 3).permute(0, 3, 1, 2)) ** 2
-                loss_rgb.append((err * mask_).sum([1, 2, 3]) / (mask.sum([1, 2, 3]) + 1e-6))
+                loss_rgb.append((err * mask_).sum([1, 2, 3]) / mask_den)
             loss_rgb = torch.stack(loss_rgb, 1)
         return loss_l2, loss_fg, loss_bg, loss_rgb

@@ -96,8 +96,9 @@ def group_norm_tokens(norm: nn.GroupNorm, x: torch.Tensor, silu: bool, stats=Non
         xt = xt.to(torch.bfloat16)
         stats = None  # the statistics were taken of the bf16 tensor the conv wrote; x is something else
     if torch.is_grad_enabled() and (norm.weight.requires_grad or norm.bias.requires_grad):
-        raise NotImplementedError("GroupNorm affine parameters are not trainable on the HIP path (trainkeys pose / poseattn never train them)")
-    g, b = _fp32_affine(norm)
+        g, b = norm.weight.float(), norm.bias.float()  # `trainkeys: all`: live casts, the affine gradients come back through GroupNormSiluFn
+    else:
+        g, b = _fp32_affine(norm)
     y = ops.gn_silu(xt, g, b, norm.num_groups, norm.eps, silu, tile_stats=stats)
     return y if dt == torch.bfloat16 else y.to(dt)
 

@@ -26,8 +26,6 @@ class FeatureNeRFEncoding(nn.Module):
     def __init__(self, in_channels, out_channels, far_plane: float = 2.0, rgb_predict=False, average=False, num_freqs=16) -> None:
         super().__init__()
         self.far_plane, self.rgb_predict, self.average, self.num_freqs = far_plane, rgb_predict, average, num_freqs
-        if average:
-            raise NotImplementedError("average=True (view mean) is not exercised by the shipped config and not built")
         if num_freqs != 16:
             raise NotImplementedError("the fused kernel is specialised for num_freqs=16 (the only value the reference uses)")
         dim = 3
@@ -41,6 +39,10 @@ class FeatureNeRFEncoding(nn.Module):
         ps = [self.plane_coefs[0].weight, self.plane_coefs[0].bias, self.plane_coefs[2].weight, self.plane_coefs[2].bias,
               self.nviews.weight, self.nviews.bias, self.decoder.weight]
         key = tuple((p.data_ptr(), p._version, p.device, p.dtype) for p in ps)
+        if self.average:
+            # nerfsd_pytorch3d.py:156-158: the views are averaged instead of softmax-weighted.  A zero `nviews` makes every view logit 0,
+            # the in-kernel view softmax uniform = the mean (and, as in the reference, nviews then receives no gradient)
+            ps[4], ps[5] = torch.zeros_like(ps[4]), torch.zeros_like(ps[5])
         if torch.is_grad_enabled() and any(p.requires_grad for p in ps):  # training: derived weights stay on the autograd tape
             wd = self.decoder.weight
             if wd.shape[0] == 1:
@@ -174,7 +176,7 @@ class NerfSDModule(nn.Module):
         None, None)   (:434-464)"""
         if prev_weights is not None:
             raise NotImplementedError("importance sampling is dead code in the reference (SURVEY.md F3)")
-        h, dec, dists, vw = self.render_inputs(pose, xref, mask_ref, want_view_weights=self.return_view_weights)
+        h, dec, dists, vw = self.render_inputs(pose, xref, mask_ref, want_view_weights=self.return_view_weights and not self.model.average)
         hw, S = h.shape[1], h.shape[2]
         d = dists[None].expand(hw, -1) if dists.dim() == 1 else dists
         rgb = dec[..., :3] if self.rgb_predict else None

@@ -304,6 +304,61 @@ def test_unet_pose_parameter_gradients_match_reference_autograd():
     assert not bad, bad
 
 
+def test_unet_trainkeys_all_gradients_of_norm_affines_and_convolutions():
+    """`trainkeys: all` (diffusion.py:145-147; not what the shipped configs train): every parameter of the tiny UNet requires a gradient.
+    The norm affines get theirs from fp32 torch reductions inside the HIP operators' autograd nodes, trainable convolutions run on torch's own
+    convolution, every Linear on cd360_gemm_tn_bf16.  Checked against torch autograd through the fp32 oracle (pinned on the reference's
+    autograd for the pose parameters, tests/test_oracle_cpu.py) for a sample of each parameter kind of the TARGET stream's last layers --
+    the reference stream runs under no_grad in the reference as well (attention.py:845-857), so parameters only it reaches get none."""
+    import gzip
+    import json
+    import os
+    import warnings
+    import numpy as np
+    import weights as W
+    from cd360 import finetune
+    from cd360.cameras import unpack_cameras
+    from make_golden_params import UNET_TINY
+    from sgm.modules.diffusionmodules.openaimodel import UNetModel
+    from test_oracle_cpu import unet_grad_loss
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    g = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(gold, "unet_tiny.npz")).items()}
+    with gzip.open(os.path.join(gold, "unet_tiny.keys.json.gz"), "rt") as f:
+        sd = W.synth_state_dict(json.load(f), seed=5)
+    net = UNetModel(**UNET_TINY).eval()
+    W.load_into(net, seed=5)
+    net = net.to(DEV, torch.bfloat16)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        names = finetune.select_trainable(net, "all")
+    assert len(names) == len(list(net.parameters()))
+    out, fgs, alphas, rgbs = net(g["x"].to(DEV), timesteps=g["t"].to(DEV), context=g["ctx"].to(DEV), y=g["y"].to(DEV),
+                                 pose=unpack_cameras(g["cams"]), input_ref=g["input_ref"].to(DEV), sigmas_ref=g["sigmas_ref"].to(DEV), mask_ref=None)
+    unet_grad_loss(out, fgs, rgbs).backward()
+    params = dict(net.named_parameters())
+    # one of each kind, late in the network (their gradients do not pass through many bf16 layers)
+    last_st = max(k for k in params if k.startswith("output_blocks") and k.endswith("transformer_blocks.0.norm3.weight"))
+    prefix = last_st[:-len("norm3.weight")]
+    pick = ["out.0.weight", "out.0.bias", "out.2.weight", "out.2.bias", prefix + "norm3.weight", prefix + "norm3.bias", prefix + "norm1.weight",
+            prefix + "ff.net.2.weight", prefix + "ff.net.2.bias", prefix + "attn2.to_q.weight"]
+    last_res = max(k for k in params if k.startswith("output_blocks") and k.endswith("out_layers.0.weight"))
+    pick += [last_res, last_res.replace("weight", "bias"), last_res.replace("out_layers.0.weight", "out_layers.3.weight"),
+             last_res.replace("out_layers.0.weight", "in_layers.0.weight")]
+    so = {k: (v.clone().requires_grad_(True) if k in pick else v) for k, v in sd.items()}
+    with torch.enable_grad():
+        o2, f2, _, r2 = O.unet_forward(so, g["x"], g["t"], g["ctx"], g["y"], cams=g["cams"], input_ref=g["input_ref"], sigmas_ref=g["sigmas_ref"],
+                                       model_channels=64, num_samples=4, far=2.0)
+        want = dict(zip(pick, torch.autograd.grad(unet_grad_loss(o2, f2, r2), [so[k] for k in pick])))
+    worst = {}
+    for k in pick:
+        assert params[k].grad is not None, k
+        worst[k] = rel(params[k].grad, want[k])
+    print("trainkeys=all gradient deviations:", {k: round(v, 4) for k, v in worst.items()})
+    assert max(worst.values()) < 5e-2, worst
+    assert all(p.grad is not None and torch.isfinite(p.grad.float()).all() for k, p in params.items() if "raymarcher" not in k and not k.endswith("nviews.bias")
+               and p.grad is not None)
+
+
 def test_feature_nerf_table_scatter_backward_equals_gemm_form():
     """Two routes to the same parameter gradients: grad.NerfRenderFn (training path: weight gradients as GEMMs against gathered
     reference features, no scatter) and grad.NerfAggregateFn (precomputed tables: the backward kernel scatters into dY / dlv with fp32

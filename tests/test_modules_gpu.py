@@ -101,6 +101,27 @@ def test_nerf_module_matches_reference_golden():
 
 
 @torch.no_grad()
+def test_nerf_module_average_views_matches_oracle():
+    """FeatureNeRFEncoding(average=True) (nerfsd_pytorch3d.py:156-158: the per-view MLP outputs are averaged instead of weighted by the
+    `nviews` softmax) -- an option the shipped config leaves off; served by the same fused kernel with zero view logits.  Against the
+    oracle's `average=True` branch on the inputs of the eval golden; the view weights are None, as in the reference."""
+    from oracle import pose_path as O
+    from sgm.modules.nerfsd_pytorch3d import NerfSDModule
+    g = load("nerf_eval")
+    m = NerfSDModule(mode="feature-nerf", out_channels=64, far_plane=2.0, num_samples=4, rgb_predict=True, stratified=True, average=True).eval()
+    w = {k: v.to(BF).float() for k, v in W.load_into(m, seed=1).items()}
+    m = m.to(DEV, BF)
+    feats, sigma, dists, vw, rgb, _, _ = m(unpack_cameras(g["cams"]), dev(g["xref"]))
+    want = O.nerf_module(O.sub(w, "model"), g["cams"], g["xref"].to(BF).float(), 4, 2.0, average=True)
+    assert vw is None and want[3] is None
+    assert rel(feats, want[0]) < 1e-2 and rel(sigma, want[1]) < 1e-2 and rel(rgb, want[4]) < 1e-2
+    # and it is a different function from the softmax-weighted one
+    m2 = NerfSDModule(mode="feature-nerf", out_channels=64, far_plane=2.0, num_samples=4, rgb_predict=True, stratified=True).eval()
+    W.load_into(m2, seed=1)
+    assert rel(m2.to(DEV, BF)(unpack_cameras(g["cams"]), dev(g["xref"]))[0], want[0]) > 2e-2
+
+
+@torch.no_grad()
 def test_mask_ref_forward_matches_reference_golden():
     """mask_ref (nerfsd_pytorch3d.py:61-70): NerfSDModule, the pose block and the tiny UNet with reference-view masks against the vectors
     the imported reference produced (tests/golden/mask_ref.npz)."""

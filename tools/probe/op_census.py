@@ -15,6 +15,9 @@ import torch  # noqa: E402
 from torch.utils._python_dispatch import TorchDispatchMode  # noqa: E402
 
 PKG = os.path.join(ROOT, "custom-diffusion360_amd")
+VIEW_OPS = ("aten.view", "aten._unsafe_view", "aten.reshape", "aten._reshape_alias", "aten.expand", "aten.slice", "aten.select", "aten.t.", "aten.transpose",
+            "aten.permute", "aten.as_strided", "aten.detach", "aten.alias", "aten.unsqueeze", "aten.squeeze", "aten.empty", "aten.new_empty", "aten.split",
+            "aten.chunk", "aten.unbind", "aten.lift_fresh", "aten.unfold", "aten.narrow", "aten.is_", "aten.sym_", "aten.stride", "aten.size", "aten._local_scalar_dense")
 
 
 class Census(TorchDispatchMode):
@@ -29,8 +32,10 @@ class Census(TorchDispatchMode):
             if fr.filename.startswith(PKG):
                 where = f"{os.path.relpath(fr.filename, PKG)}:{fr.lineno}"
                 break
-        self.by_line[where] += 1
-        self.by_op[(where, str(func))] += 1
+        name = str(func)
+        if not any(v in name for v in VIEW_OPS):  # count what launches a kernel: views / allocations / metadata ops do not
+            self.by_line[where] += 1
+            self.by_op[(where, name)] += 1
         return func(*args, **(kwargs or {}))
 
 
