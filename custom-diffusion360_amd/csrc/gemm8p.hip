@@ -410,13 +410,21 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
           acc[i % NCB][i / NCB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fw[set][i % NCB], fx[set][i / NCB], acc[i % NCB][i / NCB], 0, 0, 0);
       }
     };
-    // With three or more buffers the NP pieces that refill a released buffer are SPREAD over a whole tile's worth of MFMAs -- the
-    // first share between the MFMAs of this tile's last k-step (as soon as the barrier has released the buffer), the rest between the
-    // MFMAs of the next tile's earlier k-steps -- instead of all of them in the last k-step: every wave issuing its pieces at the
-    // same moment queues 32 KB on the CU's one address path while the matrix pipe has two MFMAs per wave to chew on.  The counted
-    // waits are unchanged (every piece of tile t+NBUF-1 is still issued before tile t's wait, none of tile t+NBUF).
-    constexpr bool SPREAD = NBUF >= 3;
-    constexpr int NSLOT = KPW * NMMA;
+    // The NP pieces that refill a released buffer are SPREAD over the MFMAs that follow instead of all of them in the last k-step: the
+    // CU's one address path takes ~26 cycles per 1-KiB piece (tools/probe/dma_probe.hip: 47-49 B/clk/CU), i.e. 1700 cycles for the 64
+    // pieces of a 256 x 256 tile -- queued inside ONE k-step (512 cycles of MFMAs per SIMD) the matrix pipe then idles behind the queue.
+    // With three or more buffers the pieces go behind a whole tile's worth of MFMAs (the first share in this tile's last k-step, as soon
+    // as the barrier has released the buffer, the rest in the next tile's k-steps 0 .. 2); with TWO buffers (round 4) the refilled tile
+    // is already needed at the NEXT barrier, so the shares stop one k-step short of it (last k-step, then k-steps 0 and 1: their pieces
+    // have a k-step or two of MFMAs to land in, L2-warm latency 250-400 cycles).  The counted waits are unchanged (every piece of tile
+    // t+NBUF-1 is still issued before tile t's wait, none of tile t+NBUF).  -DCD360_NO_SPREAD2 builds the two-buffer loop of round 3 (A/B).
+#ifdef CD360_NO_SPREAD2
+    constexpr bool spread2 = NBUF >= 3;
+#else
+    constexpr bool spread2 = true;
+#endif
+    constexpr bool SPREAD = spread2;
+    constexpr int NSLOT = (NBUF >= 3 ? KPW : (KPW > 1 ? KPW - 1 : 1)) * NMMA;
     auto slot_pieces = [&](int j, int i, int tile, uint32_t obx, uint32_t obw) {  // pieces of `tile` that go behind MFMA i of k-step group j
 #pragma unroll
       for (int q = 0; q < NP; ++q)
@@ -428,7 +436,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
     for (int t = 0; t < nk; ++t) {
       // fences pin the order "reads of k-step ks+1, then the MFMAs of ks": the compiler otherwise sinks the reads to the end of the
       // MFMA run (exposing the LDS latency) or hoists later k-steps' reads (spilling)
-      const bool prev_more = MOVE && SPREAD && t >= 1 && t - 1 + NBUF < nk && !(abl & 4);
+      const bool prev_more = MOVE && spread2 && t >= 1 && t - 1 + NBUF < nk && !(abl & 4);
 #ifdef CD360_GEMM_STAMP
       const uint64_t stA = __builtin_amdgcn_s_memtime();
       uint64_t stB = stA, stD = stA, stC1 = stA, stC2 = stA;
