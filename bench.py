@@ -79,9 +79,10 @@ class Sampler:
         self.guider = S.ScheduledCFGImgTextRef(scale, scale_im)
         self.sigmas = S.LegacyDDPMDiscretization()(n_steps, device=dev)  # n_steps + 1 values, last = 0
         # conditioning is constant over a trajectory: the guider's (uc, uc, c) batch is assembled once per image, not per step
-        c = {"crossattn": ctx[2:3], "vector": y[2:3]}
-        uc = {"crossattn": ctx[0:1], "vector": y[0:1]}
-        _, _, cond3 = self.guider.prepare_inputs(ctx.new_zeros(1, 1), ctx.new_zeros(1), c, uc)
+        self.bs = bs = ctx.shape[0] // 3  # diffusion samples (target poses) per replay: ctx / y hold [uc x bs | . | c x bs]
+        c = {"crossattn": ctx[2 * bs:], "vector": y[2 * bs:]}
+        uc = {"crossattn": ctx[:bs], "vector": y[:bs]}
+        _, _, cond3 = self.guider.prepare_inputs(ctx.new_zeros(bs, 1), ctx.new_zeros(bs), c, uc)
         self.ctx, self.y = cond3["crossattn"].contiguous(), cond3["vector"].contiguous()
         self.use_graph, self.graph = use_graph, None
         self.graph_render, self.rgraph = use_graph and not os.environ.get("CD360_BENCH_EAGER_RENDER"), None
@@ -90,9 +91,10 @@ class Sampler:
         """Point the sampler at another target pose / conditioning (the next pose of this rank's share).  The captured graphs read both
         through fixed device buffers, so the new values are copied INTO them: the CFG conditioning batch, and the packed
         [3, n+1, 16] camera tensor the render path memoises for `self.pose` (sgm/modules/utils_cameraray.py::packed_pose)."""
-        c = {"crossattn": ctx[2:3], "vector": y[2:3]}
-        uc = {"crossattn": ctx[0:1], "vector": y[0:1]}
-        _, _, cond3 = self.guider.prepare_inputs(ctx.new_zeros(1, 1), ctx.new_zeros(1), c, uc)
+        bs = self.bs
+        c = {"crossattn": ctx[2 * bs:], "vector": y[2 * bs:]}
+        uc = {"crossattn": ctx[:bs], "vector": y[:bs]}
+        _, _, cond3 = self.guider.prepare_inputs(ctx.new_zeros(bs, 1), ctx.new_zeros(bs), c, uc)
         self.ctx.copy_(cond3["crossattn"])
         self.y.copy_(cond3["vector"])
         if self.use_graph:
@@ -106,16 +108,16 @@ class Sampler:
         """One sampler step = guider.prepare_inputs -> DiscreteDenoiser (sigma -> table index, c_in) -> UNet -> fused
         [c_out, 3-way CFG, to_d, Euler] kernel."""
         from cd360.sampler import cfg_euler_update
-        x3 = x.expand(3, -1, -1, -1)
-        x_in, c_noise, _, _, _ = self.denoiser.network_inputs(x3, s.expand(3), {})
+        x3 = x.expand(3, -1, -1, -1) if x.shape[0] == 1 else torch.cat([x] * 3)
+        x_in, c_noise, _, _, _ = self.denoiser.network_inputs(x3, s.expand(x3.shape[0]), {})
         eps = self.net(x_in, timesteps=c_noise, context=self.ctx, y=self.y, pose=self.pose)[0]
         return cfg_euler_update(x, eps.contiguous(), s.reshape(1), s_next.reshape(1), self.scale, self.scale_im)
 
     @torch.no_grad()
     def eps(self, x, i):
         """The UNet's output for step i of the schedule (the three CFG branches), launched eagerly: what --fp8-attn's tolerance report compares."""
-        x3 = x.expand(3, -1, -1, -1)
-        x_in, c_noise, _, _, _ = self.denoiser.network_inputs(x3, self.sigmas[i].expand(3), {})
+        x3 = x.expand(3, -1, -1, -1) if x.shape[0] == 1 else torch.cat([x] * 3)
+        x_in, c_noise, _, _, _ = self.denoiser.network_inputs(x3, self.sigmas[i].expand(x3.shape[0]), {})
         return self.net(x_in, timesteps=c_noise, context=self.ctx, y=self.y, pose=self.pose)[0].float()
 
     def _pin_rendered(self):
@@ -274,6 +276,9 @@ def main():
     ap.add_argument("--traj", type=int, default=50, help="sampler steps per image (render on step 0 of each)")
     ap.add_argument("--poses", type=int, default=0, help="target poses of the whole job (default: one per GPU); P > GPUs gives every rank "
                     "its cd360.shard.assign_poses share and runs them one after the other (BASELINE configs[2] on fewer than 8 GPUs)")
+    ap.add_argument("--poses-per-replay", type=int, default=1, help="target poses batched into ONE denoise step (CFG batch 3 x this): what a rank "
+                    "with several poses to sample gains from batching them (the 1280-level GEMMs then run 256-row tiles).  A separate line -- "
+                    "`config.poses_per_replay`, metric suffixed -- never the headline; --poses must be a multiple of it per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying the steady-state step from a hipGraph")
@@ -316,12 +321,16 @@ def main():
             if isinstance(m, BasicTransformerBlock):
                 m.register_forward_hook(lambda mod, inp, out: None)
     jobs = []
-    for pi in mine:  # one target pose = one CFG-3 batch with its own latent; the 50 reference cameras are shared
-        pose = synth.pose_batch(1, args.refs, seed=100 + pi, n_train=50) * 3
-        g = torch.Generator(device=dev).manual_seed(7 + pi)
-        ctx = torch.randn(3, 77, 2048, generator=g, device=dev).to(torch.bfloat16)
-        y = torch.randn(3, 2816, generator=g, device=dev).to(torch.bfloat16)
-        jobs.append((pose, ctx, y, torch.randn(1, 4, args.latent, args.latent, generator=g, device=dev)))
+    ppr = max(1, args.poses_per_replay)
+    assert len(mine) % ppr == 0, "--poses-per-replay must divide the poses of every rank"
+    for j0 in range(0, len(mine), ppr):  # one job = `ppr` target poses = one CFG-3 batch of 3 * ppr with their own latents; the 50 reference cameras are shared
+        group = mine[j0:j0 + ppr]
+        one = [synth.pose_batch(1, args.refs, seed=100 + pi, n_train=50)[0] for pi in group]
+        pose = one * 3  # [null image x ppr | image x ppr | image + text x ppr]: the last two thirds are the SAME camera objects (de-duplicated render)
+        g = torch.Generator(device=dev).manual_seed(7 + group[0])
+        ctx = torch.randn(3 * ppr, 77, 2048, generator=g, device=dev).to(torch.bfloat16)
+        y = torch.randn(3 * ppr, 2816, generator=g, device=dev).to(torch.bfloat16)
+        jobs.append((pose, ctx, y, torch.randn(ppr, 4, args.latent, args.latent, generator=g, device=dev)))
     pose, ctx, y, x = jobs[0]
     smp = Sampler(net, pose, ctx, y, args.traj, use_graph=not args.no_graph)
 
@@ -354,7 +363,7 @@ def main():
         finals.append(xs)
     sync()
     elapsed = time.perf_counter() - t0
-    steps_done = args.steps * len(jobs)
+    steps_done = args.steps * len(jobs)  # replays of this rank; each advances `ppr` poses by one denoise step
     if len(jobs) > 1:
         smp.retarget(*jobs[0][:3])
 
@@ -382,7 +391,7 @@ def main():
     elapsed = float(tmax.item())
     assert all(torch.isfinite(f).all() for f in finals)
 
-    sum_steps = args.steps * n_poses
+    sum_steps = args.steps * n_poses  # pose-steps of the whole job
     if rank == 0:
         # ---- rooflines.  `achieved` = ALGORITHMIC flops (MFMA-bound kernels) or bytes (HBM-bound) of the launches / their HIP-event time on
         # the launch stream (ops._timed: SURVEY.md section 8d formulas, stated per kernel in DESIGN.md section 7b) ----
@@ -445,11 +454,12 @@ def main():
                     roofs[k]["what"] = notes[k]
             # whole steady-state step: 2.03e13 FLOP per CFG-3 step at 1024^2 (FlopCounterMode on the plain UNet)
             if args.latent == 128:
-                roofs["steady_step"] = {"bound": "mfma", "achieved": round(2.03e13 / (steady_ms * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TF,
-                                        "unit": "TFLOP/s", "frac": round(2.03e13 / (steady_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4),
+                roofs["steady_step"] = {"bound": "mfma", "achieved": round(ppr * 2.03e13 / (steady_ms * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TF,
+                                        "unit": "TFLOP/s", "frac": round(ppr * 2.03e13 / (steady_ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TF, 4),
                                         "what": "2.03e13 algorithmic FLOP of one CFG-3 UNet step / steady_step_ms (hipGraph replay wall time)"}
         out = {
-            "metric": _baseline_metric(), "value": round(sum_steps / elapsed, 4), "unit": "steps/s",
+            "metric": _baseline_metric() + ("" if ppr == 1 else f" [{ppr} poses batched per replay: NOT the headline configuration]"),
+            "value": round(sum_steps / elapsed, 4), "unit": "steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / steps_done * 1e3, 3),
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "sample.py 50-step sampling, SDXL UNet (random init), latent %d^2, CFG x3, %d ref views (synthetic ring cameras), "
@@ -459,12 +469,14 @@ def main():
                                    "capture.  Inside the timed render step, once per image: the text K / V projections (reused by the 49 cached steps)"
                                    % (args.latent, args.refs, n_poses, world, args.traj),
                        "render_step_ms": round(render_ms, 2), "steady_step_ms": round(steady_ms, 2), "prepare_ms": round(prepare_ms, 1),
+                       **({"replay_note": f"one replay = one denoise step of {ppr} poses (CFG batch {3 * ppr}): value counts pose-steps, ms_per_step and "
+                                          "render / steady_step_ms are per REPLAY"} if ppr > 1 else {}),
                        "prepare_ms_what": "Sampler.prepare(), once per job and outside every timed number: first eager render step (builds the reference "
                                           "tables Y / lv of the 51 distinct reference images for the 12 pose blocks, packs every block's weights) + capture "
                                           "of the steady-state and render hipGraphs; amortise it over the images of a job",
                        "attention_arith": "fp8 MFMA (e4m3 q / K / P / V, fp32 accumulate) in the fused cross-attentions" if args.fp8_attn else "bf16 MFMA",
-                       "cfg_batch": 3, "latent": args.latent,
-                       "n_ref": args.refs, "poses": n_poses, "poses_per_gpu": len(mine), "world_size": world,
+                       "cfg_batch": 3 * ppr, "latent": args.latent,
+                       "n_ref": args.refs, "poses": n_poses, "poses_per_gpu": len(mine), "poses_per_replay": ppr, "world_size": world,
                        "rccl_ranks": dist.get_world_size() if dist.is_initialized() else 1,
                        **({"sanity_run": "CD360_BENCH_ONE_GPU: all ranks on GPU 0 over gloo -- not a measurement"} if one_gpu else {}),
                        "parallelism": "pose-dp%d" % world,
