@@ -8,7 +8,7 @@ mkdir -p $OUT
 cd /tmp
 for K in $K1 $K2; do
   rm -rf /tmp/sd_$K
-  timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/sd_$K -o b -- python $GRAFT_REPO_ROOT/bench.py --steps $K --warmup 2 --no-cpu-baseline --no-train-step --no-profile --no-graph > $OUT/log_$K.txt 2>&1
+  timeout 900 rocprofv3 --kernel-trace --output-format csv -d /tmp/sd_$K -o b -- python $GRAFT_REPO_ROOT/bench.py --steps $K --warmup 2 --no-cpu-baseline --no-train-step --no-profile ${STEADY_NOGRAPH---no-graph} > $OUT/log_$K.txt 2>&1
   echo "K=$K exit $?"
 done
 python - $(find /tmp/sd_$K1 -name "*kernel_trace.csv" | head -1) $(find /tmp/sd_$K2 -name "*kernel_trace.csv" | head -1) $((K2-K1)) > $OUT/steady_step.csv <<'PY'

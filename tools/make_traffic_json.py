@@ -40,7 +40,7 @@ def load(counter):
             targs = [int(t) for t in m.group(1).split(",")] if m else []
             if targs and targs[-1] == 5:
                 key = "conv_igemm"
-            elif targs and 2 <= targs[-1] <= 4:
+            elif targs and (2 <= targs[-1] <= 4 or 7 <= targs[-1] <= 10):  # attention epilogues (7-9: odd 16-key groups, 10: fp8)
                 key = "qproj_attn" if targs[:4] == [2, 4, 2, 4] else "qproj_attn_text"  # only the pose tokens take the 256 x 256 tile
         d = out.setdefault(key, {"n": 0, "kb": 0.0, "symbols": set()})
         d["n"] += int(r["dispatches"])
