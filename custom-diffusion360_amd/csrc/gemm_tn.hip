@@ -160,13 +160,20 @@ __global__ __launch_bounds__(256) void tn_reduce_kernel(const float* __restrict_
 }
 
 int tn_slabs(long M, int N, int K) {
+  // Slabs of the contraction range per output tile.  512 workgroups run at once (two per CU); a launch of 600 takes TWO rounds, the second
+  // one at 17 % occupancy -- round 3 chose ceil(512 / tiles) and paid exactly that on the fine-tune step's dominant shapes (100 tiles x 6
+  // slabs, 25 tiles x 21 slabs: half the kernel's time).  Pick the count that minimises rounds x (K-tiles per workgroup + its fixed
+  // prologue / partial-tile store, ~6 K-tiles' worth) plus the second kernel's pass over the slabs.
   const long tiles = (long)((N + 127) / 128) * ((K + 127) / 128);
   const long mt = (M + TBM - 1) / TBM;
-  long s = (512 + tiles - 1) / tiles;  // about two workgroups per CU in total
-  if (s > mt) s = mt;
-  if (s > 64) s = 64;
-  if (s < 1) s = 1;
-  return (int)s;
+  long best = 1;
+  double best_cost = 1e30;
+  for (long s = 1; s <= 64 && s <= mt; ++s) {
+    const long rounds = (tiles * s + 511) / 512, per = (mt + s - 1) / s;
+    const double cost = (double)rounds * (double)(per + 6) + 0.5 * (double)s;
+    if (cost < best_cost) { best_cost = cost; best = s; }
+  }
+  return (int)best;
 }
 
 }  // namespace
