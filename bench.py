@@ -69,7 +69,7 @@ class Sampler:
     With `use_graph` the steady-state step (cached render) and the render step are each captured once into a hipGraph and
     replayed: ~3000 launches per step are then issued by the GPU front end instead of the Python interpreter."""
 
-    def __init__(self, net, pose, ctx, y, n_steps, scale=7.5, scale_im=3.5, use_graph=False):
+    def __init__(self, net, pose, ctx, y, n_steps, scale=7.5, scale_im=3.5, use_graph=False, prefetch=None):
         from cd360 import sampler as S
         self.net, self.pose, self.n_steps = net, pose, n_steps
         self.scale, self.scale_im = scale, scale_im
@@ -84,6 +84,7 @@ class Sampler:
         uc = {"crossattn": ctx[:bs], "vector": y[:bs]}
         _, _, cond3 = self.guider.prepare_inputs(ctx.new_zeros(bs, 1), ctx.new_zeros(bs), c, uc)
         self.ctx, self.y = cond3["crossattn"].contiguous(), cond3["vector"].contiguous()
+        self.prefetch = prefetch  # cd360.prefetch.WeightPrefetcher or None: armed around both captures
         self.use_graph, self.graph = use_graph, None
         self.graph_render, self.rgraph = use_graph and not os.environ.get("CD360_BENCH_EAGER_RENDER"), None
 
@@ -157,8 +158,12 @@ class Sampler:
         # barrier) while this thread captures: only the thread-local capture mode tolerates that (tools/probe/rccl_graph_probe.py)
         import torch.distributed as dist
         mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
+        import contextlib
         with torch.cuda.graph(graph, capture_error_mode=mode):
-            out = fn()
+            # every GEMM / convolution launch of the captured step also enqueues, on a forked side stream, a touch of its weights that runs
+            # beside the preceding launches (one step streams 5.3 GB of weights through a 256 MB Infinity Cache: cd360/prefetch.py)
+            with (self.prefetch if self.prefetch is not None else contextlib.nullcontext()):
+                out = fn()
         return graph, out
 
     def _render(self):
@@ -285,6 +290,10 @@ def main():
     ap.add_argument("--route", choices=["fused", "module"], default="fused", help="module: a no-op forward hook on every transformer block, so the "
                     "blocks take the strict module route a patched sample.py (sample.py:247-262) or a hooked run takes -- same kernels, un-fused")
     ap.add_argument("--no-train-step", action="store_true", help="skip the fine-tuning step measurement appended after the timed region (BASELINE configs[3])")
+    ap.add_argument("--no-weight-prefetch", action="store_true", help="capture the steps without the weight prefetcher (cd360/prefetch.py): the A/B partner")
+    ap.add_argument("--prefetch-wgs", type=int, default=128)
+    ap.add_argument("--prefetch-lag", type=int, default=2)
+    ap.add_argument("--prefetch-min-mb", type=float, default=1.0)
     ap.add_argument("--fp8-attn", action="store_true", help="BASELINE configs[4]: the text / pose-token cross-attention of every block with q K^T and P V on "
                     "fp8 MFMA (cd360_qproj_attn_fp8_bf16) for the whole run; adds an `fp8_tolerance` object (rendered features and eps against the bf16 run)")
     args = ap.parse_args()
@@ -332,7 +341,11 @@ def main():
         y = torch.randn(3 * ppr, 2816, generator=g, device=dev).to(torch.bfloat16)
         jobs.append((pose, ctx, y, torch.randn(ppr, 4, args.latent, args.latent, generator=g, device=dev)))
     pose, ctx, y, x = jobs[0]
-    smp = Sampler(net, pose, ctx, y, args.traj, use_graph=not args.no_graph)
+    pf = None
+    if not args.no_graph and not args.no_weight_prefetch:
+        from cd360.prefetch import WeightPrefetcher
+        pf = WeightPrefetcher(dev, lag=args.prefetch_lag, wgs=args.prefetch_wgs, min_bytes=int(args.prefetch_min_mb * (1 << 20)))
+    smp = Sampler(net, pose, ctx, y, args.traj, use_graph=not args.no_graph, prefetch=pf)
 
     def sync():
         torch.cuda.synchronize()
@@ -481,6 +494,8 @@ def main():
                        **({"sanity_run": "CD360_BENCH_ONE_GPU: all ranks on GPU 0 over gloo -- not a measurement"} if one_gpu else {}),
                        "parallelism": "pose-dp%d" % world,
                        "hipgraph": not args.no_graph, "hipgraph_render_step": smp.rgraph is not None, "route": args.route,
+                       "weight_prefetch": None if pf is None else {"lag": pf.lag, "wgs": pf.wgs, "what": "touch kernels of every GEMM-family launch's "
+                                                                   "weights on a side branch of the captured graph (cd360/prefetch.py)"},
                        "rank_ms_per_step": {"min": round(min(rank_ms), 3), "max": round(max(rank_ms), 3)},
                        "kernel_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])},
                        "kernel_ms_per_step_source": "a separate EAGER replay of the same K steps after the timed region, HIP events around every launch "

@@ -72,6 +72,8 @@ SIGNATURES = {
     "cd360_gemm_tn_bf16": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_int64, c_int64, c_int, _P, _P]),
     "cd360_adamw_tick": (c_int, [_P, _P]),
     "cd360_adamw_bf16": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, _P]),
+    "cd360_prefetch_arm": (c_int, [_P, c_int, c_int, c_int64, _P]),
+    "cd360_prefetch_disarm": (c_int, []),
     "cd360_set_tuning": (c_int, [_P]),
     "cd360_get_tuning": (c_int, [_P]),
     "cd360_whatif_build": (c_int, []),

@@ -340,7 +340,7 @@ class GraphedTrainStep:
     that edits `optimizer.param_groups` has no effect on replays (re-capture to change them)."""
 
     def __init__(self, unet: torch.nn.Module, loss_fn, optimizer: "MasterAdamW", batch: dict, warmup: int = 3, warmup_restore: bool = False,
-                 **loss_kw):
+                 weight_prefetch: bool = False, **loss_kw):
         if not optimizer.capturable:
             raise ValueError("GraphedTrainStep: the torch fall-back of MasterAdamW must be built with capturable=True (the fused path is as it is)")
         self.unet, self.loss_fn, self.optimizer, self.loss_kw = unet, loss_fn, optimizer, loss_kw
@@ -369,8 +369,14 @@ class GraphedTrainStep:
         # group's watchdog thread polls events meanwhile, which only the thread-local capture mode tolerates.  Every rank captures the same
         # sequence and must replay in lock-step, as with any collective.
         mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
+        import contextlib
+        pf = contextlib.nullcontext()
+        if weight_prefetch:  # (cd360/prefetch.py; measured SLOWER here, 121.3 vs 117.9 ms: 3400 short launches leave the touches no room -- off)
+            from .prefetch import WeightPrefetcher
+            pf = WeightPrefetcher(next(unet.parameters()).device)
         with torch.cuda.graph(self.graph, capture_error_mode=mode):
-            self.total, self.logged = train_step(unet, loss_fn, optimizer, as_tensors=True, **self.static, **loss_kw)
+            with pf:
+                self.total, self.logged = train_step(unet, loss_fn, optimizer, as_tensors=True, **self.static, **loss_kw)
 
     @staticmethod
     def _load(dst, src):

@@ -27,6 +27,7 @@
 // (x * gelu(gate), weight rows interleaved per 64 at pack time so value and gate of a column sit in the same lane).
 #include "cd360_common.h"
 #include "cd360_tuning.h"
+#include "cd360_prefetch.h"
 #include <stdlib.h>
 #include <type_traits>
 
@@ -1132,11 +1133,15 @@ int launch_mv(const GemmParams& p0, hipStream_t stream) {
 #endif
   const long nwg = (long)p.tiles_m * p.tiles_n * ((EPI == 5 && p.cv_up) ? 4 : 1);
   if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
+  // weight prefetcher (prefetch.hip; armed only while a step is being captured): a small kernel on the forked side stream touches THIS
+  // launch's weights as soon as the launch `lag` positions earlier has finished, i.e. while its predecessors compute
+  cd360_prefetch_before_launch(p.w, ((long)p.N * ((EPI == 5 && p.cv_up) ? 4 : 1) - 1) * p.ldw * 2 + (long)p.K * 2);
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_kernel<WM, WN, NCB, NMB, NBUF, KS, MV, EPI>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   if (attr != hipSuccess) return CD360_ERR_LAUNCH;
   hipLaunchKernelGGL((gemm_mfma_kernel<WM, WN, NCB, NMB, NBUF, KS, MV, EPI>), dim3((unsigned)nwg), dim3(64 * (WM * WN * KS + MV)), LDS_BYTES, stream, p);
   CD360_LAUNCH_CHECK();
+  cd360_prefetch_after_launch(stream);
   return CD360_OK;
 }
 

@@ -62,6 +62,18 @@ int cd360_set_tuning(const cd360_tuning* t);
 int cd360_get_tuning(cd360_tuning* t);
 int cd360_whatif_build(void);
 
+/* ---- weight prefetcher of a captured step --------------------------------------------------------------------
+ * One denoise step streams 5.3 GB of weights through a 256 MB Infinity Cache: every GEMM / convolution launch finds its weights in HBM.
+ * The launches of a captured step are a fixed sequence, so they can be fetched ahead.  cd360_prefetch_arm -- called INSIDE a stream
+ * capture, after `side_stream` has been forked into it -- makes every following launch of the GEMM family (cd360_gemm_bf16,
+ * cd360_qproj_attn*_bf16, cd360_conv3x3_dma_bf16, cd360_conv_up2x_bf16, cd360_gemm_cstats_bf16) enqueue on the side stream a small kernel
+ * (`wgs` workgroups) that touches one dword per 128-byte line of that launch's weights (weights below `min_bytes` are skipped) and waits
+ * only for the completion of the launch `lag` (1 .. 7) positions earlier: in the replayed graph the weights of launch i arrive in the
+ * Infinity Cache while launches i - lag + 1 ... i - 1 compute.  The main stream never waits for the side stream; the caller joins it once,
+ * after cd360_prefetch_disarm(), before the capture ends.  sink: 4 bytes of device scratch.  Process-wide state: one capture at a time. */
+int cd360_prefetch_arm(void* side_stream, int lag, int wgs, int64_t min_bytes, void* sink);
+int cd360_prefetch_disarm(void);
+
 /* ---- attention ---------------------------------------------------------------------------------------------
  * replaces xformers.ops.memory_efficient_attention(q, k, v, attn_bias=None, op=None)
  *          sgm/modules/attention.py:393-408 (MemoryEfficientCrossAttention.forward), head dim 64, no mask.

@@ -60,7 +60,7 @@ def _measure(steps, warmup, batch, views, latent, eval_mode, profile, finetune, 
     losses = []
     step = lambda: finetune.train_step(net, loss_fn, opt, **bt)
     if graph:
-        step = finetune.GraphedTrainStep(net, loss_fn, opt, bt, warmup=max(warmup, 1))
+        step = finetune.GraphedTrainStep(net, loss_fn, opt, bt, warmup=max(warmup, 1), weight_prefetch=bool(os.environ.get("CD360_TRAIN_PREFETCH")))
     for _ in range(warmup):
         losses.append(float(step()[0]))
     torch.cuda.synchronize()

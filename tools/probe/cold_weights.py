@@ -16,7 +16,8 @@ from cd360 import ops
 dev = "cuda"
 
 
-def graph_time(fns, reps=5):
+def graph_time(fns, reps=5, prefetch=None):
+    import contextlib
     s = torch.cuda.Stream()
     s.wait_stream(torch.cuda.current_stream())
     with torch.cuda.stream(s):
@@ -26,8 +27,9 @@ def graph_time(fns, reps=5):
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
-        for f in fns:
-            f()
+        with (prefetch if prefetch is not None else contextlib.nullcontext()):
+            for f in fns:
+                f()
     g.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -56,7 +58,13 @@ for name, M, N, K, kw in (("L2 ff1+geglu", 3072, 10240, 1280, "geglu"), ("L2 ff2
         return lambda: ops.gemm(a, w, bias=b32, res=r, want_stats=True)
 
     warm = graph_time([call(pool[0])] * 20)
-    cold = graph_time([call(pool[i % pool_n]) for i in range(max(20, pool_n))])
-    print(f"{name:14s} M={M} N={N} K={K}: warm weights {warm:6.1f} us | cold weights ({pool_n} x {N * K * 2 / 1e6:.1f} MB pool) {cold:6.1f} us | +{(cold / warm - 1) * 100:.0f} %", flush=True)
+    seq = [call(pool[i % pool_n]) for i in range(max(20, pool_n))]
+    cold = graph_time(seq)
+    line = f"{name:14s} M={M} N={N} K={K}: warm weights {warm:6.1f} us | cold weights ({pool_n} x {N * K * 2 / 1e6:.1f} MB pool) {cold:6.1f} us | +{(cold / warm - 1) * 100:.0f} %"
+    from cd360.prefetch import WeightPrefetcher
+    for lag, wgs in ((2, 32), (3, 32), (2, 128)):
+        t = graph_time(seq, prefetch=WeightPrefetcher(dev, lag=lag, wgs=wgs))
+        line += f" | prefetched lag {lag} x {wgs} WGs {t:6.1f}"
+    print(line, flush=True)
     del pool
     torch.cuda.empty_cache()
