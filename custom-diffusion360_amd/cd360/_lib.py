@@ -35,6 +35,7 @@ SIGNATURES = {
     "cd360_volrender": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cd360_volrender_bwd": (c_int, [_P, _P, _P, _P, c_int] + [_P] * 8 + [c_int] * 6 + [_P]),
     "cd360_rowdot4_bf16": (c_int, [_P, _P, _P, c_int64, c_int, _P]),
+    "cd360_rowdot1_bf16": (c_int, [_P, _P, _P, c_int64, c_int, _P]),
     "cd360_geglu_bf16": (c_int, [_P, _P, c_int64, c_int, _P]),
     "cd360_concat_channels_bf16": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P]),
     "cd360_add_layernorm_bf16": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, c_float, _P]),

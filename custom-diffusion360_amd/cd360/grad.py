@@ -257,7 +257,8 @@ class NerfRenderFn(torch.autograd.Function):
             Y = ops.linear(x2.detach(), Wf.detach()).reshape(b * n, hw, C)
         else:
             Y = torch.mm(x2.to(Wf.dtype), Wf.detach().t()).reshape(b * n, hw, C).contiguous()
-        lv = torch.mv(x2.float(), vf).reshape(b * n, hw).contiguous()
+        from .nerf import _view_logit_column
+        lv = _view_logit_column(x2.detach(), vf).reshape(b * n, hw).contiguous()
         g, logits, lse = ops.nerf_mlp_aggregate(cams, xs, ys, t, Y, zP, lv, cview, Wk, want_logits=True)
         ctx.save_for_backward(cams, xs, ys, t, xref, Y, lv, zP, cview, Wk, g, lse)
         ctx.wf_dtype = Wf.dtype

@@ -268,6 +268,14 @@ def fused_feature_nerf(fw: FusedNerfWeights, cams: torch.Tensor, xref: Optional[
     return h, dec, dists, vw
 
 
+def _view_logit_column(x2: torch.Tensor, vf: torch.Tensor) -> torch.Tensor:
+    """lv = x2 . vf in fp32 (one read of the bf16 features on cd360_rowdot1_bf16; torch.mv elsewhere)."""
+    vf = vf.detach()
+    if x2.is_cuda and x2.dtype == torch.bfloat16 and x2.shape[-1] % 8 == 0 and x2.is_contiguous() and not routes.library_linear:
+        return ops.rowdot1(x2, vf.float().contiguous())
+    return torch.mv(x2.float(), vf.float())
+
+
 def reference_tables(fw: FusedNerfWeights, xref: torch.Tensor):
     """Per-pixel tables that depend only on the reference features (cacheable across target poses and steps):
     Y = xref @ Wf^T (bf16) and lv = xref @ vf (fp32)."""
@@ -277,5 +285,5 @@ def reference_tables(fw: FusedNerfWeights, xref: torch.Tensor):
         Y = ops.linear(x2, fw.Wf).reshape(b * n, hw, C)
     else:
         Y = torch.mm(x2.to(fw.Wf_t.dtype), fw.Wf_t).reshape(b * n, hw, C)
-    lv = torch.mv(x2.float(), fw.vf).reshape(b * n, hw)
+    lv = _view_logit_column(x2, fw.vf).reshape(b * n, hw)
     return Y.contiguous(), lv.contiguous()

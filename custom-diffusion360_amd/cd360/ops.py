@@ -406,6 +406,19 @@ def rowdot4(h: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def rowdot1(h: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
+    """h [..., C] bf16, w [C] fp32 -> [...] fp32 (cd360_rowdot1_bf16: the view-logit column lv = xref . vf of the reference tables).
+    Not differentiable: the training path differentiates vf through grad.NerfRenderFn's own reductions."""
+    _need_gpu(h, w)
+    C = h.shape[-1]
+    assert h.dtype == torch.bfloat16 and h.is_contiguous() and w.shape == (C,) and w.dtype == torch.float32 and w.is_contiguous()
+    rows = h.numel() // C
+    out = torch.empty(h.shape[:-1], dtype=torch.float32, device=h.device)
+    with _timed("rowdot1", 0.0, 2.0 * rows * C):
+        check(_lib.load().cd360_rowdot1_bf16(_ptr(h), _ptr(w), _ptr(out), rows, C, _stream()), "cd360_rowdot1_bf16")
+    return out
+
+
 def rowdot4_bwd(d_out: torch.Tensor, h: torch.Tensor, w: torch.Tensor, need_dh: bool = True, need_dw: bool = True):
     """Backward of rowdot4: d_out [..., 4] fp32 -> (dh [..., C] bf16 | None, dw [4, C] fp32 | None) (cd360_rowdot4_bwd_bf16)."""
     _need_gpu(d_out, h, w)

@@ -829,30 +829,43 @@ __global__ void plucker_features_kernel(const float* __restrict__ cams, const fl
   v[3] = co[1] * v[2] - co[2] * v[1];
   v[4] = co[2] * v[0] - co[0] * v[2];
   v[5] = co[0] * v[1] - co[1] * v[0];
-  float f[104];
-#pragma unroll
+  // every value goes from registers to its place in the row: no per-thread feature array (a 104-float array indexed inside the
+  // partially unrolled sin/cos loops lived in 432 B of scratch)
+  uint32_t* dst16 = reinterpret_cast<uint32_t*>(out_) + gid * 64;
+  float* dst32 = reinterpret_cast<float*>(out_) + gid * 104;
+#pragma unroll 1
   for (int kf = 0; kf < 8; ++kf) {
     const float freq = __builtin_bit_cast(float, (uint32_t)((127 + kf - 4) << 23)) * 3.14159274101257324f;
+    float sn[6], cs[6];
 #pragma unroll
     for (int c = 0; c < 6; ++c) {
       const float arg = v[c] * freq;
-      f[kf * 6 + c] = sinf(arg);
-      f[48 + kf * 6 + c] = cosf(arg);
+      sn[c] = sinf(arg);
+      cs[c] = cosf(arg);
+    }
+    if (BF) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        dst16[kf * 3 + c] = pack_bf16x2(sn[2 * c], sn[2 * c + 1]);
+        dst16[24 + kf * 3 + c] = pack_bf16x2(cs[2 * c], cs[2 * c + 1]);
+      }
+    } else {
+#pragma unroll
+      for (int c = 0; c < 6; ++c) {
+        dst32[kf * 6 + c] = sn[c];
+        dst32[48 + kf * 6 + c] = cs[c];
+      }
     }
   }
-  f[96] = cd[0]; f[97] = cd[1]; f[98] = cd[2];
-#pragma unroll
-  for (int j = 99; j < 104; ++j) f[j] = 0.f;
   if (BF) {
-    uint32_t* dst = reinterpret_cast<uint32_t*>(out_) + gid * 64;
+    dst16[48] = pack_bf16x2(cd[0], cd[1]);
+    dst16[49] = pack_bf16x2(cd[2], 0.f);
 #pragma unroll
-    for (int j = 0; j < 52; ++j) dst[j] = pack_bf16x2(f[2 * j], f[2 * j + 1]);
-#pragma unroll
-    for (int j = 52; j < 64; ++j) dst[j] = 0u;
+    for (int j = 50; j < 64; ++j) dst16[j] = 0u;
   } else {
-    float* dst = reinterpret_cast<float*>(out_) + gid * 104;
+    dst32[96] = cd[0]; dst32[97] = cd[1]; dst32[98] = cd[2];
 #pragma unroll
-    for (int j = 0; j < 104; ++j) dst[j] = f[j];
+    for (int j = 99; j < 104; ++j) dst32[j] = 0.f;
   }
 }
 

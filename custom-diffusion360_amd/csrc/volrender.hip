@@ -247,45 +247,67 @@ extern "C" int cd360_volrender_bwd(const void* feats, const void* sigma_raw, con
 // fp32 weights, fp32 accumulation and fp32 output (sigma_raw feeds exp(): it must not be rounded to bf16).
 // One wave per row; HBM-bound (reads h once).
 namespace {
-__global__ __launch_bounds__(256) void rowdot4_kernel(const uint16_t* __restrict__ h, const float* __restrict__ w, float* __restrict__ out,
-                                                      long rows, int C) {
+template <int NW>
+__global__ __launch_bounds__(256) void rowdot_kernel(const uint16_t* __restrict__ h, const float* __restrict__ w, float* __restrict__ out,
+                                                     long rows, int C) {
   const int lane = threadIdx.x & 63;
   const long wave0 = ((long)blockIdx.x * blockDim.x + threadIdx.x) >> 6, nwaves = ((long)gridDim.x * blockDim.x) >> 6;
   for (long row = wave0; row < rows; row += nwaves) {
-    float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+    float a[NW];
+#pragma unroll
+    for (int j = 0; j < NW; ++j) a[j] = 0.f;
     for (int c = lane * 8; c < C; c += 64 * 8) {
       const u32x4 v = *reinterpret_cast<const u32x4*>(h + row * C + c);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const float lo = bf16lo_to_f32(v[e]), hi = bf16hi_to_f32(v[e]);
         const int ci = c + 2 * e;
-        a0 = fmaf(lo, w[ci], a0); a0 = fmaf(hi, w[ci + 1], a0);
-        a1 = fmaf(lo, w[C + ci], a1); a1 = fmaf(hi, w[C + ci + 1], a1);
-        a2 = fmaf(lo, w[2 * C + ci], a2); a2 = fmaf(hi, w[2 * C + ci + 1], a2);
-        a3 = fmaf(lo, w[3 * C + ci], a3); a3 = fmaf(hi, w[3 * C + ci + 1], a3);
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+          a[j] = fmaf(lo, w[j * C + ci], a[j]);
+          a[j] = fmaf(hi, w[j * C + ci + 1], a[j]);
+        }
       }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) {
-      a0 += __shfl_xor(a0, off); a1 += __shfl_xor(a1, off); a2 += __shfl_xor(a2, off); a3 += __shfl_xor(a3, off);
+#pragma unroll
+      for (int j = 0; j < NW; ++j) a[j] += __shfl_xor(a[j], off);
     }
     if (lane == 0) {
-      f32x4 o = {a0, a1, a2, a3};
-      *reinterpret_cast<f32x4*>(out + row * 4) = o;
+      if constexpr (NW == 4) {
+        f32x4 o = {a[0], a[1], a[2], a[3]};
+        *reinterpret_cast<f32x4*>(out + row * 4) = o;
+      } else {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) out[row * NW + j] = a[j];
+      }
     }
   }
 }
 }  // namespace
 
-// h [rows, C] bf16, w [4, C] fp32 -> out [rows, 4] fp32
-extern "C" int cd360_rowdot4_bf16(const void* h, const void* w, void* out, int64_t rows, int C, void* stream) {
+static int rowdot_launch(int nw, const void* h, const void* w, void* out, int64_t rows, int C, void* stream) {
   if (!h || !w || !out || rows <= 0 || C <= 0) return CD360_ERR_ARG;
   if (C % 8) return CD360_ERR_SHAPE;
   const long nblk = (rows + 3) / 4 > 256 * 32 ? 256 * 32 : (rows + 3) / 4;
-  hipLaunchKernelGGL(rowdot4_kernel, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)h, (const float*)w,
-                     (float*)out, (long)rows, C);
+  if (nw == 4) hipLaunchKernelGGL(rowdot_kernel<4>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)h,
+                                  (const float*)w, (float*)out, (long)rows, C);
+  else hipLaunchKernelGGL(rowdot_kernel<1>, dim3((unsigned)nblk), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)h, (const float*)w,
+                          (float*)out, (long)rows, C);
   CD360_LAUNCH_CHECK();
   return CD360_OK;
+}
+
+// h [rows, C] bf16, w [4, C] fp32 -> out [rows, 4] fp32
+extern "C" int cd360_rowdot4_bf16(const void* h, const void* w, void* out, int64_t rows, int C, void* stream) {
+  return rowdot_launch(4, h, w, out, rows, C, stream);
+}
+
+// h [rows, C] bf16, w [C] fp32 -> out [rows] fp32: the view-logit column lv = xref . vf of the reference tables (plane_coefs.0's rows of the
+// feature block folded with the aggregation head, cd360/nerf.py reference_tables; nerfsd_pytorch3d.py:130-146).  One read of h.
+extern "C" int cd360_rowdot1_bf16(const void* h, const void* w, void* out, int64_t rows, int C, void* stream) {
+  return rowdot_launch(1, h, w, out, rows, C, stream);
 }
 
 // Backward of cd360_rowdot4_bf16 (the FeatureNeRF decoder is trained: trainkeys = pose, diffusion.py:139-144):

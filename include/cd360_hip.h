@@ -194,6 +194,10 @@ int cd360_volrender_bwd(const void* feats, const void* sigma_raw, const void* rg
 /* replaces FeatureNeRFEncoding.decoder, Linear(C -> 1+3, bias=False) (nerfsd_pytorch3d.py:49-51,160) and the channel split in
  * NerfSDModule.forward (:443-449): h [rows, C] bf16, w [4, C] fp32 -> out [rows, 4] fp32 = (rgb_raw 0..2, sigma_raw 3). */
 int cd360_rowdot4_bf16(const void* h, const void* w, void* out, int64_t rows, int C, void* stream);
+/* The view-logit column of the FeatureNeRF reference tables: lv = xref . vf, where vf folds the aggregation head with the feature rows of
+ * plane_coefs.0 (nerfsd_pytorch3d.py:130-146; cd360/nerf.py reference_tables): h [rows, C] bf16, w [C] fp32 -> out [rows] fp32, fp32
+ * accumulation, one read of h (this was a torch.mv -> library gemv over an fp32 copy of the features). */
+int cd360_rowdot1_bf16(const void* h, const void* w, void* out, int64_t rows, int C, void* stream);
 /* Backward of cd360_rowdot4_bf16 (the decoder is in the reference's trainkeys `pose`, sgm/models/diffusion.py:139-144; the reference
  * differentiates nn.Linear through autograd): d [rows, 4] fp32 = gradient of the output; dh [rows, C] bf16 = d w (NULL to skip);
  * dw_part [cd360_rowdot4_bwd_slabs(rows), 4, C] fp32 = per slab of rows the partial sums of dw = d^T h (NULL to skip; the caller

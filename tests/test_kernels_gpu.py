@@ -509,3 +509,15 @@ def test_pose_embed_c_abi():
         d = lambda t: t.to(DEV, torch.bfloat16).contiguous()
         got = ops.pose_embed(d(x), d(xr), d(w[:, :C]), d(w[:, C:]))
         assert rel(got, want) < 1e-2
+
+
+@pytest.mark.parametrize("C", [64, 640, 1280])
+def test_rowdot1(C):
+    """cd360_rowdot1_bf16 (lv = xref . vf of the reference tables, cd360/nerf.py reference_tables) vs the fp32 product"""
+    from cd360 import ops
+    torch.manual_seed(3)
+    h = torch.randn(3, 1000, C).to(torch.bfloat16).float()
+    w = torch.randn(C)
+    got = ops.rowdot1(h.to(DEV, torch.bfloat16), w.to(DEV))
+    assert got.shape == (3, 1000) and rel(got, h @ w) < 1e-5
+    assert torch.equal(got, ops.rowdot1(h.to(DEV, torch.bfloat16), w.to(DEV)))
