@@ -26,6 +26,7 @@ SIGNATURES = {
     "cd360_attn_fwd_xformers_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_float, _P]),
     "cd360_patch_rays": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "cd360_ray_project_index": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P, _P, _P, _P, _P, _P]),
+    "cd360_sample_pdf": (c_int, [_P, _P, _P, _P, _P, c_float, c_int64, c_int, c_int, _P]),
     "cd360_feature_gather": (c_int, [_P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "cd360_plucker_features": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "cd360_plucker_features_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),

@@ -228,15 +228,17 @@ def _camera_constants(cams: torch.Tensor):
 
 
 def fused_feature_nerf(fw: FusedNerfWeights, cams: torch.Tensor, xref: Optional[torch.Tensor], num_samples: int, far: float,
-                       near: float = 0.0, xy_jitter=None, depth_jitter=None, want_view_weights: bool = False, tables=None, dims=None):
+                       near: float = 0.0, xy_jitter=None, depth_jitter=None, want_view_weights: bool = False, tables=None, dims=None,
+                       depths=None):
     """cams [b, n+1, 16] fp32 (device), xref [b, n, hw, C] -> (h [b,hw,S,C] bf16, dec [b,hw,S,4] fp32, dists, view_weights|None).
-    With precomputed `tables` = (Y, lv, img_map) xref may be None and `dims` = (b, n, hw, C)."""
+    With precomputed `tables` = (Y, lv, img_map) xref may be None and `dims` = (b, n, hw, C).  `depths` = (t, dists), [S] or [hw, S]
+    each: sample depths chosen by the caller (importance sampling) instead of the uniform / jittered ones."""
     b, n, hw, C = xref.shape if dims is None else dims
     r = int(math.isqrt(hw))
     dev = cams.device
     xs = patch_positions(r, dev, None if xy_jitter is None else xy_jitter[0])
     ys = patch_positions(r, dev, None if xy_jitter is None else xy_jitter[1])
-    t, dists = depth_samples(num_samples, far, near, dev, hw, depth_jitter)
+    t, dists = depths if depths is not None else depth_samples(num_samples, far, near, dev, hw, depth_jitter)
     # the three table GEMMs run on cd360_gemm_bf16 in every mode (ops.linear: recorded by autograd when the weights are live) -- Plucker
     # features written as bf16 rows of 128 by their kernel (no fp32 intermediate, no cast pass), bias fused; CD360_LIBRARY_LINEAR=1 = the
     # round-1 torch GEMMs (A/B)

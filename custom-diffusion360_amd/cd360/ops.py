@@ -243,6 +243,25 @@ def ray_project_index(cams, xs, ys, t, want_points=True, want_grid=True, want_in
     return dict(points=pts, grid=grid, x0=x0, y0=y0, mask=mask)
 
 
+def sample_pdf(bins: torch.Tensor, weights: torch.Tensor, u: torch.Tensor, eps: float = 1e-5, want_dists: bool = False, inplace: bool = False):
+    """Inverse-CDF depth sampling (cd360_sample_pdf; replaces pytorch3d._C.sample_pdf at nerfsd_pytorch3d.py:300-305).
+    bins [..., n_bins + 1], weights [..., n_bins], u [..., n_samples] in [0, 1), fp32 -> samples [..., n_samples]
+    (inplace=True writes them over u, as pytorch3d does) and, with want_dists, the gaps to the next sample (:306)."""
+    _need_gpu(bins, weights, u)
+    n_bins, n_samples = weights.shape[-1], u.shape[-1]
+    rows = weights.numel() // n_bins
+    assert bins.shape[-1] == n_bins + 1 and bins.numel() == rows * (n_bins + 1) and u.numel() == rows * n_samples
+    assert bins.dtype == weights.dtype == u.dtype == torch.float32
+    if inplace and (want_dists or not u.is_contiguous()):
+        raise ValueError("sample_pdf(inplace=True) needs a contiguous u and cannot return dists")
+    bins, weights, uc = bins.contiguous(), weights.contiguous(), u.contiguous()
+    out = uc if inplace else torch.empty_like(uc)
+    dists = torch.empty_like(uc) if want_dists else None
+    check(_lib.load().cd360_sample_pdf(_ptr(bins), _ptr(weights), _ptr(uc), _ptr(out), _ptr(dists), float(eps), rows, n_bins, n_samples,
+                                       _stream()), "cd360_sample_pdf")
+    return (out, dists) if want_dists else out
+
+
 def feature_gather(xref: torch.Tensor, grid: torch.Tensor) -> torch.Tensor:
     """xref [n_img, r*r, C] (fp32|bf16), grid [n_img, P, 2] fp32 -> [n_img, P, C]."""
     _need_gpu(xref, grid)

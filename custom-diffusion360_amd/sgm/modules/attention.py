@@ -338,11 +338,43 @@ class BasicTransformerBlock(nn.Module):
                 torch.mm(flat, wb, out=self._static_proj)
         self._rendered_proj = (rf, rf._version, wb, self._static_proj)
 
+    def _reference_attn_importance(self, x, context_ref, context, pose, prev_weights, mask_ref, tables=None, dims=None):
+        """reference_attn with importance-sampled depths (attention.py:571-598 with use_prev_weights_imp_sample; SURVEY.md section 8 row f4,
+        dead upstream -- see sgm/modules/nerfsd_pytorch3d.py).  The plain order of the reference: render inputs at the sampled depths,
+        pose-token cross-attention, volume render; the third return value is the rendering weights at the UNIFORM depths (the next
+        block's prev_weights) when the FeatureNeRF module honours imp_sample_next_step, else None as upstream."""
+        nerf = self.pose_featurenerf
+        h, dec, dists, _ = nerf.render_inputs(pose, context_ref, mask_ref, tables=tables, dims=dims, prev_weights=prev_weights)
+        b, hw, S, C = h.shape
+        tok = h.reshape(b, hw * S, C)
+        if tok.dtype != x.dtype:
+            tok = tok.to(x.dtype)
+        if self.fused_ready(tok):
+            tok = self._pose_tokens_attn(tok.contiguous(), context)
+        else:
+            tok = self.attn2(self.norm2(tok), context=context) + tok
+        rgb_raw = dec[..., :3] if self.rgb_predict else None
+        tok = tok.reshape(b, hw, S, C)
+        if dists.dim() == 3:  # per batch element: the render kernel shares dists across the batch of a launch
+            parts = [ops.volrender(tok[i:i + 1], dec[i:i + 1, ..., 3], dists[i].contiguous(), None if rgb_raw is None else rgb_raw[i:i + 1])
+                     for i in range(b)]
+            rendered, fg, alphas, _, rgb = (None if parts[0][k] is None else torch.cat([p_[k] for p_ in parts], 0) for k in range(5))
+        else:
+            rendered, fg, alphas, _, rgb = ops.volrender(tok, dec[..., 3], dists, rgb_raw)
+        w_u = None
+        if self.imp_sample_next_step and nerf.honour_imp_sample_next_step:  # :453-457, :590-596
+            with torch.no_grad():
+                dec_u, du = nerf.render_inputs(pose, context_ref, mask_ref, tables=tables, dims=dims, uniform_depths=True)[1:3]
+                d_u = (du[None].expand(hw, -1) if du.dim() == 1 else du)[None, :, :, None]
+                w_u = self.renderer.get_weights(trunc_exp(dec_u[..., 3:]), d_u)[0]
+        return rendered, fg, w_u, alphas, rgb
+
     def reference_attn(self, x, context_ref, context, pose, prev_weights, mask_ref, tables=None, dims=None):
         """FeatureNeRF render of the reference features at the target pose (attention.py:571-598).
-        context_ref [b, n, hw, C].  -> (xref [b,hw,C], fg [b,hw,1], prev_weights(None), alphas [b,hw,S,1], rgb [b,hw,3])"""
-        if prev_weights is not None and self.use_prev_weights_imp_sample:
-            raise NotImplementedError("importance sampling is dead code in the reference (SURVEY.md F3)")
+        context_ref [b, n, hw, C].  -> (xref [b,hw,C], fg [b,hw,1], prev_weights|None, alphas [b,hw,S,1], rgb [b,hw,3])"""
+        nerf = self.pose_featurenerf
+        if self.use_prev_weights_imp_sample and (prev_weights is not None or (self.imp_sample_next_step and nerf.honour_imp_sample_next_step)):
+            return self._reference_attn_importance(x, context_ref, context, pose, prev_weights, mask_ref, tables, dims)
         dup = self._duplicate_cfg_branch(pose, dims) if (tables is not None and context_ref is None and mask_ref is None) else 0
         if dup:
             # 3-way CFG (guiders.py:102-133): the image-conditional and the image+text-conditional thirds see the same target
@@ -788,7 +820,11 @@ class SpatialTransformer(nn.Module):
     def forward(self, x, xr, context=None, contextr=None, pose=None, mask_ref=None, prev_weights=None):
         if not isinstance(context, list):
             context, contextr = [context], [contextr]
-        if self._fused_route(x):
+        # importance sampling revived (f4; nerfsd_pytorch3d.py honour_imp_sample_next_step): the blocks hand rendering weights to each
+        # other (attention.py:849-858), which the module route below carries; never the case in the reference's own configuration
+        chained = self.image_cross and any(getattr(b, "image_cross", False) and b.use_prev_weights_imp_sample
+                                           and b.pose_featurenerf.honour_imp_sample_next_step for b in self.transformer_blocks)
+        if self._fused_route(x) and not chained:
             return self._forward_fused(x, xr, context, contextr, pose, mask_ref)
         x_in, xr_in = x, xr
         sampling = xr is None and pose is not None and any(getattr(b, "reference_choices", None) is not None for b in self.transformer_blocks)
@@ -802,6 +838,7 @@ class SpatialTransformer(nn.Module):
         fg_masks, alphas, rgbs = [], [], []
         t = self._tokens(x)
         tr = pend = pendr = str_ = None
+        prev_weights = None  # attention.py:849: the argument is reset; blocks chain their own
         # The reference stream runs under no_grad (attention.py:845-857) even inside a fine-tuning step: it takes the fused inference
         # path (LayerNorm folds, GEGLU / residual epilogues) while the target stream, which carries the tape, takes the module route.
         ref_fused = False
@@ -827,8 +864,8 @@ class SpatialTransformer(nn.Module):
                             tr, pendr = self._settle(tr, pendr), None  # a pose block reads the reference stream's tokens
             if pose_block:
                 cref = tr.detach() if tr is not None else t  # sample.py passes context_ref=x as a non-None marker (sample.py:57)
-                (t, fg, _, al, rgb), pend = self._run(block, t, pend, context=context[ci], context_ref=cref, pose=pose, mask_ref=mask_ref,
-                                                      prev_weights=None)
+                (t, fg, prev_weights, al, rgb), pend = self._run(block, t, pend, context=context[ci], context_ref=cref, pose=pose,
+                                                                 mask_ref=mask_ref, prev_weights=prev_weights)
                 fg_masks.append(fg)
                 if al is not None:
                     alphas.append(al)
@@ -843,5 +880,5 @@ class SpatialTransformer(nn.Module):
             with torch.no_grad():
                 outr = (self._leave(tr, xr_in) if ref_fused else self._image(self._settle(tr, pendr), xr_in)).detach()
         if len(fg_masks) > 0:
-            return out, outr, fg_masks, None, (alphas if alphas else None), (rgbs if rgbs else None)
+            return out, outr, fg_masks, prev_weights, (alphas if alphas else None), (rgbs if rgbs else None)
         return out, outr, None, None, None, None

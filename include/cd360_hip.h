@@ -132,6 +132,16 @@ int cd360_patch_rays(const void* cams, const void* xs, const void* ys, void* ray
  * Bit-exact against oracle/pose_path.py (sample_grid, bilinear_corners). */
 int cd360_ray_project_index(const void* cams, const void* xs, const void* ys, const void* t, int t_ray_stride, int b, int n, int r, int S,
                             void* points, void* grid, void* x0, void* y0, void* mask, void* stream);
+/* replaces pytorch3d._C.sample_pdf(bins, weights, outputs, eps) as called by Raymarcher.importance_sampling
+ * (sgm/modules/nerfsd_pytorch3d.py:300-306; SURVEY.md section 8 row f4 -- dead code upstream: NerfSDModule.forward never forwards
+ * imp_sample_next_step, :442 vs :333).  pytorch3d is not part of the reference tree; the algorithm is its published sample_pdf_python
+ * (inverse-CDF sampling, the NeRF hierarchical sampler): w = weights + eps, pdf = w / sum w, cdf = (0, cumsum pdf), k = searchsorted(cdf,
+ * u, right), sample = bins[k-1] + (u - cdf[k-1]) / (cdf[k] - cdf[k-1]) (bins[k] - bins[k-1]) (denominator 1 when < eps, indices clamped).
+ * bins [rows, n_bins + 1], weights [rows, n_bins], u [rows, n_samples] in [0, 1) -> samples [rows, n_samples] (may alias u: pytorch3d's
+ * in-place form); dists (may be NULL; needs samples != u) [rows, n_samples] = gap to the next sample, the last to bins[n_bins] (:306).
+ * fp32 throughout.  Errors: CD360_ERR_ARG for NULL / non-positive sizes / eps <= 0 / dists with samples == u. */
+int cd360_sample_pdf(const void* bins, const void* weights, const void* u, void* samples, void* dists, float eps, int64_t rows,
+                     int n_bins, int n_samples, void* stream);
 
 /* ---- feature gather --------------------------------------------------------------------------------------------
  * replaces F.grid_sample(input[b*n, C, r, r], grid[b*n, hw, S, 2], bilinear, align_corners=True, zeros)

@@ -119,6 +119,62 @@ def depth_samples(num_samples: int, far: float, near: float = 0.0, jitter: Optio
     return (j[..., :-1] + j[..., 1:]) / 2.0, j[..., 1:] - j[..., :-1]
 
 
+def sample_pdf(bins: Tensor, weights: Tensor, u: Tensor, eps: float = 1e-5) -> Tensor:
+    """pytorch3d's sample_pdf for given uniforms `u` (called in place as _C.sample_pdf(bins, weights, outputs, eps) at
+    nerfsd_pytorch3d.py:300-305).  PARITY UNPINNED: pytorch3d is not vendored in the reference and not installed here; this restates its
+    published `sample_pdf_python` (pytorch3d/renderer/implicit/sample_pdf.py, the hierarchical sampler of NeRF) and is anchored by
+    known-answer tests (tests/test_oracle_cpu.py).  bins [..., S+1], weights [..., S], u [..., N] -> samples [..., N]."""
+    w = weights + eps
+    pdf = w / w.sum(-1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    cdf = torch.cat([torch.zeros_like(cdf[..., :1]), cdf], -1)
+    inds = torch.searchsorted(cdf, u.contiguous(), right=True)
+    below = (inds - 1).clamp(0)
+    above = inds.clamp(max=cdf.shape[-1] - 1)
+    c0, c1 = torch.gather(cdf, -1, below), torch.gather(cdf, -1, above)
+    b0, b1 = torch.gather(bins, -1, below), torch.gather(bins, -1, above)
+    denom = c1 - c0
+    denom = torch.where(denom < eps, torch.ones_like(denom), denom)
+    return b0 + (u - c0) / denom * (b1 - b0)
+
+
+def importance_sampling_inputs(prev_weights: Tensor, num_rays: int, num_samples: int, far: float, near: float = 0.0,
+                               rand: Optional[Tensor] = None):
+    """Raymarcher.importance_sampling up to its call of sample_pdf (nerfsd_pytorch3d.py:264-299): -> (bins, pdf, u), each
+    [b, num_rays, S(+1)].  PINNED: tests/golden/importance_sampling.npz holds the arguments the reference itself hands to
+    pytorch3d._C.sample_pdf (recorded by tests/golden/make_golden.py case_importance_sampling)."""
+    cdf = prev_weights[..., 0] + 0.01
+    if cdf.shape[1] != num_rays:  # :269-286: antialiased bilinear resize of the per-sample weight maps
+        size, size_ = int(math.isqrt(num_rays)), int(math.isqrt(cdf.shape[1]))
+        m = cdf.permute(0, 2, 1).reshape(cdf.shape[0], -1, size_, size_)
+        m = F.interpolate(m, size=[size, size], antialias=True, mode="bilinear")
+        cdf = m.reshape(cdf.shape[0], -1, size * size).permute(0, 2, 1)
+    lengths = torch.linspace(near, near + (near + far), num_samples + 1)[None, None].expand(cdf.shape[0], num_rays, -1)
+    cdf_sum = torch.sum(cdf, dim=-1, keepdim=True)
+    padding = torch.relu(1e-5 - cdf_sum)
+    cdf = cdf + padding / cdf.shape[-1]
+    cdf_sum = cdf_sum + padding
+    pdf = cdf / cdf_sum
+    u_max = 1.0 / num_samples
+    u = torch.linspace(0, 1 - u_max, num_samples)[None, None].expand(cdf.shape[0], num_rays, -1)
+    if rand is not None:
+        u = u + rand * u_max
+    return lengths, pdf, u
+
+
+def importance_sampling(prev_weights: Tensor, num_rays: int, num_samples: int, far: float, near: float = 0.0,
+                        rand: Optional[Tensor] = None):
+    """Raymarcher.importance_sampling (nerfsd_pytorch3d.py:264-306) as its arithmetic states it.  Upstream this is dead code (SURVEY.md
+    F3) and, as written, would not return the samples: `u` is an expanded view of the buffer, so `u.reshape(-1, S)` hands
+    _C.sample_pdf a copy and the in-place result is dropped (and the stratified `u += rand` on that view raises).  The oracle states
+    the evident intent: the returned lengths ARE sample_pdf's outputs.
+    prev_weights [b, hw', S, 1] (the previous block's rendering weights at uniform depths), `rand` [b, num_rays, S] uniforms of the
+    stratified training mode (:296-298) or None.  Returns (lengths [b, num_rays, S], dists [b, num_rays, S])."""
+    lengths, pdf, u = importance_sampling_inputs(prev_weights, num_rays, num_samples, far, near, rand)
+    t = sample_pdf(lengths, pdf, u, 1e-5)
+    return t, torch.cat([t[..., 1:] - t[..., :-1], lengths[..., -1:] - t[..., -1:]], -1)
+
+
 def ray_points(rays: Tensor, lengths: Tensor) -> Tensor:
     """ray_bundle_to_ray_points on the target camera only (nerfsd_pytorch3d.py:381-387).
     rays [b,n+1,hw,6], lengths [1,hw|1,S] -> [b, hw, S, 3]."""
@@ -254,18 +310,28 @@ def feature_nerf(w: Dict[str, Tensor], cams: Tensor, xref: Tensor, rays: Tensor,
 
 def nerf_module(w: Dict[str, Tensor], cams: Tensor, xref: Tensor, num_samples: int, far: float, near: float = 0.0,
                 mask_ref: Optional[Tensor] = None, rgb_predict: bool = True, average: bool = False,
-                xy_jitter=None, depth_jitter: Optional[Tensor] = None, num_freqs: int = 16):
-    """NerfSDModule.forward (nerfsd_pytorch3d.py:434-464) with prev_weights=None (importance
-    sampling is dead code).  `w` keys are relative to `pose_featurenerf.model.`.
+                xy_jitter=None, depth_jitter: Optional[Tensor] = None, num_freqs: int = 16, prev_weights: Optional[Tensor] = None,
+                imp_rand: Optional[Tensor] = None, uniform_pass: bool = False):
+    """NerfSDModule.forward (nerfsd_pytorch3d.py:434-464).  `w` keys are relative to `pose_featurenerf.model.`.
+    prev_weights (dead upstream): the sample depths come from importance_sampling (:345-353, the branch taken in eval mode
+    and with probability imp_sampling_percent in training); uniform_pass: what `imp_sample_next_step` would add had :442 forwarded
+    it -- the raw density at the uniform depths (:453-457) as dbg["sigma_uniform"], dbg["dists_uniform"].
     Returns (features [b,hw,S,C], sigma_raw [b,hw,S,1], dists [1|b,hw|1,S,1], view_weights, rgb_raw|None, debug)."""
     hw = xref.shape[2]
     r = int(math.isqrt(hw))
     xs = patch_positions(r, None if xy_jitter is None else xy_jitter[0])
     ys = patch_positions(r, None if xy_jitter is None else xy_jitter[1])
     rays = patch_rays(cams, xs, ys)
-    lengths, dists = depth_samples(num_samples, far, near, depth_jitter, hw)
+    if prev_weights is not None:
+        lengths, dists = importance_sampling(prev_weights, hw, num_samples, far, near, imp_rand)
+    else:
+        lengths, dists = depth_samples(num_samples, far, near, depth_jitter, hw)
     pts = ray_points(rays, lengths)
     out, attn, dbg = feature_nerf(w, cams, xref, rays, pts, mask_ref, average, num_freqs)
+    if uniform_pass:
+        lu, du = depth_samples(num_samples, far, near, None, hw)
+        out_u = feature_nerf(w, cams, xref, rays, ray_points(rays, lu), mask_ref, average, num_freqs)[0]
+        dbg.update(sigma_uniform=out_u[..., -1:], dists_uniform=du.unsqueeze(-1))
     sigma = out[..., -1:]
     feats = out[..., :-1]
     rgb = None
@@ -355,12 +421,16 @@ trunc_exp = _TruncExp.apply
 
 def reference_attn(w: Dict[str, Tensor], context_ref: Tensor, context: Tensor, cams: Tensor, heads: int,
                    num_samples: int, far: float, near: float = 0.0, mask_ref=None, rgb_predict=True,
-                   average=False, xy_jitter=None, depth_jitter=None):
+                   average=False, xy_jitter=None, depth_jitter=None, prev_weights=None, imp_rand=None, uniform_pass=False):
     """BasicTransformerBlock.reference_attn (attention.py:571-598). context_ref [b,n,hw,C].
+    prev_weights / uniform_pass: the importance-sampling chain (use_prev_weights_imp_sample; dead upstream, see nerf_module) --
+    dbg["weights_uniform"] is what :590-596 would hand to the next block.
     Returns (xref [b,hw,C], fg [b,hw,1], alphas [b,hw,S,1], rgb [b,hw,3]|None, debug)."""
     feats, sigma, dists, attn, rgb, dbg = nerf_module(
         sub(w, "pose_featurenerf.model"), cams, context_ref, num_samples, far, near, mask_ref, rgb_predict, average,
-        xy_jitter, depth_jitter)
+        xy_jitter, depth_jitter, prev_weights=prev_weights, imp_rand=imp_rand, uniform_pass=uniform_pass)
+    if uniform_pass:
+        dbg["weights_uniform"] = vol_render(torch.zeros_like(dbg["sigma_uniform"]), trunc_exp(dbg["sigma_uniform"]), dbg["dists_uniform"])[3]
     b, hw, S, C = feats.shape
     tok = feats.reshape(b, hw * S, C)
     tok = cross_attention(sub(w, "attn2"), layer_norm(w, "norm2", tok), context, heads) + tok  # (:581-586)

@@ -444,6 +444,36 @@ def case_loss():
     npz("loss", **out)
 
 
+# ---------------------------------------------------------------- importance sampling (dead upstream)
+def case_importance_sampling():
+    """Raymarcher.importance_sampling (nerfsd_pytorch3d.py:264-306) up to its third-party call: the reference's own arithmetic turns the
+    previous block's weights into (bins, pdf, u) and hands them to pytorch3d._C.sample_pdf, which is not installed.  The call is RECORDED
+    (its arguments are the fixture), not emulated: what pytorch3d does with them stays parity-unpinned.  Two cases: the weight maps at
+    the ray grid's size, and at a quarter of it (the antialiased resize of :269-286)."""
+    import pytorch3d
+    S = 8
+    rm = ns.nerf.Raymarcher(num_samples=S, far_plane=2.5, stratified=False, training=False, near_plane=0.5)
+    got = {}
+
+    def record(bins, weights, outputs, eps):
+        got.update(bins=bins.clone(), pdf=weights.clone(), u=outputs.clone(), eps=torch.tensor(eps))
+
+    keep = pytorch3d._C.sample_pdf
+    ns.nerf._C.sample_pdf = record
+    try:
+        out = {}
+        for tag, hw_prev, num_rays in (("same", 16, 16), ("resized", 16, 64)):
+            g = torch.Generator().manual_seed(5 + hw_prev + num_rays)
+            pw = torch.rand(2, hw_prev, S, 1, generator=g) ** 3
+            pw[0, 3] = 0.0
+            pw[1, 5] = -0.01  # cdf = weights + 0.01 sums to 0: the padding branch of :290-293
+            rm.importance_sampling(pw, num_rays, S, "cpu")
+            out.update({f"{tag}_prev_weights": pw, f"{tag}_bins": got["bins"], f"{tag}_pdf": got["pdf"], f"{tag}_u": got["u"], f"{tag}_eps": got["eps"]})
+        npz("importance_sampling", far=torch.tensor(2.0), near=torch.tensor(0.5), **out)
+    finally:
+        ns.nerf._C.sample_pdf = keep
+
+
 def refshim_join(lst):
     from cd360.cameras import join_cameras_as_batch
     return join_cameras_as_batch(lst)
@@ -467,4 +497,5 @@ if __name__ == "__main__":
     case_unet_grads()
     case_sampler()
     case_sdxl_keys()
+    case_importance_sampling()
     assert not os.path.exists(os.path.join(refshim.REF_ROOT, "sgm", "__pycache__")), "bytecode leaked into the reference tree"

@@ -521,3 +521,41 @@ def test_rowdot1(C):
     got = ops.rowdot1(h.to(DEV, torch.bfloat16), w.to(DEV))
     assert got.shape == (3, 1000) and rel(got, h @ w) < 1e-5
     assert torch.equal(got, ops.rowdot1(h.to(DEV, torch.bfloat16), w.to(DEV)))
+
+
+@pytest.mark.parametrize("S,N", [(24, 24), (32, 32), (8, 20)])
+def test_sample_pdf(S, N):
+    """cd360_sample_pdf (pytorch3d._C.sample_pdf's place at nerfsd_pytorch3d.py:300-305; f4) against the oracle's inverse-CDF sampler:
+    random, empty and single-bin weight rows, u at both ends, the in-place form and the gaps."""
+    from cd360 import ops
+    g = torch.Generator().manual_seed(S)
+    rows = 4099
+    bins = (torch.linspace(0.5, 3.0, S + 1)[None] + 0.01 * torch.rand(rows, S + 1, generator=g)).sort(-1).values
+    w = torch.rand(rows, S, generator=g) ** 3
+    w[5] = 0.0
+    w[6] = 0.0
+    w[6, S // 2] = 2.0
+    u = torch.rand(rows, N, generator=g)
+    u[7, 0], u[7, -1] = 0.0, 0.999999
+    u[8] = u[8].sort().values
+    want = O.sample_pdf(bins, w, u, 1e-5)
+    got, dists = ops.sample_pdf(bins.to(DEV), w.to(DEV), u.to(DEV), 1e-5, want_dists=True)
+    # conditioning: inside a bin of probability mass p the sample moves by (bin width) x (cdf rounding, ~1e-7) / p, so bins that barely clear
+    # eps amplify the last bit of the cdf (a sequential fp32 sum here, torch's blocked sum in the oracle) to ~1e-4: the agreement
+    # asked scales with 1 / p -- and everywhere the forward map must hold: F(sample) = u for the float64 cdf F
+    wdd = (w + 1e-5).double()
+    cdf = torch.cat([torch.zeros(rows, 1, dtype=torch.float64), torch.cumsum(wdd / wdd.sum(-1, keepdim=True), -1)], -1)
+    k = (torch.searchsorted(cdf, u.double().contiguous(), right=True) - 1).clamp(0, S - 1)
+    mass = torch.gather(cdf, -1, k + 1) - torch.gather(cdf, -1, k)
+    err = (got.cpu() - want).abs()
+    assert (err <= 2e-6 + 1e-7 / mass.clamp_min(1e-5).float()).all()  # bin width ~0.1 x (cdf error <~ 1e-6) / mass
+    F = torch.from_numpy(np.stack([np.interp(got[i].double().cpu().numpy(), bins[i].double().numpy(), cdf[i].numpy()) for i in range(0, rows, 37)]))
+    assert (F - u[::37].double()).abs().max() < 2e-5  # eps-sized steps where a bin's mass is below eps (the `denom = 1` rule)
+    gc = got.cpu()
+    wd = torch.cat([gc[:, 1:] - gc[:, :-1], bins[:, -1:] - gc[:, -1:]], -1)
+    assert (dists.cpu() - wd).abs().max() < 1e-6
+    ud = u.to(DEV).clone()
+    assert ops.sample_pdf(bins.to(DEV), w.to(DEV), ud, 1e-5, inplace=True) is ud and torch.equal(ud, got)
+    assert ((got >= bins[:, :1].to(DEV)) & (got <= bins[:, -1:].to(DEV))).all()
+    srt = ops.sample_pdf(bins.to(DEV), w.to(DEV), u.sort(-1).values.to(DEV))
+    assert (srt[:, 1:] >= srt[:, :-1]).all()

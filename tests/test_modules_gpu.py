@@ -122,6 +122,103 @@ def test_nerf_module_average_views_matches_oracle():
 
 
 @torch.no_grad()
+def test_importance_sampled_depths_match_the_oracle():
+    """SURVEY section 8 row f4 (dead upstream, F3): Raymarcher.importance_sampling on cd360_sample_pdf against the oracle's restatement --
+    the recorded inputs of the reference's own call (tests/golden/importance_sampling.npz), both grid sizes, and the FeatureNeRF
+    evaluated at those per-ray depths (NerfSDModule.forward(prev_weights=...)) against the oracle at the same depths."""
+    from oracle import pose_path as O
+    from sgm.modules.nerfsd_pytorch3d import NerfSDModule, Raymarcher
+    gi = np.load(os.path.join(GOLD, "importance_sampling.npz"))
+    far, near = float(gi["far"]), float(gi["near"])
+    for tag, num_rays in (("same", 16), ("resized", 64)):
+        pw = torch.from_numpy(gi[f"{tag}_prev_weights"])
+        S = pw.shape[2]
+        rm = Raymarcher(num_samples=S, far_plane=near + far, stratified=False, training=False, near_plane=near).to(DEV)
+        t, d = rm.importance_sampling(pw.to(DEV), num_rays, S, DEV)
+        wt, wd = O.importance_sampling(pw, num_rays, S, far, near)
+        # the 0.01 floor keeps every bin's mass above ~1e-3: the last bit of the cdf moves a sample by < 1e-4 (see test_sample_pdf)
+        assert (t.cpu() - wt).abs().max() < 1e-4 and (d.cpu() - wd).abs().max() < 2e-4
+        assert (t[..., 1:] >= t[..., :-1]).all() and (t >= near).all() and (t <= near + near + far).all()
+    g = load("nerf_eval")
+    S, hw = 4, 64
+    m = NerfSDModule(mode="feature-nerf", out_channels=64, far_plane=2.0, num_samples=S, rgb_predict=True, stratified=True).eval()
+    m.raymarcher.training = False
+    w = {k: v.to(BF).float() for k, v in W.load_into(m, seed=1).items()}
+    m = m.to(DEV, BF)
+    pw = torch.rand(2, hw, S, 1, generator=torch.Generator().manual_seed(8)) ** 2
+    pose, xref = unpack_cameras(g["cams"]), g["xref"].to(BF).float()
+    feats, sigma, dists, vw, rgb, su, du = m(pose, dev(g["xref"]), prev_weights=pw.to(DEV))
+    want = O.nerf_module(O.sub(w, "model"), g["cams"], xref, S, 2.0, prev_weights=pw)
+    assert su is None and du is None  # as upstream: imp_sample_next_step is dropped unless honour_imp_sample_next_step
+    assert dists.shape == (2, hw, S, 1) and (dists.cpu() - want[2]).abs().max() < 2e-4
+    assert rel(feats, want[0]) < 1e-2 and rel(sigma, want[1]) < 1e-2 and rel(rgb, want[4]) < 1e-2 and rel(vw, want[3]) < 1e-2
+    # the depths are not the uniform ones, and the uniform pass returns what the next block would sample from
+    assert rel(m(pose, dev(g["xref"]))[0], want[0]) > 2e-2
+    m.honour_imp_sample_next_step = True
+    out = m(pose, dev(g["xref"]), prev_weights=pw.to(DEV), imp_sample_next_step=True)
+    want_u = O.nerf_module(O.sub(w, "model"), g["cams"], xref, S, 2.0, prev_weights=pw, uniform_pass=True)[5]
+    assert rel(out[5], want_u["sigma_uniform"]) < 1e-2 and torch.equal(out[6].cpu().expand_as(want_u["dists_uniform"]), want_u["dists_uniform"])
+    assert torch.equal(out[0], feats)
+
+
+@torch.no_grad()
+def test_pose_blocks_chain_importance_sampling_when_revived():
+    """attention.py:571-598, 849-858 with use_prev_weights_imp_sample: block k renders at depths drawn from block k-1's weights at the
+    uniform depths.  Upstream the chain never starts (F3); with NerfSDModule.honour_imp_sample_next_step the module route carries it.
+    Block level against the oracle (reference_attn with prev_weights / uniform pass), then a SpatialTransformer whose pose blocks chain."""
+    from oracle import pose_path as O
+    from sgm.modules.attention import BasicTransformerBlock, SpatialTransformer
+    g = load("block_eval")
+    C, heads, cd, S = 64, 1, 32, 4
+    blk = BasicTransformerBlock(C, heads, 64, context_dim=cd, checkpoint=False, attn_mode="softmax-xformers", image_cross=True, far=2,
+                                num_samples=S, rgb_predict=True, mode="feature-nerf", stratified=True, use_prev_weights_imp_sample=True,
+                                imp_sample_next_step=True).eval()
+    blk.pose_featurenerf.raymarcher.training = False
+    w = {k: v.to(BF).float() for k, v in W.load_into(blk, seed=2).items()}
+    blk = blk.to(DEV, BF)
+    pose = unpack_cameras(g["cams"])
+    x, ctx, cref = dev(g["x"]), dev(g["ctx"]), dev(g["cref"])
+    b, n = g["cams"].shape[0], g["cams"].shape[1] - 1
+    hw = cref.shape[-2]
+    # default = the reference: nothing is handed on, the result is the golden's
+    out = blk(x, context=ctx, context_ref=cref, pose=pose)
+    assert out[2] is None and rel(out[0], g["out"]) < TOL
+    blk.pose_featurenerf.honour_imp_sample_next_step = True
+    cref4 = g["cref"].to(BF).float().reshape(b, n, hw, C)
+    first = blk(x, context=ctx, context_ref=cref, pose=pose)
+    want1 = O.reference_attn(w, cref4, g["ctx"].to(BF).float(), g["cams"], heads, S, 2.0, uniform_pass=True)
+    assert first[2] is not None and first[2].shape == (b, hw, S, 1) and rel(first[2], want1[4]["weights_uniform"]) < 1e-2
+    assert rel(first[1], want1[1]) < TOL and rel(first[3], want1[2]) < TOL
+    second = blk(x, context=ctx, context_ref=cref, pose=pose, prev_weights=first[2])
+    want2 = O.reference_attn(w, cref4, g["ctx"].to(BF).float(), g["cams"], heads, S, 2.0, prev_weights=want1[4]["weights_uniform"],
+                             uniform_pass=True)
+    assert rel(second[1], want2[1]) < TOL and rel(second[3], want2[2]) < TOL and rel(second[4], want2[3]) < TOL
+    assert rel(second[2], want2[4]["weights_uniform"]) < 1e-2
+    assert rel(second[3], first[3]) > 1e-3  # the sampled depths moved
+    # SpatialTransformer: depth 5, pose blocks at 0 and 4 -> the second samples from the first's weights
+    g2 = load("st_dual")
+    st = SpatialTransformer(128, 2, 64, depth=5, context_dim=32, use_linear=True, attn_type="softmax-xformers", use_checkpoint=False,
+                            image_cross=True, rgb_predict=True, far=2, num_samples=4, mode="feature-nerf", stratified=True,
+                            use_prev_weights_imp_sample=True).eval()
+    W.load_into(st, seed=3)
+    st = st.to(DEV, BF)
+    args = (dev(g2["x"]), dev(g2["xr"]))
+    kw = dict(context=dev(g2["ctx"]), contextr=dev(g2["ctxr"]), pose=unpack_cameras(g2["cams"]))
+    plain = st(*args, **kw)
+    assert plain[3] is None
+    flags = [blk_.imp_sample_next_step for blk_ in st.transformer_blocks]
+    for blk_ in st.transformer_blocks:
+        if blk_.image_cross:
+            blk_.pose_featurenerf.honour_imp_sample_next_step = True
+            blk_.pose_featurenerf.raymarcher.training = False
+    chained = st(*args, **kw)
+    assert any(flags) and all(torch.isfinite(t).all() for t in (chained[0], chained[1]))
+    assert rel(chained[2][0], plain[2][0]) < 1e-6  # the first pose block has nothing to sample from
+    if flags[-1] is False and len(chained[2]) > 1:
+        assert rel(chained[2][-1], plain[2][-1]) > 1e-4  # the last one rendered at importance-sampled depths
+
+
+@torch.no_grad()
 def test_mask_ref_forward_matches_reference_golden():
     """mask_ref (nerfsd_pytorch3d.py:61-70): NerfSDModule, the pose block and the tiny UNet with reference-view masks against the vectors
     the imported reference produced (tests/golden/mask_ref.npz)."""
