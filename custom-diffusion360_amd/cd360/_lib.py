@@ -37,6 +37,10 @@ SIGNATURES = {
     "cd360_volrender_bwd": (c_int, [_P, _P, _P, _P, c_int] + [_P] * 8 + [c_int] * 6 + [_P]),
     "cd360_rowdot4_bf16": (c_int, [_P, _P, _P, c_int64, c_int, _P]),
     "cd360_rowdot1_bf16": (c_int, [_P, _P, _P, c_int64, c_int, _P]),
+    "cd360_render_loss_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "cd360_render_loss_bwd_f32": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, _P]),
+    "cd360_nerf_pack_weights_bf16": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, _P]),
+    "cd360_nerf_unpack_grads_bf16": (c_int, [ctypes.POINTER(c_void_p), ctypes.POINTER(c_int), _P, _P, _P, c_int, c_int, _P]),
     "cd360_geglu_bf16": (c_int, [_P, _P, c_int64, c_int, _P]),
     "cd360_concat_channels_bf16": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P]),
     "cd360_add_layernorm_bf16": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, c_float, _P]),

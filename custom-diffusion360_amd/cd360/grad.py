@@ -175,20 +175,23 @@ class AddLayerNormFn(torch.autograd.Function):
     arrived on `sum` to the LayerNorm gradient in the same pass; a and b receive the same tensor."""
 
     @staticmethod
-    def forward(ctx, a, b, gamma, beta, eps):
+    def forward(ctx, a, b, gamma, beta, eps, alias=False):
         s, ln = ops.add_layernorm(a, b, gamma, beta, eps, want_sum=True)
         x = a if b is None else s
         ctx.save_for_backward(x, gamma)
         ctx.set_materialize_grads(False)
-        ctx.eps, ctx.has_b = eps, b is not None
+        ctx.eps, ctx.has_b, ctx.alias = eps, b is not None, alias and b is None
         if b is None:
-            return ln
+            # alias: `a` itself comes back as the "sum" output, so a caller that keeps using the residual stream uses THIS tensor and the
+            # gradient arriving on it joins the LayerNorm gradient inside the backward kernel (otherwise autograd adds the two in a pass
+            # of its own over the whole tensor)
+            return (a.view_as(a), ln) if alias else ln
         return s, ln
 
     @staticmethod
     def backward(ctx, *grads):
         x, gamma = ctx.saved_tensors
-        d_sum, d_ln = (grads if ctx.has_b else (None, grads[0]))
+        d_sum, d_ln = (grads if (ctx.has_b or ctx.alias) else (None, grads[0]))
         if d_ln is None:
             dx = d_sum
         else:
@@ -202,12 +205,14 @@ class AddLayerNormFn(torch.autograd.Function):
             g2 = d_ln.float().reshape(-1, C)
             dgamma = (g2 * xhat).sum(0).to(gamma.dtype) if ctx.needs_input_grad[2] else None
             dbeta = g2.sum(0).to(gamma.dtype) if ctx.needs_input_grad[3] else None
-        return dx, (dx if ctx.has_b else None), dgamma, dbeta, None
+        return dx, (dx if ctx.has_b else None), dgamma, dbeta, None, None
 
 
-def add_layernorm(a, b, gamma, beta, eps, want_sum=True):
-    """ops.add_layernorm's (sum | None, ln) contract under autograd."""
+def add_layernorm(a, b, gamma, beta, eps, want_sum=True, alias=False):
+    """ops.add_layernorm's (sum | None, ln) contract under autograd.  alias (b None): (a as a fresh autograd alias, ln), see AddLayerNormFn."""
     if b is None:
+        if alias:
+            return AddLayerNormFn.apply(a, None, gamma, beta, eps, True)
         return None, AddLayerNormFn.apply(a, None, gamma, beta, eps)
     s, ln = AddLayerNormFn.apply(a, b, gamma, beta, eps)
     return (s if want_sum else None), ln
@@ -288,6 +293,22 @@ class NerfRenderFn(torch.autograd.Function):
         dzP = dz.reshape(b * n, hw, S, C).sum(2, dtype=torch.float32).to(zP.dtype)
         dcview = dlogit.reshape(b, n, npts).sum(-1)
         return None, None, None, None, None, dWf, dvf, dzP, dcview, dWk
+
+
+class RenderLossFn(torch.autograd.Function):
+    """ops.render_loss: the foreground / background / rgb terms of one pose block (loss.py:188-207 of the reference) as one kernel each way
+    (cd360_render_loss_f32, cd360_render_loss_bwd_f32); the resized targets are constants of the step."""
+
+    @staticmethod
+    def forward(ctx, fg, alphas, rgb, op, bgw, mask_, want, den):
+        ctx.save_for_backward(fg, alphas, rgb, op, bgw, mask_, want, den)
+        return ops._render_loss_fwd(fg, alphas, rgb, op, bgw, mask_, want, den)
+
+    @staticmethod
+    def backward(ctx, g):
+        fg, alphas, rgb, op, bgw, mask_, want, den = ctx.saved_tensors
+        d_fg, d_al, d_rgb = ops.render_loss_bwd(fg, alphas, rgb, op, bgw, mask_, want, den, g)
+        return d_fg, d_al, d_rgb, None, None, None, None, None
 
 
 class RowDot4Fn(torch.autograd.Function):

@@ -75,6 +75,20 @@ class _LiveNerfWeights(torch.autograd.Function):
     def forward(ctx, W1, b1, W2, b2, wv, bv, Wd):
         C, dev = W2.shape[0], W1.device
         cols = xyz_k_columns(C)
+        ps = (W1, b1, W2, b2, wv, bv, Wd)
+        if (all(p.is_cuda and p.dtype == torch.bfloat16 and p.is_contiguous() for p in ps) and Wd.shape[0] == 4 and C % 4 == 0
+                and not routes.no_train_fusions):
+            # every parameter bf16 (the fine-tuning step: bf16 parameters beside fp32 masters): one kernel each way
+            NK = len(cols)
+            kcol, kpos = _const(("xyz_k_tables", C, str(dev)), lambda: (
+                torch.tensor(cols, dtype=torch.int32, device=dev),
+                torch.tensor([cols.index(c) if c in cols else -1 for c in range(C + 198)], dtype=torch.int32, device=dev)))
+            wb, wf = ops.nerf_pack_weights(W1, b1, b2, wv.reshape(-1), bv.reshape(-1), Wd, kcol)
+            ctx.fast = (C, NK, kpos, wv.shape, bv.shape)
+            nWf, nWk = C * C, C * NK
+            return (wb[:nWf].view(C, C), wb[nWf:nWf + nWk].view(C, NK), wb[nWf + nWk:].view(C, 128), wf[:C], W2, wf[C:2 * C],
+                    wf[2 * C:3 * C], wf[3 * C:3 * C + 99], wf[3 * C + 100].reshape(()), wf[3 * C + 104:].view(4, C))
+        ctx.fast = None
         idx, pos = _const(("xyz_k", C, str(dev)), lambda: (torch.tensor([c for c in cols if c >= 0], device=dev),
                                                            torch.tensor([i for i, c in enumerate(cols) if c >= 0], device=dev)))
         bf = torch.bfloat16
@@ -85,12 +99,22 @@ class _LiveNerfWeights(torch.autograd.Function):
         wvf = wv.reshape(-1).float()
         ctx.meta = (C, len(cols), idx, pos, tuple(t.dtype for t in (W1, b1, W2, b2, wv, bv, Wd)), wv.shape, bv.shape)
         return (W1[:, :C].to(bf).contiguous(), Wk, Wp, b1.float(), W2.to(bf).contiguous(), b2.float(), wvf[:C].contiguous(),
-                wvf[C + 99:C + 102].contiguous(), wvf[C + 102:C + 198].contiguous(), bv.float().reshape(()), Wd.float().contiguous())
+                wvf[C + 99:C + 198].contiguous(), bv.float().reshape(()), Wd.float().contiguous())
 
     @staticmethod
-    def backward(ctx, dWf, dWk, dWp, db1, dW2, db2, dvf, dvo, dve, dbv, dWd):
+    def backward(ctx, dWf, dWk, dWp, db1, dW2, db2, dvf, dvc, dbv, dWd):
+        if ctx.fast is not None:
+            C, NK, kpos, wv_shape, bv_shape = ctx.fast
+            grads = (dWf, dWk, dWp, db1, db2, dvf, dvc, dbv, dWd)
+            if all(g is None for g in grads):
+                return None, None, dW2, None, None, None, None
+            dW1, sm = ops.nerf_unpack_grads(grads, kpos, C, NK)
+            some_w1 = dWf is not None or dWk is not None or dWp is not None
+            return (dW1 if some_w1 else None, None if db1 is None else sm[:C], None if dW2 is None else dW2.to(torch.bfloat16),
+                    None if db2 is None else sm[C:2 * C], sm[2 * C:3 * C + 198].view(wv_shape) if (dvf is not None or dvc is not None) else None,
+                    None if dbv is None else sm[3 * C + 198].reshape(bv_shape), None if dWd is None else sm[3 * C + 200:].view(4, C))
         C, nk, idx, pos, dts, wv_shape, bv_shape = ctx.meta
-        some = next(g for g in (dWf, dWk, dWp, db1, dW2, db2, dvf, dvo, dve, dbv, dWd) if g is not None)
+        some = next(g for g in (dWf, dWk, dWp, db1, dW2, db2, dvf, dvc, dbv, dWd) if g is not None)
         dev = some.device
         dW1 = None
         if dWf is not None or dWk is not None or dWp is not None:
@@ -102,9 +126,9 @@ class _LiveNerfWeights(torch.autograd.Function):
             if dWp is not None:
                 dW1[:, C + 99:C + 198] = dWp[:, :99]
         dwv = None
-        if dvf is not None or dvo is not None or dve is not None:
+        if dvf is not None or dvc is not None:
             z = lambda g, n_: torch.zeros(n_, dtype=torch.float32, device=dev) if g is None else g.reshape(-1).float()
-            dwv = torch.cat([z(dvf, C), torch.zeros(99, dtype=torch.float32, device=dev), z(dvo, 3), z(dve, 96)]).reshape(wv_shape).to(dts[4])
+            dwv = torch.cat([z(dvf, C), torch.zeros(99, dtype=torch.float32, device=dev), z(dvc, 99)]).reshape(wv_shape).to(dts[4])
         cast = lambda g, i: None if g is None else g.to(dts[i])
         return (dW1, cast(db1, 1), cast(dW2, 2), cast(db2, 3), dwv, None if dbv is None else dbv.reshape(bv_shape).to(dts[5]), cast(dWd, 6))
 
@@ -120,7 +144,7 @@ class FusedNerfWeights:
         dev = W1.device
         if live and W1.is_cuda and dtype == torch.bfloat16 and not routes.library_linear:
             # what the fused render reads, as one autograd node (the torch-GEMM route below keeps its transposed / fp32 forms)
-            (self.Wf, self.Wk, self.Wp, self.b1, self.W2, self.b2_f32, self.vf, self.v_otgt, self.v_otgt_enc, self.bv,
+            (self.Wf, self.Wk, self.Wp, self.b1, self.W2, self.b2_f32, self.vf, self.v_cam, self.bv,
              self.Wd) = _LiveNerfWeights.apply(W1, b1, W2, b2, wv, bv, Wd)
             self.live = True
             return
@@ -143,8 +167,7 @@ class FusedNerfWeights:
         self.b2 = b2.to(dtype).contiguous()
         wvf = wv.float().reshape(-1)
         self.vf = wvf[:C].contiguous()
-        self.v_otgt = wvf[C + 99:C + 102].contiguous()
-        self.v_otgt_enc = wvf[C + 102:C + 198].contiguous()
+        self.v_cam = wvf[C + 99:C + 198].contiguous()  # [o_tgt (3) | enc16(o_tgt) (96)] rows of nviews.weight
         self.bv = bv.float().reshape(())
         self.Wd = Wd.float().contiguous()  # [4, C]
         # Linear-layout bf16 operands of the table GEMMs on cd360_gemm_bf16 (ops.linear).  live: slices / pads / casts are recorded by
@@ -203,8 +226,7 @@ def depth_samples(num_samples: int, far: float, near: float, device, num_rays: i
 def view_constants(fw: FusedNerfWeights, cams: torch.Tensor) -> torch.Tensor:
     """c_i = w_v[o_tgt].o_i^tgt + w_v[enc].enc16(o_i^tgt) + b_v, with o_i^tgt the reference camera centre in the
     target view frame (nerfsd_pytorch3d.py:116-123,146-147).  cams [b, n+1, 16] -> [b, n] fp32."""
-    o, enc = _camera_constants(cams)
-    return ((o * fw.v_otgt).sum(-1) + (enc * fw.v_otgt_enc).sum(-1) + fw.bv).contiguous()
+    return ((_camera_constants(cams) * fw.v_cam).sum(-1) + fw.bv).contiguous()
 
 
 _CAM_CONSTS = []  # the last few (cams, version, (o, enc16(o))): the twelve pose blocks of a forward share one packed camera tensor
@@ -221,7 +243,7 @@ def _camera_constants(cams: torch.Tensor):
         T = cams[..., 9:12]
         center = -(T[..., None, :] * R).sum(-1)  # -T @ R^T
         o = (center[:, 1:, :, None] * R[:, :1]).sum(-2) + T[:, :1]  # centre_i @ R_0 + T_0
-        val = (o, positional_encoding(o, NUM_FREQS))
+        val = torch.cat([o, positional_encoding(o, NUM_FREQS)], -1).contiguous()  # [b, n, 3 + 96]
     _CAM_CONSTS.insert(0, (cams, cams._version, val))  # (inside a graph capture too: the first pose block's kernels are captured, the others read)
     del _CAM_CONSTS[4:]
     return val
@@ -271,7 +293,11 @@ def fused_feature_nerf(fw: FusedNerfWeights, cams: torch.Tensor, xref: Optional[
 
 
 def _view_logit_column(x2: torch.Tensor, vf: torch.Tensor) -> torch.Tensor:
-    """lv = x2 . vf in fp32 (one read of the bf16 features on cd360_rowdot1_bf16; torch.mv elsewhere)."""
+    """lv = x2 . vf in fp32 (one read of the bf16 features on cd360_rowdot1_bf16; torch.mv elsewhere, and whenever autograd has to
+    differentiate the product with respect to vf -- the precomputed-tables route under grad; the training path proper forms lv inside
+    grad.NerfRenderFn and differentiates it there)."""
+    if torch.is_grad_enabled() and vf.requires_grad:
+        return torch.mv(x2.float(), vf.float())
     vf = vf.detach()
     if x2.is_cuda and x2.dtype == torch.bfloat16 and x2.shape[-1] % 8 == 0 and x2.is_contiguous() and not routes.library_linear:
         return ops.rowdot1(x2, vf.float().contiguous())

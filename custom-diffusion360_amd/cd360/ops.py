@@ -438,6 +438,83 @@ def rowdot1(h: torch.Tensor, w: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def render_loss_ok(fg, alphas, rgb, op, mask_, want) -> bool:
+    """Can cd360_render_loss_f32 serve these tensors (fp32, on the GPU, a one-channel mask)?"""
+    ts = [t for t in (fg, alphas, rgb, op, mask_, want) if t is not None]
+    from . import routes
+    return (not routes.no_train_fusions and all(t.is_cuda and t.dtype == torch.float32 for t in ts) and (mask_ is None or mask_.shape[1] == 1)
+            and (rgb is None or (mask_ is not None and want is not None)))
+
+
+def render_loss(fg, alphas, rgb, op, bgw, mask_, want, den) -> torch.Tensor:
+    """The fg / bg / rgb loss terms of one pose block (loss.py:188-207 of the reference) -> [b, 3] fp32; differentiable with respect
+    to fg [b, hw, 1], alphas [b, hw, S, 1] and rgb [b, hw, 3] | None (grad.RenderLossFn).  op, bgw [b, hw]; mask_ [b, 1, r, r];
+    want [b, 3, r, r]; den [b]."""
+    if _wants_grad(fg, alphas, rgb):
+        from . import grad
+        return grad.RenderLossFn.apply(fg, alphas, rgb, op, bgw, mask_, want, den)
+    return _render_loss_fwd(fg, alphas, rgb, op, bgw, mask_, want, den)
+
+
+def _render_loss_fwd(fg, alphas, rgb, op, bgw, mask_, want, den):
+    _need_gpu(fg, alphas, rgb, op, bgw, mask_, want, den)
+    b, hw = op.shape
+    S = alphas.numel() // (b * hw)
+    c = lambda t: None if t is None else t.detach().contiguous()
+    fg, alphas, rgb, op, bgw, mask_, want, den = map(c, (fg, alphas, rgb, op, bgw, mask_, want, den))
+    assert fg.numel() == b * hw and (rgb is None or rgb.numel() == b * hw * 3)
+    out = torch.empty(b, 3, dtype=torch.float32, device=op.device)
+    check(_lib.load().cd360_render_loss_f32(_ptr(fg), _ptr(alphas), _ptr(rgb), _ptr(op), _ptr(bgw), _ptr(mask_), _ptr(want), _ptr(den), _ptr(out),
+                                            b, hw, S, _stream()), "cd360_render_loss_f32")
+    return out
+
+
+def render_loss_bwd(fg, alphas, rgb, op, bgw, mask_, want, den, g):
+    """-> (d_fg, d_alphas, d_rgb | None) in the shapes of fg, alphas, rgb."""
+    _need_gpu(fg, alphas, rgb, op, bgw, mask_, want, den, g)
+    b, hw = op.shape
+    S = alphas.numel() // (b * hw)
+    c = lambda t: None if t is None else t.detach().contiguous()
+    fgc, alc, rgbc, op, bgw, mask_, want, den = map(c, (fg, alphas, rgb, op, bgw, mask_, want, den))
+    d_fg, d_al = torch.empty_like(fgc), torch.empty_like(alc)
+    d_rgb = None if rgbc is None else torch.empty_like(rgbc)
+    check(_lib.load().cd360_render_loss_bwd_f32(_ptr(fgc), _ptr(alc), _ptr(rgbc), _ptr(op), _ptr(bgw), _ptr(mask_), _ptr(want), _ptr(den),
+                                                _ptr(g.contiguous().float()), _ptr(d_fg), _ptr(d_al), _ptr(d_rgb), b, hw, S, _stream()),
+          "cd360_render_loss_bwd_f32")
+    return d_fg, d_al, d_rgb
+
+
+def nerf_pack_weights(W1, b1, b2, wv, bv, Wd, kcol):
+    """cd360_nerf_pack_weights_bf16: bf16 parameters of one FeatureNeRFEncoding -> (bf16 arena Wf | Wk | Wp, fp32 arena b1 | b2 | vf |
+    v_cam | bv | Wd); the caller slices (see the header)."""
+    _need_gpu(W1, b1, b2, wv, bv, Wd, kcol)
+    C, NK = W1.shape[0], kcol.numel()
+    assert all(t.dtype == torch.bfloat16 and t.is_contiguous() for t in (W1, b1, b2, wv, bv, Wd)) and kcol.dtype == torch.int32
+    assert W1.shape == (C, C + 198) and wv.numel() == C + 198 and Wd.shape == (4, C) and b1.numel() == C and b2.numel() == C
+    wb = torch.empty(C * (C + NK + 128), dtype=torch.bfloat16, device=W1.device)
+    wf = torch.empty(7 * C + 104, dtype=torch.float32, device=W1.device)
+    check(_lib.load().cd360_nerf_pack_weights_bf16(_ptr(W1), _ptr(b1), _ptr(b2), _ptr(wv), _ptr(bv), _ptr(Wd), _ptr(kcol), _ptr(wb), _ptr(wf),
+                                                   C, NK, _stream()), "cd360_nerf_pack_weights_bf16")
+    return wb, wf
+
+
+def nerf_unpack_grads(grads, kpos, C: int, NK: int):
+    """cd360_nerf_unpack_grads_bf16: the nine gradients of the packed operands (None = none arrived) -> (dW1 [C, C + 198] bf16, small
+    bf16 arena db1 | db2 | dwv | dbv | dWd)."""
+    import ctypes
+    some = next(g for g in grads if g is not None)
+    gs = [None if g is None else g.contiguous() for g in grads]
+    _need_gpu(kpos, *gs)
+    for g, n_ in zip(gs, (C * C, C * NK, C * 128, C, C, C, 99, 1, 4 * C)):
+        assert g is None or (g.numel() == n_ and g.dtype in (torch.float32, torch.bfloat16)), "nerf_unpack_grads: unexpected gradient"
+    ptrs = (ctypes.c_void_p * 9)(*[None if g is None else g.data_ptr() for g in gs])
+    dts = (ctypes.c_int * 9)(*[1 if (g is not None and g.dtype == torch.bfloat16) else 0 for g in gs])
+    dW1 = torch.empty(C, C + 198, dtype=torch.bfloat16, device=some.device)
+    small = torch.empty(7 * C + 200, dtype=torch.bfloat16, device=some.device)
+    check(_lib.load().cd360_nerf_unpack_grads_bf16(ptrs, dts, _ptr(kpos), _ptr(dW1), _ptr(small), C, NK, _stream()), "cd360_nerf_unpack_grads_bf16")
+    return dW1, small
+
+
 def rowdot4_bwd(d_out: torch.Tensor, h: torch.Tensor, w: torch.Tensor, need_dh: bool = True, need_dw: bool = True):
     """Backward of rowdot4: d_out [..., 4] fp32 -> (dh [..., C] bf16 | None, dw [4, C] fp32 | None) (cd360_rowdot4_bwd_bf16)."""
     _need_gpu(d_out, h, w)
@@ -978,12 +1055,14 @@ def pose_embed(x: torch.Tensor, xref: torch.Tensor, wa: torch.Tensor, wb: torch.
     return out
 
 
-def add_layernorm(a: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor, eps: float, want_sum: bool = True):
+def add_layernorm(a: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor, eps: float, want_sum: bool = True,
+                  alias: bool = False):
     """(a + b, LayerNorm(a + b) * gamma + beta) in one pass; b None -> (None, LayerNorm(a)).  All bf16, last dim C.
-    Differentiable with respect to a and b (grad.AddLayerNormFn)."""
+    Differentiable with respect to a and b (grad.AddLayerNormFn).  alias (only with b None): the first result is `a` again -- under
+    autograd an alias whose gradient the LayerNorm backward kernel adds in its own pass; use it as the residual stream from here on."""
     if _wants_grad(a, b, gamma, beta):
         from . import grad
-        return grad.add_layernorm(a, b, gamma, beta, eps, want_sum)
+        return grad.add_layernorm(a, b, gamma, beta, eps, want_sum, alias)
     _need_gpu(a, b, gamma, beta)
     C = a.shape[-1]
     assert a.dtype == torch.bfloat16 and a.is_contiguous() and gamma.dtype == torch.bfloat16 and beta.dtype == torch.bfloat16
@@ -994,7 +1073,7 @@ def add_layernorm(a: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tenso
     with _timed("add_layernorm", 0.0, 2.0 * rows * C * (2 + (b is not None) + (s is not None))):
         check(_lib.load().cd360_add_layernorm_bf16(_ptr(a), _ptr(b), _ptr(gamma), _ptr(beta), _ptr(s), _ptr(ln), rows, C, float(eps), _stream()),
               "cd360_add_layernorm_bf16")
-    return s, ln
+    return (a if (alias and b is None) else s), ln
 
 
 def add_layernorm_bwd(x: torch.Tensor, gamma: torch.Tensor, d_ln: torch.Tensor, d_sum: Optional[torch.Tensor], eps: float) -> torch.Tensor:

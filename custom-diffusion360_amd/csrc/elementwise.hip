@@ -306,3 +306,240 @@ extern "C" int cd360_add_layernorm_bwd_bf16(const void* x, const void* gamma, co
   CD360_LAUNCH_CHECK();
   return CD360_OK;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The operands the fused FeatureNeRF render reads, derived from TRAINABLE parameters (fine-tuning: trainkeys = pose, diffusion.py:139-144)
+// in one launch, and the way back for their gradients in another.  plane_coefs.0.weight W1 [C, C + 198] is read by three GEMM-side
+// operands: Wf = W1[:, :C] (features), Wk = the 99 xyz-encoding columns permuted into the kernel's 112-wide k order (cd360/nerf.py
+// xyz_k_columns), Wp = the 99 Plucker / direction columns padded to 128; nviews.weight splits into the feature part vf and the camera part
+// v_cam; biases and the decoder go to fp32.  Recorded op by op this was ~13 torch kernels forward and ~14 backward per pose block.
+namespace {
+
+struct NerfPackArgs {
+  const uint16_t *W1, *b1, *b2, *wv, *bv, *Wd;  // bf16 parameters
+  const int* kcol;                               // [NK]: column of W1 behind k-input j of the kernel, -1 = zero pad
+  uint16_t* wb;                                  // bf16 out: Wf [C, C] | Wk [C, NK] | Wp [C, 128]
+  float* wf;                                     // fp32 out: b1 [C] | b2 [C] | vf [C] | v_cam [99] + 1 pad | bv [1] + 3 pad | Wd [4, C]
+  int C, NK;
+};
+
+__global__ __launch_bounds__(256) void nerf_pack_weights_kernel(NerfPackArgs a) {
+  const int C = a.C, NK = a.NK, ld = C + 198;
+  const long nWf = (long)C * C, nWk = (long)C * NK, nWp = (long)C * 128, nB = nWf + nWk + nWp, nF = 7L * C + 104;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nB + nF; i += (long)gridDim.x * blockDim.x) {
+    if (i < nWf) {
+      const long r = i / C, c = i - r * C;
+      a.wb[i] = a.W1[r * ld + c];
+    } else if (i < nWf + nWk) {
+      const long k = i - nWf, r = k / NK;
+      const int src = a.kcol[k - r * NK];
+      a.wb[i] = src < 0 ? (uint16_t)0 : a.W1[r * ld + src];
+    } else if (i < nB) {
+      const long k = i - nWf - nWk, r = k >> 7;
+      const int j = (int)(k & 127);
+      a.wb[i] = j < 99 ? a.W1[r * ld + C + 99 + j] : (uint16_t)0;
+    } else {
+      const long k = i - nB;
+      float v = 0.f;
+      if (k < C) v = bf16_to_f32(a.b1[k]);
+      else if (k < 2L * C) v = bf16_to_f32(a.b2[k - C]);
+      else if (k < 3L * C) v = bf16_to_f32(a.wv[k - 2L * C]);
+      else if (k < 3L * C + 99) v = bf16_to_f32(a.wv[C + 99 + (k - 3L * C)]);
+      else if (k == 3L * C + 100) v = bf16_to_f32(a.bv[0]);
+      else if (k >= 3L * C + 104) v = bf16_to_f32(a.Wd[k - 3L * C - 104]);
+      a.wf[k] = v;
+    }
+  }
+}
+
+struct NerfUnpackArgs {
+  const void *dWf, *dWk, *dWp, *db1, *db2, *dvf, *dvc, *dbv, *dWd;  // gradients of the packed operands (NULL = none arrived)
+  int dt[9];                                                         // 0 fp32, 1 bf16
+  const int* kpos;                                                   // [C + 198]: k-input fed by W1 column c, -1 = none
+  uint16_t* dW1;                                                     // bf16 out [C, C + 198]
+  uint16_t* small;                                                   // bf16 out: db1 [C] | db2 [C] | dwv [C + 198] | dbv [1] + 1 pad | dWd [4, C]
+  int C, NK;
+};
+
+__device__ __forceinline__ float ld_grad(const void* p, int dt, long i) {
+  if (!p) return 0.f;
+  return dt ? bf16_to_f32(reinterpret_cast<const uint16_t*>(p)[i]) : reinterpret_cast<const float*>(p)[i];
+}
+
+__global__ __launch_bounds__(256) void nerf_unpack_grads_kernel(NerfUnpackArgs a) {
+  const int C = a.C, NK = a.NK, ld = C + 198;
+  const long nW = (long)C * ld, nS = 7L * C + 200;
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nW + nS; i += (long)gridDim.x * blockDim.x) {
+    if (i < nW) {
+      const long r = i / ld;
+      const int c = (int)(i - r * ld);
+      float v = 0.f;
+      if (c < C) v = ld_grad(a.dWf, a.dt[0], r * C + c);
+      else if (c >= C + 99) v = ld_grad(a.dWp, a.dt[2], r * 128 + (c - C - 99));
+      else {
+        const int k = a.kpos[c];
+        if (k >= 0) v = ld_grad(a.dWk, a.dt[1], r * NK + k);
+      }
+      a.dW1[i] = f32_to_bf16(v);
+    } else {
+      const long k = i - nW;
+      float v = 0.f;
+      if (k < C) v = ld_grad(a.db1, a.dt[3], k);
+      else if (k < 2L * C) v = ld_grad(a.db2, a.dt[4], k - C);
+      else if (k < 3L * C) v = ld_grad(a.dvf, a.dt[5], k - 2L * C);
+      else if (k < 3L * C + 99) v = 0.f;  // the xyz-encoding columns of nviews.weight: the view logits never read them
+      else if (k < 3L * C + 198) v = ld_grad(a.dvc, a.dt[6], k - 3L * C - 99);
+      else if (k == 3L * C + 198) v = ld_grad(a.dbv, a.dt[7], 0);
+      else if (k >= 3L * C + 200) v = ld_grad(a.dWd, a.dt[8], k - 3L * C - 200);
+      a.small[k] = f32_to_bf16(v);
+    }
+  }
+}
+
+}  // namespace
+
+// W1 [C, C + 198], b1 [C], b2 [C], wv [C + 198], bv [1], Wd [4, C]: bf16, contiguous.  kcol [NK] int32 (device).  Outputs as in NerfPackArgs.
+extern "C" int cd360_nerf_pack_weights_bf16(const void* W1, const void* b1, const void* b2, const void* wv, const void* bv, const void* Wd,
+                                            const void* kcol, void* out_bf16, void* out_f32, int C, int NK, void* stream) {
+  if (!W1 || !b1 || !b2 || !wv || !bv || !Wd || !kcol || !out_bf16 || !out_f32 || C <= 0 || NK <= 0) return CD360_ERR_ARG;
+  if (C % 4) return CD360_ERR_SHAPE;
+  NerfPackArgs a{(const uint16_t*)W1, (const uint16_t*)b1, (const uint16_t*)b2, (const uint16_t*)wv, (const uint16_t*)bv, (const uint16_t*)Wd,
+                 (const int*)kcol, (uint16_t*)out_bf16, (float*)out_f32, C, NK};
+  const long total = (long)C * (C + NK + 128) + 7L * C + 104;
+  const long nblk = (total + 255) / 256;
+  hipLaunchKernelGGL(nerf_pack_weights_kernel, dim3((unsigned)(nblk > 4096 ? 4096 : nblk)), dim3(256), 0, (hipStream_t)stream, a);
+  CD360_LAUNCH_CHECK();
+  return CD360_OK;
+}
+
+// grads[9] = dWf [C, C], dWk [C, NK], dWp [C, 128], db1 [C], db2 [C], dvf [C], dvc [99], dbv [1], dWd [4, C] (NULL = zero), dtypes[9]
+// (0 fp32, 1 bf16); kpos [C + 198] int32 (device).  Outputs: dW1 [C, C + 198] bf16 and the small arena of NerfUnpackArgs.
+extern "C" int cd360_nerf_unpack_grads_bf16(const void* const* grads, const int* dtypes, const void* kpos, void* dW1, void* small, int C, int NK,
+                                            void* stream) {
+  if (!grads || !dtypes || !kpos || !dW1 || !small || C <= 0 || NK <= 0) return CD360_ERR_ARG;
+  NerfUnpackArgs a{};
+  a.dWf = grads[0]; a.dWk = grads[1]; a.dWp = grads[2]; a.db1 = grads[3]; a.db2 = grads[4]; a.dvf = grads[5]; a.dvc = grads[6];
+  a.dbv = grads[7]; a.dWd = grads[8];
+  for (int i = 0; i < 9; ++i) {
+    if (dtypes[i] != 0 && dtypes[i] != 1) return CD360_ERR_ARG;
+    a.dt[i] = dtypes[i];
+  }
+  a.kpos = (const int*)kpos; a.dW1 = (uint16_t*)dW1; a.small = (uint16_t*)small; a.C = C; a.NK = NK;
+  const long total = (long)C * (C + 198) + 7L * C + 200;
+  const long nblk = (total + 255) / 256;
+  hipLaunchKernelGGL(nerf_unpack_grads_kernel, dim3((unsigned)(nblk > 4096 ? 4096 : nblk)), dim3(256), 0, (hipStream_t)stream, a);
+  CD360_LAUNCH_CHECK();
+  return CD360_OK;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The three rendering terms of the fine-tuning loss for ONE pose block (sgm/modules/diffusionmodules/loss.py:188-207 of the reference:
+// foreground, background and rgb terms of StandardDiffusionLossImgRef.get_loss), forward and backward.  In torch each block costs ~14
+// elementwise / reduce kernels forward and ~20 backward on tensors of a few thousand values; twelve blocks per step.
+//   l_fg[b]  = mean_k (clamp(fg[b,k], 0, 1) - op[b,k])^2
+//   l_bg[b]  = mean_{k,s} |alpha[b,k,s] - op[b,k]| * bgw[b,k]            bgw = (1 - op) [op < 0.1], precomputed by the caller
+//   l_rgb[b] = sum_{c,k} (want[b,c,k] - rgb[b,k,c])^2 mask[b,k] / den[b]
+// One workgroup per batch element (fixed summation order: deterministic).
+namespace {
+
+__device__ __forceinline__ float block_sum256(float v, float* red) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void render_loss_kernel(const float* __restrict__ fg, const float* __restrict__ alpha, const float* __restrict__ rgb,
+                                                          const float* __restrict__ op, const float* __restrict__ bgw,
+                                                          const float* __restrict__ mask, const float* __restrict__ want,
+                                                          const float* __restrict__ den, float* __restrict__ out, int hw, int S) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  float sfg = 0.f, sbg = 0.f, srgb = 0.f;
+  for (int k = threadIdx.x; k < hw; k += 256) {
+    const float o = op[(long)b * hw + k];
+    const float f = fminf(fmaxf(fg[(long)b * hw + k], 0.f), 1.f) - o;
+    sfg += f * f;
+    if (rgb) {
+      const float m = mask[(long)b * hw + k];
+      float e = 0.f;
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const float d = want[((long)b * 3 + c) * hw + k] - rgb[((long)b * hw + k) * 3 + c];
+        e += d * d;
+      }
+      srgb += e * m;
+    }
+  }
+  for (long i = threadIdx.x; i < (long)hw * S; i += 256) {
+    const long k = i / S;
+    sbg += fabsf(alpha[(long)b * hw * S + i] - op[(long)b * hw + k]) * bgw[(long)b * hw + k];
+  }
+  sfg = block_sum256(sfg, red);
+  sbg = block_sum256(sbg, red);
+  srgb = block_sum256(srgb, red);
+  if (threadIdx.x == 0) {
+    out[b * 3] = sfg / (float)hw;
+    out[b * 3 + 1] = sbg / ((float)hw * (float)S);
+    out[b * 3 + 2] = rgb ? srgb / den[b] : 0.f;
+  }
+}
+
+__global__ __launch_bounds__(256) void render_loss_bwd_kernel(const float* __restrict__ fg, const float* __restrict__ alpha, const float* __restrict__ rgb,
+                                                              const float* __restrict__ op, const float* __restrict__ bgw,
+                                                              const float* __restrict__ mask, const float* __restrict__ want,
+                                                              const float* __restrict__ den, const float* __restrict__ g, float* __restrict__ d_fg,
+                                                              float* __restrict__ d_alpha, float* __restrict__ d_rgb, int nb, int hw, int S) {
+  const long per = (long)hw * (S + 1 + (rgb ? 3 : 0));
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < nb * per; i += (long)gridDim.x * blockDim.x) {
+    const int b = (int)(i / per);
+    long j = i - b * per;
+    if (j < hw) {  // torch's clamp passes the gradient where min <= x <= max
+      const float x = fg[(long)b * hw + j];
+      const float f = fminf(fmaxf(x, 0.f), 1.f) - op[(long)b * hw + j];
+      d_fg[(long)b * hw + j] = (x >= 0.f && x <= 1.f) ? g[b * 3] * 2.f * f / (float)hw : 0.f;
+    } else if (j < (long)hw * (S + 1)) {
+      j -= hw;
+      const long k = j / S;
+      const float d = alpha[(long)b * hw * S + j] - op[(long)b * hw + k];
+      const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+      d_alpha[(long)b * hw * S + j] = g[b * 3 + 1] * sg * bgw[(long)b * hw + k] / ((float)hw * (float)S);
+    } else {
+      j -= (long)hw * (S + 1);
+      const long k = j / 3;
+      const int c = (int)(j - k * 3);
+      const float d = want[((long)b * 3 + c) * hw + k] - rgb[(long)b * hw * 3 + j];
+      d_rgb[(long)b * hw * 3 + j] = g[b * 3 + 2] * (-2.f) * d * mask[(long)b * hw + k] / den[b];
+    }
+  }
+}
+
+}  // namespace
+
+// fg [b, hw], alpha [b, hw, S], rgb [b, hw, 3] | NULL, op / bgw / mask [b, hw], want [b, 3, hw], den [b]: fp32 -> out [b, 3] = (l_fg, l_bg, l_rgb)
+extern "C" int cd360_render_loss_f32(const void* fg, const void* alpha, const void* rgb, const void* op, const void* bgw, const void* mask,
+                                     const void* want, const void* den, void* out, int b, int hw, int S, void* stream) {
+  if (!fg || !alpha || !op || !bgw || !out || b <= 0 || hw <= 0 || S <= 0) return CD360_ERR_ARG;
+  if (rgb && (!mask || !want || !den)) return CD360_ERR_ARG;
+  hipLaunchKernelGGL(render_loss_kernel, dim3(b), dim3(256), 0, (hipStream_t)stream, (const float*)fg, (const float*)alpha, (const float*)rgb,
+                     (const float*)op, (const float*)bgw, (const float*)mask, (const float*)want, (const float*)den, (float*)out, hw, S);
+  CD360_LAUNCH_CHECK();
+  return CD360_OK;
+}
+
+// g [b, 3] = the gradient arriving on out -> d_fg [b, hw], d_alpha [b, hw, S], d_rgb [b, hw, 3] (with rgb)
+extern "C" int cd360_render_loss_bwd_f32(const void* fg, const void* alpha, const void* rgb, const void* op, const void* bgw, const void* mask,
+                                         const void* want, const void* den, const void* g, void* d_fg, void* d_alpha, void* d_rgb, int b, int hw,
+                                         int S, void* stream) {
+  if (!fg || !alpha || !op || !bgw || !g || !d_fg || !d_alpha || b <= 0 || hw <= 0 || S <= 0) return CD360_ERR_ARG;
+  if (rgb && (!mask || !want || !den || !d_rgb)) return CD360_ERR_ARG;
+  const long total = (long)b * hw * (S + 1 + (rgb ? 3 : 0));
+  const long nblk = (total + 255) / 256;
+  hipLaunchKernelGGL(render_loss_bwd_kernel, dim3((unsigned)(nblk > 2048 ? 2048 : nblk)), dim3(256), 0, (hipStream_t)stream, (const float*)fg,
+                     (const float*)alpha, (const float*)rgb, (const float*)op, (const float*)bgw, (const float*)mask, (const float*)want,
+                     (const float*)den, (const float*)g, (float*)d_fg, (float*)d_alpha, (float*)d_rgb, b, hw, S);
+  CD360_LAUNCH_CHECK();
+  return CD360_OK;
+}

@@ -421,11 +421,24 @@ class BasicTransformerBlock(nn.Module):
         if self.fused_ready(tok):
             tok = self._pose_tokens_attn(tok.contiguous(), context)  # norm2 folded into the q GEMM, residual into the out GEMM
         else:
-            if tok.is_cuda and tok.dtype == torch.bfloat16 and self.norm2.weight.dtype == torch.bfloat16 and C <= 2048:
-                n2 = ops.add_layernorm(tok.contiguous(), None, self.norm2.weight, self.norm2.bias, self.norm2.eps)[1]  # HIP LayerNorm (fwd + bwd)
+            hip_ln = tok.is_cuda and tok.dtype == torch.bfloat16 and self.norm2.weight.dtype == torch.bfloat16 and C <= 2048
+            a2 = self.attn2
+            lin = a2.to_out[0]
+            if (hip_ln and not _watched(a2) and not (self.training and a2.to_out[1].p > 0) and lin.bias is not None
+                    and ops.linear_ok(tok, lin.weight) and not routes.library_linear and not routes.no_train_fusions):
+                # training: the residual rides through the two GEMM-side operators instead of two passes over the [b hw S, C] tokens --
+                # the LayerNorm hands `tok` on as an alias whose gradient its backward kernel adds itself, the out projection takes it
+                # as the accumulator input (grad.LinearFn passes the gradient straight through to it)
+                tok_s, n2 = ops.add_layernorm(tok.contiguous(), None, self.norm2.weight, self.norm2.bias, self.norm2.eps, alias=True)
+                k, v, nk = a2.project_context(context)
+                o = ops.attention(_linear(n2, a2.to_q.weight), k, v, a2.heads, nk)
+                tok = ops.linear(o, lin.weight, lin.bias, res=tok_s)
             else:
-                n2 = self.norm2(tok)
-            tok = self.attn2(n2, context=context) + tok  # pose-token cross-attention (:581-586)
+                if hip_ln:
+                    n2 = ops.add_layernorm(tok.contiguous(), None, self.norm2.weight, self.norm2.bias, self.norm2.eps)[1]  # HIP LayerNorm (fwd + bwd)
+                else:
+                    n2 = self.norm2(tok)
+                tok = a2(n2, context=context) + tok  # pose-token cross-attention (:581-586)
         rendered, fg, alphas, _, rgb = ops.volrender(tok.reshape(b, hw, S, C), dec[..., 3], dists,
                                                     dec[..., :3] if self.rgb_predict else None)
         return rendered, fg, (None if not self.use_prev_weights_imp_sample else None), alphas, rgb
@@ -732,7 +745,7 @@ class SpatialTransformer(nn.Module):
         (saves one elementwise pass per block).  Falls back to the public call when hooks (e.g. the references harvest,
         diffusion.py:151-163) or a patched forward (sample.py:247-262) are attached, so those see exactly the reference's values."""
         plain = type(block).forward is BasicTransformerBlock.forward
-        if plain and not torch.is_grad_enabled() and not _watched(block):
+        if plain and not _watched(block) and not (routes.no_train_fusions and torch.is_grad_enabled()):  # under autograd too: AddLayerNormFn takes the deferred add and hands its gradient on in one pass
             x, fg, w, al, rgb, d = block._forward(t, kw.get("context"), kw.get("context_ref"), kw.get("pose"), kw.get("mask_ref"),
                                                   kw.get("prev_weights"), pending=pend, defer=True)
             return (x, fg, w, al, rgb), d

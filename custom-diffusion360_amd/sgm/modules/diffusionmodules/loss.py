@@ -8,8 +8,10 @@ returns the per-sample terms the engine weights (diffusion.py:226-241, see cd360
   loss_bg  [b, blocks]  |alpha - opacity| (1 - opacity) on rays with opacity < 0.1
   loss_rgb [b, blocks]  masked (rgb_target_r - rgb_pred)^2 / sum(mask)
 The arithmetic is a few small elementwise/resize ops on [b, 4, 64, 64]-sized tensors, done with torch on whatever device the
-model outputs live; the UNet forward it wraps is the HIP path, and under autograd its backward runs on the HIP backward kernels
-(cd360/grad.py; cd360.finetune.train_step is one optimisation step of config 4).
+model outputs live -- except the three rendering terms of each pose block on the GPU, which are one kernel forward and one backward
+(cd360_render_loss_f32: ~35 torch kernels per block otherwise, twelve blocks per step); the UNet forward it wraps is the HIP path, and
+under autograd its backward runs on the HIP backward kernels (cd360/grad.py; cd360.finetune.train_step is one
+optimisation step of config 4).
 """
 import math
 from typing import List, Optional, Union
@@ -17,6 +19,8 @@ from typing import List, Optional, Union
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
+
+from cd360 import ops
 
 from ...util import append_dims, instantiate_from_config
 
@@ -75,6 +79,30 @@ class StandardDiffusionLossImgRef(nn.Module):
             loss_l2 = (loss * mask).sum([1, 2, 3]) / (mask.sum([1, 2, 3]) + 1e-6)
         else:
             loss_l2 = torch.mean(loss.reshape(target.shape[0], -1), 1)
+        n_blk = len(fg_mask_list)
+        if (n_blk > 0 and n_blk == len(alphas_list) and len(predicted_rgb_list) in (0, n_blk) and (mask is not None or not predicted_rgb_list)
+                and all(fg_mask.size(1) == rgb.size(1) for fg_mask, rgb in zip(fg_mask_list, predicted_rgb_list))
+                and ops.render_loss_ok(fg_mask_list[0], alphas_list[0], predicted_rgb_list[0] if predicted_rgb_list else None, opacity, mask, target_rgb)):
+            # GPU: the three terms of a block in one kernel (and one for their gradients); the resized targets are shared as below
+            terms, resized, bg_w = [], {}, None
+            mask_den = mask.sum([1, 2, 3]) + 1e-6 if predicted_rgb_list else None
+            for i, (fg_mask, alphas) in enumerate(zip(fg_mask_list, alphas_list)):
+                size = int(math.sqrt(fg_mask.size(1)))
+                if opacity.shape[-2:] != (size, size):
+                    opacity = F.interpolate(opacity, size=size, antialias=True, mode="bilinear").detach()
+                    bg_w = None
+                op = opacity.reshape(-1, size * size)
+                if bg_w is None:
+                    bg_w = ((1 - op) * ((op < 0.1) * 1)).contiguous()
+                rgb = mask_ = want = None
+                if predicted_rgb_list:
+                    if size not in resized:
+                        resized[size] = (F.interpolate(mask, size=size, antialias=True, mode="bilinear").detach().contiguous(),
+                                         F.interpolate(target_rgb * 0.5 + 0.5, size=size, antialias=True, mode="bilinear").detach().contiguous())
+                    (mask_, want), rgb = resized[size], predicted_rgb_list[i]
+                terms.append(ops.render_loss(fg_mask, alphas, rgb, op, bg_w, mask_, want, mask_den))
+            terms = torch.stack(terms, 1)  # [b, blocks, 3]
+            return loss_l2, terms[..., 0], terms[..., 1], (terms[..., 2] if predicted_rgb_list else loss_rgb)
         if len(fg_mask_list) > 0 and len(alphas_list) > 0:
             bg_w = None  # (1 - opacity) * [opacity < 0.1] of the current map: constant until the next resize (the factor [..] is 0 / 1, so
             for fg_mask, alphas in zip(fg_mask_list, alphas_list):  # folding it into the weight first changes no bit of the product)

@@ -208,6 +208,29 @@ int cd360_rowdot4_bf16(const void* h, const void* w, void* out, int64_t rows, in
  * plane_coefs.0 (nerfsd_pytorch3d.py:130-146; cd360/nerf.py reference_tables): h [rows, C] bf16, w [C] fp32 -> out [rows] fp32, fp32
  * accumulation, one read of h (this was a torch.mv -> library gemv over an fp32 copy of the features). */
 int cd360_rowdot1_bf16(const void* h, const void* w, void* out, int64_t rows, int C, void* stream);
+/* Fine-tuning (trainkeys = pose, sgm/models/diffusion.py:139-144): the operands the fused render reads, derived from the LIVE FeatureNeRF
+ * parameters in one launch -- the slices of plane_coefs.0.weight W1 [C, C + 198] behind FeatureNeRFEncoding.forward's concatenated input
+ * (nerfsd_pytorch3d.py:130-134: features | xyz encoding | Plucker / direction), the two parts of nviews.weight (:146-147), biases and the
+ * decoder in fp32 -- and the way back for their gradients.  All parameters bf16, contiguous; kcol [NK] / kpos [C + 198] int32 device tables
+ * (cd360/nerf.py xyz_k_columns and its inverse).
+ * pack:   out_bf16 = Wf [C, C] | Wk [C, NK] | Wp [C, 128];  out_f32 = b1 [C] | b2 [C] | vf [C] | v_cam [99], 1 pad | bv, 3 pad | Wd [4, C].
+ * unpack: grads[9] = dWf, dWk, dWp, db1, db2, dvf, dvc [99], dbv, dWd (NULL = zero), dtypes[9] (0 fp32, 1 bf16) -> dW1 [C, C + 198] bf16,
+ *         small = db1 [C] | db2 [C] | dwv [C + 198] | dbv, 1 pad | dWd [4, C] (bf16). */
+/* The three rendering terms of the fine-tuning loss for one pose block (StandardDiffusionLossImgRef.get_loss, sgm/modules/diffusionmodules/
+ * loss.py:188-207): out[b] = (mean_k (clamp(fg, 0, 1) - op)^2, mean_{k,s} |alpha - op| bgw, sum_{c,k} (want - rgb)^2 mask / den), with op the
+ * resized opacity, bgw = (1 - op) [op < 0.1], mask / want the resized mask and rgb target (constants of the step, prepared by the caller),
+ * den = mask.sum + 1e-6 of the full-size mask.  fg [b, hw], alpha [b, hw, S], rgb [b, hw, 3] (NULL: no rgb term), op / bgw / mask [b, hw],
+ * want [b, 3, hw], den [b], out [b, 3]; fp32; one workgroup per batch element, fixed summation order.  _bwd: g [b, 3] arriving on out ->
+ * d_fg, d_alpha, d_rgb (clamp passes the gradient on the closed interval, |x| has sign(0) = 0: torch's conventions). */
+int cd360_render_loss_f32(const void* fg, const void* alpha, const void* rgb, const void* op, const void* bgw, const void* mask,
+                          const void* want, const void* den, void* out, int b, int hw, int S, void* stream);
+int cd360_render_loss_bwd_f32(const void* fg, const void* alpha, const void* rgb, const void* op, const void* bgw, const void* mask,
+                              const void* want, const void* den, const void* g, void* d_fg, void* d_alpha, void* d_rgb, int b, int hw, int S,
+                              void* stream);
+int cd360_nerf_pack_weights_bf16(const void* W1, const void* b1, const void* b2, const void* wv, const void* bv, const void* Wd,
+                                 const void* kcol, void* out_bf16, void* out_f32, int C, int NK, void* stream);
+int cd360_nerf_unpack_grads_bf16(const void* const* grads, const int* dtypes, const void* kpos, void* dW1, void* small, int C, int NK,
+                                 void* stream);
 /* Backward of cd360_rowdot4_bf16 (the decoder is in the reference's trainkeys `pose`, sgm/models/diffusion.py:139-144; the reference
  * differentiates nn.Linear through autograd): d [rows, 4] fp32 = gradient of the output; dh [rows, C] bf16 = d w (NULL to skip);
  * dw_part [cd360_rowdot4_bwd_slabs(rows), 4, C] fp32 = per slab of rows the partial sums of dw = d^T h (NULL to skip; the caller

@@ -551,3 +551,68 @@ def test_pose_block_mask_ref_train_mode_gradients(monkeypatch):
         worst[k] = rel(params[k].grad, g["blk_grad." + k])
     print("worst:", sorted(worst.items(), key=lambda kv: -kv[1])[:4])
     assert max(worst.values()) < 5e-2, worst
+
+
+def test_render_loss_kernels_match_the_torch_expression():
+    """cd360_render_loss_f32 / _bwd_f32: the fg / bg / rgb terms of one pose block (loss.py:188-207 of the reference) and their gradients
+    against the torch statement of the same lines (sgm.modules.diffusionmodules.loss with the fusions switched off), including clamped
+    and zero-gradient positions."""
+    from cd360 import ops
+    g = torch.Generator().manual_seed(12)
+    b, r, S = 4, 16, 24
+    hw = r * r
+    for with_rgb in (True, False):
+        fg = (torch.rand(b, hw, 1, generator=g) * 1.4 - 0.2).to(DEV).requires_grad_(True)
+        al = torch.rand(b, hw, S, 1, generator=g).to(DEV).requires_grad_(True)
+        rgb = torch.rand(b, hw, 3, generator=g).to(DEV).requires_grad_(True) if with_rgb else None
+        op = (torch.rand(b, hw, generator=g) ** 3).to(DEV)
+        op[0, :7] = al.detach()[0, :7, 0, 0]  # |alpha - op| = 0 somewhere: sign(0) = 0
+        bgw = ((1 - op) * ((op < 0.1) * 1)).contiguous()
+        mask_ = torch.rand(b, 1, r, r, generator=g).to(DEV)
+        want = torch.rand(b, 3, r, r, generator=g).to(DEV)
+        den = (torch.rand(b, generator=g) * 100 + 1).to(DEV)
+        gout = torch.randn(b, 3, generator=g).to(DEV)
+        got = ops.render_loss(fg, al, rgb, op, bgw, mask_ if with_rgb else None, want if with_rgb else None, den if with_rgb else None)
+        got.backward(gout)
+        mine = [t.grad.clone() for t in (fg, al) + ((rgb,) if with_rgb else ())]
+        for t in (fg, al, rgb):
+            if t is not None:
+                t.grad = None
+        l_fg = ((torch.clamp(fg.reshape(b, hw), 0.0, 1.0) - op) ** 2).mean(1)
+        l_bg = ((al - op.reshape(b, hw, 1, 1)).abs() * bgw.reshape(b, hw, 1, 1)).mean([1, 2, 3])
+        l_rgb = (((want - rgb.reshape(b, r, r, 3).permute(0, 3, 1, 2)) ** 2) * mask_).sum([1, 2, 3]) / den if with_rgb else torch.zeros(b, device=DEV)
+        want_out = torch.stack([l_fg, l_bg, l_rgb], 1)
+        assert torch.allclose(got, want_out, rtol=2e-5, atol=1e-7)
+        want_out.backward(gout)
+        for m, t in zip(mine, (fg, al) + ((rgb,) if with_rgb else ())):
+            assert torch.allclose(m, t.grad, rtol=2e-5, atol=1e-9), (m - t.grad).abs().max()
+
+
+def test_live_nerf_weights_one_kernel_each_way_equals_the_recorded_ops():
+    """nerf._LiveNerfWeights on bf16 parameters (cd360_nerf_pack_weights_bf16 / cd360_nerf_unpack_grads_bf16) against the same node on the
+    op-by-op torch path (routes.no_train_fusions): every derived operand bit-equal, every parameter gradient bit-equal for random
+    gradients of the operands, and None gradients stay None-shaped zeros."""
+    from cd360 import nerf, routes
+    import weights as W
+    for C in (64, 640):
+        shapes = {"plane_coefs.0.weight": (C, C + 198), "plane_coefs.0.bias": (C,), "plane_coefs.2.weight": (C, C),
+                  "plane_coefs.2.bias": (C,), "nviews.weight": (1, C + 198), "nviews.bias": (1,), "decoder.weight": (4, C)}
+        w = W.synth_state_dict(shapes, 5)
+        g = torch.Generator().manual_seed(C)
+        res = []
+        for off in (False, True):
+            ps = [w[k].to(DEV, torch.bfloat16).requires_grad_(True) for k in NERF_KEYS]
+            with routes.override(no_train_fusions=off):
+                outs = nerf._LiveNerfWeights.apply(*ps)
+            if not res:
+                gs = [torch.randn(o.shape, generator=g).to(DEV, o.dtype) for o in outs]
+                gs[4] = None  # W2 is passed through: its gradient comes from the GEMM that reads it
+            sel = [i for i in range(len(outs)) if i != 4 and i != 6]  # ... and leave dvf out once: the zero-fill path
+            torch.autograd.backward([outs[i] for i in sel], [gs[i] for i in sel])
+            res.append((outs, [p.grad for p in ps]))
+        for a, b_ in zip(res[0][0], res[1][0]):
+            assert a.dtype == b_.dtype and torch.equal(a.reshape(b_.shape), b_)
+        for k, a, b_ in zip(NERF_KEYS, res[0][1], res[1][1]):
+            assert (a is None) == (b_ is None), k
+            if a is not None:
+                assert a.shape == b_.shape and torch.equal(a, b_), (k, (a.float() - b_.float()).abs().max())

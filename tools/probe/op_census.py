@@ -25,6 +25,7 @@ class Census(TorchDispatchMode):
         super().__init__()
         self.by_line = collections.Counter()
         self.by_op = collections.Counter()
+        self.by_shape = collections.Counter()
 
     def __torch_dispatch__(self, func, types, args=(), kwargs=None):
         where = "<autograd>"
@@ -36,6 +37,9 @@ class Census(TorchDispatchMode):
         if not any(v in name for v in VIEW_OPS):  # count what launches a kernel: views / allocations / metadata ops do not
             self.by_line[where] += 1
             self.by_op[(where, name)] += 1
+            if where == "<autograd>":  # no repo frame on the engine's stack: the operand shapes say which forward op this is the backward of
+                shapes = tuple((tuple(a.shape), str(a.dtype).replace("torch.", "")) for a in args if isinstance(a, torch.Tensor))[:2]
+                self.by_shape[(name, shapes)] += 1
         return func(*args, **(kwargs or {}))
 
 
@@ -62,6 +66,9 @@ def main():
     for where, c in census.by_line.most_common(a.top):
         ops = sorted(((n, op) for (w, op), n in census.by_op.items() if w == where), reverse=True)[:4]
         print(f"{c:6d}  {where:55s} " + "  ".join(f"{op.replace('aten.', '')}x{n}" for n, op in ops))
+    print("\n<autograd> ops by operand shapes:")
+    for (name, shapes), c in census.by_shape.most_common(a.top):
+        print(f"{c:6d}  {name.replace('aten.', ''):28s} {shapes}")
 
 
 if __name__ == "__main__":
