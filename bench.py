@@ -287,8 +287,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true", help="skip per-kernel HIP-event timing")
     ap.add_argument("--no-graph", action="store_true", help="launch every step eagerly instead of replaying the steady-state step from a hipGraph")
-    ap.add_argument("--route", choices=["fused", "module"], default="fused", help="module: a no-op forward hook on every transformer block, so the "
-                    "blocks take the strict module route a patched sample.py (sample.py:247-262) or a hooked run takes -- same kernels, un-fused")
+    ap.add_argument("--route", choices=["fused", "hooked", "module"], default="fused",
+                    help="hooked: a no-op forward hook on every transformer BLOCK (what the references harvest registers, diffusion.py:151-163): "
+                    "the SpatialTransformer leaves its fused route, the blocks keep their fused internals.  module: a no-op hook on a SUBMODULE "
+                    "of every block, so the blocks take the strict module route a patched sample.py (sample.py:247-262) takes -- every "
+                    "submodule through the module protocol, same kernels, un-fused")
     ap.add_argument("--no-train-step", action="store_true", help="skip the fine-tuning step measurement appended after the timed region (BASELINE configs[3])")
     ap.add_argument("--no-weight-prefetch", action="store_true", help="capture the steps without the weight prefetcher (cd360/prefetch.py): the A/B partner")
     ap.add_argument("--prefetch-wgs", type=int, default=128)
@@ -324,11 +327,11 @@ def main():
     mine = shard.assign_poses(n_poses, world, rank)  # indices of the target poses this rank samples (independent trajectories)
     assert len(mine) >= 1, "--poses must be >= --gpus"
     net = build_model(args.latent, args.refs, 50, dev)
-    if args.route == "module":
+    if args.route != "fused":
         from sgm.modules.attention import BasicTransformerBlock
         for m in net.modules():
             if isinstance(m, BasicTransformerBlock):
-                m.register_forward_hook(lambda mod, inp, out: None)
+                (m if args.route == "hooked" else m.norm1).register_forward_hook(lambda mod, inp, out: None)
     jobs = []
     ppr = max(1, args.poses_per_replay)
     assert len(mine) % ppr == 0, "--poses-per-replay must divide the poses of every rank"

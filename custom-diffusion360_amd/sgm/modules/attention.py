@@ -98,6 +98,13 @@ def _watched(*mods: nn.Module) -> bool:
     return False
 
 
+def _watched_inside(mod: nn.Module) -> bool:
+    """Somebody observes a SUBMODULE of `mod` (not `mod` itself).  An observer of the block alone -- the references harvest hooks exactly
+    the pose blocks (diffusion.py:151-163) -- sees the block's inputs and outputs through `__call__` whatever happens inside, so the
+    block may keep its fused internals; observers further in need every submodule called through the module protocol."""
+    return any(_watched(child) for child in mod.children())
+
+
 def Normalize(in_channels):
     return torch.nn.GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
 
@@ -634,7 +641,7 @@ class BasicTransformerBlock(nn.Module):
                 n_times_crossframe_attn_in_self=0):
         if additional_tokens is not None or n_times_crossframe_attn_in_self:
             raise NotImplementedError("additional_tokens / cross-frame attention are not used by the shipped config")
-        watched = _watched(self)
+        watched = _watched_inside(self)  # hooks on this block itself have what they need: they fire around this very call
         if not watched and self.fused_ready(x):
             return self._forward_fused(x, None, context, context_ref, pose, mask_ref, prev_weights)[:5]
         return self._forward(x, context, context_ref, pose, mask_ref, prev_weights, strict=watched)

@@ -171,6 +171,25 @@ def test_rebound_forward_and_hooked_blocks_stay_on_the_hand_written_gemm():
     assert rel(patched, fused) < 2e-2 and rel(got, want) < 2e-2
 
 
+@torch.no_grad()
+def test_block_level_hooks_keep_the_fused_internals_submodule_hooks_do_not():
+    """A forward hook on a block (the references harvest, diffusion.py:151-163) sees the block's inputs and outputs around `__call__`: the
+    block keeps its fused internals and returns the un-hooked result bit for bit.  A hook on a submodule needs that submodule called
+    through the module protocol: the strict route (checked against the fused result within rounding; the hook must fire)."""
+    blk = make_block()
+    x, ctx = rnd(3, 256, 128, seed=1).to(BF), rnd(3, 77, 64, seed=2).to(BF)
+    fused = blk(x, context=ctx)[0]
+    seen = []
+    h = blk.register_forward_hook(lambda m, i, o: seen.append(("block", i[0].data_ptr() == x.data_ptr(), o[0].shape)))
+    assert torch.equal(blk(x, context=ctx)[0], fused) and seen == [("block", True, (3, 256, 128))]
+    h.remove()
+    h = blk.norm2.register_forward_hook(lambda m, i, o: seen.append(("norm2", o.shape)))
+    with no_library_gemm():
+        strict = blk(x, context=ctx)[0]
+    h.remove()
+    assert seen[-1] == ("norm2", (3, 256, 128)) and not torch.equal(strict, fused) and rel(strict, fused) < 2e-2
+
+
 def test_finetune_step_reaches_no_library_gemm():
     """One optimisation step of the reduced UNet (trainkeys = pose; forward of both streams, four-term loss, backward, AdamW) with every
     library GEMM entry guarded: Linear forward / dgrad / wgrad, the FeatureNeRF table GEMMs and their parameter gradients all run on
