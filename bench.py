@@ -294,9 +294,9 @@ def main():
                     "submodule through the module protocol, same kernels, un-fused")
     ap.add_argument("--no-train-step", action="store_true", help="skip the fine-tuning step measurement appended after the timed region (BASELINE configs[3])")
     ap.add_argument("--no-weight-prefetch", action="store_true", help="capture the steps without the weight prefetcher (cd360/prefetch.py): the A/B partner")
-    ap.add_argument("--prefetch-wgs", type=int, default=128)
+    ap.add_argument("--prefetch-wgs", type=int, default=256)
     ap.add_argument("--prefetch-lag", type=int, default=2)
-    ap.add_argument("--prefetch-min-mb", type=float, default=1.0)
+    ap.add_argument("--prefetch-min-mb", type=float, default=0.25)
     ap.add_argument("--fp8-attn", action="store_true", help="BASELINE configs[4]: the text / pose-token cross-attention of every block with q K^T and P V on "
                     "fp8 MFMA (cd360_qproj_attn_fp8_bf16) for the whole run; adds an `fp8_tolerance` object (rendered features and eps against the bf16 run)")
     args = ap.parse_args()

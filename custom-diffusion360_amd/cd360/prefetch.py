@@ -19,7 +19,7 @@ from ._lib import check
 
 
 class WeightPrefetcher:
-    def __init__(self, device, lag: int = 2, wgs: int = 32, min_bytes: int = 1 << 20):
+    def __init__(self, device, lag: int = 2, wgs: int = 256, min_bytes: int = 1 << 18):
         self.device, self.lag, self.wgs, self.min_bytes = torch.device(device), int(lag), int(wgs), int(min_bytes)
         self.sink = torch.zeros(1, dtype=torch.int32, device=self.device)
         self.side = torch.cuda.Stream(device=self.device)
