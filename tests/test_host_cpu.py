@@ -94,6 +94,17 @@ def test_cpu_forward_fails_loudly():
         att(torch.randn(1, 8, 64))
     with pytest.raises(Cd360Error):
         ops.memory_efficient_attention(torch.randn(2, 8, 64), torch.randn(2, 8, 64), torch.randn(2, 8, 64))
+    # the operators added in round 4: inverse-CDF depth sampling (f4), the view-logit column, the render loss terms, the derived FeatureNeRF weights
+    from sgm.modules.nerfsd_pytorch3d import Raymarcher
+    bf = lambda *s: torch.randn(*s, dtype=torch.bfloat16)
+    calls = [lambda: ops.sample_pdf(torch.linspace(0, 2, 5)[None], torch.ones(1, 4), torch.rand(1, 4)),
+             lambda: Raymarcher(num_samples=4, stratified=False, training=False).importance_sampling(torch.rand(1, 16, 4, 1), 16, 4, "cpu"),
+             lambda: ops.rowdot1(bf(4, 64), torch.randn(64)),
+             lambda: ops.render_loss(torch.rand(2, 16, 1), torch.rand(2, 16, 4, 1), None, torch.rand(2, 16), torch.rand(2, 16), None, None, None),
+             lambda: ops.nerf_pack_weights(bf(64, 262), bf(64), bf(64), bf(262), bf(1), bf(4, 64), torch.zeros(112, dtype=torch.int32))]
+    for call in calls:
+        with pytest.raises(Cd360Error):
+            call()
 
 
 def test_cpu_autograd_path_fails_loudly_too():
