@@ -20,7 +20,7 @@ from typing import Optional
 import numpy as np
 import torch
 
-from . import ops, routes
+from . import memo, ops, routes
 
 NUM_FREQS = 16
 
@@ -229,24 +229,29 @@ def view_constants(fw: FusedNerfWeights, cams: torch.Tensor) -> torch.Tensor:
     return ((_camera_constants(cams) * fw.v_cam).sum(-1) + fw.bv).contiguous()
 
 
-_CAM_CONSTS = []  # the last few (cams, version, (o, enc16(o))): the twelve pose blocks of a forward share one packed camera tensor
+_CAM_CONSTS = memo.Memo()  # (packed cameras, version) -> camera constants: the twelve pose blocks of a forward share one packed camera tensor
+_PLUCKER = memo.Memo(2)    # ... -> Plucker features of a level (one entry per resolution in flight)
 
 
 def _camera_constants(cams: torch.Tensor):
     """Reference camera centres in the target view frame and their positional encoding: camera-only values, computed once per packed
-    camera tensor instead of once per pose block (a dozen tiny kernels each)."""
-    for ent in _CAM_CONSTS:
-        if ent[0] is cams and ent[1] == cams._version:
-            return ent[2]
-    with torch.no_grad():
-        R = cams[..., :9].reshape(*cams.shape[:-1], 3, 3)
-        T = cams[..., 9:12]
-        center = -(T[..., None, :] * R).sum(-1)  # -T @ R^T
-        o = (center[:, 1:, :, None] * R[:, :1]).sum(-2) + T[:, :1]  # centre_i @ R_0 + T_0
-        val = torch.cat([o, positional_encoding(o, NUM_FREQS)], -1).contiguous()  # [b, n, 3 + 96]
-    _CAM_CONSTS.insert(0, (cams, cams._version, val))  # (inside a graph capture too: the first pose block's kernels are captured, the others read)
-    del _CAM_CONSTS[4:]
-    return val
+    camera tensor instead of once per pose block (a dozen tiny kernels each).  Memoised under cd360.memo's capture rule."""
+    def make():
+        with torch.no_grad():
+            R = cams[..., :9].reshape(*cams.shape[:-1], 3, 3)
+            T = cams[..., 9:12]
+            center = -(T[..., None, :] * R).sum(-1)  # -T @ R^T
+            o = (center[:, 1:, :, None] * R[:, :1]).sum(-2) + T[:, :1]  # centre_i @ R_0 + T_0
+            return torch.cat([o, positional_encoding(o, NUM_FREQS)], -1).contiguous()  # [b, n, 3 + 96]
+    return _CAM_CONSTS.get(cams, make)
+
+
+def _plucker_rows(cams: torch.Tensor, xs: torch.Tensor, ys: torch.Tensor) -> torch.Tensor:
+    """ops.plucker_features_bf16 -- a function of the cameras and the patch grid only, so the blocks of one resolution share it within a
+    forward when the grid is the cached eval-mode one (a stratified training step draws a grid per block: always recomputed)."""
+    if torch.is_grad_enabled() or xs.requires_grad or ys.requires_grad:
+        return ops.plucker_features_bf16(cams, xs, ys)
+    return _PLUCKER.get(cams, lambda: ops.plucker_features_bf16(cams, xs, ys), extra=(id(xs), xs._version, id(ys), ys._version))
 
 
 def fused_feature_nerf(fw: FusedNerfWeights, cams: torch.Tensor, xref: Optional[torch.Tensor], num_samples: int, far: float,
@@ -266,7 +271,7 @@ def fused_feature_nerf(fw: FusedNerfWeights, cams: torch.Tensor, xref: Optional[
     # round-1 torch GEMMs (A/B)
     fused = cams.is_cuda and C % 64 == 0 and fw.Wp.dtype == torch.bfloat16 and not routes.library_linear
     if fused:
-        zP = ops.linear(ops.plucker_features_bf16(cams, xs, ys).reshape(b * n * hw, 128), fw.Wp, fw.b1).reshape(b * n, hw, C)
+        zP = ops.linear(_plucker_rows(cams, xs, ys).reshape(b * n * hw, 128), fw.Wp, fw.b1).reshape(b * n, hw, C)
     else:
         pf = ops.plucker_features(cams, xs, ys).reshape(b * n * hw, 104)
         zP = torch.addmm(fw.b1, pf, fw.Wp_t).to(torch.bfloat16).reshape(b * n, hw, C)

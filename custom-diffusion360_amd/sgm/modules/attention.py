@@ -28,7 +28,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from cd360 import ops, routes
+from cd360 import memo, ops, routes
 from ..modules.diffusionmodules.util import HipLayerNorm, HipLinear, checkpoint, group_norm_tokens, tag_gn_stats, tokens_to_image, zero_module  # noqa: F401
 from ..modules.nerfsd_pytorch3d import NerfSDModule, VolRender
 from ..util import default, exists
@@ -109,24 +109,19 @@ def Normalize(in_channels):
     return torch.nn.GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
 
 
-_PADDED = []  # the last few (context, version, padded context): every block of a forward pads the SAME one or two context tensors
+_PADDED = memo.Memo()  # (context, version) -> padded context: every block of a forward pads the SAME one or two context tensors
 
 
 def _pad_tokens(ctx: torch.Tensor, mult: int = 8) -> torch.Tensor:
     """The context with its token count rounded up to a multiple of 8 (77 -> 80 zero rows: whole 16-byte rows for the K / V kernels).
-    One pad per context tensor and forward instead of one per attention module (152 pad kernels in a fine-tuning step)."""
+    One pad per context tensor and forward instead of one per attention module (152 pad kernels in a fine-tuning step); memoised
+    under cd360.memo's capture rule (an eager run's padded copy never feeds a hipGraph capture)."""
     pad = (-ctx.shape[1]) % mult
     if pad == 0:
         return ctx
     if ctx.requires_grad:
         return F.pad(ctx, (0, 0, 0, pad))
-    for ent in _PADDED:
-        if ent[0] is ctx and ent[1] == ctx._version:
-            return ent[2]
-    out = F.pad(ctx, (0, 0, 0, pad))
-    _PADDED.insert(0, (ctx, ctx._version, out))
-    del _PADDED[4:]
-    return out
+    return _PADDED.get(ctx, lambda: F.pad(ctx, (0, 0, 0, pad)), extra=mult)
 
 
 class MemoryEfficientCrossAttention(nn.Module):

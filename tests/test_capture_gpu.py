@@ -1,0 +1,62 @@
+"""hipGraph capture against the per-forward memo tables (cd360/memo.py).  Needs an MI355X.
+
+bench.py's graph mode runs one eager render, captures the render step, and later points the captured sampler at the next target pose by
+rewriting the packed camera tensor IN PLACE (Sampler.retarget).  A value memoised by the eager run under (tensor, version) must not be
+served to the capture: its kernels would be missing from the graph and every replay after a retarget would read the old pose's value."""
+import os
+import sys
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def _capture(fn):
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        fn()
+    torch.cuda.current_stream().wait_stream(side)
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        out = fn()
+    return g, out
+
+
+@torch.no_grad()
+def test_memoised_values_of_an_eager_run_never_feed_a_capture():
+    from cd360 import nerf, synth
+    from cd360.cameras import pack_cameras
+    from sgm.modules.attention import _pad_tokens
+    cams = pack_cameras(synth.pose_batch(2, 5, seed=1)).to(DEV)
+    other = pack_cameras(synth.pose_batch(2, 5, seed=2)).to(DEV)
+    xs, ys = nerf.patch_positions(8, DEV), nerf.patch_positions(8, DEV)
+    ctx = torch.randn(2, 77, 64, device=DEV).to(torch.bfloat16)
+    ctx2 = torch.randn(2, 77, 64, device=DEV).to(torch.bfloat16)
+
+    def step():  # what every pose block of a forward asks for
+        return nerf._camera_constants(cams) + 0.0, nerf._plucker_rows(cams, xs, ys).float() + 0.0, _pad_tokens(ctx).float() + 0.0
+
+    eager = [t.clone() for t in step()]  # fills the memo tables under (tensor, version)
+    g, outs = _capture(step)
+    g.replay()
+    torch.cuda.synchronize()
+    for a, b in zip(outs, eager):
+        assert torch.equal(a, b)
+    cams.copy_(other)  # Sampler.retarget: the next pose, written into the buffer the graph reads
+    ctx.copy_(ctx2)
+    g.replay()
+    torch.cuda.synchronize()
+    fresh = step()  # eager, new versions: recomputed
+    for a, b, old in zip(outs, fresh, eager):
+        assert torch.equal(a, b), "the replay must follow the rewritten buffers"
+        assert not torch.equal(b, old)
+    # within one eager forward the tables still serve their purpose: the same object comes back
+    assert nerf._camera_constants(cams) is nerf._camera_constants(cams)
+    assert nerf._plucker_rows(cams, xs, ys) is nerf._plucker_rows(cams, xs, ys)
+    assert _pad_tokens(ctx) is _pad_tokens(ctx)
