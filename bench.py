@@ -72,6 +72,9 @@ class Sampler:
     def __init__(self, net, pose, ctx, y, n_steps, scale=7.5, scale_im=3.5, use_graph=False, prefetch=None):
         from cd360 import sampler as S
         self.net, self.pose, self.n_steps = net, pose, n_steps
+        if use_graph:  # the graphs read the cameras through ONE buffer this sampler owns (retarget rewrites it in place)
+            from sgm.modules.utils_cameraray import PoseBuffer
+            self.pose = PoseBuffer(pose, ctx.device)
         self.scale, self.scale_im = scale, scale_im
         dev = ctx.device
         # the reference's own stack (cd360/sampler.py mirrors sampling.py / guiders.py / denoiser.py; parity: tests/test_sampler_cpu.py)
@@ -91,7 +94,7 @@ class Sampler:
     def retarget(self, pose, ctx, y):
         """Point the sampler at another target pose / conditioning (the next pose of this rank's share).  The captured graphs read both
         through fixed device buffers, so the new values are copied INTO them: the CFG conditioning batch, and the packed
-        [3, n+1, 16] camera tensor the render path memoises for `self.pose` (sgm/modules/utils_cameraray.py::packed_pose)."""
+        [3, n+1, 16] camera tensor this sampler owns (sgm/modules/utils_cameraray.py::PoseBuffer)."""
         bs = self.bs
         c = {"crossattn": ctx[2 * bs:], "vector": y[2 * bs:]}
         uc = {"crossattn": ctx[:bs], "vector": y[:bs]}
@@ -99,9 +102,7 @@ class Sampler:
         self.ctx.copy_(cond3["crossattn"])
         self.y.copy_(cond3["vector"])
         if self.use_graph:
-            from cd360.cameras import pack_cameras
-            from sgm.modules.utils_cameraray import packed_pose
-            packed_pose(self.pose, self.ctx.device).copy_(pack_cameras(pose, self.ctx.device))
+            self.pose.rewrite(pose)
         else:
             self.pose = pose
 

@@ -109,6 +109,7 @@ def Normalize(in_channels):
     return torch.nn.GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
 
 
+_CAM_VIEWS = memo.Memo()  # (packed cameras of a forward, version, k) -> its first k rows as ONE view object
 _PADDED = memo.Memo()  # (context, version) -> padded context: every block of a forward pads the SAME one or two context tensors
 
 
@@ -383,7 +384,14 @@ class BasicTransformerBlock(nn.Module):
             # pose and the same references, so everything BEFORE the text cross-attention is identical for them: render the
             # first two thirds only and reuse the second for the third (the reference computes it twice).
             t2, d2 = self._sampling_tables(dup, dup)  # the layout is stated, never re-inferred from the de-duplicated batch size
-            h, dec, dists, _ = self.pose_featurenerf.render_inputs(list(pose[:2 * dup]), None, None, tables=t2, dims=d2)
+            # the cameras of the first two thirds as a VIEW of the forward's packed camera tensor -- not a packing of their own: a captured
+            # sampler is pointed at its next pose by rewriting that one tensor in place (bench.py Sampler.retarget), and a separately
+            # packed sub-list kept rendering the first pose (found by tests/test_capture_gpu.py).  The view object is memoised per
+            # (packed tensor, version), so the per-camera memo tables downstream still see one object per forward.
+            from ..modules.utils_cameraray import packed_pose
+            cams_all = packed_pose(pose, x.device)
+            cams2 = _CAM_VIEWS.get(cams_all, lambda: cams_all[:2 * dup], extra=2 * dup)
+            h, dec, dists, _ = self.pose_featurenerf.render_inputs(cams2, None, None, tables=t2, dims=d2)
             b2, hw, S, C = h.shape
             tok = h.reshape(b2, hw * S, C)
             if (tok.dtype == x.dtype and self.fused_ready(tok) and not routes.no_render_commute and not routes.no_qproj_attn

@@ -12,8 +12,26 @@ from cd360 import ops
 from cd360.cameras import pack_cameras
 
 
+class PoseBuffer(list):
+    """The camera batches of a forward (a plain list to every consumer: same objects, same identities -- the CFG de-duplication looks at
+    those) together with the packed tensor the kernels read, owned by the caller.  A sampler whose steps are captured into hipGraphs
+    points them at the next target pose with `rewrite(pose)`: the graphs keep reading the same buffer.  (Writing into the memoised
+    packing of `packed_pose` instead would leave that memo entry describing cameras it no longer holds.)"""
+
+    def __init__(self, pose, device):
+        super().__init__(pose)
+        self.packed = pack_cameras(pose, device)
+
+    def rewrite(self, pose) -> None:
+        new = pack_cameras(pose, self.packed.device)
+        assert new.shape == self.packed.shape, "the captured graphs were sized for another camera layout"
+        self.packed.copy_(new)
+
+
 def packed_pose(pose, device) -> torch.Tensor:
     """Pack (and memoise on the list object's elements) the cameras of one forward call."""
+    if isinstance(pose, PoseBuffer) and pose.packed.device == torch.device(device):
+        return pose.packed
     if isinstance(pose, torch.Tensor):
         return pack_cameras(pose, device)
     # keyed on the camera objects AND on the storage / version of their fields: an in-place edit (cam.T = ..., the crop / scale adjusters

@@ -60,3 +60,41 @@ def test_memoised_values_of_an_eager_run_never_feed_a_capture():
     assert nerf._camera_constants(cams) is nerf._camera_constants(cams)
     assert nerf._plucker_rows(cams, xs, ys) is nerf._plucker_rows(cams, xs, ys)
     assert _pad_tokens(ctx) is _pad_tokens(ctx)
+
+
+@torch.no_grad()
+def test_graph_mode_sampler_follows_a_retarget_like_the_eager_one():
+    """bench.py's Sampler end to end at the SDXL UNet (small latent): two target poses sampled one after the other by ONE sampler -- the
+    second through Sampler.retarget -- replayed from the captured render / steady graphs, against the same two trajectories launched
+    eagerly.  Every value a captured step derives from the pose or the conditioning must be re-derived inside the graph."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from cd360 import synth
+    latent, refs, steps = 32, 6, 3
+    net = bench.build_model(latent, refs, 50, DEV)
+    jobs = []
+    for pi in (0, 1):
+        one = [synth.pose_batch(1, refs, seed=100 + pi, n_train=50)[0]]
+        g = torch.Generator(device=DEV).manual_seed(7 + pi)
+        ctx = torch.randn(3, 77, 2048, generator=g, device=DEV).to(torch.bfloat16)
+        y = torch.randn(3, 2816, generator=g, device=DEV).to(torch.bfloat16)
+        jobs.append((one * 3, ctx, y, torch.randn(1, 4, latent, latent, generator=g, device=DEV)))
+
+    def run(use_graph):
+        smp = bench.Sampler(net, *jobs[0][:3], 50, use_graph=use_graph)
+        outs = []
+        for j, (pose, ctx, y, x) in enumerate(jobs):
+            if j > 0:
+                smp.retarget(pose, ctx, y)
+            xs = x.clone()
+            for i in range(steps):
+                xs = smp.step(xs, i)
+            outs.append(xs.clone())
+        return outs
+
+    eager = run(False)
+    graph = run(True)
+    rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+    assert rel(eager[1], eager[0]) > 1e-2  # two different trajectories
+    for e, g_ in zip(eager, graph):
+        assert torch.isfinite(g_).all() and rel(g_, e) < 2e-3, rel(g_, e)

@@ -1,0 +1,58 @@
+"""Graph-mode sampler vs eager sampler over two poses (the second through Sampler.retarget): where do they part?"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "custom-diffusion360_amd"))
+import torch
+import bench
+from cd360 import synth
+DEV = "cuda"
+latent, refs, steps = 32, 6, 3
+torch.set_grad_enabled(False)
+net = bench.build_model(latent, refs, 50, DEV)
+jobs = []
+for pi in (0, 1):
+    one = [synth.pose_batch(1, refs, seed=100 + pi, n_train=50)[0]]
+    g = torch.Generator(device=DEV).manual_seed(7 + pi)
+    ctx = torch.randn(3, 77, 2048, generator=g, device=DEV).to(torch.bfloat16)
+    y = torch.randn(3, 2816, generator=g, device=DEV).to(torch.bfloat16)
+    jobs.append((one * 3, ctx, y, torch.randn(1, 4, latent, latent, generator=g, device=DEV)))
+rel = lambda a, b: float((a - b).abs().max() / b.abs().max())
+
+def run(use_graph, order=(0, 1), fresh=False):
+    outs = {}
+    smp = None
+    for k, j in enumerate(order):
+        pose, ctx, y, x = jobs[j]
+        if smp is None or fresh:
+            smp = bench.Sampler(net, pose, ctx, y, 50, use_graph=use_graph)
+        elif k > 0:
+            smp.retarget(pose, ctx, y)
+        xs = x.clone()
+        traj = []
+        for i in range(steps):
+            xs = smp.step(xs, i)
+            traj.append(xs.clone())
+        outs[j] = traj
+    return outs
+
+e = run(False)
+e2 = run(False)
+print("eager vs eager", [[rel(a, b) for a, b in zip(e[j], e2[j])] for j in (0, 1)])
+ef = run(False, fresh=True)
+print("eager retarget vs eager fresh", [[rel(a, b) for a, b in zip(e[j], ef[j])] for j in (0, 1)])
+g = run(True)
+print("graph vs eager", [[rel(a, b) for a, b in zip(g[j], e[j])] for j in (0, 1)])
+gf = run(True, fresh=True)
+print("graph fresh vs eager", [[rel(a, b) for a, b in zip(gf[j], e[j])] for j in (0, 1)])
+g10 = run(True, order=(1, 0))
+print("graph (1 first) vs eager", [[rel(a, b) for a, b in zip(g10[j], e[j])] for j in (0, 1)])
+
+# which input goes stale?  second job differs from the first in ONE thing
+base = jobs[0]
+variants = {"pose only": (jobs[1][0], base[1], base[2], base[3]), "ctx only": (base[0], jobs[1][1], base[2], base[3]),
+            "y only": (base[0], base[1], jobs[1][2], base[3]), "x only": (base[0], base[1], base[2], jobs[1][3])}
+for name, job in variants.items():
+    jobs[1] = job
+    e = run(False)
+    g = run(True)
+    print(name, "graph vs eager, second job:", [rel(a, b) for a, b in zip(g[1], e[1])])
