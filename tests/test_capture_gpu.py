@@ -101,3 +101,36 @@ def test_graph_mode_sampler_follows_a_retarget_like_the_eager_one(fp8):
     assert rel(eager[1], eager[0]) > 1e-2  # two different trajectories
     for e, g_ in zip(eager, graph):
         assert torch.isfinite(g_).all() and rel(g_, e) < 2e-3, rel(g_, e)
+
+
+@torch.no_grad()
+def test_two_poses_per_replay_equal_two_single_pose_trajectories():
+    """bench.py --poses-per-replay 2: two target poses batched into one denoise step (CFG batch 6 = [null x2 | image x2 | image+text x2],
+    de-duplicated render of four elements) against the same two poses sampled one by one, replayed from hipGraphs."""
+    sys.path.insert(0, ROOT)
+    import bench
+    from cd360 import synth
+    latent, refs, steps = 32, 6, 3
+    net = bench.build_model(latent, refs, 50, DEV)
+    singles = []
+    for pi in (0, 1):
+        one = [synth.pose_batch(1, refs, seed=100 + pi, n_train=50)[0]]
+        g = torch.Generator(device=DEV).manual_seed(7 + pi)
+        ctx = torch.randn(3, 77, 2048, generator=g, device=DEV).to(torch.bfloat16)
+        y = torch.randn(3, 2816, generator=g, device=DEV).to(torch.bfloat16)
+        singles.append((one * 3, ctx, y, torch.randn(1, 4, latent, latent, generator=g, device=DEV)))
+    pose2 = [singles[0][0][0], singles[1][0][0]] * 3
+    ctx2 = torch.cat([torch.cat([singles[0][1][k:k + 1], singles[1][1][k:k + 1]]) for k in range(3)])
+    y2 = torch.cat([torch.cat([singles[0][2][k:k + 1], singles[1][2][k:k + 1]]) for k in range(3)])
+
+    def sample(pose, ctx, y, x):
+        smp = bench.Sampler(net, pose, ctx, y, 50, use_graph=True)
+        for i in range(steps):
+            x = smp.step(x, i)
+        return x.clone()
+
+    outs = [sample(*job[:3], job[3].clone()) for job in singles]
+    both = sample(pose2, ctx2, y2, torch.cat([singles[0][3], singles[1][3]]))
+    for k in range(2):  # the level-2 GEMMs take other tiles at M = 6144 than at 3072: same products, other blocking -- rounding only
+        assert float((both[k:k + 1] - outs[k]).abs().max() / outs[k].abs().max()) < 5e-3
+    assert float((outs[0] - outs[1]).abs().max() / outs[1].abs().max()) > 1e-2

@@ -56,3 +56,32 @@ for name, job in variants.items():
     e = run(False)
     g = run(True)
     print(name, "graph vs eager, second job:", [rel(a, b) for a, b in zip(g[1], e[1])])
+
+# two poses batched into one replay (bench.py --poses-per-replay 2: CFG batch 6 = [null x2 | image x2 | image+text x2]) against the two
+# poses sampled one by one
+jobs[1] = base if False else jobs[1]
+from cd360 import synth as _s
+singles = []
+for pi in (0, 1):
+    one = [_s.pose_batch(1, refs, seed=100 + pi, n_train=50)[0]]
+    g = torch.Generator(device=DEV).manual_seed(7 + pi)
+    ctx = torch.randn(3, 77, 2048, generator=g, device=DEV).to(torch.bfloat16)
+    y = torch.randn(3, 2816, generator=g, device=DEV).to(torch.bfloat16)
+    singles.append((one * 3, ctx, y, torch.randn(1, 4, latent, latent, generator=g, device=DEV)))
+pose2 = [singles[0][0][0], singles[1][0][0]] * 3
+ctx2 = torch.cat([torch.cat([singles[0][1][k:k + 1], singles[1][1][k:k + 1]]) for k in range(3)])
+y2 = torch.cat([torch.cat([singles[0][2][k:k + 1], singles[1][2][k:k + 1]]) for k in range(3)])
+x2 = torch.cat([singles[0][3], singles[1][3]])
+for use_graph in (False, True):
+    outs = []
+    for pose, ctx, y, x in singles:
+        smp = bench.Sampler(net, pose, ctx, y, 50, use_graph=use_graph)
+        xs = x.clone()
+        for i in range(steps):
+            xs = smp.step(xs, i)
+        outs.append(xs)
+    smp = bench.Sampler(net, pose2, ctx2, y2, 50, use_graph=use_graph)
+    xs = x2.clone()
+    for i in range(steps):
+        xs = smp.step(xs, i)
+    print("graph" if use_graph else "eager", "two poses per replay vs singles:", [rel(xs[k:k + 1], outs[k]) for k in range(2)])
