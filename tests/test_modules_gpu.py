@@ -664,6 +664,21 @@ def test_full_sdxl_unet_configA_matches_cpu_oracle():
     from cd360 import sampling
     from sgm.modules.attention import BasicTransformerBlock, SpatialTransformer
     from sgm.modules.diffusionmodules.openaimodel import Downsample, ResBlock, Upsample
+    # The other two routes of the same modules, end to end against the same oracle output: forward hooks on the 70 blocks (what the
+    # references harvest registers: the SpatialTransformers leave their fused route, the blocks keep their fused internals) and hooks on a
+    # submodule of every block (the strict route of a rebound forward).  Between themselves the routes differ by where bf16 rounds.
+    kwargs = dict(timesteps=t.to(DEV), context=ctx.to(DEV), y=y.to(DEV), pose=unpack_cameras(cams), input_ref=xr.to(DEV), sigmas_ref=tr.to(DEV), mask_ref=None)
+    route_errs = {}
+    for route, pick in (("hooked", lambda m: m), ("strict", lambda m: m.norm1)):
+        fired = []
+        hs = [pick(m).register_forward_hook(lambda mod, i, o: fired.append(1)) for m in net.modules() if isinstance(m, BasicTransformerBlock)]
+        out_r = net(x.to(DEV), **kwargs)
+        for h_ in hs:
+            h_.remove()
+        assert len(fired) >= 70
+        route_errs[route] = (rel(out_r[0], want), rel(out_r[0], got), max(rel(a, b_) for a, b_ in zip(out_r[1], wfg)))
+    print("full-SDXL cfg-A routes (eps vs oracle, eps vs fused route, worst fg vs oracle):", {k: tuple(round(v, 4) for v in vs) for k, vs in route_errs.items()})
+    assert all(vs[0] < 4e-2 and vs[2] < 6e-2 for vs in route_errs.values()), route_errs
     cl = lambda v: dev(v).contiguous(memory_format=torch.channels_last)
     margins = {}
     # ---- the 12 renders: each HIP pose block gets the oracle's own block inputs (rounded to bf16) ----
