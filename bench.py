@@ -64,174 +64,7 @@ def build_model(latent: int, n_ref: int, n_train: int, device, seed: int = 0):
     return net
 
 
-class Sampler:
-    """Minimal Euler (DDIM-equivalent, EpsScaling) step with the 3-way image/text CFG of guiders.py:102-133.
-    With `use_graph` the steady-state step (cached render) and the render step are each captured once into a hipGraph and
-    replayed: ~3000 launches per step are then issued by the GPU front end instead of the Python interpreter."""
-
-    def __init__(self, net, pose, ctx, y, n_steps, scale=7.5, scale_im=3.5, use_graph=False, prefetch=None):
-        from cd360 import sampler as S
-        self.net, self.pose, self.n_steps = net, pose, n_steps
-        if use_graph:  # the graphs read the cameras through ONE buffer this sampler owns (retarget rewrites it in place)
-            from sgm.modules.utils_cameraray import PoseBuffer
-            self.pose = PoseBuffer(pose, ctx.device)
-        self.scale, self.scale_im = scale, scale_im
-        dev = ctx.device
-        # the reference's own stack (cd360/sampler.py mirrors sampling.py / guiders.py / denoiser.py; parity: tests/test_sampler_cpu.py)
-        self.denoiser = S.DiscreteDenoiser().to(dev)
-        self.guider = S.ScheduledCFGImgTextRef(scale, scale_im)
-        self.sigmas = S.LegacyDDPMDiscretization()(n_steps, device=dev)  # n_steps + 1 values, last = 0
-        # conditioning is constant over a trajectory: the guider's (uc, uc, c) batch is assembled once per image, not per step
-        self.bs = bs = ctx.shape[0] // 3  # diffusion samples (target poses) per replay: ctx / y hold [uc x bs | . | c x bs]
-        c = {"crossattn": ctx[2 * bs:], "vector": y[2 * bs:]}
-        uc = {"crossattn": ctx[:bs], "vector": y[:bs]}
-        _, _, cond3 = self.guider.prepare_inputs(ctx.new_zeros(bs, 1), ctx.new_zeros(bs), c, uc)
-        self.ctx, self.y = cond3["crossattn"].contiguous(), cond3["vector"].contiguous()
-        self.prefetch = prefetch  # cd360.prefetch.WeightPrefetcher or None: armed around both captures
-        self.use_graph, self.graph = use_graph, None
-        self.graph_render, self.rgraph = use_graph and not os.environ.get("CD360_BENCH_EAGER_RENDER"), None
-
-    def retarget(self, pose, ctx, y):
-        """Point the sampler at another target pose / conditioning (the next pose of this rank's share).  The captured graphs read both
-        through fixed device buffers, so the new values are copied INTO them: the CFG conditioning batch, and the packed
-        [3, n+1, 16] camera tensor this sampler owns (sgm/modules/utils_cameraray.py::PoseBuffer)."""
-        bs = self.bs
-        c = {"crossattn": ctx[2 * bs:], "vector": y[2 * bs:]}
-        uc = {"crossattn": ctx[:bs], "vector": y[:bs]}
-        _, _, cond3 = self.guider.prepare_inputs(ctx.new_zeros(bs, 1), ctx.new_zeros(bs), c, uc)
-        self.ctx.copy_(cond3["crossattn"])
-        self.y.copy_(cond3["vector"])
-        if self.use_graph:
-            self.pose.rewrite(pose)
-        else:
-            self.pose = pose
-
-    def _math(self, x, s, s_next, t_unused=None):
-        """One sampler step = guider.prepare_inputs -> DiscreteDenoiser (sigma -> table index, c_in) -> UNet -> fused
-        [c_out, 3-way CFG, to_d, Euler] kernel."""
-        from cd360.sampler import cfg_euler_update
-        x3 = x.expand(3, -1, -1, -1) if x.shape[0] == 1 else torch.cat([x] * 3)
-        x_in, c_noise, _, _, _ = self.denoiser.network_inputs(x3, s.expand(x3.shape[0]), {})
-        eps = self.net(x_in, timesteps=c_noise, context=self.ctx, y=self.y, pose=self.pose)[0]
-        return cfg_euler_update(x, eps.contiguous(), s.reshape(1), s_next.reshape(1), self.scale, self.scale_im)
-
-    @torch.no_grad()
-    def eps(self, x, i):
-        """The UNet's output for step i of the schedule (the three CFG branches), launched eagerly: what --fp8-attn's tolerance report compares."""
-        x3 = x.expand(3, -1, -1, -1) if x.shape[0] == 1 else torch.cat([x] * 3)
-        x_in, c_noise, _, _, _ = self.denoiser.network_inputs(x3, self.sigmas[i].expand(x3.shape[0]), {})
-        return self.net(x_in, timesteps=c_noise, context=self.ctx, y=self.y, pose=self.pose)[0].float()
-
-    def _pin_rendered(self):
-        """Keep every block's cached render in a fixed buffer so a captured graph keeps reading the current image's render."""
-        from cd360 import sampling
-        for _, blk in sampling.pose_blocks(self.net):
-            blk.pin_rendered()  # render + its pose_emb_layers half (rendered_feat @ Wb^T) in buffers that stay put across images
-        for att in sampling._cross_attentions(self.net):  # same for the per-image context K / V^T cache
-            if att._kv_cache is None:
-                continue
-            key, (k, vt, nk) = att._kv_cache[:2]
-            st = getattr(att, "_static_kv", None)
-            if st is None or st[0].shape != k.shape:
-                att._static_kv = (k.clone(), vt.clone())
-            else:
-                st[0].copy_(k)
-                st[1].copy_(vt)
-            att._kv_cache = (key, (att._static_kv[0], att._static_kv[1], nk)) + tuple(att._kv_cache[2:])
-            from cd360 import routes
-            if routes.fp8_attn and 64 < nk <= 96:  # --fp8-attn: the e4m3 image of the pinned K / V, re-packed by every (captured) render step
-                sk = att._static_kv[0]
-                if getattr(att, "_static_kv8", None) is None or att._static_kv8[0].shape[0] != sk.shape[0]:
-                    att._static_kv8 = ops_kv8_buffers(sk, att.heads)
-                from cd360 import ops
-                ops.kv_pack_fp8(sk, att._static_kv[1], nk, att.heads, out=att._static_kv8)
-                att._kv8_cache = (sk, sk._version, att._static_kv8)
-
-    def _capture(self, fn):
-        """Warm `fn` on a side stream (allocator / library workspaces), then capture it into a hipGraph."""
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            fn()
-        torch.cuda.current_stream().wait_stream(side)
-        graph = torch.cuda.CUDAGraph()
-        # under torch.distributed the process group's watchdog thread may still poll the events of finished collectives (the launch
-        # barrier) while this thread captures: only the thread-local capture mode tolerates that (tools/probe/rccl_graph_probe.py)
-        import torch.distributed as dist
-        mode = "thread_local" if dist.is_available() and dist.is_initialized() else "global"
-        import contextlib
-        with torch.cuda.graph(graph, capture_error_mode=mode):
-            # every GEMM / convolution launch of the captured step also enqueues, on a forked side stream, a touch of its weights that runs
-            # beside the preceding launches (one step streams 5.3 GB of weights through a 256 MB Infinity Cache: cd360/prefetch.py)
-            with (self.prefetch if self.prefetch is not None else contextlib.nullcontext()):
-                out = fn()
-        return graph, out
-
-    def _render(self):
-        """Step 0 of an image: clear the cached render, run the full step (all 12 FeatureNeRF renders), re-pin the caches."""
-        from cd360 import sampling
-        sampling.clear_rendered_feat(self.net)
-        out = self._math(self.gx, self.gs[0], self.gs[1], self.gt)
-        self._pin_rendered()
-        return out
-
-    @torch.no_grad()
-    def prepare(self, x):
-        """Untimed set-up of the graph mode: one eager render (builds the per-image tables and the static cache buffers), then the
-        steady-state step and the render step are each captured once.  Both graphs read / write the same static buffers."""
-        if not self.use_graph or self.graph is not None:
-            return
-        s, s_next, t = self.sigmas[0], self.sigmas[1], self.sigmas[0:1]
-        self.gx, self.gs, self.gt = x.clone(), torch.stack([s, s_next]), t.clone()
-        self._render()
-        self.graph, self.gout = self._capture(lambda: self._math(self.gx, self.gs[0], self.gs[1], self.gt))
-        if self.graph_render:
-            try:
-                self.rgraph, self.rout = self._capture(self._render)
-                self._pins = self._snapshot_pins()
-            except Exception as e:  # a host synchronisation inside the render path would make it uncapturable: stay eager
-                print(f"[bench] render step not captured ({type(e).__name__}: {e}); launching it eagerly", file=sys.stderr)
-                self.rgraph = None
-                torch.cuda.synchronize()
-
-    def _snapshot_pins(self):
-        from cd360 import sampling
-        return ([(blk, blk.rendered_feat, blk._rendered_proj) for _, blk in sampling.pose_blocks(self.net)],
-                [(att, att._kv_cache) for att in sampling._cross_attentions(self.net)])
-
-    def _restore_pins(self):
-        for blk, r, proj in self._pins[0]:
-            blk.rendered_feat, blk._rendered_proj = r, proj
-        for att, kv in self._pins[1]:
-            att._kv_cache = kv
-
-    @torch.no_grad()
-    def step(self, x, i):
-        i = i % self.n_steps
-        s, s_next, t = self.sigmas[i], self.sigmas[i + 1], self.sigmas[i:i + 1]
-        if not self.use_graph:
-            if i == 0:
-                from cd360 import sampling
-                sampling.clear_rendered_feat(self.net)  # new image: the render runs again
-            return self._math(x, s, s_next, t)
-        self.prepare(x)
-        self.gx.copy_(x)
-        self.gs[0].copy_(s)
-        self.gs[1].copy_(s_next)
-        self.gt.copy_(t)
-        if i == 0:
-            if self.rgraph is not None:
-                self.rgraph.replay()
-                self._restore_pins()
-                return self.rout.clone()
-            return self._render().clone()
-        self.graph.replay()
-        return self.gout.clone()
-
-
-def ops_kv8_buffers(k, heads):
-    return (torch.empty(k.shape[0], heads, 96 * 64 + 64 * 128, dtype=torch.uint8, device=k.device),
-            torch.empty(k.shape[0], heads, 2, dtype=torch.float32, device=k.device))
+from cd360.job import Sampler, ops_kv8_buffers, sample_assigned  # noqa: E402,F401  (the sampling job lives in the package: cd360/job.py)
 
 
 def cpu_baseline(net, latent: int, threads: int):
@@ -272,6 +105,18 @@ def _baseline_metric() -> str:
         return "UNet denoise steps/sec @ SDXL 1024\u00b2, 50 ref views, 1/2/4/8 MI355X"
 
 
+def self_launch_argv(n: int, argv, port: int = 0):
+    """argv of the N-rank launch of this same command: `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr
+    127.0.0.1 --master-port P bench.py <the caller's arguments>` (the form the driver uses for N > 1).  port = 0 picks a free one."""
+    if not port:
+        import socket
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(argv[0])] + list(argv[1:])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -302,10 +147,14 @@ def main():
                     "fp8 MFMA (cd360_qproj_attn_fp8_bf16) for the whole run; adds an `fp8_tolerance` object (rendered features and eps against the bf16 run)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` on its own: become the launcher.  The same command line is re-run as N ranks (one per GPU) under
+        # torch.distributed.run on this node, rendezvous on 127.0.0.1 at a free port; rank 0 prints the one JSON line.
+        os.execv(sys.executable, self_launch_argv(args.gpus, sys.argv))
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     world = int(os.environ.get("WORLD_SIZE", 1))
-    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world} (launch N>1 through torch.distributed.run)"
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher started a different number of ranks"
     # CD360_BENCH_ONE_GPU=1: every rank on GPU 0 over gloo -- a SANITY run of the N > 1 control path (sharding, barriers, captures under a
     # process group, per-rank times, the final all-gather) on a 1-GPU box; RCCL refuses two ranks on one device.  Never a measurement.
     one_gpu = bool(os.environ.get("CD360_BENCH_ONE_GPU"))
@@ -349,7 +198,7 @@ def main():
     if not args.no_graph and not args.no_weight_prefetch:
         from cd360.prefetch import WeightPrefetcher
         pf = WeightPrefetcher(dev, lag=args.prefetch_lag, wgs=args.prefetch_wgs, min_bytes=int(args.prefetch_min_mb * (1 << 20)))
-    smp = Sampler(net, pose, ctx, y, args.traj, use_graph=not args.no_graph, prefetch=pf)
+    smp = Sampler(net, pose, ctx, y, args.traj, use_graph=not args.no_graph, prefetch=pf, graph_render=not os.environ.get("CD360_BENCH_EAGER_RENDER"))
 
     def sync():
         torch.cuda.synchronize()
@@ -368,16 +217,9 @@ def main():
 
     # timed region: K steps of EVERY pose of this rank, one pose after the other (the graphs read the pose / conditioning of the job
     # through the sampler's static buffers: switching pose = pointing the sampler at the next job and re-rendering on its step 0)
-    finals = []
     sync()
     t0 = time.perf_counter()
-    for j, (pose_j, ctx_j, y_j, x_j) in enumerate(jobs):
-        if j > 0:
-            smp.retarget(pose_j, ctx_j, y_j)
-        xs = x_j.clone()
-        for i in range(args.steps):
-            xs = smp.step(xs, i)
-        finals.append(xs)
+    finals = sample_assigned(smp, jobs, args.steps)  # cd360/job.py: retarget -> K steps, pose after pose
     sync()
     elapsed = time.perf_counter() - t0
     steps_done = args.steps * len(jobs)  # replays of this rank; each advances `ppr` poses by one denoise step

@@ -94,7 +94,10 @@ def combine_losses(loss, loss_fg, loss_bg, loss_rgb, drop_im, *, rgb: bool = Tru
     render losses only count those samples.  Defaults are configs/train_co3d_concept.yaml:9-11.
     as_tensors=True: the logged terms stay 0-d device tensors and the `loss_rgb.mean() > 0` test of the reference becomes a device-side
     select (torch.where: a zero or NaN rgb term contributes nothing to the total, as skipping it does) -- no host synchronisation between
-    the forward and the backward pass, and the step can be captured into a hipGraph."""
+    the forward and the backward pass, and the step can be captured into a hipGraph.  The skipped term's GRADIENT is an exact zero on the
+    product route too: `cd360_render_loss_bwd_f32` writes 0 (not 0 * NaN) where the upstream gradient of the rgb term is 0
+    (tests/test_backward_gpu.py::test_render_loss_skipped_rgb_term_has_zero_gradient).  The op-by-op torch route kept for A/B
+    (`routes.no_train_fusions`) has torch's semantics there: 0 * NaN = NaN."""
     total = loss.mean()
     out = {"loss": total.detach()}
     den = drop_im.sum() + 1e-12
@@ -365,6 +368,8 @@ class GraphedTrainStep:
                     optimizer._master.copy_(saved[1]); optimizer.exp_avg.copy_(saved[2]); optimizer.exp_avg_sq.copy_(saved[3]); optimizer.steps.copy_(saved[4])
         torch.cuda.current_stream().wait_stream(side)
         self.graph = torch.cuda.CUDAGraph()
+        from . import memo
+        memo.new_epoch()  # nothing memoised before this point -- by the warm-up steps or by an earlier capture -- may feed this graph
         # with a process group the gradient all-reduce (one flat RCCL all-reduce, MasterAdamW.allreduce_grads) is captured with the step; the
         # group's watchdog thread polls events meanwhile, which only the thread-local capture mode tolerates.  Every rank captures the same
         # sequence and must replay in lock-step, as with any collective.
@@ -377,6 +382,7 @@ class GraphedTrainStep:
         with torch.cuda.graph(self.graph, capture_error_mode=mode):
             with pf:
                 self.total, self.logged = train_step(unet, loss_fn, optimizer, as_tensors=True, **self.static, **loss_kw)
+        memo.new_epoch()
 
     @staticmethod
     def _load(dst, src):

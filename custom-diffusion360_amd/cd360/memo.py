@@ -22,6 +22,13 @@ def _now():
     return cap, _state["epoch"]
 
 
+def new_epoch() -> None:
+    """Advance the capture epoch explicitly.  The polled flip in `_now` is only seen when some `Memo.get` happens to run between two
+    captures; a capture helper calls this right before it begins capturing and right after it ends, so that two captures with no eager
+    lookup between them (two GraphedTrainStep(warmup=0) in a row) can never share an epoch."""
+    _state["epoch"] += 1
+
+
 class Memo:
     """The last `keep` (source tensor, version) -> value entries.  `get(src, make)` returns the memoised value or makes it."""
 

@@ -142,7 +142,7 @@ class FusedNerfWeights:
         C = W2.shape[0]
         self.C = C
         dev = W1.device
-        if live and W1.is_cuda and dtype == torch.bfloat16 and not routes.library_linear:
+        if live and W1.is_cuda and dtype == torch.bfloat16 and C % 64 == 0 and not routes.library_linear:  # the predicate of `fused` below
             # what the fused render reads, as one autograd node (the torch-GEMM route below keeps its transposed / fp32 forms)
             (self.Wf, self.Wk, self.Wp, self.b1, self.W2, self.b2_f32, self.vf, self.v_cam, self.bv,
              self.Wd) = _LiveNerfWeights.apply(W1, b1, W2, b2, wv, bv, Wd)
@@ -251,7 +251,25 @@ def _plucker_rows(cams: torch.Tensor, xs: torch.Tensor, ys: torch.Tensor) -> tor
     forward when the grid is the cached eval-mode one (a stratified training step draws a grid per block: always recomputed)."""
     if torch.is_grad_enabled() or xs.requires_grad or ys.requires_grad:
         return ops.plucker_features_bf16(cams, xs, ys)
-    return _PLUCKER.get(cams, lambda: ops.plucker_features_bf16(cams, xs, ys), extra=(id(xs), xs._version, id(ys), ys._version))
+    # The entry HOLDS xs / ys and is matched by identity: a jittered grid drawn per block (stratified mode under no_grad) is freed when its
+    # block returns, and the next block's fresh grid may be handed the same id() -- an id-keyed entry would then serve the previous
+    # block's features for another jitter.
+    key = _GridKey(xs, ys)
+    return _PLUCKER.get(cams, lambda: ops.plucker_features_bf16(cams, xs, ys), extra=key)
+
+
+class _GridKey:
+    """(xs, ys) of a patch grid as a memo key: equal only to a key made of the SAME tensor objects at the same versions; the key keeps
+    both tensors alive, so their ids cannot be recycled while the entry exists."""
+    __slots__ = ("xs", "ys", "vx", "vy")
+
+    def __init__(self, xs, ys):
+        self.xs, self.ys, self.vx, self.vy = xs, ys, xs._version, ys._version
+
+    def __eq__(self, other):
+        return isinstance(other, _GridKey) and other.xs is self.xs and other.ys is self.ys and other.vx == self.vx and other.vy == self.vy
+
+    __hash__ = None
 
 
 def fused_feature_nerf(fw: FusedNerfWeights, cams: torch.Tensor, xref: Optional[torch.Tensor], num_samples: int, far: float,

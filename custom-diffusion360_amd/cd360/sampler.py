@@ -233,3 +233,21 @@ def cfg_euler_update(x: torch.Tensor, eps: torch.Tensor, sigma: torch.Tensor, si
     den = [x - sigma * e for e in (e_u, e_ic, e_c)]
     d0 = den[0] + scale * (den[2] - den[1]) + scale_im * (den[1] - den[0])
     return x + (x - d0) / sigma * (sigma_next - sigma)
+
+
+def fused_cfg3_euler_step(denoiser: "DiscreteDenoiser", network: Callable, x: torch.Tensor, sigma: torch.Tensor, sigma_next: torch.Tensor,
+                          scale: float, scale_im: float, fused: bool = True) -> torch.Tensor:
+    """ONE step of EulerEDMSampler.sampler_step (sampling.py:85-136) under ScheduledCFGImgTextRef (guiders.py:102-133) and
+    DiscreteDenoiser + EpsScaling (denoiser.py:47-79), in the form the product's sampling job launches it (cd360/job.py):
+
+        x3 = [x | x | x]                                   guider.prepare_inputs (the conditioning batch is assembled once per image)
+        x_in, c_noise = c_in(sigma_q) x3, idx(sigma_q)     DiscreteDenoiser.network_inputs, sigma snapped to the table ON the device
+        eps = network(x_in, c_noise)                       the UNet over the CFG batch
+        x' = cfg_euler_update(x, eps, sigma, sigma_next)   c_out scaling + 3-way combine + to_d + Euler: cd360_cfg_euler_step_f32
+
+    `network(x_in, c_noise) -> eps [3 n, ...]`; sigma / sigma_next 0-d device tensors of the sampler's schedule (table entries, so the
+    snapped sigma_q of c_out equals the sigma of to_d, as in the reference's own run).  No host synchronisation anywhere in the step."""
+    x3 = x.expand(3, *x.shape[1:]) if x.shape[0] == 1 else torch.cat([x] * 3)
+    x_in, c_noise, _, _, _ = denoiser.network_inputs(x3, sigma.expand(x3.shape[0]), {})
+    eps = network(x_in, c_noise)
+    return cfg_euler_update(x, eps.contiguous(), sigma.reshape(1), sigma_next.reshape(1), scale, scale_im, fused=fused)

@@ -511,7 +511,10 @@ __global__ __launch_bounds__(256) void render_loss_bwd_kernel(const float* __res
       const long k = j / 3;
       const int c = (int)(j - k * 3);
       const float d = want[((long)b * 3 + c) * hw + k] - rgb[(long)b * hw * 3 + j];
-      d_rgb[(long)b * hw * 3 + j] = g[b * 3 + 2] * (-2.f) * d * mask[(long)b * hw + k] / den[b];
+      // a zero upstream gradient means the term was dropped from the total (combine_losses' device-side `loss_rgb.mean() > 0` select, the
+      // reference's host-side `if`, diffusion.py:236-240): write an exact zero, not 0 * d -- d is NaN where the prediction is
+      const float gg = g[b * 3 + 2];
+      d_rgb[(long)b * hw * 3 + j] = gg == 0.f ? 0.f : gg * (-2.f) * d * mask[(long)b * hw + k] / den[b];
     }
   }
 }

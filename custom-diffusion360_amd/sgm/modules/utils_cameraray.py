@@ -30,8 +30,13 @@ class PoseBuffer(list):
 
 def packed_pose(pose, device) -> torch.Tensor:
     """Pack (and memoise on the list object's elements) the cameras of one forward call."""
-    if isinstance(pose, PoseBuffer) and pose.packed.device == torch.device(device):
-        return pose.packed
+    if isinstance(pose, PoseBuffer):
+        # the buffer IS the pose (rewrite() changes it in place): never fall through to the memo over the original camera objects.
+        # torch.device("cuda") != torch.device("cuda:0"), so compare type and resolved index
+        want = torch.device(device)
+        have = pose.packed.device
+        same = want.type == have.type and (want.index is None or want.index == have.index)
+        return pose.packed if same else pose.packed.to(want)
     if isinstance(pose, torch.Tensor):
         return pack_cameras(pose, device)
     # keyed on the camera objects AND on the storage / version of their fields: an in-place edit (cam.T = ..., the crop / scale adjusters

@@ -138,6 +138,28 @@ def case_block(train: bool):
         keyfile("block", blk)
 
 
+from make_golden_params import sdxl_block_inputs  # noqa: E402  (shared with the tests: inputs regenerated on both sides)
+
+
+def case_block_sdxl():
+    """"plus one SDXL-dim block slice".  The pose block at the two widths of the shipped config
+    (configs/train_co3d_concept.yaml:27-54: C = 640 with 10 heads, C = 1280 with 20 heads, head dim 64, text context 2048 wide, 77
+    tokens) on a small ray grid (r = 8, n = 2 reference views, S = 4 samples), eval mode: the reference's own BasicTransformerBlock
+    (attention.py:428-637) end to end -- FeatureNeRF render, pose-token cross-attention over the text context, volume render, injection,
+    GEGLU feed-forward -- plus the same block called without a pose."""
+    out = {}
+    for C, heads in ((640, 10), (1280, 20)):
+        blk = make_block(C, heads, 2048, 4)
+        W.load_into(blk, seed=6)
+        blk.eval()
+        x, ctx, cref, pose = sdxl_block_inputs(C)
+        o, fg, wts, alphas, rgb = blk(x, context=ctx, context_ref=cref, pose=pose)
+        assert wts is None
+        out.update({f"c{C}_cams": pack_cameras(pose), f"c{C}_out": o, f"c{C}_fg": fg, f"c{C}_alphas": alphas, f"c{C}_rgb": rgb,
+                    f"c{C}_plain": blk(x, context=ctx)[0]})
+    npz("block_sdxl", **out)
+
+
 # ---------------------------------------------------------------- 2b. mask_ref (nerfsd_pytorch3d.py:61-70; live in config 4: data_co3d.py:485, loss.py:154)
 def case_mask_ref():
     """The reference-view masks: NerfSDModule, the pose block (eval, and train mode with the jitter draws recorded plus the reference's
@@ -490,6 +512,7 @@ if __name__ == "__main__":
     case_nerf(True)
     case_block(False)
     case_block(True)
+    case_block_sdxl()
     case_mask_ref()
     case_st_dual()
     case_customforward()

@@ -51,3 +51,16 @@ class LossDenoiser:
 
     def w(self, sigma):
         return sigma ** -2.0
+
+
+# ---- SDXL-width pose block (tests/golden/block_sdxl.npz) ----
+SDXL_BLOCK_WIDTHS = ((640, 10), (1280, 20))  # (channels, heads) of the two pose-block levels of the shipped config
+
+
+def sdxl_block_inputs(C):
+    """Inputs of make_golden.py::case_block_sdxl, regenerated on both sides from names and seeds (the fixture stores the packed cameras
+    and the reference's outputs only): x [1, 64, C], text context [1, 77, 2048], reference features [2, 64, C], pose (target + 2 views)."""
+    from cd360 import synth
+    r, n, b, T, cd = 8, 2, 1, 77, 2048
+    return (W.tensor(f"sdxl{C}.x", (b, r * r, C), seed=6), W.tensor(f"sdxl{C}.ctx", (b, T, cd), seed=6),
+            W.tensor(f"sdxl{C}.cref", (b * n, r * r, C), seed=6), synth.pose_batch(b, n, seed=14 + C // 640))

@@ -588,6 +588,33 @@ def test_render_loss_kernels_match_the_torch_expression():
             assert torch.allclose(m, t.grad, rtol=2e-5, atol=1e-9), (m - t.grad).abs().max()
 
 
+def test_render_loss_skipped_rgb_term_has_zero_gradient():
+    """diffusion.py:236-240 adds the rgb term only `if loss_rgb.mean() > 0`; with a NaN prediction the comparison is False and the reference
+    skips the term, graph included.  combine_losses(as_tensors=True) makes that a device-side select, whose upstream gradient into the term
+    is an exact 0: the backward kernel must then write 0, not 0 * NaN, so the NaN never reaches the parameters."""
+    from cd360 import finetune, ops
+    g = torch.Generator().manual_seed(3)
+    b, r, S = 2, 8, 4
+    hw = r * r
+    fg = torch.rand(b, hw, 1, generator=g).to(DEV).requires_grad_(True)
+    al = torch.rand(b, hw, S, 1, generator=g).to(DEV).requires_grad_(True)
+    rgb0 = torch.rand(b, hw, 3, generator=g)
+    rgb0[1, 5, 2] = float("nan")
+    rgb = rgb0.to(DEV).requires_grad_(True)
+    op = torch.rand(b, hw, generator=g).to(DEV)
+    bgw = ((1 - op) * ((op < 0.1) * 1)).contiguous()
+    mask_, want = torch.rand(b, 1, r, r, generator=g).to(DEV), torch.rand(b, 3, r, r, generator=g).to(DEV)
+    den = (torch.rand(b, generator=g) * 10 + 1).to(DEV)
+    terms = ops.render_loss(fg, al, rgb, op, bgw, mask_, want, den)  # [b, 3]
+    assert torch.isnan(terms[1, 2]) and torch.isfinite(terms[:, :2]).all()
+    total, logged = finetune.combine_losses(torch.ones(b, device=DEV), terms[:, 0:1], terms[:, 1:2], terms[:, 2:3], torch.ones(b, device=DEV),
+                                            as_tensors=True)
+    assert torch.isfinite(total) and float(logged["loss_rgb"]) == 0.0
+    total.backward()
+    assert torch.isfinite(fg.grad).all() and torch.isfinite(al.grad).all() and float(fg.grad.abs().max()) > 0
+    assert torch.equal(rgb.grad, torch.zeros_like(rgb.grad))  # the skipped term: exact zeros, the NaN position included
+
+
 def test_live_nerf_weights_one_kernel_each_way_equals_the_recorded_ops():
     """nerf._LiveNerfWeights on bf16 parameters (cd360_nerf_pack_weights_bf16 / cd360_nerf_unpack_grads_bf16) against the same node on the
     op-by-op torch path (routes.no_train_fusions): every derived operand bit-equal, every parameter gradient bit-equal for random

@@ -63,3 +63,22 @@ def test_bench_defaults_finish_quickly():
     steps = re.search(r'add_argument\("--steps", type=int, default=(\d+)', src)
     warm = re.search(r'add_argument\("--warmup", type=int, default=(\d+)', src)
     assert gpus and int(gpus.group(1)) == 1 and steps and int(steps.group(1)) <= 100 and warm and int(warm.group(1)) <= 10
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 8` with no WORLD_SIZE in the environment must not die on an assert: it re-executes itself as 8 ranks under
+    torch.distributed.run (127.0.0.1 rendezvous), the form the driver uses for N > 1; under a launcher (WORLD_SIZE set) it runs as a rank."""
+    import sys
+    sys.path.insert(0, ROOT)
+    import bench
+    argv = bench.self_launch_argv(8, ["bench.py", "--gpus", "8", "--steps", "20", "--warmup", "5"], port=29517)
+    assert argv[0] == sys.executable and argv[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in argv and "--nproc-per-node=8" in argv
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1" and argv[argv.index("--master-port") + 1] == "29517"
+    script = [a for a in argv if a.endswith("bench.py")]
+    assert len(script) == 1 and os.path.isabs(script[0])
+    assert argv[argv.index(script[0]) + 1:] == ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    port = int(bench.self_launch_argv(2, ["bench.py"])[bench.self_launch_argv(2, ["bench.py"]).index("--master-port") + 1])
+    assert 1024 < port < 65536
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert 'args.gpus > 1 and "WORLD_SIZE" not in os.environ' in src and "os.execv(sys.executable, self_launch_argv(" in src

@@ -84,6 +84,31 @@ def test_block_matches_reference(mode):
         assert not torch.allclose(g["out"], g["plain"], atol=1e-2), "pose path must not be a no-op (SURVEY.md F7)"
 
 
+@pytest.mark.parametrize("C,heads", [(640, 10), (1280, 20)])
+def test_block_at_sdxl_width_matches_reference(C, heads):
+    """SURVEY.md section 8(c) "plus one SDXL-dim block slice": the oracle against the REFERENCE's own pose block at the shipped config's
+    widths (heads 10 / 20 of 64, text context 2048 x 77; r = 8, n = 2, S = 4) -- tests/golden/block_sdxl.npz, written by the imported
+    reference (make_golden.py::case_block_sdxl).  Inputs and weights are regenerated from names and seeds on both sides."""
+    from make_golden_params import sdxl_block_inputs
+    from sgm.modules.attention import BasicTransformerBlock
+    g = load("block_sdxl")
+    with torch.device("meta"):
+        shapes = {k: v.shape for k, v in BasicTransformerBlock(C, heads, 64, context_dim=2048, checkpoint=False, attn_mode="softmax-xformers",
+                                                                image_cross=True, far=2, num_samples=4, rgb_predict=True, mode="feature-nerf",
+                                                                stratified=True).state_dict().items()}
+    sd = W.synth_state_dict(shapes, seed=6)
+    x, ctx, cref, pose = sdxl_block_inputs(C)
+    from cd360.cameras import pack_cameras
+    assert torch.equal(pack_cameras(pose), g[f"c{C}_cams"])
+    out, fg, alphas, rgb, _ = O.transformer_block(sd, x, ctx, heads, context_ref=cref, cams=g[f"c{C}_cams"], num_samples=4, far=2.0)
+    close(out, g[f"c{C}_out"], atol=2e-4)
+    close(fg, g[f"c{C}_fg"])
+    close(alphas, g[f"c{C}_alphas"])
+    close(rgb, g[f"c{C}_rgb"])
+    close(O.transformer_block(sd, x, ctx, heads)[0], g[f"c{C}_plain"], atol=2e-4)
+    assert not torch.allclose(g[f"c{C}_out"], g[f"c{C}_plain"], atol=1e-2)
+
+
 def test_spatial_transformer_dual_stream_matches_reference():
     g = load("st_dual")
     sd = W.synth_state_dict(keys("st"), seed=3)

@@ -76,3 +76,29 @@ def test_fused_tail_formula_equals_the_unfused_chain():
     d0 = ScheduledCFGImgTextRef(7.5, 3.5)(den, None)
     want = x + (x - d0) / s * (sn - s)
     assert torch.allclose(cfg_euler_update(x, eps, s, sn, 7.5, 3.5, fused=False), want, atol=1e-6)
+
+
+def run_product_steps(g, dev, fused):
+    """The 12-step cfg3 trajectory of sampler.npz through the product's step function (cd360.sampler.fused_cfg3_euler_step: what
+    cd360/job.py's Sampler launches per denoise step), around the golden's dummy network."""
+    from cd360 import sampler as S
+    den = S.DiscreteDenoiser().to(dev)
+    guider = S.ScheduledCFGImgTextRef(7.5, 3.5)
+    c = {"crossattn": g["c_crossattn"].to(dev), "vector": g["c_vector"].to(dev)}
+    uc = {"crossattn": g["uc_crossattn"].to(dev), "vector": g["uc_vector"].to(dev)}
+    x = g["x"].to(dev)
+    _, _, cond3 = guider.prepare_inputs(x, x.new_ones(x.shape[0]), c, uc)  # once per image: constant over the trajectory
+    sigmas = S.LegacyDDPMDiscretization()(12, device=dev)
+    x = x * torch.sqrt(1.0 + sigmas[0] ** 2.0)  # EulerEDMSampler.prepare_sampling_loop (sampling.py:52-66)
+    network = lambda x_in, c_noise: dummy_network(x_in, c_noise, cond3)[0]  # noqa: E731
+    for i in range(12):
+        x = S.fused_cfg3_euler_step(den, network, x, sigmas[i], sigmas[i + 1], 7.5, 3.5, fused=fused)
+    return x
+
+
+def test_product_step_function_walks_the_reference_trajectory():
+    """f2 on CPU: the un-fused form of the product's step (same function, fused=False) reproduces the reference's 12-step trajectory;
+    tests/test_f_rows_gpu.py runs the SAME function with the HIP kernel on the GPU against the same golden."""
+    g = load()
+    res = run_product_steps(g, "cpu", fused=False)
+    assert torch.allclose(res, g["cfg3"], atol=2e-5, rtol=1e-5), (res - g["cfg3"]).abs().max()

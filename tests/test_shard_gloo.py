@@ -151,3 +151,64 @@ def test_data_parallel_gradient_allreduce(world):
         assert p.exitcode == 0
     assert all(avg_ok and same for _, avg_ok, same, _ in res)
     assert all(abs(v - (1.0 - 1e-2)) < 1e-6 for _, _, _, v in res)  # first AdamW step = -lr * sign(grad)
+
+
+class _CpuSampler:
+    """Stand-in with the Sampler protocol of cd360/job.py (retarget / step) on CPU tensors: a deterministic 'denoise step' that depends on
+    the pose, the conditioning and the step index, so that a pose sampled on the wrong rank, with stale conditioning, or for the wrong number
+    of steps gives a different latent."""
+
+    def __init__(self, pose, ctx, y):
+        self.retarget(pose, ctx, y)
+
+    def retarget(self, pose, ctx, y):
+        self.k = float(pose) + float(ctx.sum()) * 1e-3 + float(y.sum()) * 1e-4
+
+    def step(self, x, i):
+        return x * 0.5 + self.k + 0.01 * i
+
+
+def _job_of(p):
+    g = torch.Generator().manual_seed(50 + p)
+    return (p, torch.randn(3, 7, generator=g), torch.randn(3, 5, generator=g), torch.randn(1, 4, 8, 8, generator=g))
+
+
+def _job_worker(rank, world, port, num_poses, steps, q):
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.join(root, "custom-diffusion360_amd"))
+    from cd360 import job
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    latents, mine = job.sample_poses(_CpuSampler, _job_of, num_poses, steps, world, rank)
+    q.put((rank, mine, latents))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,num_poses", [(2, 8), (3, 8)])
+def test_sample_poses_job_matches_one_fresh_sampler_per_pose(world, num_poses):
+    """BASELINE configs[2] on CPU: cd360.job.sample_poses (assign_poses -> ONE sampler per rank, retargeted pose after pose -> one
+    all-gather) over gloo.  Every rank ends with the latents of ALL poses in pose order, each bit-identical to a fresh single-pose
+    sampler's (the same loop `bench.py` times and tests/test_job_gpu.py runs on the GPU with the captured Sampler)."""
+    sys_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "custom-diffusion360_amd")
+    import sys
+    sys.path.insert(0, sys_path)
+    from cd360 import job
+    steps = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_job_worker, args=(r, world, port, num_poses, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=120) for _ in range(world)), key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    want = torch.cat([job.sample_assigned(_CpuSampler(*_job_of(p)[:3]), [_job_of(p)], steps)[0] for p in range(num_poses)])
+    assert sum((m for _, m, _ in res), []) == list(range(num_poses))
+    for _, _, latents in res:
+        assert latents.shape == (num_poses, 4, 8, 8) and torch.equal(latents, want)
+    with pytest.raises(ValueError):
+        job.sample_poses(_CpuSampler, _job_of, 1, steps, world=2, rank=1)
