@@ -87,12 +87,12 @@ SIGNATURES = {
 
 TUNING_FIELDS = ("gemm_cfg", "gemm_group_m", "gemm_movers", "gemm_ksplit", "conv_cfg", "conv_dma", "conv_kgroup", "conv_wide", "conv_wmajor",
                  "conv_split", "attn_smallk", "attn_smallk_wgs", "attn_self", "attn_fast", "nerf_kernel", "qattn_cfg", "whatif", "gemm_small", "qattn_keys16",
-                 "qattn_split")
+                 "qattn_split", "store_wt")
 
 
 class Tuning(ctypes.Structure):
     """struct cd360_tuning of include/cd360_hip.h: -1 = choose by shape (the default of every field)."""
-    _fields_ = [("size", ctypes.c_int32)] + [(f, ctypes.c_int32) for f in TUNING_FIELDS] + [("reserved", ctypes.c_int32 * 3)]
+    _fields_ = [("size", ctypes.c_int32)] + [(f, ctypes.c_int32) for f in TUNING_FIELDS] + [("reserved", ctypes.c_int32 * 2)]
 
 
 # environment variable -> tuning field: read ONCE, when the library is loaded (the C side never reads the environment)
@@ -102,6 +102,7 @@ TUNING_ENV = {
     "CD360_CONV_WMAJOR": "conv_wmajor", "CD360_CONV_SPLIT": "conv_split", "CD360_ATTN_SMALLK": "attn_smallk", "CD360_SMALLK_WGS": "attn_smallk_wgs",
     "CD360_ATTN_SELF": "attn_self", "CD360_ATTN_FAST": "attn_fast", "CD360_NERF_KERNEL": "nerf_kernel", "CD360_QATTN_CFG": "qattn_cfg",
     "CD360_GEMM_ABL": "whatif", "CD360_GEMM_SMALL": "gemm_small", "CD360_QATTN_KEYS16": "qattn_keys16", "CD360_QATTN_SPLIT": "qattn_split",
+    "CD360_STORE_WT": "store_wt",
 }
 
 _lib = None

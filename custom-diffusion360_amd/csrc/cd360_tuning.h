@@ -28,7 +28,8 @@ typedef struct cd360_tuning {
   int32_t gemm_small;       // 0: pick_cfg without its small-batch rules (64 x 128 tiles; 128-wide tiles for wide outputs of <= 512 tiles)
   int32_t qattn_keys16;     // 0: cd360_qproj_attn_bf16 pads 65 .. 80 keys to three full 32-key blocks (96) instead of five groups of 16
   int32_t qattn_split;      // 1: second launch for the last 128 columns of a width that is 128 short of a multiple of 256 (A/B: slower)
-  int32_t reserved[3];
+  int32_t store_wt;         // 0 | 1: output tiles of the GEMM family leave by plain stores / by write-through (sc1) stores (gemm8p.hip: store_tile)
+  int32_t reserved[2];
 } cd360_tuning;
 
 int cd360_set_tuning(const cd360_tuning* t);

@@ -62,6 +62,7 @@ struct GemmParams {
   int a_heads;
   int a_dup_from, a_dup;  // query batch elements >= a_dup_from attend to TWO key / value sets (batch i and i + a_dup; output rows of
                           // batch i and i + a_dup): the de-duplicated CFG branch, whose q is projected once
+  int wt;   // 1: the output tile leaves by write-through (sc1) buffer stores (set by the launcher: cd360_tuning.store_wt, outputs below 2 GiB)
   int abl;  // what-if timing knob (cd360_tuning.whatif, -DCD360_WHATIF probe builds only; results are wrong when set): 8 no DMA wait,
             // 16 no barrier, 32 no LDS wait, 4 no DMA, 64 no stores, 512 no fragment reads / MFMAs / epilogue (a pure L2 -> LDS streamer)
   // EPI 5: A is the implicit im2col matrix of a 3x3 / stride 1 / pad 1 convolution over a channels-last [images, H, W, Cin] tensor
@@ -927,7 +928,9 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
           const int row = 8 * i + lrow;
           const long m = m0 + wr * (NMB * 32) + mb * 32 + row;
           const u32x4 v = *reinterpret_cast<const u32x4*>(Os + row * 128 + ((lchunk ^ ((row >> 1) & 7)) << 4));
-          *reinterpret_cast<u32x4*>(p.out + (m + orow) * p.ldo + ocol) = v;
+          if (p.wt) __builtin_amdgcn_raw_buffer_store_b128(v, __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, 0x7fffffff, 0x00020000),
+                                                           (int)(((m + orow) * p.ldo + ocol) * 2), 0, 16);
+          else *reinterpret_cast<u32x4*>(p.out + (m + orow) * p.ldo + ocol) = v;
         }
       }
       }  // rep
@@ -1000,6 +1003,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
     // convolution epilogue accumulate in registers); chunk counts that do not divide 64 leave the last lanes idle
     constexpr int RPI = 64 / NCH;
     const int j = lane % NCH, rl = lane / NCH;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.out, 0, 0x7fffffff, 0x00020000);
     float cs[CSTATS ? 8 : 1], cq[CSTATS ? 8 : 1];
     if constexpr (CSTATS) {
 #pragma unroll
@@ -1020,7 +1024,8 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
             orow_ = (n_ * (2 * p.cv_H) + 2 * i_ + up_a) * (2L * p.cv_W) + 2 * j_ + up_b;
           }
         }
-        *reinterpret_cast<u32x4*>(p.out + orow_ * p.ldo + ocol0 + j * 8) = o;
+        if (p.wt) __builtin_amdgcn_raw_buffer_store_b128(o, orsrc, (int)((orow_ * p.ldo + ocol0 + j * 8) * 2), 0, 16);  // aux 16 = sc1
+        else *reinterpret_cast<u32x4*>(p.out + orow_ * p.ldo + ocol0 + j * 8) = o;
         if constexpr (CSTATS) {
           if (p.cstats) {
 #pragma unroll
@@ -1122,6 +1127,14 @@ int launch_mv(const GemmParams& p0, hipStream_t stream) {
   p.tiles_n = (p.N + BN - 1) / BN;
   const cd360_tuning& tune = cd360_tune();
   p.group_m = tune.gemm_group_m > 0 ? tune.gemm_group_m : 6;  // token tiles per group (swept 1 .. 48 on the block's shapes: 6 best or tied)
+  // Write-through output stores.  The eight XCDs' L2s are not coherent with each other, so a kernel boundary has to write back every line
+  // the kernel left dirty before its consumer may start (MI355X_MICROARCH.md, price row "boundary": + B / 6 TB/s behind B dirty bytes --
+  // 1.3 us behind the 7.9 MB of a C -> C projection, 5 us behind FF1's 31 MB).  Stores with agent scope (sc1) go through to memory as
+  // they are issued, under the other workgroups' K loops and epilogues, and the boundary finds nothing to write back.
+  {
+    const long out_rows = ((EPI == 5 && p.cv_up) ? 4L : ATTN ? 2L : 1L) * p.M;  // (the de-duplicated attention writes rows of batch i + a_dup too)
+    p.wt = (tune.store_wt != 0 && (out_rows - 1) * p.ldo * 2 + (long)p.N * 2 < 0x7fffffffL) ? 1 : 0;
+  }
   p.abl = 0;
 #ifdef CD360_WHATIF
   if (tune.whatif > 0) p.abl = tune.whatif;

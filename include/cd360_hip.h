@@ -56,7 +56,8 @@ typedef struct cd360_tuning {
   int32_t gemm_small;       /* 0: no small-batch tilings (64 x 128 tiles, 128-wide tiles for wide outputs): the A/B partner */
   int32_t qattn_keys16;     /* 0: 65 .. 80 keys padded to 96 in cd360_qproj_attn_bf16 (default: five groups of 16) */
   int32_t qattn_split;      /* 1: second launch for the last 128 columns of a 256 k + 128 wide projection (A/B only: measured slower) */
-  int32_t reserved[3];
+  int32_t store_wt;         /* 0 | 1: GEMM-family output tiles by plain / write-through (sc1) stores; -1 = the measured default */
+  int32_t reserved[2];
 } cd360_tuning;
 int cd360_set_tuning(const cd360_tuning* t);
 int cd360_get_tuning(cd360_tuning* t);

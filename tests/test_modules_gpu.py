@@ -30,6 +30,17 @@ def rel(got, want):
     return (got - want).abs().max().item() / max(want.abs().max().item(), 1e-12)
 
 
+def elem(got, want, rtol=1e-2, floor=1e-3):
+    """Element-wise form of the parity bar: max over elements of |got - want| / (rtol |want| + floor max|want|); <= 1 means EVERY element is
+    within `rtol` of its own reference value, with an absolute floor of `floor` of the tensor's maximum for the entries near zero.  `rel`
+    above (max-norm) is how this repository reads north_star's "within 1e-2 relative" (DESIGN.md section 2); for tensors that hold many
+    entries near 0 beside a few near 1 (alphas, fg) the max-norm alone would hide per-element errors of any size below 1 % of the
+    maximum, so the render outputs are held to this form as well."""
+    got, want = got.detach().float().cpu(), want.detach().float().cpu()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    return ((got - want).abs() / (rtol * want.abs() + floor * want.abs().max().clamp_min(1e-12))).max().item()
+
+
 def dev(x):
     return x.to(DEV, BF)
 
@@ -67,8 +78,8 @@ def test_pose_block_at_sdxl_width_matches_reference_golden(C, heads):
     """The HIP pose block at the shipped config's widths (10 / 20 heads of 64, text context 2048 x 77) against the REFERENCE's own block
     on the same inputs (tests/golden/block_sdxl.npz from make_golden.py::case_block_sdxl; the oracle is pinned on the same fixture in
     tests/test_oracle_cpu.py).  The reference computes in fp32 on fp32 weights; the module holds bf16 weights and rounds its
-    activations to bf16 between kernels: render outputs at the 1e-2 bar of the north star, the whole block (three attention + one
-    GEGLU round trips through bf16) at the module-level bar of this file."""
+    activations to bf16 between kernels: every output -- the render's fg / alphas / rgb and the whole block with and without the pose
+    path -- inside the 1e-2 bar of the north star."""
     from make_golden_params import sdxl_block_inputs
     from sgm.modules.attention import BasicTransformerBlock
     g = load("block_sdxl")
@@ -82,8 +93,7 @@ def test_pose_block_at_sdxl_width_matches_reference_golden(C, heads):
             "plain": rel(blk(dev(x), context=dev(ctx))[0], g[f"c{C}_plain"])}
     print(f"SDXL-width pose block C = {C} vs the reference's golden:", {k: round(v, 5) for k, v in errs.items()})
     assert wts is None
-    assert max(errs["fg"], errs["alphas"], errs["rgb"]) < 1e-2, errs
-    assert max(errs["out"], errs["plain"]) < TOL, errs
+    assert max(errs.values()) < 1e-2, errs  # measured: out 7.5e-3 / 6.2e-3, plain 6.6e-3 / 6.5e-3, fg / alphas / rgb <= 8.4e-4
 
 
 @torch.no_grad()
@@ -462,17 +472,23 @@ def _cfgB_ray_subset(level, fp8):
     torch.set_num_threads(min(os.cpu_count() or 8, 32))
     cond = refs[:-1][torch.tensor(choices)].float()[None]          # [1, n, hw, C]
     null = refs[-1:].float()[None].expand(1, n, -1, -1)           # the unconditional third: the null image for every view
-    errs, dbg = {}, None
+    errs, elems, dbg = {}, {}, None
     for br in range(3):
         want = _oracle_render_on_rays(w, cams, null if br == 0 else cond, ctx[br:br + 1].float(), heads, S, 2.0, idx)
         dbg = want[4]
-        errs[br] = (rel(rend[br:br + 1, idx.to(DEV)], want[0]), rel(fg[br:br + 1, idx.to(DEV)].reshape(want[1].shape), want[1]),
-                    rel(alphas[br:br + 1, idx.to(DEV)].reshape(want[2].shape), want[2]), rel(rgb[br:br + 1, idx.to(DEV)].reshape(want[3].shape), want[3]))
+        pairs = ((rend[br:br + 1, idx.to(DEV)], want[0]), (fg[br:br + 1, idx.to(DEV)].reshape(want[1].shape), want[1]),
+                 (alphas[br:br + 1, idx.to(DEV)].reshape(want[2].shape), want[2]), (rgb[br:br + 1, idx.to(DEV)].reshape(want[3].shape), want[3]))
+        errs[br] = tuple(rel(a_, b_) for a_, b_ in pairs)
+        elems[br] = tuple(elem(a_, b_) for a_, b_ in pairs)
     print(f"cfg-B level-{level} pose block ({'fp8' if fp8 else 'bf16'} attention) vs oracle on {len(idx)} rays (xref, fg, alphas, rgb) per CFG branch:",
           {k: tuple(round(e, 4) for e in v) for k, v in errs.items()})
     assert max(max(v) for v in errs.values()) < (5e-2 if fp8 else 1e-2), errs
     if fp8:
         return
+    # element-wise: every fg / alphas / rgb entry within 1e-2 of ITS OWN oracle value (+ 1e-3 of the tensor maximum for entries near 0);
+    # the rendered features are zero-centred sums over 24 samples (no scale of their own per element), so for them the floor is the bar
+    print("   element-wise |d| / (1e-2 |want| + 1e-3 max|want|) (xref, fg, alphas, rgb):", {k: tuple(round(e, 3) for e in v) for k, v in elems.items()})
+    assert max(max(v[1:]) for v in elems.values()) <= 1.0, elems
     # integer ray indices at the full camera set: bit-exact
     xs = nerf.patch_positions(r, DEV)
     t, _ = nerf.depth_samples(S, 2.0, 0.0, DEV, hw)
@@ -710,7 +726,7 @@ def test_full_sdxl_unet_configA_matches_cpu_oracle():
     all_blocks = [m for m in net.modules() if isinstance(m, BasicTransformerBlock)]
     assert len(blocks_rec) == len(all_blocks) == 70
     pose = unpack_cameras(cams)
-    tf, tpose, tplain = {}, {}, {}
+    tf, tfe, tpose, tplain = {}, {}, {}, {}
     for i, (blk, rec) in enumerate(zip(all_blocks, blocks_rec)):
         C = rec["x"].shape[-1]
         xin, cin = dev(rec["x"]).contiguous(), dev(rec["ctx"])
@@ -720,12 +736,16 @@ def test_full_sdxl_unet_configA_matches_cpu_oracle():
             cref4 = cref.reshape(b, cref.shape[0] // b, *cref.shape[1:]) if cref.dim() == 3 else cref
             xref, fg, _, al, rgb = blk.reference_attn(xin, dev(cref4), cin, pose, None, None)
             tf[i] = (rel(xref, rec["xref"]), rel(fg, rec["fg"]), rel(al, rec["alphas"]), rel(rgb, rec["rgb"]))
+            tfe[i] = (elem(xref, rec["xref"]), elem(fg, rec["fg"]), elem(al, rec["alphas"]), elem(rgb, rec["rgb"]))
             whole = blk(xin, context=cin, context_ref=dev(cref4).reshape(-1, *cref4.shape[2:]), pose=pose)[0]
             tpose[i] = rel(whole, rec["out"])
         else:
             assert blk.norm1.weight.shape[0] == C and blk.fused_ready(xin)
             tplain[i] = (C, rel(blk._forward_fused(xin, None, cin)[0], rec["out"]))
     print("teacher-forced render errors (xref, fg, alphas, rgb) per pose block:", {k: tuple(round(e, 4) for e in v) for k, v in tf.items()})
+    print("   element-wise |d| / (1e-2 |want| + 1e-3 max|want|) of the same (xref, fg, alphas, rgb):", {k: tuple(round(e, 3) for e in v) for k, v in tfe.items()})
+    # every fg / alphas / rgb entry of the 12 renders within 1e-2 of its own oracle value (+ 1e-3 of the tensor maximum): measured <= 0.88
+    assert max(max(v[1:]) for v in tfe.values()) <= 1.0, tfe
     print("teacher-forced whole pose blocks (x -> out):", {k: round(v, 4) for k, v in tpose.items()})
     assert len(tf) == 12 and len(tplain) == 58
     margins["render (12 pose blocks: xref, fg, alphas, rgb)"] = max(max(v) for v in tf.values())
