@@ -80,6 +80,11 @@ SIGNATURES = {
     "cd360_adamw_bf16": (c_int, [c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_float, c_float, c_float, _P]),
     "cd360_prefetch_arm": (c_int, [_P, c_int, c_int, c_int64, _P]),
     "cd360_prefetch_disarm": (c_int, []),
+    "cd360_prefetch_arm_on": (c_int, [_P, _P, c_int, c_int, c_int64, _P]),
+    "cd360_prefetch_disarm_on": (c_int, [_P]),
+    "cd360_set_stream_tuning": (c_int, [_P, _P]),
+    "cd360_get_stream_tuning": (c_int, [_P, _P]),
+    "cd360_query_stream": (c_int, [_P]),
     "cd360_set_tuning": (c_int, [_P]),
     "cd360_get_tuning": (c_int, [_P]),
     "cd360_whatif_build": (c_int, []),
@@ -166,6 +171,50 @@ def set_tuning(**fields) -> None:
         setattr(t, k, int(v))
     t.size = ctypes.sizeof(Tuning)
     check(lib.cd360_set_tuning(ctypes.byref(t)), "cd360_set_tuning")
+
+
+# ---- per-stream tuning (cd360_set_stream_tuning): launches on ONE stream read their own struct; the default above stays what it is ----
+_stream_overrides = set()  # raw stream handles with an override (so that the hot path can skip cd360_query_stream while there is none)
+
+
+def _stream_handle(stream) -> int:
+    return int(getattr(stream, "cuda_stream", stream))
+
+
+def set_stream_tuning(stream, **fields) -> None:
+    """Tuning override for launches issued on `stream` (a torch.cuda.Stream or a raw handle): starts from the stream's current effective
+    tuning, sets the named fields.  Two samplers / captures on two streams can hold different tilings in one process."""
+    lib = _lib if _lib is not None else load()
+    h = _stream_handle(stream)
+    t = Tuning()
+    check(lib.cd360_get_stream_tuning(ctypes.c_void_p(h), ctypes.byref(t)), "cd360_get_stream_tuning")
+    for k, v in fields.items():
+        if k not in TUNING_FIELDS:
+            raise KeyError(f"unknown tuning field {k}")
+        setattr(t, k, int(v))
+    t.size = ctypes.sizeof(Tuning)
+    check(lib.cd360_set_stream_tuning(ctypes.c_void_p(h), ctypes.byref(t)), "cd360_set_stream_tuning")
+    _stream_overrides.add(h)
+
+
+def get_stream_tuning(stream) -> dict:
+    t = Tuning()
+    check(load().cd360_get_stream_tuning(ctypes.c_void_p(_stream_handle(stream)), ctypes.byref(t)), "cd360_get_stream_tuning")
+    return {f: getattr(t, f) for f in TUNING_FIELDS}
+
+
+def clear_stream_tuning(stream) -> None:
+    h = _stream_handle(stream)
+    check(load().cd360_set_stream_tuning(ctypes.c_void_p(h), None), "cd360_set_stream_tuning")
+    _stream_overrides.discard(h)
+    if not _stream_overrides:
+        load().cd360_query_stream(None)
+
+
+def query_stream(handle) -> None:
+    """Before a shape query (cd360_gemm_tile_n, ...): answer for launches on this stream.  Free while no stream has an override."""
+    if _stream_overrides:
+        _lib.cd360_query_stream(handle)
 
 
 def reset_tuning() -> None:

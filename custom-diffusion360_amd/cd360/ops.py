@@ -659,6 +659,7 @@ def conv_igemm(x: torch.Tensor, w_packed: torch.Tensor, bias: Optional[torch.Ten
     lib = _lib.load()
     stats = None
     if want_stats:
+        _lib.query_stream(_stream())
         rows = lib.cd360_conv_stats_rows(N, H, W, cin, cout, taps, stride)  # pixels per slab: the kernel serving this shape decides
         if rows <= 0 or (ho * wo) % rows or (rows < 64 and (ho * wo) % 128):  # slabs must not straddle images (register-staged kernel: 128-pixel tiles)
             raise Cd360Error(f"conv_igemm(want_stats=True): Ho*Wo = {ho * wo} is not a whole number of the kernel's {rows}-pixel slabs")
@@ -724,6 +725,7 @@ def _rows2d(t: torch.Tensor):
 
 
 def gemm_tile_n(M: int, N: int) -> int:
+    _lib.query_stream(_stream())
     return _lib.load().cd360_gemm_tile_n(M, N)
 
 
@@ -789,6 +791,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     lib = _lib.load()
     stats_out = None
     if want_stats:
+        _lib.query_stream(_stream())
         tn = lib.cd360_gemm_tile_n(M, N)
         stats_out = torch.empty(M, (N + tn - 1) // tn, 2, dtype=torch.float32, device=a.device)
     with _timed(_shape_tag("gemm8p", M, N, K), 2.0 * M * N * K, 2.0 * (M * K + N * K + M * nout + (M * N if res is not None else 0))):
@@ -950,6 +953,7 @@ def gemm_cstats(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] =
     M, lda = _rows2d(a)
     K, N = a.shape[-1], w.shape[0]
     lib = _lib.load()
+    _lib.query_stream(_stream())
     slab = lib.cd360_gemm_cstats_rows(M, N)
     if M % 64 or slab <= 0:
         return gemm(a, w, bias=bias, res=res), None

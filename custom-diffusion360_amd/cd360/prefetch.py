@@ -26,11 +26,13 @@ class WeightPrefetcher:
 
     def __enter__(self):
         self.side.wait_stream(torch.cuda.current_stream(self.device))  # fork: the side stream joins the capture
-        check(_lib.load().cd360_prefetch_arm(ctypes.c_void_p(self.side.cuda_stream), self.lag, self.wgs, self.min_bytes,
-                                             ctypes.c_void_p(self.sink.data_ptr())), "cd360_prefetch_arm")
+        # armed for THIS capture's stream only: launches on other streams (another sampler's capture) are not touched
+        self.main = torch.cuda.current_stream(self.device).cuda_stream
+        check(_lib.load().cd360_prefetch_arm_on(ctypes.c_void_p(self.main), ctypes.c_void_p(self.side.cuda_stream), self.lag, self.wgs,
+                                                self.min_bytes, ctypes.c_void_p(self.sink.data_ptr())), "cd360_prefetch_arm_on")
         return self
 
     def __exit__(self, *exc):
-        check(_lib.load().cd360_prefetch_disarm(), "cd360_prefetch_disarm")
+        check(_lib.load().cd360_prefetch_disarm_on(ctypes.c_void_p(self.main)), "cd360_prefetch_disarm_on")
         torch.cuda.current_stream(self.device).wait_stream(self.side)  # join
         return False

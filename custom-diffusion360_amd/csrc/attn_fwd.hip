@@ -833,6 +833,7 @@ static int attn_launch(const void* q, const void* k, const void* v, void* o, int
 extern "C" int cd360_attn_fwd_bf16(const void* q, const void* k, const void* v, void* o, int B, int H, int Nq, int Nk,
                                    const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                                    const int64_t* o_strides, float scale, void* stream) {
+  CD360_TUNE_SCOPE(stream);
   return attn_launch(q, k, v, o, B, H, Nq, Nk, q_strides, k_strides, v_strides, o_strides, scale, nullptr, nullptr, stream);
 }
 
@@ -843,6 +844,7 @@ extern "C" int cd360_attn_fwd_bf16(const void* q, const void* k, const void* v, 
 extern "C" int cd360_attn_fwd_prescaled_bf16(const void* q, const void* k, const void* v, void* o, int B, int H, int Nq, int Nk,
                                              const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                                              const int64_t* o_strides, void* stream) {
+  CD360_TUNE_SCOPE(stream);
   return attn_launch(q, k, v, o, B, H, Nq, Nk, q_strides, k_strides, v_strides, o_strides, 1.f, nullptr, nullptr, stream, true);
 }
 
@@ -851,6 +853,7 @@ extern "C" int cd360_attn_fwd_prescaled_bf16(const void* q, const void* k, const
 extern "C" int cd360_attn_fwd_lse_bf16(const void* q, const void* k, const void* v, void* o, void* lse, int B, int H, int Nq, int Nk,
                                        const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                                        const int64_t* o_strides, float scale, void* stream) {
+  CD360_TUNE_SCOPE(stream);
   if (!lse) return CD360_ERR_ARG;
   return attn_launch(q, k, v, o, B, H, Nq, Nk, q_strides, k_strides, v_strides, o_strides, scale, nullptr, (float*)lse, stream);
 }
@@ -860,6 +863,7 @@ extern "C" int cd360_attn_fwd_lse_bf16(const void* q, const void* k, const void*
 extern "C" int cd360_attn_fwd_fp8mfma_bf16(const void* q, const void* k, const void* v, void* o, int B, int H, int Nq, int Nk,
                                            const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                                            const int64_t* o_strides, float scale, const float* amax, void* stream) {
+  CD360_TUNE_SCOPE(stream);
   if (!amax) return CD360_ERR_ARG;
   return attn_launch(q, k, v, o, B, H, Nq, Nk, q_strides, k_strides, v_strides, o_strides, scale, amax, nullptr, stream);
 }
@@ -867,6 +871,7 @@ extern "C" int cd360_attn_fwd_fp8mfma_bf16(const void* q, const void* k, const v
 // xformers-layout convenience entry: q, k, v, o all contiguous [BH, N, 64] (attention.py:393-408), consumed in place
 extern "C" int cd360_attn_fwd_xformers_bf16(const void* q, const void* k, const void* v, void* o, int BH, int Nq, int Nk, float scale,
                                             void* stream) {
+  CD360_TUNE_SCOPE(stream);
   if (BH <= 0) return CD360_ERR_ARG;
   const int64_t qs[3] = {0, (int64_t)Nq * 64, 64}, ks[3] = {0, (int64_t)Nk * 64, 64};
   return cd360_attn_fwd_bf16(q, k, v, o, 1, BH, Nq, Nk, qs, ks, ks, qs, scale, stream);

@@ -1,5 +1,6 @@
-// Tuning / A-B state of libcd360_hip.so (declared publicly in include/cd360_hip.h: cd360_tuning, cd360_set_tuning, cd360_get_tuning).
-// The launch functions read the ONE process-wide copy through cd360_tune(); nothing in a launch path calls getenv.  Every field is
+// Tuning / A-B state of libcd360_hip.so (declared publicly in include/cd360_hip.h: cd360_tuning, cd360_set_tuning, cd360_get_tuning,
+// cd360_set_stream_tuning).  The launch functions read it through cd360_tune(): the override of the stream they were called with, else
+// the process-wide default; nothing in a launch path calls getenv.  Every field is
 // -1 by default = "the measured best for the shape"; the Python binding fills the struct once from the CD360_* environment variables
 // when it loads the library (cd360/_lib.py) and tools / tests change it explicitly (cd360.ops.tuning(...)).
 #pragma once
@@ -34,6 +35,28 @@ typedef struct cd360_tuning {
 
 int cd360_set_tuning(const cd360_tuning* t);
 int cd360_get_tuning(cd360_tuning* t);
+int cd360_set_stream_tuning(void* stream, const cd360_tuning* t);
+int cd360_get_stream_tuning(void* stream, cd360_tuning* t);
+int cd360_query_stream(void* stream);
 }
 
-const cd360_tuning& cd360_tune();  // the current process-wide copy (tuning.hip)
+// The tuning a launch function reads: the override of the stream the running entry point was called with (CD360_TUNE_SCOPE), else the
+// process-wide default (tuning.hip).
+const cd360_tuning& cd360_tune();
+
+// First statement of every entry point that takes a stream and reads the tuning: for the duration of the call cd360_tune() answers
+// with that stream's override, if one was set (cd360_set_stream_tuning).  Thread-local, nothing shared is written; with no per-stream
+// override registered anywhere (the normal case) the constructor is one relaxed atomic load.
+class Cd360TuneScope {
+ public:
+  explicit Cd360TuneScope(void* stream);
+  ~Cd360TuneScope();
+  Cd360TuneScope(const Cd360TuneScope&) = delete;
+  Cd360TuneScope& operator=(const Cd360TuneScope&) = delete;
+
+ private:
+  const cd360_tuning* prev_;
+  bool set_;
+  cd360_tuning local_;
+};
+#define CD360_TUNE_SCOPE(stream) Cd360TuneScope cd360_tune_scope_((void*)(stream))

@@ -364,6 +364,7 @@ extern "C" int cd360_conv_stats_rows(int N, int H, int W, int Cin, int Cout, int
 
 extern "C" int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const void* bias, const void* emb, int64_t emb_stride, const void* res,
                                      void* out, int N, int H, int W, int Cin, int Cout, int taps, int stride, void* tile_stats, void* stream) {
+  CD360_TUNE_SCOPE(stream);
   if (!x || !w_packed || !out || N <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0) return CD360_ERR_ARG;
   if (cd360_conv_dma_slab_rows(N, H, W, Cin, Cout, taps, stride) > 0) {  // 3 x 3 / stride 1: the LDS-DMA core (gemm8p.hip, EPI 5)
     const int rc = cd360_conv3x3_dma_bf16(x, w_packed, bias, emb, emb_stride, res, out, N, H, W, Cin, Cout, tile_stats, stream);
@@ -438,6 +439,7 @@ extern "C" int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const 
 // written by the same lane).  x, xref, out: [rows, C] bf16; C % 64 == 0.
 extern "C" int cd360_pose_embed_bf16(const void* x, const void* xref, const void* wa, const void* wb, void* out, int64_t rows, int C,
                                      void* stream) {
+  CD360_TUNE_SCOPE(stream);
   if (!x || !xref || !wa || !wb || !out || rows <= 0 || C <= 0) return CD360_ERR_ARG;
   if (rows > 0x7fffffffL) return CD360_ERR_SHAPE;
   const int rc = cd360_conv_igemm_bf16(x, wa, nullptr, nullptr, 0, nullptr, out, 1, (int)rows, 1, C, C, 1, 1, nullptr, stream);

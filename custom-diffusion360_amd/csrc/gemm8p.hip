@@ -1131,9 +1131,12 @@ int launch_mv(const GemmParams& p0, hipStream_t stream) {
   // the kernel left dirty before its consumer may start (MI355X_MICROARCH.md, price row "boundary": + B / 6 TB/s behind B dirty bytes --
   // 1.3 us behind the 7.9 MB of a C -> C projection, 5 us behind FF1's 31 MB).  Stores with agent scope (sc1) go through to memory as
   // they are issued, under the other workgroups' K loops and epilogues, and the boundary finds nothing to write back.
+  // MEASURED (round 5, profiles/r05_store_wt_ab.txt): chains of one shape -0.4 ... -3.8 % per launch, outputs bit-identical -- and the
+  // captured denoise step unchanged (27.69 / 27.75 ms plain, 27.71 / 28.25 ms write-through, alternating on one box): inside the step the
+  // write-back already overlaps the next launch's prologue.  Off by default; cd360_tuning.store_wt = 1 turns it on.
   {
     const long out_rows = ((EPI == 5 && p.cv_up) ? 4L : ATTN ? 2L : 1L) * p.M;  // (the de-duplicated attention writes rows of batch i + a_dup too)
-    p.wt = (tune.store_wt != 0 && (out_rows - 1) * p.ldo * 2 + (long)p.N * 2 < 0x7fffffffL) ? 1 : 0;
+    p.wt = (tune.store_wt > 0 && (out_rows - 1) * p.ldo * 2 + (long)p.N * 2 < 0x7fffffffL) ? 1 : 0;
   }
   p.abl = 0;
 #ifdef CD360_WHATIF
@@ -1148,7 +1151,7 @@ int launch_mv(const GemmParams& p0, hipStream_t stream) {
   if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
   // weight prefetcher (prefetch.hip; armed only while a step is being captured): a small kernel on the forked side stream touches THIS
   // launch's weights as soon as the launch `lag` positions earlier has finished, i.e. while its predecessors compute
-  cd360_prefetch_before_launch(p.w, ((long)p.N * ((EPI == 5 && p.cv_up) ? 4 : 1) - 1) * p.ldw * 2 + (long)p.K * 2);
+  cd360_prefetch_before_launch(stream, p.w, ((long)p.N * ((EPI == 5 && p.cv_up) ? 4 : 1) - 1) * p.ldw * 2 + (long)p.K * 2);
   static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_mfma_kernel<WM, WN, NCB, NMB, NBUF, KS, MV, EPI>),
                                                      hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   if (attr != hipSuccess) return CD360_ERR_LAUNCH;
@@ -1271,6 +1274,7 @@ extern "C" int cd360_gemm_cstats_rows(int64_t M, int N) {
 extern "C" int cd360_gemm_bf16(const void* a, const void* w, void* out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldo,
                                const void* bias, const void* res, int64_t ldr, const void* ln_stats, int ln_parts, int ln_dim, float ln_eps,
                                const void* wsum, void* stats_out, int flags, void* stream) {
+  CD360_TUNE_SCOPE(stream);
   if (!a || !w || !out || M <= 0 || N <= 0 || K <= 0) return CD360_ERR_ARG;
   if (K % 64 || N % 16 || lda % 8 || ldw % 8 || ldo % 8 || (res && ldr % 8) || lda < K || ldw < K) return CD360_ERR_SHAPE;
   if (((uintptr_t)a | (uintptr_t)w | (uintptr_t)out | (uintptr_t)res) % 16) return CD360_ERR_ARG;
@@ -1310,6 +1314,7 @@ extern "C" int cd360_gemm_bf16(const void* a, const void* w, void* out, int64_t 
 // of cd360_gn_silu_bf16, like the convolution epilogue's.  CD360_ERR_SHAPE when the tiling chosen for (M, N) writes none (rows == 0).
 extern "C" int cd360_gemm_cstats_bf16(const void* a, const void* w, void* out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldo,
                                       const void* bias, const void* res, int64_t ldr, void* cstats, void* stream) {
+  CD360_TUNE_SCOPE(stream);
   if (!a || !w || !out || !cstats || M <= 0 || N <= 0 || K <= 0) return CD360_ERR_ARG;
   if (K % 64 || N % 16 || lda % 8 || ldw % 8 || ldo % 8 || (res && ldr % 8) || lda < K || ldw < K || M % 64) return CD360_ERR_SHAPE;
   if (((uintptr_t)a | (uintptr_t)w | (uintptr_t)out | (uintptr_t)res | (uintptr_t)cstats) % 16 || (uintptr_t)bias % 8) return CD360_ERR_ARG;
@@ -1373,6 +1378,7 @@ extern "C" int cd360_qproj_attn_dedup_bf16(const void* a, const void* w, void* o
                                            const void* bias, const void* ln_stats, int ln_parts, int ln_dim, float ln_eps, const void* wsum,
                                            const void* k, const void* v, int64_t k_sb, int64_t k_sn, int64_t v_sb, int64_t v_sn, int Nq, int Nk,
                                            float scale, int dup, void* stream) {
+  CD360_TUNE_SCOPE(stream);
   if (!a || !w || !out || !k || !v || M <= 0 || N <= 0 || K <= 0 || Nq <= 0 || Nk <= 0 || dup < 0 || (int64_t)dup * Nq > M) return CD360_ERR_ARG;
   if (K % 64 || N % 64 || lda % 8 || ldw % 8 || ldo % 8 || lda < K || ldw < K || Nk > 96 || Nq % 128 || M % Nq) return CD360_ERR_SHAPE;
   // tile (cd360_tuning.qattn_cfg): 1 = 256 tokens x 256 channels (four heads, eight waves of 128 x 64: the FeatureNeRF pose tokens, 10^5
@@ -1498,6 +1504,7 @@ extern "C" int64_t cd360_kv_fp8_bytes(int B, int H) { return (int64_t)B * H * (9
 // scales fp32 [B, H, 2] = (K scale, V scale) per head; Nk <= 96
 extern "C" int cd360_kv_pack_fp8(const void* k, const void* v, void* kv8, void* scales, int B, int H, int Nk, int64_t k_sb, int64_t k_sn,
                                  int64_t v_sb, int64_t v_sn, void* stream) {
+  CD360_TUNE_SCOPE(stream);
   if (!k || !v || !kv8 || !scales || B <= 0 || H <= 0 || Nk <= 0) return CD360_ERR_ARG;
   if (Nk > 96 || (uintptr_t)kv8 % 16 || (uintptr_t)scales % 4) return CD360_ERR_SHAPE;
   hipLaunchKernelGGL(kv_pack_fp8_kernel, dim3((unsigned)(B * H)), dim3(256), 0, (hipStream_t)stream, (const uint16_t*)k, (const uint16_t*)v,
@@ -1511,6 +1518,7 @@ extern "C" int cd360_kv_pack_fp8(const void* k, const void* v, void* kv8, void* 
 extern "C" int cd360_qproj_attn_fp8_bf16(const void* a, const void* w, void* out, int64_t M, int N, int K, int64_t lda, int64_t ldw, int64_t ldo,
                                          const void* bias, const void* ln_stats, int ln_parts, int ln_dim, float ln_eps, const void* wsum,
                                          const void* kv8, const void* scales, int Nq, int Nk, float scale, int dup, void* stream) {
+  CD360_TUNE_SCOPE(stream);
   if (!a || !w || !out || !kv8 || !scales || M <= 0 || N <= 0 || K <= 0 || Nq <= 0 || Nk <= 0 || dup < 0 || (int64_t)dup * Nq > M) return CD360_ERR_ARG;
   if (K % 64 || N % 64 || lda % 8 || ldw % 8 || ldo % 8 || lda < K || ldw < K || Nk > 96 || Nq % 128 || M % Nq) return CD360_ERR_SHAPE;
   if (Nk <= 64) return CD360_ERR_SHAPE;  // the fp8 epilogue masks the padding keys of its LAST 32-key block only: 65 .. 96 keys (SDXL: 77)
@@ -1538,6 +1546,7 @@ extern "C" int cd360_qproj_attn_bf16(const void* a, const void* w, void* out, in
                                      const void* bias, const void* ln_stats, int ln_parts, int ln_dim, float ln_eps, const void* wsum,
                                      const void* k, const void* v, int64_t k_sb, int64_t k_sn, int64_t v_sb, int64_t v_sn, int Nq, int Nk,
                                      float scale, void* stream) {
+  CD360_TUNE_SCOPE(stream);
   return cd360_qproj_attn_dedup_bf16(a, w, out, M, N, K, lda, ldw, ldo, bias, ln_stats, ln_parts, ln_dim, ln_eps, wsum, k, v, k_sb, k_sn, v_sb, v_sn,
                                      Nq, Nk, scale, 0, stream);
 }
@@ -1588,6 +1597,7 @@ extern "C" int cd360_conv_dma_slab_rows(int N, int H, int W, int Cin, int Cout, 
 // CD360_ERR_SHAPE when the shape is outside the envelope (the caller then uses the register-staged kernel).
 extern "C" int cd360_conv3x3_dma_bf16(const void* x, const void* w_packed, const void* bias, const void* emb, int64_t emb_stride, const void* res,
                                       void* out, int N, int H, int W, int Cin, int Cout, void* tile_stats, void* stream) {
+  CD360_TUNE_SCOPE(stream);
   if (!x || !w_packed || !out) return CD360_ERR_ARG;
   if (!conv_dma_ok(N, H, W, Cin, Cout, 9, 1)) return CD360_ERR_SHAPE;
   if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)out | (uintptr_t)emb | (uintptr_t)res | (uintptr_t)tile_stats) % 16) return CD360_ERR_ARG;
@@ -1620,6 +1630,7 @@ extern "C" int cd360_conv3x3_dma_bf16(const void* x, const void* w_packed, const
 // (cd360.ops.pack_upsample_conv_weight); bias fp32 [Cout] | NULL; out [N, 2H, 2W, Cout] bf16.  Cin % 64 == 0, Cout % 16 == 0.
 extern "C" int cd360_conv_up2x_bf16(const void* x, const void* w_phases, const void* bias, void* out, int N, int H, int W, int Cin, int Cout,
                                     void* stream) {
+  CD360_TUNE_SCOPE(stream);
   if (!x || !w_phases || !out || N <= 0 || H <= 0 || W <= 0) return CD360_ERR_ARG;
   if (Cin % 64 || Cout % 16) return CD360_ERR_SHAPE;
   if (((uintptr_t)x | (uintptr_t)w_phases | (uintptr_t)out) % 16 || (uintptr_t)bias % 8) return CD360_ERR_ARG;
@@ -1674,6 +1685,7 @@ __global__ __launch_bounds__(256) void row_stats_kernel(const uint16_t* __restri
 }  // namespace
 
 extern "C" int cd360_row_stats_bf16(const void* x, void* stats, int64_t rows, int C, int64_t ld, void* stream) {
+  CD360_TUNE_SCOPE(stream);
   if (!x || !stats || rows <= 0 || C <= 0) return CD360_ERR_ARG;
   if (C % 8 || ld % 8 || ld < C || (uintptr_t)x % 16) return CD360_ERR_SHAPE;
   const long blocks = (rows + 3) / 4;

@@ -883,11 +883,13 @@ static int plucker_launch(bool bf, const void* cams, const void* xs, const void*
 }
 
 extern "C" int cd360_plucker_features(const void* cams, const void* xs, const void* ys, void* out, int b, int n, int r, void* stream) {
+  CD360_TUNE_SCOPE(stream);
   return plucker_launch(false, cams, xs, ys, out, b, n, r, stream);
 }
 
 // The same features as bf16 rows of 128 (99 values + zero pad): the A operand of the zP table GEMM on cd360_gemm_bf16
 extern "C" int cd360_plucker_features_bf16(const void* cams, const void* xs, const void* ys, void* out, int b, int n, int r, void* stream) {
+  CD360_TUNE_SCOPE(stream);
   if ((uintptr_t)out % 16) return CD360_ERR_ARG;
   return plucker_launch(true, cams, xs, ys, out, b, n, r, stream);
 }
@@ -898,6 +900,7 @@ extern "C" int cd360_nerf_k_padded(void) { return KP; }
 extern "C" int cd360_nerf_mlp_aggregate(const void* cams, const void* xs, const void* ys, const void* t, int t_ray_stride, const void* Y,
                                         const void* zP, const void* lv, const void* cview, const void* Wk, const void* img_map, void* g,
                                         void* logits, void* lse, int b, int n, int r, int S, int C, void* stream) {
+  CD360_TUNE_SCOPE(stream);
   if (!cams || !xs || !ys || !t || !Y || !zP || !lv || !cview || !Wk || !g) return CD360_ERR_ARG;
   if (b <= 0 || n <= 0 || r <= 0 || S <= 0 || C <= 0 || C % CN) return CD360_ERR_SHAPE;
   if (t_ray_stride != 0 && t_ray_stride != S) return CD360_ERR_SHAPE;

@@ -105,6 +105,54 @@ def _watched_inside(mod: nn.Module) -> bool:
     return any(_watched(child) for child in mod.children())
 
 
+# ---- sample.py's monkey patch, recognised (sample.py:33-136, 247-262) --------------------------------------------------------------------
+# sample.py rebinds `forward` on every SpatialTransformer (`customforward`) and BasicTransformerBlock (`_customforward`) INSTANCE.  What those
+# two functions do differently from the class forwards is exactly the sampling mode these classes carry natively (`reference_choices`: the
+# reference features come from the block's `references` buffer picked by the driver's global `choices`, the null image for the unconditional
+# CFG part; the render runs once per image and is cached in `rendered_feat`) -- pinned against the outputs of sample.py's own functions
+# in tests/golden/customforward_cfg3.npz.  A rebound Python forward would force every block onto the un-fused module route (it calls
+# norm1 / attn1 / ... one by one), so an assignment of one of THOSE TWO functions to `forward` is recorded instead of installed: the class
+# forward keeps running, in sampling mode, with `choices` read from the rebound function's own globals at every call.  Recognition is
+# structural -- the function's name plus the attribute and global names its code touches -- and anything else assigned to `forward`
+# is installed as usual (and sends the module to the strict route).  `cd360.routes.strict_sample_py` switches the recognition off.
+_BLOCK_PATCH_NAMES = {"references", "rendered_feat", "reference_attn", "pose_emb_layers", "attn1", "attn2", "norm1", "norm2", "norm3", "ff", "choices"}
+_ST_PATCH_NAMES = {"norm", "proj_in", "proj_out", "transformer_blocks", "image_cross", "poscontrol_interval", "use_linear"}
+
+
+def _sample_py_patch_kind(value) -> Optional[str]:
+    fn = getattr(value, "__func__", None)
+    code = getattr(fn, "__code__", None)
+    if code is None or routes.strict_sample_py:
+        return None
+    names = set(code.co_names)
+    if fn.__name__ == "_customforward" and _BLOCK_PATCH_NAMES <= names:
+        return "block"
+    if fn.__name__ == "customforward" and _ST_PATCH_NAMES <= names:
+        return "st"
+    return None
+
+
+def _sync_sample_py(block) -> None:
+    """Point a recognised block at the driver's current `choices` (sample.py:274-278 assigns the global after patching; :91 reads it in
+    every call) and keep the text K / V of the image resident like cd360.sampling.enable_reference_sampling does."""
+    sp = block.__dict__.get("_sample_py")
+    if sp is None:
+        return
+    # the text K / V of the image stay resident between steps: the cache entry is keyed on (and holds) the context tensor, its version
+    # and the projection weights, so a new image's context, an in-place rewrite or a weight update all miss (project_context)
+    block.attn2.cache_context_kv = True
+    if not getattr(block, "image_cross", False):
+        return
+    ch = sp.__func__.__globals__.get("choices")
+    if ch is None:
+        raise RuntimeError("sample.py's `_customforward` is bound to this block but its module has no global `choices` yet "
+                           "(sample.py:274-278 sets it before the first sampler call)")
+    cur = block.reference_choices
+    if cur is None or len(cur) != len(ch) or any(int(a) != int(b_) for a, b_ in zip(cur, ch)):
+        block.reference_choices = [int(c) for c in ch]
+        block.rendered_feat = None
+
+
 def Normalize(in_channels):
     return torch.nn.GroupNorm(num_groups=32, num_channels=in_channels, eps=1e-6, affine=True)
 
@@ -265,6 +313,12 @@ class BasicTransformerBlock(nn.Module):
         self._rendered_proj = None  # (rendered_feat object, its version, Wb, rendered_feat @ Wb^T) of _pose_embed_cached
         self._pack = None  # (parameter versions, packed weights) of the fused inference path
         self._static_rendered = self._static_proj = None  # pin_rendered()
+
+    def __setattr__(self, name, value):
+        if name == "forward" and _sample_py_patch_kind(value) == "block":
+            object.__setattr__(self, "_sample_py", value)  # recorded, not installed: see the note above _sample_py_patch_kind
+            return
+        super().__setattr__(name, value)
 
     # ------------------------------------------------------------------------------------------------ pose path
     def _pose_weights(self):
@@ -644,6 +698,8 @@ class BasicTransformerBlock(nn.Module):
                 n_times_crossframe_attn_in_self=0):
         if additional_tokens is not None or n_times_crossframe_attn_in_self:
             raise NotImplementedError("additional_tokens / cross-frame attention are not used by the shipped config")
+        if context_ref is not None and "_sample_py" in self.__dict__:
+            _sync_sample_py(self)
         watched = _watched_inside(self)  # hooks on this block itself have what they need: they fire around this very call
         if not watched and self.fused_ready(x):
             return self._forward_fused(x, None, context, context_ref, pose, mask_ref, prev_weights)[:5]
@@ -742,6 +798,12 @@ class SpatialTransformer(nn.Module):
         self.proj_out = zero_module(HipLinear(inner_dim, in_channels))
         self.use_linear = use_linear
         self._ppack = None
+
+    def __setattr__(self, name, value):
+        if name == "forward" and _sample_py_patch_kind(value) == "st":
+            object.__setattr__(self, "_sample_py", value)  # recorded, not installed: see the note above _sample_py_patch_kind
+            return
+        super().__setattr__(name, value)
 
     def _tokens(self, x):
         return self.proj_in(group_norm_tokens(self.norm, x, silu=False))
@@ -843,6 +905,12 @@ class SpatialTransformer(nn.Module):
     def forward(self, x, xr, context=None, contextr=None, pose=None, mask_ref=None, prev_weights=None):
         if not isinstance(context, list):
             context, contextr = [context], [contextr]
+        if "_sample_py" in self.__dict__:
+            # sample.py's customforward (sample.py:33-79): no reference stream (it returns None for it), every pose block is handed
+            # `context_ref=x` as a marker and takes its reference features from its own `references` buffer
+            xr, contextr = None, [None] * len(context)
+            for blk in self.transformer_blocks:
+                _sync_sample_py(blk)
         # importance sampling revived (f4; nerfsd_pytorch3d.py honour_imp_sample_next_step): the blocks hand rendering weights to each
         # other (attention.py:849-858), which the module route below carries; never the case in the reference's own configuration
         chained = self.image_cross and any(getattr(b, "image_cross", False) and b.use_prev_weights_imp_sample

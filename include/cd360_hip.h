@@ -8,8 +8,10 @@
  * Conventions
  *   - every pointer is a DEVICE pointer owned by the caller (torch allocates; nothing is allocated here);
  *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it, no hidden synchronisation; re-entrant across
- *     streams.  No entry point reads the environment.  The only process-wide state is the tuning struct below
- *     (cd360_set_tuning): an explicit A/B interface whose defaults (-1 everywhere) are the measured-best choices;
+ *     streams.  No entry point reads the environment.  State: (1) a process-wide DEFAULT tuning struct (cd360_set_tuning: an explicit
+ *     A/B interface whose defaults, -1 everywhere, are the measured-best choices); (2) keyed BY STREAM and mutex-protected, so that two
+ *     samplers / captures on two streams never see each other's: tuning overrides (cd360_set_stream_tuning) and weight-prefetch arms
+ *     (cd360_prefetch_arm_on).  A launch consults only the entries of the stream it is given;
  *   - workspace sizes come from the *_workspace_bytes() queries, the caller provides the buffer;
  *   - return 0 on success, <0 on error (CD360_ERR_*): the Python side raises;
  *   - bf16 tensors are raw uint16 storage; "fp32"/"int32" as named;
@@ -32,7 +34,7 @@ extern "C" {
 /* ---- tuning / A-B interface --------------------------------------------------------------------------------
  * Kernel and tiling choices are made per call from the shapes.  A harness that wants to compare two tilings in one process
  * overrides them here (field = -1: choose by shape).  `size` must be sizeof(cd360_tuning).  cd360_set_tuning(NULL) restores the
- * defaults.  Set it between launches, not concurrently with them.  `whatif` (timing experiments that produce wrong results) is
+ * defaults.  Set the default between launches, not concurrently with them (per-stream overrides: cd360_set_stream_tuning).  `whatif` (timing experiments that produce wrong results) is
  * ignored unless the library was built with -DCD360_WHATIF (cd360_whatif_build() == 1); the product build has no such code. */
 typedef struct cd360_tuning {
   int32_t size;
@@ -59,8 +61,17 @@ typedef struct cd360_tuning {
   int32_t store_wt;         /* 0 | 1: GEMM-family output tiles by plain / write-through (sc1) stores; -1 = the measured default */
   int32_t reserved[2];
 } cd360_tuning;
-int cd360_set_tuning(const cd360_tuning* t);
+int cd360_set_tuning(const cd360_tuning* t);   /* the process-wide DEFAULT (NULL restores the built-in defaults) */
 int cd360_get_tuning(cd360_tuning* t);
+/* Per-stream override -- the re-entrant form ("no global mutable state, re-entrant across streams"): every launch
+ * issued ON `stream` reads *t instead of the default, so two samplers / two captures in one process hold different tilings; t == NULL
+ * removes the override; at most 16 streams; thread-safe.  cd360_get_stream_tuning returns what launches on `stream` read (override or
+ * default).  The shape queries below that size a buffer for a following launch (cd360_gemm_tile_n, cd360_gemm_cstats_rows,
+ * cd360_conv_stats_slabs, cd360_conv_stats_rows, cd360_conv_dma_slab_rows, cd360_conv_k_order) take no stream: on the CALLING THREAD they
+ * answer for the stream named by the last cd360_query_stream (NULL or a stream without override: the default) -- thread-local state only. */
+int cd360_set_stream_tuning(void* stream, const cd360_tuning* t);
+int cd360_get_stream_tuning(void* stream, cd360_tuning* t);
+int cd360_query_stream(void* stream);
 int cd360_whatif_build(void);
 
 /* ---- weight prefetcher of a captured step --------------------------------------------------------------------
@@ -71,7 +82,12 @@ int cd360_whatif_build(void);
  * (`wgs` workgroups) that touches one dword per 128-byte line of that launch's weights (weights below `min_bytes` are skipped) and waits
  * only for the completion of the launch `lag` (1 .. 7) positions earlier: in the replayed graph the weights of launch i arrive in the
  * Infinity Cache while launches i - lag + 1 ... i - 1 compute.  The main stream never waits for the side stream; the caller joins it once,
- * after cd360_prefetch_disarm(), before the capture ends.  sink: 4 bytes of device scratch.  Process-wide state: one capture at a time. */
+ * after the disarm, before the capture ends.  sink: 4 bytes of device scratch. */
+int cd360_prefetch_arm_on(void* main_stream, void* side_stream, int lag, int wgs, int64_t min_bytes, void* sink);
+int cd360_prefetch_disarm_on(void* main_stream);
+/* cd360_prefetch_arm_on arms ONE capturing stream: only launches issued on `main_stream` enqueue touches (on `side_stream`, forked into the
+ * same capture), so two captures on two streams prefetch independently (up to 8 armed streams; thread-safe).  The two entry points below
+ * are the round-4 forms: a wildcard arm serving launches on any stream that has no arm of its own (one capture at a time). */
 int cd360_prefetch_arm(void* side_stream, int lag, int wgs, int64_t min_bytes, void* sink);
 int cd360_prefetch_disarm(void);
 

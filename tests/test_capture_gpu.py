@@ -134,3 +134,60 @@ def test_two_poses_per_replay_equal_two_single_pose_trajectories():
     for k in range(2):  # the level-2 GEMMs take other tiles at M = 6144 than at 3072: same products, other blocking -- rounding only
         assert float((both[k:k + 1] - outs[k]).abs().max() / outs[k].abs().max()) < 5e-3
     assert float((outs[0] - outs[1]).abs().max() / outs[1].abs().max()) > 1e-2
+
+
+@torch.no_grad()
+def test_two_streams_hold_their_own_tuning_and_prefetch_arm():
+    """SURVEY.md section 8b "re-entrant across streams": a tiling override set for ONE stream (cd360_set_stream_tuning) is read by the
+    launches issued on that stream and by nothing else -- the shape query that sizes the row-statistics buffer follows it
+    (cd360_query_stream), the default and the other stream keep the shape-chosen tiling -- and a weight-prefetch arm of one capturing
+    stream (cd360_prefetch_arm_on) adds touch kernels to THAT capture only.  Same products either way: results agree to bf16 round-off."""
+    from cd360 import _lib, ops
+    from cd360.prefetch import WeightPrefetcher
+    g = torch.Generator(device=DEV).manual_seed(0)
+    M, N, K = 3072, 1280, 1280
+    a = torch.randn(M, K, generator=g, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g, device=DEV) * K ** -0.5).to(torch.bfloat16)
+    res = torch.randn(M, N, generator=g, device=DEV).to(torch.bfloat16)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    base = _lib.get_tuning()
+    default_tile = ops.gemm_tile_n(M, N)
+    forced = 3 if default_tile != 256 else 2  # gemm_cfg 3 = 256 x 256 tiles, 2 = 128 x 128: whichever the shape does NOT pick
+    _lib.set_stream_tuning(s1, gemm_cfg=forced)
+    try:
+        assert _lib.get_tuning() == base and _lib.get_stream_tuning(s2) == base and _lib.get_stream_tuning(s1)["gemm_cfg"] == forced
+        outs, parts = {}, {}
+        torch.cuda.synchronize()
+        for name, st in (("s1", s1), ("s2", s2)):
+            with torch.cuda.stream(st):
+                parts[name] = ops.gemm_tile_n(M, N)
+                o, stats = ops.gemm(a, w, res=res, want_stats=True)
+                outs[name] = (o, stats)
+        torch.cuda.synchronize()
+        assert parts["s2"] == default_tile and parts["s1"] != default_tile, parts
+        assert outs["s1"][1].shape[1] != outs["s2"][1].shape[1]  # the statistics buffer was sized for the tiling its stream launched
+        rel = lambda x, y: float((x.float() - y.float()).abs().max() / y.float().abs().max())
+        assert rel(outs["s1"][0], outs["s2"][0]) < 1e-2 and not torch.equal(outs["s1"][1].sum(1), outs["s1"][1].sum(1) * 0)
+        assert rel(outs["s1"][1].sum(1), outs["s2"][1].sum(1)) < 2e-2  # per-row (sum, sumsq) over all column tiles: same rows
+        assert ops.gemm_tile_n(M, N) == default_tile  # back on the default stream: untouched
+    finally:
+        _lib.clear_stream_tuning(s1)
+    assert _lib.get_stream_tuning(s1) == base
+    # prefetch arms are per capturing stream too: s1 captures two launches WITH the prefetcher (armed for s1 only), s2 launches the same
+    # product eagerly with nothing armed on it; the replayed capture and the eager launch agree bit for bit
+    big_w = (torch.randn(10240, 1280, generator=g, device=DEV) * 0.03).to(torch.bfloat16)  # 26 MB: above the prefetcher's size floor
+    x = torch.randn(3072, 1280, generator=g, device=DEV).to(torch.bfloat16)
+    ops.gemm(x, big_w)
+    torch.cuda.synchronize()
+    pf = WeightPrefetcher(torch.device(DEV))
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph, stream=s1):
+        with pf:
+            assert pf.main == s1.cuda_stream
+            y1 = ops.gemm(x, big_w)
+            y1b = ops.gemm(y1[:, :1280].contiguous(), big_w)
+    with torch.cuda.stream(s2):
+        y2 = ops.gemm(x, big_w)
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y2) and torch.isfinite(y1b.float()).all()

@@ -84,6 +84,48 @@ def test_attention_modes_and_signatures():
                                                                          "dists_uniform", "return_weights_uniform", "rgb"]
 
 
+def test_sample_py_rebinding_is_recognised_and_served_natively():
+    """sample.py:247-262 rebinds `forward` on every SpatialTransformer / BasicTransformerBlock instance.  Those two functions ARE the
+    sampling mode these classes carry natively, so the assignment is recorded instead of installed (no instance-level `forward`: the fused
+    routes stay available), `choices` is read from the rebound function's own globals at call time, and anything else assigned to `forward`
+    is installed as usual.  (Equivalence with sample.py's own functions: tests/golden/customforward_cfg3.npz, GPU tests.)"""
+    import sample_py_stub as SP
+    from cd360 import routes
+    from sgm.modules import attention as A
+    st = A.SpatialTransformer(128, 2, 64, depth=5, context_dim=32, use_linear=True, attn_type="softmax-xformers", use_checkpoint=False,
+                              image_cross=True, rgb_predict=True, far=2, num_samples=4, mode="feature-nerf", stratified=True)
+    SP.register(st, [0, 2])
+    blocks = list(st.transformer_blocks)
+    assert "forward" not in st.__dict__ and all("forward" not in b.__dict__ for b in blocks)
+    assert "_sample_py" in st.__dict__ and all("_sample_py" in b.__dict__ for b in blocks)
+    assert not A._watched(st), "a recognised rebinding is not an observer: the fused route stays open"
+    pose_blk, plain_blk = blocks[0], blocks[1]
+    assert pose_blk.image_cross and not plain_blk.image_cross and pose_blk.reference_choices is None
+    pose_blk.rendered_feat = torch.zeros(1)
+    A._sync_sample_py(pose_blk)
+    assert pose_blk.reference_choices == [0, 2] and pose_blk.rendered_feat is None and pose_blk.attn2.cache_context_kv
+    pose_blk.rendered_feat = torch.zeros(1)
+    A._sync_sample_py(pose_blk)  # unchanged choices: the cached render survives
+    assert pose_blk.rendered_feat is not None
+    SP.choices = [1, 3]          # the driver picked other views: the cached render is for the old ones
+    A._sync_sample_py(pose_blk)
+    assert pose_blk.reference_choices == [1, 3] and pose_blk.rendered_feat is None
+    A._sync_sample_py(plain_blk)
+    assert plain_blk.reference_choices is None
+    SP.choices = None
+    with pytest.raises(RuntimeError):
+        A._sync_sample_py(pose_blk)
+    # any other function assigned to `forward` is installed (and observed: strict module route)
+    other = A.BasicTransformerBlock(64, 1, 64, context_dim=32, checkpoint=False, attn_mode="softmax-xformers")
+    other.forward = (lambda self, x, **kw: x).__get__(other, type(other))
+    assert "forward" in other.__dict__ and A._watched(other)
+    # ... and so are sample.py's own, when the recognition is switched off
+    with routes.override(strict_sample_py=True):
+        blk = A.BasicTransformerBlock(64, 1, 64, context_dim=32, checkpoint=False, attn_mode="softmax-xformers")
+        SP.register(blk, [0])
+        assert "forward" in blk.__dict__ and "_sample_py" not in blk.__dict__
+
+
 def test_cpu_forward_fails_loudly():
     """There is no CPU / PyTorch fallback behind the operators."""
     from cd360 import ops

@@ -321,6 +321,49 @@ def test_native_reference_sampling_matches_sample_py_golden():
 
 
 @torch.no_grad()
+def test_sample_py_style_rebinding_runs_the_fused_route_and_matches_sample_py_golden():
+    """The UNCHANGED driver: `forward` rebound on the SpatialTransformer and on every block the way sample.py:247-262 does it (stand-in
+    functions named and shaped like sample.py's, which raise if executed: tests/golden/sample_py_stub.py), `references` registered as the
+    delta checkpoint loader does (sgm/util.py:231-235), the global `choices` set afterwards -- and NO call into cd360.sampling.  The
+    rebinding is recognised, the fused route serves it (render on the first call, cached render on the second), and the outputs are the
+    ones sample.py's OWN functions produced on the reference's modules (tests/golden/customforward_cfg3.npz); clearing `rendered_feat`
+    by plain attribute assignment, as DiffusionEngine.clear_rendered_feat does (diffusion.py:165-170), renders again."""
+    import sample_py_stub as SP
+    g = load("customforward_cfg3")
+    st = make_st(4)
+    for d in (0, 4):
+        st.transformer_blocks[d].register_buffer("references", dev(W.tensor(f"references.{d}", (5, 64, 128), seed=4)))
+    SP.register(st, g["choices"].tolist())
+    assert st._fused_route(dev(g["x0"])), "the recognised rebinding must leave the fused route open"
+    pose = unpack_cameras(g["cams"])
+    out0, xr, fgs, _, alphas, rgbs = st(dev(g["x0"]), None, context=dev(g["ctx"]), pose=pose)
+    assert xr is None
+    assert rel(out0, g["out0"]) < TOL
+    assert rel(st.transformer_blocks[0].rendered_feat, g["rend0"]) < TOL and rel(st.transformer_blocks[4].rendered_feat, g["rend4"]) < TOL
+    assert rel(fgs[0], g["fg0"]) < TOL and rel(rgbs[1], g["rgb1"]) < TOL
+    kept = st.transformer_blocks[0].rendered_feat
+    out1 = st(dev(g["x1"]), None, context=dev(g["ctx"]), pose=pose)[0]
+    assert rel(out1, g["out1"]) < TOL and st.transformer_blocks[0].rendered_feat is kept  # cached render reused (sample.py:122-124)
+    # ... bit-identical to the native switch (cd360.sampling.enable_reference_sampling) on a second instance
+    from cd360 import sampling
+    st2 = make_st(4)
+    sampling.set_references(st2, {f"transformer_blocks.{d}": dev(W.tensor(f"references.{d}", (5, 64, 128), seed=4)) for d in (0, 4)})
+    sampling.enable_reference_sampling(st2, g["choices"].tolist())
+    assert torch.equal(st2(dev(g["x0"]), None, context=dev(g["ctx"]), pose=pose)[0], out0)
+    for m in st.modules():  # DiffusionEngine.clear_rendered_feat
+        if hasattr(m, "pose_emb_layers"):
+            m.rendered_feat = None
+    out0b = st(dev(g["x0"]), None, context=dev(g["ctx"]), pose=pose)[0]
+    assert torch.equal(out0b, out0) and st.transformer_blocks[0].rendered_feat is not kept
+    # a single block entered through __call__ (a driver that patches blocks only) is served the same way
+    blk = st.transformer_blocks[0]
+    blk.rendered_feat = None
+    xt = dev(W.tensor("tok", (3, 64, 128), seed=4))
+    o = blk(xt, context=dev(g["ctx"]), context_ref=xt, pose=pose)
+    assert blk.rendered_feat is not None and rel(blk.rendered_feat, g["rend0"]) < TOL and torch.isfinite(o[0]).all()
+
+
+@torch.no_grad()
 def test_unet_dual_stream_matches_reference_golden():
     from make_golden_params import UNET_TINY
     from sgm.modules.diffusionmodules.openaimodel import UNetModel

@@ -706,9 +706,42 @@ def stride_sweep():
         print(line, flush=True)
 
 
+def store_wt():
+    """Write-through (sc1) output stores against plain ones, per shape of the step, as chains of n dependent-by-stream launches replayed
+    from one hipGraph (every launch's boundary -- the write-back of the lines its predecessor left dirty -- is inside the time)."""
+    for name, M, N, K, epi in SHAPES:
+        a = rnd(M, K, seed=1).to(torch.bfloat16)
+        w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
+        b32 = rnd(N, seed=3)
+        r = rnd(M, N, seed=4).to(torch.bfloat16) if epi == "res" else None
+        st, ws = ops.row_stats(a), w.float().sum(1).contiguous()
+        if epi == "res":
+            fn = lambda: ops.gemm(a, w, bias=b32, res=r, want_stats=True)
+        elif epi == "geglu":
+            fn = lambda: ops.gemm(a, w, bias=b32, ln=(st, ws, 1e-5), geglu=True)
+        elif epi == "ln":
+            fn = lambda: ops.gemm(a, w, bias=b32, ln=(st, ws, 1e-5))
+        else:
+            fn = lambda: ops.gemm(a, w, bias=b32)
+        ts = {0: [], 1: []}
+        outs = {}
+        for rep in range(3):
+            for wt in (0, 1):
+                ENV["CD360_STORE_WT"] = str(wt)
+                ts[wt].append(timeit_graph(fn, n=20))
+                o = fn()
+                outs[wt] = (o[0] if isinstance(o, tuple) else o).clone()
+        same = torch.equal(outs[0], outs[1])
+        print(f"{name:8s} M={M:6d} N={N:5d} K={K:4d} {epi:5s} | plain {min(ts[0]):7.1f} us | write-through {min(ts[1]):7.1f} us "
+              f"({(min(ts[1]) / min(ts[0]) - 1) * 100:+.1f} %) | outputs bit-identical: {same}", flush=True)
+    ENV.pop("CD360_STORE_WT", None)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["check", "time"]
     good = True
+    if "store_wt" in what:
+        store_wt()
     if "movers" in what:
         good = movers() and good
     if "ff1" in what:
