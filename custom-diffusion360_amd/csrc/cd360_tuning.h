@@ -13,7 +13,7 @@ typedef struct cd360_tuning {
   int32_t gemm_group_m;     // > 0: token tiles per tile group
   int32_t gemm_movers;      // 0 | 4: mover waves off / on wherever the arrangement can take them
   int32_t gemm_ksplit;      // 0 | 1 | 2: wave arrangement of the 128 x 128 four-buffer tiling
-  int32_t conv_cfg;         // 1..4: tiling of cd360_conv3x3_dma_bf16
+  int32_t conv_cfg;         // 1..6: tiling of cd360_conv3x3_dma_bf16
   int32_t conv_dma;         // 0: 3 x 3 / 1 x 1 convolutions on the register-staged kernel
   int32_t conv_kgroup;      // > 0: K-order group size (set BEFORE weights are packed)
   int32_t conv_wide;        // 0: register-staged kernel never uses its 160-channel tiles

@@ -129,7 +129,11 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   static_assert(MV == 0 || (EPI >= 0 && EPI <= 10), "mover waves: every epilogue (in the attention epilogues they also fetch K / V)");
   constexpr int KPW = 4 / KS;                      // k-steps of a K-tile that one wave multiplies
   constexpr int BM = WM * NMB * 32, BN = WN * NCB * 32;
-  constexpr uint32_t XB = BM * 128, WB = BN * 128;  // bytes of one buffer of each operand (64-deep K-tile, 128-byte rows)
+  // bytes of one buffer of each operand (64-deep K-tile, 128-byte rows), rounded UP to whole DMA pieces: a tile side that is not a
+  // multiple of the 8 * (moving waves) rows one piece covers (192 x 320 with six waves: 320 = 6.67 pieces) gets a last piece whose tail
+  // rows -- past the operand's end: zeros; or the next tile's rows: never read -- land in padding rows of the buffer
+  constexpr int PR_ = 8 * (MV ? MV : WM * WN * KS);
+  constexpr uint32_t XB = ((BM + PR_ - 1) / PR_) * PR_ * 128, WB = ((BN + PR_ - 1) / PR_) * PR_ * 128;
   // epilogue: 0 linear, 1 GEGLU, 2 / 3 / 4 small-Nk attention on the projected tile with 2 / 4 / 6 groups of 16 keys, 7 / 8 / 9 the same
   // with 5 / 3 / 1 groups (the last 32-key block of scores is half used: 77 text keys are 5 groups, not 6)
   // EPI 6 = linear epilogue + the per-slab channel statistics of EPI 5 (a Linear whose output feeds a GroupNorm: SpatialTransformer.proj_out)
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   constexpr uint32_t XSTR = ATTN ? BB : XB, WSTR = ATTN ? BB : WB;  // byte distance between consecutive buffers of one operand
   constexpr uint32_t XREG = 0, WREG = ATTN ? XB : NBUF * XB;
   constexpr int PR = 8 * NWD;                      // rows one DMA piece of all moving waves covers (8 per wave)
-  constexpr int XP = BM / PR, WP = BN / PR;        // pieces per wave per K-tile
+  constexpr int XP = (BM + PR - 1) / PR, WP = (BN + PR - 1) / PR;  // pieces per wave per K-tile
   constexpr int NP = XP + WP, NMMA = NCB * NMB;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   // (LDS-DMA destinations of the attention epilogues are formed in address space 3 from here: a generic pointer that reaches the cast
@@ -1113,7 +1117,8 @@ int launch_mv(const GemmParams& p0, hipStream_t stream) {
   constexpr int NK16 = (EPI == 4 || EPI == 10) ? 6 : EPI == 2 ? 2 : EPI == 3 ? 4 : EPI == 7 ? 5 : EPI == 8 ? 3 : 1;
   constexpr int ATTN_KV_END = (BM + BN) * 128 + WN * (EPI == 10 ? 96 * 64 + 64 * 128 : 2 * NK16 * 16 * 128);  // (EPI 10: the packed fp8 image)
   constexpr int ATTN_BYTES = ATTN ? ATTN_KV_END + ((BN * 4 <= 1024 && ATTN_KV_END + 2048 <= 160 * 1024) ? 2048 : 0) : 0;  // + bias / wsum slices (BW_LDS)
-  constexpr int RING_BYTES = NBUF * (BM + BN) * 128, STAGE_BYTES0 = ATTN ? 0 : BM * BN * 2 + (KS == 2 ? BM * BN * 4 : 0);
+  constexpr int PRL = 8 * (MV ? MV : WM * WN * KS);  // rows per DMA piece: the ring's buffers are whole pieces (see XB / WB in the kernel)
+  constexpr int RING_BYTES = NBUF * (((BM + PRL - 1) / PRL) * PRL + ((BN + PRL - 1) / PRL) * PRL) * 128, STAGE_BYTES0 = ATTN ? 0 : BM * BN * 2 + (KS == 2 ? BM * BN * 4 : 0);
   constexpr int STAGE_BYTES = STAGE_BYTES0 > ATTN_BYTES ? STAGE_BYTES0 : ATTN_BYTES;
 #ifdef CD360_GEMM_STAMP
   constexpr int BASE_BYTES = RING_BYTES > STAGE_BYTES ? RING_BYTES : STAGE_BYTES;
@@ -1123,6 +1128,7 @@ int launch_mv(const GemmParams& p0, hipStream_t stream) {
   constexpr int LDS_BYTES = RING_BYTES > STAGE_BYTES ? RING_BYTES : STAGE_BYTES;
 #endif
   static_assert(LDS_BYTES <= 160 * 1024, "LDS of one CU");
+  static_assert(!ATTN || (BM % PRL == 0 && BN % PRL == 0), "attention epilogues: exact pieces (ATTN_KV_END assumes unpadded buffers)");
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.N + BN - 1) / BN;
   const cd360_tuning& tune = cd360_tune();
@@ -1558,17 +1564,26 @@ extern "C" int cd360_qproj_attn_bf16(const void* a, const void* w, void* out, in
 namespace {
 // tilings (pixels x channels): 1 = 256 x 320 (Cout % 320 == 0: the 128^2 level, one channel tile), 2 = 256 x 128 / 3 buffers,
 // 3 = 256 x 256, 4 = 128 x 128 / 4 buffers (the 32^2 level: 240 tiles)
-constexpr int CONV_BM[5] = {0, 256, 256, 256, 128}, CONV_BN[5] = {0, 320, 128, 256, 128}, CONV_SLAB[5] = {0, 64, 64, 128, 64};
+// 5 = 192 x 320 (round 5; six waves of 64 x 160): the 320-channel convolutions at 128^2, M = 49152 = 256 tiles of 192 -- one per CU, where
+// tiling 1 leaves a quarter of the CUs without a workgroup (192 tiles)
+// (six waves put two on two SIMDs and one on the others); 6 = the same tile as twelve waves of 32 x 160 (three per SIMD)
+constexpr int NCONV = 6;
+constexpr int CONV_BM[NCONV + 1] = {0, 256, 256, 256, 128, 192, 192}, CONV_BN[NCONV + 1] = {0, 320, 128, 256, 128, 320, 320},
+              CONV_SLAB[NCONV + 1] = {0, 64, 64, 128, 64, 64, 32};
 int pick_conv_cfg(long M, int Cout) {
   {
     const int c = cd360_tune().conv_cfg;
-    if (c >= 1 && c <= 4 && !(c == 1 && Cout % 320)) return c;
+    if (c >= 1 && c <= NCONV && !((c == 1 || c >= 5) && Cout % 320)) return c;
   }
-  static const double weight[5] = {0, 1.0, 0.93, 1.0, 0.85};  // relative speed of the tilings on full tiles (tools/bench_kernels.py conv)
+  // relative speed of the tilings on full tiles (tools/bench_kernels.py conv / conv_tilings).  Round 5, same box, interleaved, us (tiling 1 /
+  // 5 / 6): 320 -> 320 at 128^2 95.5 / 94.9 / 91.6, 640 -> 320 175.6 / 174.5 / 169.0, 960 -> 320 256.6 / 257.6 / 247.7, 640 -> 640 351.6 /
+  // 337.2 / 331.4, outputs bit-identical: six waves (5) put two waves on two of the SIMDs and gain nothing from the 256 busy CUs; twelve
+  // (6) finish a 192-row tile in 0.96 of a 256-row tile's time = 0.78 of tiling 1 per row, which beats its 0.75 CU fill.  5 stays A/B only.
+  static const double weight[NCONV + 1] = {0, 1.0, 0.93, 1.0, 0.85, 0.0, 0.78};  // relative speed of the tilings on full tiles (tools/bench_kernels.py conv)
   int best = 4;
   double best_eff = -1.0;
-  for (int c = 1; c <= 4; ++c) {
-    if (c == 1 && Cout % 320) continue;
+  for (int c = 1; c <= NCONV; ++c) {
+    if ((c == 1 || c >= 5) && Cout % 320) continue;
     const long tm = (M + CONV_BM[c] - 1) / CONV_BM[c], tn = (Cout + CONV_BN[c] - 1) / CONV_BN[c], nwg = tm * tn, rounds = (nwg + 255) / 256;
     const double eff = (double)nwg / (double)(rounds * 256) * (double)Cout / (double)(tn * CONV_BN[c]) * weight[c];
     if (eff > best_eff) { best_eff = eff; best = c; }
@@ -1618,6 +1633,8 @@ extern "C" int cd360_conv3x3_dma_bf16(const void* x, const void* w_packed, const
     case 1: return launch_epi<4, 2, 5, 2, 2, 5>(p, (hipStream_t)stream);
     case 2: return launch_epi<4, 2, 2, 2, 3, 5>(p, (hipStream_t)stream);
     case 3: return launch_epi<2, 4, 2, 4, 2, 5>(p, (hipStream_t)stream);
+    case 5: return launch_epi<3, 2, 5, 2, 2, 5>(p, (hipStream_t)stream);
+    case 6: return launch_epi<6, 2, 5, 1, 2, 5>(p, (hipStream_t)stream);
     default: return launch_128x4<5>(p, (hipStream_t)stream);
   }
 }
@@ -1649,6 +1666,8 @@ extern "C" int cd360_conv_up2x_bf16(const void* x, const void* w_phases, const v
     case 1: return launch_epi<4, 2, 5, 2, 2, 5>(p, (hipStream_t)stream);
     case 2: return launch_epi<4, 2, 2, 2, 3, 5>(p, (hipStream_t)stream);
     case 3: return launch_epi<2, 4, 2, 4, 2, 5>(p, (hipStream_t)stream);
+    case 5: return launch_epi<3, 2, 5, 2, 2, 5>(p, (hipStream_t)stream);
+    case 6: return launch_epi<6, 2, 5, 1, 2, 5>(p, (hipStream_t)stream);
     default: return launch_128x4<5>(p, (hipStream_t)stream);
   }
 }

@@ -116,8 +116,38 @@ def gemm(tag, M, K, N):
     print(f"gemm {tag}: M{M} K{K} N{N}: cd360(+bias+res) {us:8.1f} us {fl / us / 1e6:7.1f} TF/s | hipBLASLt+add {us2:8.1f} us {fl / us2 / 1e6:7.1f} TF/s | hipBLASLt {us3:8.1f} us {fl / us3 / 1e6:7.1f} TF/s", flush=True)
 
 
+def conv_tilings():
+    """The 320-channel convolutions of the 128^2 level (and the 640-channel one behind the Upsample) on the tilings that fit them:
+    1 = 256 x 320 (192 tiles at M = 49152), 5 = 192 x 320 / six waves (256 tiles), 6 = 192 x 320 / twelve waves; interleaved, graph-timed,
+    outputs and slab statistics compared bit for bit with tiling 1."""
+    from cd360 import _lib
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from bench_gemm import timeit_graph
+    for tag, N, H, W, cin, cout in (("L0", 3, 128, 128, 320, 320), ("L0 up", 3, 128, 128, 960, 320), ("L0 cat", 3, 128, 128, 640, 320),
+                                    ("L0 640", 3, 128, 128, 640, 640)):
+        x = torch.randn(N, H * W, cin, device=dev).to(BF)
+        wp = (torch.randn(cout, 9 * cin, device=dev) / (9 * cin) ** 0.5).to(BF)
+        bias = torch.randn(cout, device=dev)
+        fl = 2.0 * N * H * W * 9 * cin * cout
+        ts, outs = {}, {}
+        for rep in range(3):
+            for cfg in (-1, 1, 5, 6):
+                _lib.set_tuning(conv_cfg=cfg)
+                ts.setdefault(cfg, []).append(timeit_graph(lambda: ops.conv_igemm(x, wp, bias, N, H, W, 9), n=10, reps=3))
+                if rep == 0:
+                    o = ops.conv_igemm(x, wp, bias, N, H, W, 9, want_stats=True)
+                    outs[cfg] = (o[0].clone(), o[1].float().sum(1).clone())
+        _lib.set_tuning(conv_cfg=-1)
+        same = {c: (torch.equal(outs[c][0], outs[1][0]), float((outs[c][1] - outs[1][1]).abs().max() / outs[1][1].abs().max())) for c in (5, 6)}
+        print(f"conv {tag}: N{N} {H}x{W} {cin}->{cout}: " + " | ".join(f"cfg {c}: {min(v):7.1f} us {fl / min(v) / 1e6:6.0f} TF/s" for c, v in ts.items())
+              + f" | vs cfg 1 (output bit-identical, stats rel): {same}", flush=True)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["attn", "nerf", "gn", "conv"]
+    if "conv_tilings" in which:
+        conv_tilings()
+        sys.exit(0)
     print("env CD360_ATTN_FAST =", os.environ.get("CD360_ATTN_FAST"))
     if "gemm_tn" in which:  # weight-gradient shapes of the config-4 step
         for (M, N, K) in ((98304, 1280, 1280), (393216, 640, 640), (24576, 1280, 1280), (98304, 1280, 112), (98304, 8, 1280), (1024, 1280, 1280), (4096, 1280, 128)):
