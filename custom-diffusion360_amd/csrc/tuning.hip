@@ -50,7 +50,8 @@ int sanitize(const cd360_tuning* t, cd360_tuning* out) {
 }
 }  // namespace
 
-const cd360_tuning& cd360_tune() { return tl_tune ? *tl_tune : g_tuning; }
+// (a query context left on some thread by cd360_query_stream is honoured only while overrides exist at all)
+const cd360_tuning& cd360_tune() { return (tl_tune && g_nstreams.load(std::memory_order_relaxed) > 0) ? *tl_tune : g_tuning; }
 
 Cd360TuneScope::Cd360TuneScope(void* stream) : prev_(tl_tune), set_(false) {
   if (g_nstreams.load(std::memory_order_relaxed) == 0) return;

@@ -737,9 +737,38 @@ def store_wt():
     ENV.pop("CD360_STORE_WT", None)
 
 
+def intercept():
+    """Per-launch fixed cost of the one-round shapes: time against K (1 .. 80 K-tiles) at M = 3072, N = 1280 for the epilogue variants
+    the step uses; a straight-line fit gives the time per K-tile and the intercept (launch boundary + prologue + epilogue)."""
+    M, N = 3072, 1280
+    for label, kw in (("plain", {}), ("bias", {"bias": True}), ("bias+res+stats", {"bias": True, "res": True, "stats": True}),
+                      ("ln+bias", {"bias": True, "ln": True})):
+        pts = []
+        for K in (64, 128, 256, 640, 1280, 2560, 5120):
+            a = rnd(M, K, seed=1).to(torch.bfloat16)
+            w = rnd(N, K, seed=2, scale=K ** -0.5).to(torch.bfloat16)
+            b32 = rnd(N, seed=3) if kw.get("bias") else None
+            r = rnd(M, N, seed=4).to(torch.bfloat16) if kw.get("res") else None
+            ln = (ops.row_stats(a), w.float().sum(1).contiguous(), 1e-5) if kw.get("ln") else None
+            fn = lambda: ops.gemm(a, w, bias=b32, res=r, ln=ln, want_stats=bool(kw.get("stats")))
+            pts.append((K // 64, timeit_graph(fn, n=30)))
+        n = len(pts)
+        sx, sy = sum(p[0] for p in pts[2:]), sum(p[1] for p in pts[2:])
+        sxx, sxy = sum(p[0] ** 2 for p in pts[2:]), sum(p[0] * p[1] for p in pts[2:])
+        m = n - 2
+        slope = (m * sxy - sx * sy) / (m * sxx - sx * sx)
+        icpt = (sy - slope * sx) / m
+        print(f"{label:15s}: " + "  ".join(f"K={64 * k:4d} {t:6.1f}" for k, t in pts) + f"  | fit over K >= 256: {slope:.3f} us per K-tile + {icpt:.1f} us", flush=True)
+    # the floor: a kernel with nothing to do, chained the same way
+    x = torch.zeros(64, device="cuda")
+    print(f"empty-ish torch kernel chain (x.add_(1) on 64 floats): {timeit_graph(lambda: x.add_(1.0), n=50):.2f} us per launch", flush=True)
+
+
 if __name__ == "__main__":
     what = sys.argv[1:] or ["check", "time"]
     good = True
+    if "intercept" in what:
+        intercept()
     if "store_wt" in what:
         store_wt()
     if "movers" in what:
