@@ -127,6 +127,11 @@ def load(check_symbols: bool = True):
             f"{LIB_PATH} not found: the HIP extension has not been built (run `python __graft_entry__.py`). "
             "There is no CPU or PyTorch fallback for the cd360 operators."
         )
+    # torch FIRST: its wheel carries its own HIP runtime (torch/lib/libamdhip64.so), and the device pointers and streams this library
+    # is handed belong to THAT runtime.  Loaded before torch, libcd360_hip.so would pull in the system runtime (/opt/rocm/lib) as a second
+    # copy in the process and every launch on torch's streams would fail ("HIP launch failure": build() followed by smoke() in one
+    # process did exactly that).  With torch's runtime already mapped, the dynamic loader binds this library's libamdhip64 dependency to it.
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     if os.environ.get("CD360_LIB"):
         check_symbols = False  # an explicitly named older / probe build (same-box A/B): entry points it predates stay unbound
