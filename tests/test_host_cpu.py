@@ -363,3 +363,47 @@ def test_layernorm_fold_and_geglu_packing_algebra():
     for grp in range(inner // 32):
         blk = perm[grp * 64:(grp + 1) * 64]
         assert blk[:32].tolist() == list(range(grp * 32, grp * 32 + 32)) and blk[32:].tolist() == list(range(inner + grp * 32, inner + grp * 32 + 32))
+
+
+def test_per_stream_tuning_table_semantics_without_a_gpu():
+    """cd360_set_stream_tuning / cd360_get_stream_tuning / cd360_query_stream are host-side bookkeeping: exercised here on made-up stream
+    handles (no launch).  An override belongs to its stream only; the default is untouched; removing restores the default; the table holds
+    16 streams and says so; the shape queries of the calling thread follow cd360_query_stream, other threads do not see that context."""
+    import ctypes
+    import threading
+    from cd360 import _lib
+    lib = _lib.load()
+    base = _lib.get_tuning()
+    h1, h2 = 0x1000, 0x2000
+    try:
+        _lib.set_stream_tuning(h1, gemm_cfg=3)
+        assert _lib.get_stream_tuning(h1)["gemm_cfg"] == 3 and _lib.get_stream_tuning(h2) == base and _lib.get_tuning() == base
+        _lib.set_stream_tuning(h1, conv_cfg=2)  # a second field on the same stream: the first is kept
+        assert _lib.get_stream_tuning(h1)["gemm_cfg"] == 3 and _lib.get_stream_tuning(h1)["conv_cfg"] == 2
+        # shape queries: M = 3072, N = 1280 picks 128-wide tiles by default, 256-wide under gemm_cfg = 3
+        default_tile = lib.cd360_gemm_tile_n(3072, 1280)
+        lib.cd360_query_stream(ctypes.c_void_p(h1))
+        forced_tile = lib.cd360_gemm_tile_n(3072, 1280)
+        seen = {}
+        t = threading.Thread(target=lambda: seen.update(other=lib.cd360_gemm_tile_n(3072, 1280)))
+        t.start(); t.join()
+        lib.cd360_query_stream(ctypes.c_void_p(h2))  # a stream without override: the default again
+        assert (default_tile, forced_tile, seen["other"], lib.cd360_gemm_tile_n(3072, 1280)) == (128, 256, 128, 128)
+        lib.cd360_query_stream(None)
+        # capacity: 16 streams, the 17th is refused, a known stream can still be updated
+        extra = [0x10000 + 16 * i for i in range(15)]
+        for h in extra:
+            _lib.set_stream_tuning(h, gemm_cfg=2)
+        t17 = _lib.Tuning()
+        lib.cd360_get_tuning(ctypes.byref(t17))
+        assert lib.cd360_set_stream_tuning(ctypes.c_void_p(0x99999), ctypes.byref(t17)) == -2
+        _lib.set_stream_tuning(h1, gemm_cfg=1)
+        assert _lib.get_stream_tuning(h1)["gemm_cfg"] == 1
+        bad = _lib.Tuning()
+        bad.size = 4
+        assert lib.cd360_set_stream_tuning(ctypes.c_void_p(h1), ctypes.byref(bad)) == -1  # ABI size check
+    finally:
+        for h in [h1, h2] + [0x10000 + 16 * i for i in range(15)]:
+            _lib.clear_stream_tuning(h)
+    assert _lib.get_stream_tuning(h1) == base and _lib.get_tuning() == base and not _lib._stream_overrides
+    assert lib.cd360_gemm_tile_n(3072, 1280) == 128
