@@ -33,6 +33,7 @@ SIGNATURES = {
     "cd360_nerf_k_padded": (c_int, []),
     "cd360_nerf_mlp_aggregate": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
     "cd360_nerf_mlp_aggregate_bwd": (c_int, [_P, _P, _P, _P, c_int] + [_P] * 15 + [c_int] * 5 + [_P]),
+    "cd360_nerf_mlp_aggregate_bwd_det": (c_int, [_P, _P, _P, _P, c_int] + [_P] * 16 + [c_int] * 5 + [_P]),
     "cd360_volrender": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cd360_volrender_bwd": (c_int, [_P, _P, _P, _P, c_int] + [_P] * 8 + [c_int] * 6 + [_P]),
     "cd360_rowdot4_bf16": (c_int, [_P, _P, _P, c_int64, c_int, _P]),

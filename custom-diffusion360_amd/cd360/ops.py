@@ -347,15 +347,18 @@ def nerf_mlp_aggregate_bwd(cams, xs, ys, t, Y, zP, lv, cview, Wk, img_map, g, ls
     dz = torch.empty(b, n, hw * S, C, dtype=torch.bfloat16, device=dev)
     F = torch.empty(b, n, hw * S, kp, dtype=torch.bfloat16, device=dev)
     dY = torch.zeros(Y.shape, dtype=torch.float32, device=dev) if scatter else None
-    dlogit = torch.zeros(b, n, hw * S, dtype=torch.float32, device=dev)
+    # dlogit: every 64-channel chunk stores its term into `parts`, the library sums them in chunk order -- no atomics, so the view-logit
+    # gradients (and with them a whole fine-tuning step) are bit-reproducible run to run (cd360_nerf_mlp_aggregate_bwd_det)
+    dlogit = torch.empty(b, n, hw * S, dtype=torch.float32, device=dev)
+    parts = torch.empty(C // 64, b, n, hw * S, dtype=torch.float32, device=dev)
     dlv = torch.zeros(lv.shape, dtype=torch.float32, device=dev) if scatter else None
     dcview = torch.zeros(b, n, dtype=torch.float32, device=dev) if scatter else None
     stride = 0 if t.dim() == 1 else S
     with _timed("nerf_mlp_aggregate_bwd", 2.0 * b * n * hw * S * 99 * C, 2.0 * C * (2 * b * n * hw + (2 + n) * b * hw * S)):
-        check(_lib.load().cd360_nerf_mlp_aggregate_bwd(_ptr(cams), _ptr(xs), _ptr(ys), _ptr(t.contiguous()), stride, _ptr(Y), _ptr(zP), _ptr(lv),
-                                                      _ptr(cview), _ptr(Wk), _ptr(img_map), _ptr(g), _ptr(lse), _ptr(dg), _ptr(dz), _ptr(F), _ptr(dY),
-                                                      _ptr(dlogit), _ptr(dlv), _ptr(dcview), b, n, r, S, C, _stream()),
-              "cd360_nerf_mlp_aggregate_bwd")
+        check(_lib.load().cd360_nerf_mlp_aggregate_bwd_det(_ptr(cams), _ptr(xs), _ptr(ys), _ptr(t.contiguous()), stride, _ptr(Y), _ptr(zP), _ptr(lv),
+                                                          _ptr(cview), _ptr(Wk), _ptr(img_map), _ptr(g), _ptr(lse), _ptr(dg), _ptr(dz), _ptr(F),
+                                                          _ptr(dY), _ptr(dlogit), _ptr(parts), _ptr(dlv), _ptr(dcview), b, n, r, S, C, _stream()),
+              "cd360_nerf_mlp_aggregate_bwd_det")
     return dz, F, dY, dlv, dcview, dlogit
 
 

@@ -42,7 +42,9 @@ struct NerfBwdParams {
   uint16_t* dz;         // [b, n, hw*S, C] out
   uint16_t* F;          // [b, n, hw*S, KP] out
   float* dY;            // [tables, hw, C] fp32, zero-initialised by the caller, atomically accumulated
-  float* dlogit;        // [b, n, hw*S] fp32, zero-initialised by the caller, atomically accumulated
+  float* dlogit;        // [b, n, hw*S] fp32, zero-initialised by the caller, atomically accumulated (unless dlogit_parts)
+  float* dlogit_parts;  // NULL, or [C / 64, b, n, hw*S] fp32: every channel chunk STORES its term (one writer per element), summed afterwards
+                        // in chunk order by nerf_dlogit_sum_kernel: the deterministic form (cd360_nerf_mlp_aggregate_bwd_det)
   int b, n, r, S, C, t_ray_stride, ncc, ngroups;
 };
 
@@ -223,8 +225,20 @@ __global__ __launch_bounds__(256) void nerf_bwd_kernel(NerfBwdParams p) {
         }
       }
       dot += __shfl_xor(dot, 32);
-      if (valid && hh == 0) atomicAdd(p.dlogit + img * npts + pt, a * dot);
+      if (valid && hh == 0) {
+        if (p.dlogit_parts) p.dlogit_parts[((long)cc * p.b * p.n + img) * npts + pt] = a * dot;
+        else atomicAdd(p.dlogit + img * npts + pt, a * dot);
+      }
     }
+  }
+}
+
+// dlogit[i] = sum over the channel chunks, in chunk order, of parts[cc][i]: a fixed order of additions whatever order the chunks' workgroups ran in
+__global__ __launch_bounds__(256) void nerf_dlogit_sum_kernel(const float* __restrict__ parts, float* __restrict__ dlogit, long total, int ncc) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    float acc = parts[i];
+    for (int cc = 1; cc < ncc; ++cc) acc += parts[(long)cc * total + i];
+    dlogit[i] = acc;
   }
 }
 
@@ -273,10 +287,10 @@ __global__ __launch_bounds__(256) void nerf_logit_bwd_kernel(const float* __rest
 // Outputs: dz [b, n, hw*S, C] bf16 and F [b, n, hw*S, 112] bf16 (fully written); dY [tables, hw, C], dlogit [b, n, hw*S],
 // dlv [tables, hw], dcview [b, n] fp32 -- these four are ACCUMULATED atomically: the caller zero-fills them.  dY may be NULL and
 // dlv / dcview may both be NULL (no scatter: the caller reduces dz and dlogit itself, e.g. against gathered reference features).
-extern "C" int cd360_nerf_mlp_aggregate_bwd(const void* cams, const void* xs, const void* ys, const void* t, int t_ray_stride, const void* Y,
-                                            const void* zP, const void* lv, const void* cview, const void* Wk, const void* img_map,
-                                            const void* g, const void* lse, const void* dg, void* dz, void* F, void* dY, void* dlogit, void* dlv,
-                                            void* dcview, int b, int n, int r, int S, int C, void* stream) {
+static int nerf_bwd_launch(const void* cams, const void* xs, const void* ys, const void* t, int t_ray_stride, const void* Y,
+                           const void* zP, const void* lv, const void* cview, const void* Wk, const void* img_map,
+                           const void* g, const void* lse, const void* dg, void* dz, void* F, void* dY, void* dlogit, void* dlogit_parts, void* dlv,
+                           void* dcview, int b, int n, int r, int S, int C, void* stream) {
   if (!cams || !xs || !ys || !t || !Y || !zP || !lv || !cview || !Wk || !g || !lse || !dg || !dz || !F || !dlogit) return CD360_ERR_ARG;
   if ((dlv == nullptr) != (dcview == nullptr)) return CD360_ERR_ARG;
   if (b <= 0 || n <= 0 || r <= 0 || S <= 0 || C <= 0 || C % CN) return CD360_ERR_SHAPE;
@@ -287,6 +301,7 @@ extern "C" int cd360_nerf_mlp_aggregate_bwd(const void* cams, const void* xs, co
   p.Y = (const uint16_t*)Y; p.zP = (const uint16_t*)zP; p.lv = (const float*)lv; p.cview = (const float*)cview;
   p.Wk = (const uint16_t*)Wk; p.img_map = (const int*)img_map; p.g = (const uint16_t*)g; p.lse = (const float*)lse;
   p.dg = (const uint16_t*)dg; p.dz = (uint16_t*)dz; p.F = (uint16_t*)F; p.dY = (float*)dY; p.dlogit = (float*)dlogit;
+  p.dlogit_parts = (float*)dlogit_parts;
   p.b = b; p.n = n; p.r = r; p.S = S; p.C = C; p.t_ray_stride = t_ray_stride;
   p.ncc = C / CN;
   const long npts = (long)r * r * S;
@@ -295,10 +310,37 @@ extern "C" int cd360_nerf_mlp_aggregate_bwd(const void* cams, const void* xs, co
   if (nwg > 0x7fffffffL) return CD360_ERR_SHAPE;
   hipLaunchKernelGGL(nerf_bwd_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
   CD360_LAUNCH_CHECK();
+  if (dlogit_parts) {
+    const long total = (long)b * n * npts, blocks = (total + 255) / 256;
+    hipLaunchKernelGGL(nerf_dlogit_sum_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)dlogit_parts, (float*)dlogit, total, p.ncc);
+    CD360_LAUNCH_CHECK();
+  }
   if (!dlv) return CD360_OK;
   const long blocks = (npts + 255) / 256;
   hipLaunchKernelGGL(nerf_logit_bwd_kernel, dim3((unsigned)(blocks > 1024 ? 1024 : blocks), (unsigned)(b * n)), dim3(256), 0, (hipStream_t)stream,
                      p.cams, p.xs, p.ys, p.t, t_ray_stride, p.img_map, (const float*)dlogit, (float*)dlv, (float*)dcview, n, r, S);
   CD360_LAUNCH_CHECK();
   return CD360_OK;
+}
+
+extern "C" int cd360_nerf_mlp_aggregate_bwd(const void* cams, const void* xs, const void* ys, const void* t, int t_ray_stride, const void* Y,
+                                            const void* zP, const void* lv, const void* cview, const void* Wk, const void* img_map,
+                                            const void* g, const void* lse, const void* dg, void* dz, void* F, void* dY, void* dlogit, void* dlv,
+                                            void* dcview, int b, int n, int r, int S, int C, void* stream) {
+  return nerf_bwd_launch(cams, xs, ys, t, t_ray_stride, Y, zP, lv, cview, Wk, img_map, g, lse, dg, dz, F, dY, dlogit, nullptr, dlv, dcview, b, n, r, S, C,
+                         stream);
+}
+
+// The deterministic form: dlogit is WRITTEN (no zero-fill needed), as the sum in chunk order of the per-channel-chunk terms the kernel stores
+// into dlogit_parts [C / 64, b, n, hw*S] fp32 (scratch, fully written) -- no atomic touches it, so a fine-tuning step is bit-reproducible
+// run to run (with fp32 atomics the order of ~C / 64 additions per element varied, the view-logit parameters' gradients moved in their last
+// bits, and once in a while that flipped the bf16 rounding of a trained weight: a 1e-4 change of the loss a few steps later).
+extern "C" int cd360_nerf_mlp_aggregate_bwd_det(const void* cams, const void* xs, const void* ys, const void* t, int t_ray_stride, const void* Y,
+                                                const void* zP, const void* lv, const void* cview, const void* Wk, const void* img_map,
+                                                const void* g, const void* lse, const void* dg, void* dz, void* F, void* dY, void* dlogit,
+                                                void* dlogit_parts, void* dlv, void* dcview, int b, int n, int r, int S, int C, void* stream) {
+  if (!dlogit_parts) return CD360_ERR_ARG;
+  return nerf_bwd_launch(cams, xs, ys, t, t_ray_stride, Y, zP, lv, cview, Wk, img_map, g, lse, dg, dz, F, dY, dlogit, dlogit_parts, dlv, dcview, b, n, r,
+                         S, C, stream);
 }

@@ -208,6 +208,14 @@ int cd360_nerf_mlp_aggregate_bwd(const void* cams, const void* xs, const void* y
                                  const void* zP, const void* lv, const void* cview, const void* Wk, const void* img_map, const void* g,
                                  const void* lse, const void* dg, void* dz, void* F, void* dY, void* dlogit, void* dlv, void* dcview, int b,
                                  int n, int r, int S, int C, void* stream);
+/* The deterministic form (what the package calls): dlogit is WRITTEN -- no zero-fill -- as the sum, in channel-chunk order, of the terms the
+ * kernel stores into the scratch dlogit_parts [C / 64, b, n, hw*S] fp32 (fully written); no atomic touches it.  dY / dlv / dcview as above.
+ * With fp32 atomics the ~C / 64 additions per element came in launch order, the view-logit parameters' gradients moved in their last bits
+ * from run to run, and now and then that flipped the bf16 rounding of a trained weight (1e-4 of the loss a few steps later). */
+int cd360_nerf_mlp_aggregate_bwd_det(const void* cams, const void* xs, const void* ys, const void* t, int t_ray_stride, const void* Y,
+                                     const void* zP, const void* lv, const void* cview, const void* Wk, const void* img_map, const void* g,
+                                     const void* lse, const void* dg, void* dz, void* F, void* dY, void* dlogit, void* dlogit_parts, void* dlv,
+                                     void* dcview, int b, int n, int r, int S, int C, void* stream);
 
 /* Backward of cd360_volrender for the fine-tuning loop (the reference differentiates VolRender.forward (nerfsd_pytorch3d.py:170-231)
  * and _TruncExp, whose backward is g * exp(clamp(x, -15, 15)) (attention.py:203-207), through torch autograd).  Same feats /

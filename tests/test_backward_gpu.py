@@ -512,6 +512,18 @@ def test_pose_block_gradients_at_sdxl_width_match_oracle_autograd(C, heads, r):
             worst[k] = rel(params[k].grad, want[k])
     print(f"C={C}: forward (out, fg, alphas, rgb) {tuple(round(e, 4) for e in fwd)}; gradient deviations {dict((k.split('.', 1)[-1][-28:], round(v, 4)) for k, v in worst.items())}")
     assert max(fwd) < 1e-2 and max(worst.values()) < 2e-2, (fwd, worst)  # measured: forward <= 6.0e-3, gradients <= 7.8e-3
+    # ... and bit-reproducible: the same forward + backward again, several times -- every gradient identical to the last bit.  (Until
+    # round 5 the view-logit gradients went through fp32 atomics, one addition per 64-channel chunk in launch order: nviews.weight moved in
+    # its last bits from run to run, and once in a while that flipped the bf16 rounding of a trained weight a few optimiser steps later.)
+    first = {k: params[k].grad.clone() for k in names}
+    for _ in range(6):
+        for k in names:
+            params[k].grad = None
+        o3, fg3, _, _, rgb3 = blk(x.to(DEV), context=ctx.to(DEV), context_ref=cref.to(DEV), pose=pose)
+        torch.autograd.backward([o3, fg3, rgb3], [cot[0].to(DEV, torch.bfloat16), cot[1].to(DEV).reshape(fg3.shape), cot[2].to(DEV).reshape(rgb3.shape)])
+        assert torch.equal(o3, o2)
+        for k in names:
+            assert torch.equal(params[k].grad, first[k]), k
 
 
 def test_pose_block_mask_ref_train_mode_gradients(monkeypatch):

@@ -23,11 +23,25 @@ def load(name):
     return {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLD, name + ".npz")).items()}
 
 
+_WORST = {}  # test id -> largest rel() it evaluated: printed when the module is done, so that every bar below can be read against its measurement
+
+
 def rel(got, want):
     got, want = got.detach().float().cpu(), want.detach().float().cpu()
     assert got.shape == want.shape, (got.shape, want.shape)
     assert torch.isfinite(got).all()
-    return (got - want).abs().max().item() / max(want.abs().max().item(), 1e-12)
+    r = (got - want).abs().max().item() / max(want.abs().max().item(), 1e-12)
+    test = os.environ.get("PYTEST_CURRENT_TEST", "?").split("::")[-1].split(" ")[0]
+    _WORST[test] = max(_WORST.get(test, 0.0), r)
+    return r
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _print_worst_rel():
+    yield
+    print("\nlargest max-norm relative error evaluated per test (tests/test_modules_gpu.py):")
+    for k, v in sorted(_WORST.items()):
+        print(f"  {k}: {v:.3e}")
 
 
 def elem(got, want, rtol=1e-2, floor=1e-3):
