@@ -16,7 +16,13 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda"
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 BF = torch.bfloat16
-TOL = 2.5e-2  # module level: bf16 weights AND activations through several layers vs the reference's fp32
+# Bars of the toy-width module goldens (C = 64 / 128, written by the reference in fp32 on fp32 weights; the modules hold bf16 weights and
+# round their activations to bf16 between kernels).  Each bar is the measurement of round 5 (printed per test when the module is done) plus
+# a margin: one block 7.9e-3 -> the north star's 1e-2; five blocks / the reduced UNet 1.25e-2 ... 1.36e-2 -> 1.6e-2; the mask_ref goldens
+# (features zeroed per view by a 0/1 mask: small maxima, same absolute errors) 2.24e-2 -> 2.5e-2.
+TOL_BLOCK = 1e-2
+TOL_DEEP = 1.6e-2
+TOL = 2.5e-2
 
 
 def load(name):
@@ -82,8 +88,8 @@ def test_pose_block_matches_reference_golden():
     pose = unpack_cameras(g["cams"])
     out, fg, wts, alphas, rgb = blk(dev(g["x"]), context=dev(g["ctx"]), context_ref=dev(g["cref"]), pose=pose)
     assert wts is None
-    assert rel(out, g["out"]) < TOL and rel(fg, g["fg"]) < TOL and rel(alphas, g["alphas"]) < TOL and rel(rgb, g["rgb"]) < TOL
-    assert rel(blk(dev(g["x"]), context=dev(g["ctx"]))[0], g["plain"]) < TOL
+    assert rel(out, g["out"]) < TOL_BLOCK and rel(fg, g["fg"]) < TOL_BLOCK and rel(alphas, g["alphas"]) < TOL_BLOCK and rel(rgb, g["rgb"]) < TOL_BLOCK
+    assert rel(blk(dev(g["x"]), context=dev(g["ctx"]))[0], g["plain"]) < TOL_BLOCK
 
 
 @torch.no_grad()
@@ -307,10 +313,10 @@ def test_spatial_transformer_dual_stream_matches_reference_golden():
     pose = unpack_cameras(g["cams"])
     out, xr, fgs, pw, alphas, rgbs = st(dev(g["x"]), dev(g["xr"]), context=dev(g["ctx"]), contextr=dev(g["ctxr"]), pose=pose)
     assert pw is None and len(fgs) == 2
-    assert rel(out, g["out"]) < TOL and rel(xr, g["xr_out"]) < TOL
+    assert rel(out, g["out"]) < TOL_DEEP and rel(xr, g["xr_out"]) < TOL_DEEP
     for i in range(2):
-        assert rel(fgs[i], g[f"fg{i}"]) < TOL and rel(alphas[i], g[f"alphas{i}"]) < TOL and rel(rgbs[i], g[f"rgb{i}"]) < TOL
-    assert rel(st(dev(g["x"]), None, context=dev(g["ctx"]))[0], g["plain"]) < TOL
+        assert rel(fgs[i], g[f"fg{i}"]) < TOL_DEEP and rel(alphas[i], g[f"alphas{i}"]) < TOL_DEEP and rel(rgbs[i], g[f"rgb{i}"]) < TOL_DEEP
+    assert rel(st(dev(g["x"]), None, context=dev(g["ctx"]))[0], g["plain"]) < TOL_DEEP
 
 
 @torch.no_grad()
@@ -325,11 +331,11 @@ def test_native_reference_sampling_matches_sample_py_golden():
     pose = unpack_cameras(g["cams"])
     out0, xr, fgs, _, alphas, rgbs = st(dev(g["x0"]), None, context=dev(g["ctx"]), pose=pose)
     assert xr is None
-    assert rel(out0, g["out0"]) < TOL
-    assert rel(st.transformer_blocks[0].rendered_feat, g["rend0"]) < TOL and rel(st.transformer_blocks[4].rendered_feat, g["rend4"]) < TOL
-    assert rel(fgs[0], g["fg0"]) < TOL and rel(rgbs[1], g["rgb1"]) < TOL
+    assert rel(out0, g["out0"]) < TOL_DEEP
+    assert rel(st.transformer_blocks[0].rendered_feat, g["rend0"]) < TOL_DEEP and rel(st.transformer_blocks[4].rendered_feat, g["rend4"]) < TOL_DEEP
+    assert rel(fgs[0], g["fg0"]) < TOL_DEEP and rel(rgbs[1], g["rgb1"]) < TOL_DEEP
     out1 = st(dev(g["x1"]), None, context=dev(g["ctx"]), pose=pose)[0]
-    assert rel(out1, g["out1"]) < TOL
+    assert rel(out1, g["out1"]) < TOL_DEEP
     sampling.clear_rendered_feat(st)
     assert st.transformer_blocks[0].rendered_feat is None
 
@@ -352,12 +358,12 @@ def test_sample_py_style_rebinding_runs_the_fused_route_and_matches_sample_py_go
     pose = unpack_cameras(g["cams"])
     out0, xr, fgs, _, alphas, rgbs = st(dev(g["x0"]), None, context=dev(g["ctx"]), pose=pose)
     assert xr is None
-    assert rel(out0, g["out0"]) < TOL
-    assert rel(st.transformer_blocks[0].rendered_feat, g["rend0"]) < TOL and rel(st.transformer_blocks[4].rendered_feat, g["rend4"]) < TOL
-    assert rel(fgs[0], g["fg0"]) < TOL and rel(rgbs[1], g["rgb1"]) < TOL
+    assert rel(out0, g["out0"]) < TOL_DEEP
+    assert rel(st.transformer_blocks[0].rendered_feat, g["rend0"]) < TOL_DEEP and rel(st.transformer_blocks[4].rendered_feat, g["rend4"]) < TOL_DEEP
+    assert rel(fgs[0], g["fg0"]) < TOL_DEEP and rel(rgbs[1], g["rgb1"]) < TOL_DEEP
     kept = st.transformer_blocks[0].rendered_feat
     out1 = st(dev(g["x1"]), None, context=dev(g["ctx"]), pose=pose)[0]
-    assert rel(out1, g["out1"]) < TOL and st.transformer_blocks[0].rendered_feat is kept  # cached render reused (sample.py:122-124)
+    assert rel(out1, g["out1"]) < TOL_DEEP and st.transformer_blocks[0].rendered_feat is kept  # cached render reused (sample.py:122-124)
     # ... bit-identical to the native switch (cd360.sampling.enable_reference_sampling) on a second instance
     from cd360 import sampling
     st2 = make_st(4)
@@ -374,7 +380,7 @@ def test_sample_py_style_rebinding_runs_the_fused_route_and_matches_sample_py_go
     blk.rendered_feat = None
     xt = dev(W.tensor("tok", (3, 64, 128), seed=4))
     o = blk(xt, context=dev(g["ctx"]), context_ref=xt, pose=pose)
-    assert blk.rendered_feat is not None and rel(blk.rendered_feat, g["rend0"]) < TOL and torch.isfinite(o[0]).all()
+    assert blk.rendered_feat is not None and rel(blk.rendered_feat, g["rend0"]) < TOL_DEEP and torch.isfinite(o[0]).all()
 
 
 @torch.no_grad()
@@ -388,9 +394,9 @@ def test_unet_dual_stream_matches_reference_golden():
     out, fgs, alphas, rgbs = net(g["x"].to(DEV), timesteps=g["t"].to(DEV), context=g["ctx"].to(DEV), y=g["y"].to(DEV),
                                  pose=unpack_cameras(g["cams"]), input_ref=g["input_ref"].to(DEV), sigmas_ref=g["sigmas_ref"].to(DEV), mask_ref=None)
     assert out.dtype == torch.float32 and len(fgs) == 3 and len(alphas) == 3 and len(rgbs) == 3
-    assert rel(out, g["out"]) < 4e-2
+    assert rel(out, g["out"]) < TOL_DEEP  # measured 1.34e-2 (round 5); 4e-2 until then
     for i in range(3):
-        assert rel(fgs[i], g[f"fg{i}"]) < 4e-2 and rel(rgbs[i], g[f"rgb{i}"]) < 4e-2
+        assert rel(fgs[i], g[f"fg{i}"]) < TOL_DEEP and rel(rgbs[i], g[f"rgb{i}"]) < TOL_DEEP
 
 
 @torch.no_grad()
