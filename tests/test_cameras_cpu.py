@@ -172,3 +172,43 @@ def test_reference_choices_and_pose_batches_follow_sample_py():
     assert not torch.equal(moved[0]["pose"][0].T[0], moved[1]["pose"][0].T[0]) and torch.equal(moved[0]["pose"][0].T[1:], moved[1]["pose"][0].T[1:])
     packed = pack_cameras(moved[0]["pose"])
     assert packed.shape == (1, 5, 16)
+
+
+def test_camera_methods_against_an_independent_homogeneous_matrix_restatement():
+    """pytorch3d is not in the reference tree, and the golden generator stands `cd360.cameras` in for it (tests/golden/refshim.py): a
+    convention error there would be shared by goldens, oracle and kernels.  Second opinion, written independently of cd360/cameras.py's
+    ordered fp32 chains: PerspectiveCameras as pytorch3d PUBLISHES it -- row-vector 4 x 4 world-to-view transform [[R, 0], [T, 1]], NDC
+    calibration matrix K = [[fx, 0, px, 0], [0, fy, py, 0], [0, 0, 0, 1], [0, 0, 1, 0]] applied as [x y z 1] K^T followed by the division
+    by the last coordinate, unprojection as the inverse of that composite, camera centre as the world point mapped to the view origin -- in
+    float64 homogeneous matrices, against every camera method the path uses, on random rigs."""
+    g = torch.Generator().manual_seed(11)
+    rig = join_cameras_as_batch(synth.ring_cameras(7, seed=13))
+    n = len(rig)
+    R, T = rig.R.double(), rig.T.double()
+    f, pp = rig.focal_length.double(), (rig.principal_point + 0.05 * torch.randn(n, 2, generator=g)).double()
+    rig.principal_point = pp.float()
+    w2v = torch.zeros(n, 4, 4, dtype=torch.float64)
+    w2v[:, :3, :3], w2v[:, 3, :3], w2v[:, 3, 3] = R, T, 1.0
+    K = torch.zeros(n, 4, 4, dtype=torch.float64)
+    K[:, 0, 0], K[:, 1, 1], K[:, 0, 2], K[:, 1, 2], K[:, 2, 3], K[:, 3, 2] = f[:, 0], f[:, 1], pp[:, 0], pp[:, 1], 1.0, 1.0
+    pts = torch.randn(5, 3, generator=g).double() * 0.3
+    hom = torch.cat([pts, torch.ones(5, 1, dtype=torch.float64)], 1)           # [P, 4]
+    view = torch.einsum("pi,nij->npj", hom, w2v)                                # [n, P, 4] row vectors
+    clip = torch.einsum("npi,nji->npj", view, K)                                # x K^T
+    ndc = clip[..., :3] / clip[..., 3:]                                         # (fx X/Z + px, fy Y/Z + py, 1/Z)
+    assert close(rig.get_world_to_view_points(pts.float()), view[..., :3], 1e-5)
+    assert close(rig.transform_points_ndc(pts.float()), ndc, 2e-5)
+    # unprojection of (x_ndc, y_ndc, depth): invert the composite on (x z, y z, 1, z) -- the clip vector of that NDC point at depth z
+    xy_depth = torch.cat([ndc[..., :2], view[..., 2:3]], -1)                    # what project() produced, depth = Z_view
+    z = xy_depth[..., 2:3]
+    clip_back = torch.cat([xy_depth[..., :2] * z, torch.ones_like(z), z], -1)
+    world = torch.einsum("npi,nij->npj", clip_back, torch.linalg.inv(torch.einsum("nij,nkj->nik", w2v, K)))
+    for i in range(n):
+        got = rig[i].unproject_points(xy_depth[i].float(), world_coordinates=True)
+        assert close(got.reshape(-1, 3), pts, 2e-5) and close(world[i, :, :3] / world[i, :, 3:], pts, 1e-9)
+    centre = torch.linalg.inv(w2v)[:, 3, :3]                                     # the world point with view coordinates (0, 0, 0)
+    assert close(rig.get_camera_center(), centre, 1e-5)
+    # axis conventions (+X left, +Y up, +Z into the scene): a point to the camera's own +X lands at POSITIVE ndc x
+    eye = PerspectiveCameras(R=torch.eye(3)[None], T=torch.zeros(1, 3), focal_length=torch.tensor([[2.0, 2.0]]), principal_point=torch.zeros(1, 2))
+    assert float(eye.transform_points_ndc(torch.tensor([[0.1, 0.0, 1.0]]))[0, 0, 0]) > 0
+    assert float(eye.transform_points_ndc(torch.tensor([[0.0, 0.1, 1.0]]))[0, 0, 1]) > 0
