@@ -812,10 +812,16 @@ static int attn_launch(const void* q, const void* k, const void* v, void* o, int
   if (gen2 && pick) {
     bool wide = Nq % 512 == 0 && (long)B * H * (Nq / 512) >= 240;  // enough 512-query workgroups for every CU
     if (pick > 0) wide = pick == 2 && Nq % 512 == 0;
-    p.n_qtiles = Nq / (wide ? 512 : 128);
+    // 3 (A/B, round 5): eight waves x 32 queries = 256-query workgroups with the look-ahead scores -- one workgroup per CU at the 32^2 level
+    // (240 of them) instead of two of 128 queries, i.e. one K / V stream per CU instead of two.  Measured (tools/bench_attn_self.py, same box,
+    // us, variant 1 / 3): 32^2 level 25.6-28.8 / 27.7-28.5, 64^2 level 165.8-168.0 / 169.3-170.6, bit-identical -- no gain: the K / V stream is
+    // not what this kernel waits for.  By cd360_tuning.attn_self = 3 only.
+    const bool mid = pick == 3 && Nq % 256 == 0;
+    p.n_qtiles = Nq / (mid ? 256 : wide ? 512 : 128);
     const long nwg2 = (long)p.n_qtiles * B * H;
     if (nwg2 > 0x7fffffffL) return CD360_ERR_SHAPE;
-    if (wide) hipLaunchKernelGGL((attn_self_kernel<2, 8>), dim3((unsigned)nwg2), dim3(512), 0, (hipStream_t)stream, p);
+    if (mid) hipLaunchKernelGGL((attn_self_kernel<1, 8>), dim3((unsigned)nwg2), dim3(512), 0, (hipStream_t)stream, p);
+    else if (wide) hipLaunchKernelGGL((attn_self_kernel<2, 8>), dim3((unsigned)nwg2), dim3(512), 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((attn_self_kernel<1, 4>), dim3((unsigned)nwg2), dim3(256), 0, (hipStream_t)stream, p);
     CD360_LAUNCH_CHECK();
     return CD360_OK;

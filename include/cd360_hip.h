@@ -50,7 +50,7 @@ typedef struct cd360_tuning {
   int32_t conv_split;       /* 1 | 2: in-workgroup split-K of the register-staged kernel */
   int32_t attn_smallk;      /* 0: <= 96-key attention on the tiled kernel */
   int32_t attn_smallk_wgs;  /* > 0: workgroup target of the register-resident kernel */
-  int32_t attn_self;        /* 0 | 1 | 2: self-attention kernel generation / tiling */
+  int32_t attn_self;        /* 0 | 1 | 2 | 3: self-attention kernel generation / tiling */
   int32_t attn_fast;        /* 0: guarded path of the first-generation kernel */
   int32_t nerf_kernel;      /* 0 | 1: FeatureNeRF render kernel with register gathers / full-line gathers */
   int32_t qattn_cfg;        /* 1..4: tile of cd360_qproj_attn_bf16 (256 x 256 / 128 x 128 + movers / 128 x 128 x 2 WGs / 256 x 128) */

@@ -18,6 +18,13 @@ for rnd in range(2):
         inner = H * 64
         qkv = torch.randn(b, n, 3 * inner, device=dev).to(torch.bfloat16)
         run = lambda: ops.attention(qkv[..., :inner], qkv[..., inner:2 * inner], qkv[..., 2 * inner:], H, n, prescaled=True)
-        us = timeit_graph(run, n=20)
         fl = 4.0 * b * H * n * n * 64
-        print(f"attn_self {name} b{b} H{H} N{n}: {us:8.1f} us  {fl / us / 1e6:7.1f} TF/s ({fl / us / 1e6 / 2500:.3f} of the bf16 MFMA peak)", flush=True)
+        line, outs = f"attn_self {name} b{b} H{H} N{n}:", {}
+        for variant in (-1, 1, 2, 3):  # cd360_tuning.attn_self: by shape / 4 waves x 32 queries / 8 x 64 / 8 x 32 (round 5)
+            _lib.set_tuning(attn_self=variant)
+            us = timeit_graph(run, n=20)
+            outs[variant] = run().clone()
+            line += f" | {variant}: {us:7.1f} us {fl / us / 1e6 / 2500:.3f}"
+        _lib.set_tuning(attn_self=-1)
+        line += " | bit-identical to variant 1: " + str({v: bool(torch.equal(outs[v], outs[1])) for v in (2, 3)})
+        print(line, flush=True)
