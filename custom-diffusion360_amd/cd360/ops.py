@@ -66,12 +66,23 @@ class _timed:
         return False
 
 
-def _stream() -> ctypes.c_void_p:
-    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+# Both helpers return plain Python ints (None for a null pointer): every pointer / stream parameter of the C ABI is typed c_void_p in
+# cd360/_lib.py, and ctypes converts an int itself -- building a c_void_p object per argument cost 1.5 us each, 13 000 times per eagerly
+# launched fine-tuning step, and `torch.cuda.current_stream().cuda_stream` 9 us per launch (tools/probe/train_host_profile.py: 20 + 21 ms
+# of a 147 ms step).  The raw-stream query below is what torch's own extensions use; it follows `torch.cuda.stream(...)` contexts and
+# graph captures exactly like current_stream().
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_cur_device = getattr(torch._C, "_cuda_getDevice", None)
 
 
-def _ptr(t: Optional[torch.Tensor]) -> ctypes.c_void_p:
-    return ctypes.c_void_p(0 if t is None else t.data_ptr())
+def _stream():
+    if _raw_stream is not None and _cur_device is not None:
+        return _raw_stream(_cur_device())
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
 
 
 def _need_gpu(*ts):

@@ -92,7 +92,11 @@ def _watched(*mods: nn.Module) -> bool:
     harvest, diffusion.py:151-163; attention-map capture) or an instance-level `forward` (sample.py:247-262 rebinds the blocks'
     forward).  Paths that read raw weights instead of calling the submodule would skip such observers, so they step aside."""
     for mod in mods:
-        for m in mod.modules():
+        sub = mod.__dict__.get("_cd360_submodules")  # flat list of the subtree, built once: `modules()` is a recursive generator with a
+        if sub is None:                               # memo set, and this runs for every block of every forward (7 ms of an eager step)
+            sub = list(mod.modules())
+            object.__setattr__(mod, "_cd360_submodules", sub)
+        for m in sub:
             if m._forward_hooks or m._forward_pre_hooks or "forward" in m.__dict__:
                 return True
     return False
