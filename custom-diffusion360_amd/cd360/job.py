@@ -207,9 +207,9 @@ def sample_poses(make_sampler: Callable, make_job: Callable[[int], tuple], num_p
     """BASELINE configs[2] as a function: `num_poses` target poses over `world` ranks.  `make_job(p)` builds pose p's (pose, ctx, y, x0);
     `make_sampler(pose, ctx, y)` the rank's sampler for its first pose.  Returns (latents of ALL poses [num_poses, 4, L, L] in pose
     order, identical on every rank; this rank's pose indices).  No collective on the data path; one all-gather at the end."""
-    mine = shard.assign_poses(num_poses, world, rank)
-    if not mine:
+    if num_poses < world:  # decided from the arguments alone, so EVERY rank raises (a rank-local check would leave the others in the all-gather)
         raise ValueError("more ranks than target poses: every rank needs at least one pose (the all-gather is sized per rank)")
+    mine = shard.assign_poses(num_poses, world, rank)
     jobs = [make_job(p) for p in mine]
     sampler = make_sampler(*jobs[0][:3])
     finals = sample_assigned(sampler, jobs, steps)

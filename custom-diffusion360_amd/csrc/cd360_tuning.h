@@ -15,7 +15,7 @@ typedef struct cd360_tuning {
   int32_t gemm_ksplit;      // 0 | 1 | 2: wave arrangement of the 128 x 128 four-buffer tiling
   int32_t conv_cfg;         // 1..6: tiling of cd360_conv3x3_dma_bf16
   int32_t conv_dma;         // 0: 3 x 3 / 1 x 1 convolutions on the register-staged kernel
-  int32_t conv_kgroup;      // > 0: K-order group size (set BEFORE weights are packed)
+  int32_t conv_kgroup;      // > 0: K-order group size (set BEFORE weights are packed; process-wide: cd360_set_stream_tuning rejects another value)
   int32_t conv_wide;        // 0: register-staged kernel never uses its 160-channel tiles
   int32_t conv_wmajor;      // 0 | 1: register-staged kernel's tile order
   int32_t conv_split;       // 1 | 2: register-staged kernel's in-workgroup split-K
@@ -43,6 +43,8 @@ int cd360_query_stream(void* stream);
 // The tuning a launch function reads: the override of the stream the running entry point was called with (CD360_TUNE_SCOPE), else the
 // process-wide default (tuning.hip).
 const cd360_tuning& cd360_tune();
+// The process-wide default regardless of stream: for pack-time choices (conv_kgroup), which cannot differ per stream.
+const cd360_tuning& cd360_tune_default();
 
 // First statement of every entry point that takes a stream and reads the tuning: for the duration of the call cd360_tune() answers
 // with that stream's override, if one was set (cd360_set_stream_tuning).  Thread-local, nothing shared is written; with no per-stream

@@ -336,7 +336,7 @@ extern "C" int cd360_conv_k_order(int Cin, int taps) {
   const int kchunks = Cin / 64;
   if (taps != 9 || kchunks <= 0) return kchunks > 0 ? kchunks : 1;
   int gmax = 5;
-  if (cd360_tune().conv_kgroup > 0) gmax = cd360_tune().conv_kgroup;  // tuning override (set before weights are packed)
+  if (cd360_tune_default().conv_kgroup > 0) gmax = cd360_tune_default().conv_kgroup;  // process-wide override (set before weights are packed)
   for (int g = gmax < kchunks ? gmax : kchunks; g > 1; --g)
     if (kchunks % g == 0) return g;
   return 1;

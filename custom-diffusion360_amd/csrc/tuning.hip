@@ -51,6 +51,10 @@ int sanitize(const cd360_tuning* t, cd360_tuning* out) {
 }  // namespace
 
 // (a query context left on some thread by cd360_query_stream is honoured only while overrides exist at all)
+// Pack-time choices (conv_kgroup: the K order of a packed convolution weight) are process-wide by nature: packing and every later
+// launch must agree whatever stream they run on, so they are read from the default only
+const cd360_tuning& cd360_tune_default() { return g_tuning; }
+
 const cd360_tuning& cd360_tune() { return (tl_tune && g_nstreams.load(std::memory_order_relaxed) > 0) ? *tl_tune : g_tuning; }
 
 Cd360TuneScope::Cd360TuneScope(void* stream) : prev_(tl_tune), set_(false) {
@@ -89,6 +93,10 @@ extern "C" int cd360_set_stream_tuning(void* stream, const cd360_tuning* t) {
   if (t) {
     const int rc = sanitize(t, &clean);
     if (rc != CD360_OK) return rc;
+    // conv_kgroup decides the K order weights are PACKED in (cd360_conv_k_order, read by pack_conv_weight on no stream in particular):
+    // a stream that multiplied them in another order would be silently wrong, so the field cannot differ per stream
+    if (clean.conv_kgroup > 0 && clean.conv_kgroup != g_tuning.conv_kgroup) return CD360_ERR_ARG;
+    clean.conv_kgroup = g_tuning.conv_kgroup;
   }
   std::lock_guard<std::mutex> lk(g_mu);
   int n = g_nstreams.load(std::memory_order_relaxed);

@@ -46,9 +46,16 @@ def intersect_skew_lines_high_dim(p, r, mask=None):
     d64, p64, w64 = dirs.double(), p.double(), w.double()
     dim = p.shape[-1]
     # sum_i w_i (I - d_i d_i^T)  and  sum_i w_i (p_i - d_i (d_i . p_i))
-    normal = w64.sum(-1)[..., None, None] * torch.eye(dim, dtype=torch.float64) - torch.einsum("...n,...ni,...nj->...ij", w64, d64, d64)
+    normal = w64.sum(-1)[..., None, None] * torch.eye(dim, dtype=torch.float64, device=p.device) - torch.einsum("...n,...ni,...nj->...ij", w64, d64, d64)
     rhs = (w64[..., None] * (p64 - d64 * (d64 * p64).sum(-1, keepdim=True))).sum(-2)
-    x = _solve_sym3(normal, rhs) if dim == 3 else torch.linalg.solve(normal, rhs)
+    # A rank-deficient bundle (one camera; all optical axes parallel) has no unique nearest point; the reference's lstsq (gelsy) then
+    # returns the minimum-norm one and goes on -- so does this (the closed form would divide by a vanishing determinant).
+    scale = normal.diagonal(dim1=-2, dim2=-1).abs().amax(-1).clamp_min(1e-300)
+    well = torch.linalg.det(normal).abs() > 1e-10 * scale ** dim
+    if dim == 3 and bool(well.all()):
+        x = _solve_sym3(normal, rhs)
+    else:
+        x = torch.linalg.lstsq(normal, rhs[..., None], driver="gelsy" if normal.device.type == "cpu" else None).solution[..., 0]
     if not torch.isfinite(x).all():
         raise AssertionError(f"degenerate line bundle: no unique nearest point ({x})")
     return x.to(p.dtype), dirs

@@ -28,7 +28,7 @@ import torch
 import torch.nn.functional as F
 from torch import nn
 
-from cd360 import memo, ops, routes
+from cd360 import memo, ops, routes, sample_py_patch
 from ..modules.diffusionmodules.util import HipLayerNorm, HipLinear, checkpoint, group_norm_tokens, tag_gn_stats, tokens_to_image, zero_module  # noqa: F401
 from ..modules.nerfsd_pytorch3d import NerfSDModule, VolRender
 from ..util import default, exists
@@ -87,16 +87,30 @@ def _linear(x: torch.Tensor, weight: torch.Tensor, bias=None) -> torch.Tensor:
     return F.linear(x, weight, bias)
 
 
+# Every registration of a submodule anywhere (add_module / register_module / attribute assignment of an nn.Module: a LoRA wrapper, a
+# swapped attn / ff) advances this epoch; the flat submodule lists `_watched` caches are only served within the epoch they were built in.
+_module_epoch = [0]
+
+
+def _bump_module_epoch(module, name, submodule):
+    _module_epoch[0] += 1
+    return None
+
+
+torch.nn.modules.module.register_module_module_registration_hook(_bump_module_epoch)
+
+
 def _watched(*mods: nn.Module) -> bool:
     """True when somebody observes one of `mods` or their submodules through torch's module protocol: forward (pre-)hooks (the references
     harvest, diffusion.py:151-163; attention-map capture) or an instance-level `forward` (sample.py:247-262 rebinds the blocks'
     forward).  Paths that read raw weights instead of calling the submodule would skip such observers, so they step aside."""
+    epoch = _module_epoch[0]
     for mod in mods:
-        sub = mod.__dict__.get("_cd360_submodules")  # flat list of the subtree, built once: `modules()` is a recursive generator with a
-        if sub is None:                               # memo set, and this runs for every block of every forward (7 ms of an eager step)
-            sub = list(mod.modules())
-            object.__setattr__(mod, "_cd360_submodules", sub)
-        for m in sub:
+        ent = mod.__dict__.get("_cd360_submodules")  # (epoch, flat list of the subtree): `modules()` is a recursive generator with a
+        if ent is None or ent[0] != epoch:            # memo set, and this runs for every block of every forward (7 ms of an eager step)
+            ent = (epoch, list(mod.modules()))
+            object.__setattr__(mod, "_cd360_submodules", ent)
+        for m in ent[1]:
             if m._forward_hooks or m._forward_pre_hooks or "forward" in m.__dict__:
                 return True
     return False
@@ -116,24 +130,14 @@ def _watched_inside(mod: nn.Module) -> bool:
 # CFG part; the render runs once per image and is cached in `rendered_feat`) -- pinned against the outputs of sample.py's own functions
 # in tests/golden/customforward_cfg3.npz.  A rebound Python forward would force every block onto the un-fused module route (it calls
 # norm1 / attn1 / ... one by one), so an assignment of one of THOSE TWO functions to `forward` is recorded instead of installed: the class
-# forward keeps running, in sampling mode, with `choices` read from the rebound function's own globals at every call.  Recognition is
-# structural -- the function's name plus the attribute and global names its code touches -- and anything else assigned to `forward`
-# is installed as usual (and sends the module to the strict route).  `cd360.routes.strict_sample_py` switches the recognition off.
-_BLOCK_PATCH_NAMES = {"references", "rendered_feat", "reference_attn", "pose_emb_layers", "attn1", "attn2", "norm1", "norm2", "norm3", "ff", "choices"}
-_ST_PATCH_NAMES = {"norm", "proj_in", "proj_out", "transformer_blocks", "image_cross", "poscontrol_interval", "use_linear"}
-
-
+# forward keeps running, in sampling mode, with `choices` read from the rebound function's own globals at every call.  Recognition is by
+# the function's SOURCE (cd360/sample_py_patch.py: a hash of its normalised AST against the hashes recorded from sample.py) -- a function
+# that only carries the name, e.g. a user's edited copy, is installed as written, runs its own body on the strict module route and draws
+# one warning, as does anything else assigned to `forward`.  `cd360.routes.strict_sample_py` switches the recognition off.
 def _sample_py_patch_kind(value) -> Optional[str]:
-    fn = getattr(value, "__func__", None)
-    code = getattr(fn, "__code__", None)
-    if code is None or routes.strict_sample_py:
+    if routes.strict_sample_py:
         return None
-    names = set(code.co_names)
-    if fn.__name__ == "_customforward" and _BLOCK_PATCH_NAMES <= names:
-        return "block"
-    if fn.__name__ == "customforward" and _ST_PATCH_NAMES <= names:
-        return "st"
-    return None
+    return sample_py_patch.kind_of(value)
 
 
 def _sync_sample_py(block) -> None:

@@ -44,7 +44,7 @@ typedef struct cd360_tuning {
   int32_t gemm_ksplit;      /* 0 | 1 | 2: wave arrangement of the 128 x 128 four-buffer tiling */
   int32_t conv_cfg;         /* 1..6: tiling of cd360_conv3x3_dma_bf16 */
   int32_t conv_dma;         /* 0: convolutions on the register-staged kernel */
-  int32_t conv_kgroup;      /* > 0: K-order group size (before weights are packed) */
+  int32_t conv_kgroup;      /* > 0: K-order group size (before weights are packed); process-wide only: cd360_set_stream_tuning returns CD360_ERR_ARG for a different value */
   int32_t conv_wide;        /* 0: no 160-channel tiles in the register-staged kernel */
   int32_t conv_wmajor;      /* 0 | 1: tile order of the register-staged kernel */
   int32_t conv_split;       /* 1 | 2: in-workgroup split-K of the register-staged kernel */

@@ -248,6 +248,13 @@ def _sample_py_functions():
     src = open(os.path.join(refshim.REF_ROOT, "sample.py")).read()
     tree = ast.parse(src)
     wanted = [n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in ("customforward", "_customforward")]
+    # fingerprints of the two functions (a hash of the normalised AST: data about the reference, not its text) -- what
+    # cd360/sample_py_patch.py compares a rebound forward with on the user's machine
+    from cd360 import sample_py_patch
+    import json
+    with open(os.path.join(HERE, "sample_py_fingerprints.json"), "w") as f:
+        json.dump({n.name: sample_py_patch.fingerprint_node(n) for n in wanted}, f, indent=1, sort_keys=True)
+        f.write("\n")
     mod = ast.Module(body=wanted, type_ignores=[])
     from einops import rearrange
     env = {"torch": torch, "rearrange": rearrange, "choices": []}

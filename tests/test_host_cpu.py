@@ -126,6 +126,94 @@ def test_sample_py_rebinding_is_recognised_and_served_natively():
         assert "forward" in blk.__dict__ and "_sample_py" not in blk.__dict__
 
 
+def test_sample_py_fingerprints_are_the_reference_functions():
+    """cd360/sample_py_patch.py's built-in fingerprints = the recorded ones (tests/golden/sample_py_fingerprints.json, written by
+    make_golden.py from the reference's sample.py) and, where the reference tree is present (this container, not the GPU box), = the
+    hash of sample.py's own two functions read in place -- through the same public entry point a user's rebinding goes through."""
+    import ast
+    import json
+    from cd360 import sample_py_patch as SPP
+    rec = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sample_py_fingerprints.json")))
+    assert rec["_customforward"] in SPP.KNOWN["block"] and rec["customforward"] in SPP.KNOWN["st"]
+    ref = "/root/reference/sample.py"
+    if not os.path.exists(ref):
+        pytest.skip("reference tree not present")
+    tree = ast.parse(open(ref).read())
+    got = {n.name: SPP.fingerprint_node(n) for n in tree.body if isinstance(n, ast.FunctionDef) and n.name in rec}
+    assert got == rec
+    # formatting, comments and line numbers do not move it; an edit of the body does
+    src = ast.unparse([n for n in tree.body if isinstance(n, ast.FunctionDef) and n.name == "_customforward"][0])
+    again = ast.parse("# a comment\n\n" + src.replace("\n", "\n\n", 3)).body[0]
+    assert SPP.fingerprint_node(again) == rec["_customforward"]
+    edited = ast.parse(src.replace("return", "x = x + 0\n    return", 1) if "\n    return" in src else src + "\n    pass").body[0]
+    assert SPP.fingerprint_node(edited) != rec["_customforward"]
+
+
+def test_edited_customforward_runs_its_own_body(tmp_path):
+    """A function NAMED `_customforward` that touches every attribute sample.py's touches but has another body (a user's edited copy of
+    sample.py) is not sample.py's: it is installed on the instance, runs ITS body, sends the block to the strict route, and draws one
+    warning.  (Until round 6 the recognition was by name + co_names and silently ran the built-in sampling mode instead.)"""
+    import importlib.util
+    import warnings
+    import sample_py_stub as SP
+    from sgm.modules import attention as A
+    mod_src = (
+        "calls = []\n"
+        "choices = None\n"
+        "def _customforward(self, x, context=None, context_ref=None, pose=None, mask_ref=None, prev_weights=None, additional_tokens=None,\n"
+        "                   n_times_crossframe_attn_in_self=0):\n"
+        "    _ = (self.references, choices, self.attn1, self.norm1, self.attn2, self.norm2, self.rendered_feat, self.pose_emb_layers,\n"
+        "         self.reference_attn, self.ff, self.norm3)\n"
+        "    calls.append('edited')\n"
+        "    return x * 2\n")
+    path = tmp_path / "edited_sample.py"
+    path.write_text(mod_src)
+    spec = importlib.util.spec_from_file_location("edited_sample", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    blk = A.BasicTransformerBlock(64, 1, 64, context_dim=32, checkpoint=False, attn_mode="softmax-xformers")
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        blk.forward = mod._customforward.__get__(blk, type(blk))
+    assert "forward" in blk.__dict__ and "_sample_py" not in blk.__dict__ and A._watched(blk)
+    assert any("differs from sample.py" in str(x.message) for x in w)
+    for name in ("references", "rendered_feat", "pose_emb_layers", "reference_attn"):  # (a plain block lacks the pose attributes)
+        if not hasattr(blk, name):
+            object.__setattr__(blk, name, None)
+    x = torch.ones(1, 4, 64)
+    assert torch.equal(blk(x), x * 2) and mod.calls == ["edited"]
+    # the stand-ins of the test suite are recognised only because register() declares them (trust); undeclared they are installed
+    blk2 = A.BasicTransformerBlock(64, 1, 64, context_dim=32, checkpoint=False, attn_mode="softmax-xformers")
+    from cd360 import sample_py_patch as SPP
+    saved = {k: set(v) for k, v in SPP.KNOWN.items()}
+    try:
+        for k in SPP.KNOWN:
+            SPP.KNOWN[k] = {fp for fp in saved[k] if fp in json_fingerprints()}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            SP.register(blk2, [0], declare=False)
+        assert "forward" in blk2.__dict__ and "_sample_py" not in blk2.__dict__
+    finally:
+        SPP.KNOWN.update(saved)
+
+
+def json_fingerprints():
+    import json
+    return set(json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sample_py_fingerprints.json"))).values())
+
+
+def test_submodule_swap_after_first_forward_is_seen_by_the_observer_check():
+    """`_watched` caches the flat submodule list of a block; registering a module anywhere (a wrapper swapped in for attn / ff after the
+    first forward) must invalidate it, or a hook on the new submodule would be missed and the fused route would keep reading the old weights."""
+    from sgm.modules import attention as A
+    blk = A.BasicTransformerBlock(64, 1, 64, context_dim=32, checkpoint=False, attn_mode="softmax-xformers")
+    assert not A._watched(blk)
+    wrapper = torch.nn.Sequential(blk.ff)
+    wrapper.register_forward_hook(lambda m, i, o: None)
+    blk.ff = wrapper
+    assert A._watched(blk)
+
+
 def test_cpu_forward_fails_loudly():
     """There is no CPU / PyTorch fallback behind the operators."""
     from cd360 import ops
@@ -402,6 +490,15 @@ def test_per_stream_tuning_table_semantics_without_a_gpu():
         bad = _lib.Tuning()
         bad.size = 4
         assert lib.cd360_set_stream_tuning(ctypes.c_void_p(h1), ctypes.byref(bad)) == -1  # ABI size check
+        # conv_kgroup is the K order weights are PACKED in: a pack-time, process-wide choice that a stream cannot override (the packer
+        # runs on no stream in particular) -- refused per stream, and the shape query answers from the process default whatever the context
+        kg = _lib.Tuning()
+        lib.cd360_get_tuning(ctypes.byref(kg))
+        kg.conv_kgroup = 2
+        assert lib.cd360_set_stream_tuning(ctypes.c_void_p(h1), ctypes.byref(kg)) == -1
+        lib.cd360_query_stream(ctypes.c_void_p(h1))
+        assert lib.cd360_conv_k_order(1280, 9) == 5
+        lib.cd360_query_stream(None)
     finally:
         for h in [h1, h2] + [0x10000 + 16 * i for i in range(15)]:
             _lib.clear_stream_tuning(h)
