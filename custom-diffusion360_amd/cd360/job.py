@@ -17,6 +17,11 @@ import torch
 from . import shard
 
 
+def routes_no_emb_merge() -> bool:
+    from cd360 import routes
+    return bool(routes.no_emb_merge)
+
+
 class Sampler:
     """Minimal Euler (DDIM-equivalent, EpsScaling) step with the 3-way image/text CFG of guiders.py:102-133.
     With `use_graph` the steady-state step (cached render) and the render step are each captured once into a hipGraph and
@@ -43,6 +48,11 @@ class Sampler:
         self.prefetch = prefetch  # cd360.prefetch.WeightPrefetcher or None: armed around both captures
         self.use_graph, self.graph = use_graph, None
         self.graph_render, self.rgraph = use_graph and graph_render, None  # graph_render=False: the render step launched eagerly (A/B)
+        # staged steps (round 6): the captured graphs read every per-step scalar from tables through a device-side step index and start /
+        # end on cd360_unet_stage_in / cd360_cfg_euler_step_cl, so a replay holds no torch-issued kernel (cd360.routes.no_stage: the A/B partner);
+        # eager launches (use_graph=False) run the same staged step
+        from cd360 import routes
+        self.staged = bool(not routes.no_stage and self._stageable())
 
     def retarget(self, pose, ctx, y):
         """Point the sampler at another target pose / conditioning (the next pose of this rank's share).  The captured graphs read both
@@ -58,6 +68,53 @@ class Sampler:
             self.pose.rewrite(pose)
         else:
             self.pose = pose
+        if self.staged and getattr(self, "lab", None) is not None:
+            self.lab.copy_(self.net.label_emb(self.y.to(self.net.dtype)))
+
+    # ------------------------------------------------------------------------------------------------ staged steps
+    def _stageable(self) -> bool:
+        net = self.net
+        try:
+            conv = net.input_blocks[0][0]
+            return (isinstance(conv, torch.nn.Conv2d) and conv.in_channels == 4 and conv.kernel_size == (3, 3) and conv.padding == (1, 1)
+                    and conv.stride == (1, 1) and conv.out_channels % 8 == 0 and conv.weight.dtype == torch.bfloat16 and conv.weight.is_cuda
+                    and net.out[2].out_channels == 4 and hasattr(net, "forward_staged") and not routes_no_emb_merge())
+        except (AttributeError, IndexError, TypeError):
+            return False
+
+    @torch.no_grad()
+    def _build_stage(self, x):
+        """Per-schedule tables and static buffers of the staged steps: row i = what step i of the trajectory derives from sigma_i alone,
+        computed with the denoiser's / the UNet's own modules exactly as the un-staged step computes them inside its graph."""
+        from sgm.modules.diffusionmodules.util import timestep_embedding
+        net, dev, dt = self.net, x.device, self.net.dtype
+        rows, tembs = [], []
+        for i in range(self.n_steps):
+            sq = self.denoiser.possibly_quantize_sigma(self.sigmas[i].reshape(1))
+            _, _, c_in, c_noise = self.denoiser.scaling(sq)
+            c_noise = self.denoiser.possibly_quantize_c_noise(c_noise)
+            rows.append(torch.stack([self.sigmas[i], self.sigmas[i + 1], c_in[0], torch.zeros_like(c_in[0])]))
+            tembs.append(net.time_embed(timestep_embedding(c_noise.expand(3), net.model_channels).to(dt))[0])
+        self.step_tab = torch.stack(rows).float().contiguous()
+        self.temb_tab = torch.stack(tembs).to(dt).contiguous()
+        self._iota = torch.arange(self.n_steps, dtype=torch.int32, device=dev)
+        self.gi = torch.zeros(1, dtype=torch.int32, device=dev)
+        conv = net.input_blocks[0][0]
+        self.w36 = conv.weight.detach().float().permute(2, 3, 1, 0).reshape(36, conv.out_channels).contiguous()
+        self.b_in = (conv.bias.detach().float() if conv.bias is not None else torch.zeros(conv.out_channels, device=dev)).contiguous()
+        self.lab = net.label_emb(self.y.to(dt)).contiguous()
+        bs3, (H, W) = self.y.shape[0], x.shape[2:]
+        self.h0 = torch.empty(bs3, H * W, conv.out_channels, dtype=dt, device=dev)
+        self.emb_act = torch.empty_like(self.lab)
+
+    def _math_staged(self):
+        """One sampler step on the static buffers, in place on self.gx: stage-in kernel -> UNet trunk -> fused [c_out, 3-way CFG, to_d,
+        Euler] kernel reading the output convolution's rows as they lie."""
+        from cd360 import ops
+        H, W = self.gx.shape[2:]
+        ops.unet_stage_in(self.gx, self.step_tab, self.gi, self.w36, self.b_in, self.temb_tab, self.lab, self.h0, self.emb_act)
+        eps_cl = self.net.forward_staged(self.h0, self.emb_act, self.ctx, self.pose, H, W)
+        return ops.cfg_euler_step_cl(self.gx, eps_cl, self.step_tab, self.gi, self.scale, self.scale_im)
 
     def _math(self, x, s, s_next, t_unused=None):
         """One sampler step = guider.prepare_inputs -> DiscreteDenoiser (sigma -> table index, c_in) -> UNet -> fused
@@ -125,7 +182,7 @@ class Sampler:
         """Step 0 of an image: clear the cached render, run the full step (all 12 FeatureNeRF renders), re-pin the caches."""
         from cd360 import sampling
         sampling.clear_rendered_feat(self.net)
-        out = self._math(self.gx, self.gs[0], self.gs[1], self.gt)
+        out = self._math_staged() if self.staged else self._math(self.gx, self.gs[0], self.gs[1], self.gt)
         self._pin_rendered()
         return out
 
@@ -137,8 +194,12 @@ class Sampler:
             return
         s, s_next, t = self.sigmas[0], self.sigmas[1], self.sigmas[0:1]
         self.gx, self.gs, self.gt = x.clone(), torch.stack([s, s_next]), t.clone()
+        if self.staged:
+            self._build_stage(x)
         self._render()
-        self.graph, self.gout = self._capture(lambda: self._math(self.gx, self.gs[0], self.gs[1], self.gt))
+        if self.staged:
+            self.gx.copy_(x)  # (the staged step updates gx in place: captures and warm-ups below start from a sane latent again)
+        self.graph, self.gout = self._capture(self._math_staged if self.staged else (lambda: self._math(self.gx, self.gs[0], self.gs[1], self.gt)))
         if self.graph_render:
             try:
                 self.rgraph, self.rout = self._capture(self._render)
@@ -160,9 +221,37 @@ class Sampler:
             att._kv_cache = kv
 
     @torch.no_grad()
-    def step(self, x, i):
+    def step(self, x, i, alias: bool = False):
+        """Step i of the schedule on latent x.  alias=True (the job loop): the result may be the sampler's own latent buffer, valid until
+        the next call, and passing it straight back skips the copy-in -- a staged replay is then ONE 4-byte index copy plus the graph."""
         i = i % self.n_steps
         s, s_next, t = self.sigmas[i], self.sigmas[i + 1], self.sigmas[i:i + 1]
+        if self.staged:
+            # (eager launches run the SAME staged step: the stage-in kernel's input convolution rounds a few outputs to the other bf16
+            # neighbour than the implicit-GEMM kernel does, and 70 random-init blocks amplify that to 1e-2 of eps -- graph and eager
+            # must not differ by it; tests/test_f_rows_gpu.py holds the staged ends against the module arithmetic op by op)
+            if self.use_graph:
+                self.prepare(x)
+            elif getattr(self, "step_tab", None) is None:
+                self.gx = x.clone()
+                self._build_stage(x)
+            if x is not self.gx:
+                self.gx.copy_(x)
+            self.gi.copy_(self._iota[i:i + 1])
+            if not self.use_graph:
+                if i == 0:
+                    from cd360 import sampling
+                    sampling.clear_rendered_feat(self.net)
+                self._math_staged()
+            elif i == 0:
+                if self.rgraph is not None:
+                    self.rgraph.replay()
+                    self._restore_pins()
+                else:
+                    self._render()
+            else:
+                self.graph.replay()
+            return self.gx if alias else self.gx.clone()
         if not self.use_graph:
             if i == 0:
                 from cd360 import sampling
@@ -197,9 +286,10 @@ def sample_assigned(sampler, jobs: Sequence[tuple], steps: int) -> List[torch.Te
         if j > 0:
             sampler.retarget(pose, ctx, y)
         x = x0.clone()
+        alias = isinstance(sampler, Sampler)  # (the CPU stand-ins of the gloo tests take (x, i) only)
         for i in range(steps):
-            x = sampler.step(x, i)
-        finals.append(x)
+            x = sampler.step(x, i, alias=True) if alias else sampler.step(x, i)
+        finals.append(x.clone() if alias else x)
     return finals
 
 

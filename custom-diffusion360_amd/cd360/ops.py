@@ -1119,3 +1119,35 @@ def cfg_euler_step(x: torch.Tensor, eps: torch.Tensor, sigma: torch.Tensor, sigm
     check(_lib.load().cd360_cfg_euler_step_f32(_ptr(x), _ptr(eps), _ptr(sigma), _ptr(sigma_next), float(scale), float(scale_im), _ptr(out),
                                               x.numel(), _stream()), "cd360_cfg_euler_step_f32")
     return out
+
+
+def unet_stage_in(x: torch.Tensor, step_tab: torch.Tensor, step: torch.Tensor, w_k36: torch.Tensor, bias: torch.Tensor, temb_tab: torch.Tensor,
+                  lab: torch.Tensor, h: torch.Tensor, emb_act: torch.Tensor):
+    """Head of a captured sampling step (cd360_unet_stage_in): x [bs, 4, H, W] fp32 -> h [rep bs, H W, Cout] bf16 = the UNet's input
+    convolution of bf16(c_in x) written to every CFG branch, emb_act [rep bs, E] bf16 = silu(temb_tab[step] + lab); c_in = step_tab[step][2]."""
+    _need_gpu(x, step_tab, step, w_k36, bias, temb_tab, lab, h, emb_act)
+    bs, four, H, W = x.shape
+    rep = lab.shape[0] // bs
+    cout, E = w_k36.shape[1], temb_tab.shape[1]
+    assert four == 4 and x.dtype == torch.float32 and x.is_contiguous() and step.dtype == torch.int32 and step_tab.dtype == torch.float32
+    assert w_k36.shape[0] == 36 and w_k36.dtype == torch.float32 and bias.dtype == torch.float32 and w_k36.is_contiguous()
+    assert temb_tab.dtype == lab.dtype == h.dtype == emb_act.dtype == torch.bfloat16 and lab.shape == emb_act.shape == (rep * bs, E)
+    assert h.shape == (rep * bs, H * W, cout) and h.is_contiguous() and temb_tab.is_contiguous() and lab.is_contiguous() and emb_act.is_contiguous()
+    check(_lib.load().cd360_unet_stage_in(_ptr(x), _ptr(step_tab), _ptr(step), _ptr(w_k36), _ptr(bias), _ptr(h), _ptr(temb_tab), _ptr(lab),
+                                         _ptr(emb_act), bs, rep, H, W, cout, E, _stream()), "cd360_unet_stage_in")
+    return h, emb_act
+
+
+def cfg_euler_step_cl(x: torch.Tensor, eps_cl: torch.Tensor, step_tab: torch.Tensor, step: torch.Tensor, scale: float, scale_im: float):
+    """Tail of a captured sampling step, IN PLACE on x [bs, 4, H, W] fp32: eps_cl [3 bs, H W, >= 4] bf16 channels-last rows (a channel slice
+    of wider rows is fine: the row stride is passed), sigma / sigma_next = step_tab[step][0 / 1]  (cd360_cfg_euler_step_cl)."""
+    _need_gpu(x, eps_cl, step_tab, step)
+    bs = x.shape[0]
+    hw = x.shape[2] * x.shape[3]
+    assert x.dtype == torch.float32 and x.is_contiguous() and x.shape[1] == 4 and eps_cl.dtype == torch.bfloat16
+    assert eps_cl.shape[0] == 3 * bs and eps_cl.shape[1] == hw and eps_cl.shape[2] >= 4 and eps_cl.stride(2) == 1
+    ld = eps_cl.stride(1)
+    assert eps_cl.stride(0) == hw * ld
+    check(_lib.load().cd360_cfg_euler_step_cl(_ptr(x), _ptr(eps_cl), _ptr(step_tab), _ptr(step), float(scale), float(scale_im), bs, hw, ld,
+                                             _stream()), "cd360_cfg_euler_step_cl")
+    return x

@@ -302,7 +302,17 @@ class UNetModel(nn.Module):
             w = torch.cat([b.emb_layers[1].weight.detach() for b in blocks], 0).contiguous()
             bias = torch.cat([b.emb_layers[1].bias.detach() for b in blocks], 0).contiguous()
             self._emb_cat = (key, w, bias)
-        act = torch.nn.functional.silu(emb)
+        return self._emb_outs_from_act(torch.nn.functional.silu(emb), emb, blocks)
+
+    def _emb_outs_from_act(self, act: torch.Tensor, emb: torch.Tensor, blocks=None) -> torch.Tensor:
+        """The merged emb_layers GEMM on act = silu(emb); the per-block column slices ride on `emb` (see _tag_emb_outs)."""
+        if blocks is None:
+            blocks = [m for m in self.modules() if isinstance(m, ResBlock)]
+            key = tuple((b.emb_layers[1].weight.data_ptr(), b.emb_layers[1].weight._version, b.emb_layers[1].bias._version) for b in blocks)
+            if self._emb_cat is None or self._emb_cat[0] != key:
+                w = torch.cat([b.emb_layers[1].weight.detach() for b in blocks], 0).contiguous()
+                bias = torch.cat([b.emb_layers[1].bias.detach() for b in blocks], 0).contiguous()
+                self._emb_cat = (key, w, bias)
         if ops.linear_ok(act, self._emb_cat[1]) and not routes.library_linear:
             allp = ops.linear(act, self._emb_cat[1], self._emb_cat[2])  # [b, sum(out_channels)] on the hand-written GEMM (M = batch rows)
         else:
@@ -323,7 +333,6 @@ class UNetModel(nn.Module):
         pose, mask_ref = kwargs.get("pose"), kwargs.get("mask_ref")
         reference_image = "input_ref" in kwargs and kwargs["input_ref"] is not None
         contextr = embr = hr = None
-        fg_mask_list, alphas_list, predicted_rgb_list = [], [], []
         if "input_ref" in kwargs:
             contextr = context[b:]
             yr = y[b:] if y is not None else None
@@ -351,6 +360,15 @@ class UNetModel(nn.Module):
                 contextr = contextr.to(dt)
                 hr = xr.reshape(b * n, *xr.shape[2:]).to(dt).contiguous(memory_format=torch.channels_last)
 
+        h, fg_mask_list, alphas_list, predicted_rgb_list = self._trunk(h, emb, context, hr, embr, contextr, pose, mask_ref, reference_image)
+        out = conv_image(self.out[2], tokens_to_image(group_norm_tokens(self.out[0], h, silu=True), h.shape[2], h.shape[3]))
+        return out.type(x.dtype), fg_mask_list, alphas_list, predicted_rgb_list
+
+    def _trunk(self, h, emb, context, hr, embr, contextr, pose, mask_ref, reference_image, first_done: bool = False):
+        """input_blocks -> middle_block -> output_blocks (openaimodel.py:1032-1084).  first_done: `h` already is the output of
+        input_blocks[0] (the input convolution: the sampling job's stage-in kernel computes it, forward_staged)."""
+        fg_mask_list, alphas_list, predicted_rgb_list = [], [], []
+
         def collect(fg, al, rgb):
             if fg is not None:
                 fg_mask_list.extend(fg)
@@ -360,7 +378,11 @@ class UNetModel(nn.Module):
                 predicted_rgb_list.extend(rgb)
 
         hs, hrs = [], []
-        for module in self.input_blocks:
+        for bi_, module in enumerate(self.input_blocks):
+            if bi_ == 0 and first_done:
+                hs.append(h)
+                hrs.append(hr)
+                continue
             h, hr, fg, _, al, rgb = module(h, emb, context, hr, embr, contextr, pose, mask_ref=mask_ref, prev_weights=None)
             collect(fg, al, rgb)
             hs.append(h)
@@ -382,5 +404,17 @@ class UNetModel(nn.Module):
                 hr = _cat_channels(hr, hrp)
             h, hr, fg, _, al, rgb = module(h, emb, context, hr, embr, contextr, pose, mask_ref=mask_ref, prev_weights=None)
             collect(fg, al, rgb)
-        out = conv_image(self.out[2], tokens_to_image(group_norm_tokens(self.out[0], h, silu=True), h.shape[2], h.shape[3]))
-        return out.type(x.dtype), fg_mask_list, alphas_list, predicted_rgb_list
+        return h, fg_mask_list, alphas_list, predicted_rgb_list
+
+    @torch.no_grad()
+    def forward_staged(self, h_tokens, emb_act, context, pose, H: int, W: int):
+        """The sampling job's entry (cd360/job.py::Sampler, captured steps): `h_tokens` [b, H W, model_channels] bf16 = the input
+        convolution of the scaled latent and `emb_act` [b, 4 model_channels] bf16 = silu(time_embed(..) + label_emb(y)), both written by
+        cd360_unet_stage_in; no reference stream (sample.py's mode).  Returns the output convolution's channels-last rows
+        [b, H W, out_channels] bf16 (a channel slice of the kernel's 16-wide rows) for cd360_cfg_euler_step_cl -- forward()'s arithmetic
+        between those two points, launch for launch."""
+        emb = self._emb_outs_from_act(emb_act, emb_act)
+        h = tokens_to_image(h_tokens, H, W)
+        h, _, _, _ = self._trunk(h, emb, context.to(self.dtype), None, None, None, pose, None, False, first_done=True)
+        t = group_norm_tokens(self.out[0], h, silu=True)
+        return conv_tokens(self.out[2], t, h.shape[0], H, W)

@@ -306,6 +306,21 @@ int cd360_add_layernorm_bwd_bf16(const void* x, const void* gamma, const void* d
 int cd360_cfg_euler_step_f32(const void* x, const void* eps, const void* sigma, const void* sigma_next, float scale, float scale_im,
                              void* out, int64_t n, void* stream);
 
+/* The two ends of one CAPTURED sampling step, with every per-step scalar read from tables through a device-side step index (replaces, inside
+ * the hipGraph of cd360/job.py::Sampler, the ~45 torch elementwise launches of DiscreteDenoiser.network_inputs -- denoiser.py:47-79: sigma ->
+ * table index, EpsScaling, c_in x --, timestep_embedding + time_embed + label_emb + SiLU -- openaimodel.py:1006-1030, util.py:206-231 --, the
+ * UNet's 4 -> 320 input convolution -- openaimodel.py:663-670 -- and the casts around the fused CFG + Euler tail).
+ * cd360_unet_stage_in: x [bs, 4, H, W] fp32; step_tab [nsteps, 4] fp32 = (sigma, sigma_next, c_in, -); step: device int32 (row of the tables);
+ *   w_k36 [36, Cout] fp32 = the convolution weight, k = (ky * 3 + kx) * 4 + ci; bias [Cout] fp32; h [rep * bs, H * W, Cout] bf16 out
+ *   (channels-last; the `rep` CFG branches of a sample get identical rows); temb_tab [nsteps, E] bf16 = time_embed(timestep_embedding(c_noise))
+ *   per step; lab [rep * bs, E] bf16 = label_emb(y); emb_act [rep * bs, E] bf16 out = silu(temb_tab[step] + lab).
+ * cd360_cfg_euler_step_cl: cd360_cfg_euler_step_f32's arithmetic on x [bs, 4, HW] fp32 IN PLACE with eps [3 bs, HW, ld] bf16 channels-last
+ *   (channels 0..3 of every ld-wide row: the 320 -> 4 output convolution's padded rows), sigma / sigma_next = step_tab[step][0 / 1]. */
+int cd360_unet_stage_in(const void* x, const void* step_tab, const void* step, const void* w_k36, const void* bias, void* h, const void* temb_tab,
+                        const void* lab, void* emb_act, int bs, int rep, int H, int W, int Cout, int E, void* stream);
+int cd360_cfg_euler_step_cl(void* x, const void* eps, const void* step_tab, const void* step, float scale, float scale_im, int bs, int64_t HW,
+                            int ld, void* stream);
+
 /* ---- 3x3 convolution / GEMM with fused epilogue -----------------------------------------------------------------------
  * replaces nn.Conv2d(3x3, stride 1, padding 1) + the adds around it in ResBlock._forward (openaimodel.py:350-376:
  * `h + emb_out`, `skip_connection(x) + h`) and Upsample.conv (:161-164) on channels-last bf16; taps = 1 gives out = x @ w^T

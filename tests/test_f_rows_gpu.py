@@ -134,3 +134,40 @@ def test_f2_fused_sampler_step_on_the_gpu_walks_the_reference_trajectory():
     uc = {"crossattn": g["uc_crossattn"].to(DEV), "vector": g["uc_vector"].to(DEV)}
     res, _ = smp(lambda inp, s, cc: den(dummy_network, inp, s, cc), g["x"].to(DEV), c, uc=uc, num_steps=12)
     assert torch.allclose(res.cpu(), g["cfg3"], atol=2e-5, rtol=1e-5)
+
+
+@torch.no_grad()
+def test_f2_stage_kernels_of_the_captured_step_match_the_module_arithmetic():
+    """The two ends of a captured sampling step (cd360_unet_stage_in / cd360_cfg_euler_step_cl, round 6) against the module chain they
+    replace: DiscreteDenoiser.network_inputs' c_in scaling + the UNet's 4 -> 320 input convolution on the bf16 latent (fp32 torch
+    restatement of the same roundings), silu(time_embed row + label_emb row), and cd360_cfg_euler_step_f32's update on the fp32 copy of
+    bf16 channels-last eps rows -- with the scalars read through the device-side step index."""
+    from cd360 import ops
+    g = torch.Generator(device=DEV).manual_seed(3)
+    bs, rep, H, W, cout, E, nsteps = 2, 3, 24, 40, 320, 1280, 5   # (W is not a multiple of the kernel's 64-pixel row tile)
+    x = torch.randn(bs, 4, H, W, generator=g, device=DEV)
+    w = (torch.randn(cout, 4, 3, 3, generator=g, device=DEV) * 0.2).to(BF)
+    bias = torch.randn(cout, generator=g, device=DEV)
+    tab = torch.rand(nsteps, 4, generator=g, device=DEV) + 0.5
+    temb = torch.randn(nsteps, E, generator=g, device=DEV).to(BF)
+    lab = torch.randn(rep * bs, E, generator=g, device=DEV).to(BF)
+    h = torch.empty(rep * bs, H * W, cout, dtype=BF, device=DEV)
+    act = torch.empty_like(lab)
+    for step in (0, 3):
+        gi = torch.tensor([step], dtype=torch.int32, device=DEV)
+        ops.unet_stage_in(x, tab, gi, w.float().permute(2, 3, 1, 0).reshape(36, cout).contiguous(), bias, temb, lab, h, act)
+        x_in = (x * tab[step, 2]).to(BF).float()
+        want = torch.nn.functional.conv2d(x_in.double(), w.double(), bias.double(), padding=1).float()  # [bs, cout, H, W]
+        want = want.permute(0, 2, 3, 1).reshape(bs, H * W, cout)
+        for r in range(rep):
+            assert rel(h[r * bs:(r + 1) * bs], want) < 4e-3  # one bf16 rounding of the output
+            assert torch.equal(h[r * bs:(r + 1) * bs], h[:bs])
+        emb = (temb[step][None] + lab)  # bf16 + bf16 -> bf16, as `emb = time_embed(..) + label_emb(y)` in UNetModel.forward
+        assert rel(act, torch.nn.functional.silu(emb)) < 4e-3
+        # tail: in place on x against the fp32 kernel fed the same rows
+        eps16 = torch.randn(3 * bs, H * W, 16, generator=g, device=DEV).to(BF)
+        eps_nchw = eps16[..., :4].float().reshape(3 * bs, H, W, 4).permute(0, 3, 1, 2).contiguous()
+        want_x = ops.cfg_euler_step(x, eps_nchw, tab[step, 0].reshape(1).contiguous(), tab[step, 1].reshape(1).contiguous(), 7.5, 3.5)
+        x2 = x.clone()
+        out = ops.cfg_euler_step_cl(x2, eps16[..., :4], tab, gi, 7.5, 3.5)
+        assert out is x2 and torch.equal(x2, want_x)
