@@ -32,6 +32,8 @@ SIGNATURES = {
     "cd360_plucker_features_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, _P]),
     "cd360_nerf_k_padded": (c_int, []),
     "cd360_nerf_mlp_aggregate": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, _P]),
+    "cd360_nerf_ws_bytes": (c_int64, [c_int, c_int, c_int, c_int]),
+    "cd360_nerf_mlp_aggregate_ws": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, c_int64, _P]),
     "cd360_nerf_mlp_aggregate_bwd": (c_int, [_P, _P, _P, _P, c_int] + [_P] * 15 + [c_int] * 5 + [_P]),
     "cd360_nerf_mlp_aggregate_bwd_det": (c_int, [_P, _P, _P, _P, c_int] + [_P] * 16 + [c_int] * 5 + [_P]),
     "cd360_volrender": (c_int, [_P, _P, _P, _P, c_int, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),

@@ -335,10 +335,16 @@ def nerf_mlp_aggregate(cams, xs, ys, t, Y, zP, lv, cview, Wk, want_logits=False,
     g = torch.empty(b, hw * S, C, dtype=torch.bfloat16, device=Y.device)
     logits = torch.empty(b, n, hw * S, dtype=torch.float32, device=Y.device) if want_logits else None
     lse = torch.empty(b, hw * S, 2, dtype=torch.float32, device=Y.device) if want_logits else None
+    # two passes (cd360_nerf_mlp_aggregate_ws): the per-(view, sample) geometry, view logit and softmax statistics once, into `ws`, then
+    # the per-channel-slice gather / MLP / aggregate reading 32-byte records (the library falls back to the one-pass kernels outside the
+    # two-pass envelope or under cd360_tuning.nerf_kernel = 0 | 1)
+    lib = _lib.load()
+    ws = torch.empty(int(lib.cd360_nerf_ws_bytes(b, n, r, S)), dtype=torch.uint8, device=Y.device)
     with _timed("nerf_mlp_aggregate", 2.0 * b * n * hw * S * 99 * C, 2.0 * C * (2 * b * n * hw + b * hw * S)):
-      check(_lib.load().cd360_nerf_mlp_aggregate(_ptr(cams), _ptr(xs), _ptr(ys), _ptr(t.contiguous()), stride, _ptr(Y), _ptr(zP), _ptr(lv),
-                                              _ptr(cview), _ptr(Wk), _ptr(img_map), _ptr(g), _ptr(logits), _ptr(lse), b, n, r, S, C, _stream()),
-          "cd360_nerf_mlp_aggregate")
+      check(lib.cd360_nerf_mlp_aggregate_ws(_ptr(cams), _ptr(xs), _ptr(ys), _ptr(t.contiguous()), stride, _ptr(Y), _ptr(zP), _ptr(lv),
+                                            _ptr(cview), _ptr(Wk), _ptr(img_map), _ptr(g), _ptr(logits), _ptr(lse), b, n, r, S, C, ntab,
+                                            _ptr(ws), ws.numel(), _stream()),
+          "cd360_nerf_mlp_aggregate_ws")
     return g, logits, lse
 
 
@@ -630,6 +636,19 @@ def concat_channels(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     with _timed("concat_channels", 0.0, 2.0 * 2 * N * H * W * (ca + cb)):
         check(_lib.load().cd360_concat_channels_bf16(_ptr(at), _ptr(bt), _ptr(out), N * H * W, ca, cb, _stream()), "cd360_concat_channels_bf16")
     return out.permute(0, 3, 1, 2)
+
+
+def concat_gn_stats(sa: torch.Tensor, sb: torch.Tensor) -> torch.Tensor:
+    """torch.cat([sa, sb], dim=2) of two GroupNorm slab-statistics tensors [N, slabs, C, 2] fp32 (the statistics of a channel concatenation
+    are the concatenated per-channel statistics) on cd360_concat_channels_bf16: a row of C (sum, sumsq) pairs is a row of 4 C bf16 words
+    to that kernel -- no torch-issued cat kernel inside a captured step."""
+    _need_gpu(sa, sb)
+    N, slabs, ca, two = sa.shape
+    cb = sb.shape[2]
+    assert two == 2 and sb.shape == (N, slabs, cb, 2) and sa.dtype == sb.dtype == torch.float32 and sa.is_contiguous() and sb.is_contiguous()
+    out = torch.empty(N, slabs, ca + cb, 2, dtype=torch.float32, device=sa.device)
+    check(_lib.load().cd360_concat_channels_bf16(_ptr(sa), _ptr(sb), _ptr(out), N * slabs, 4 * ca, 4 * cb, _stream()), "cd360_concat_channels_bf16")
+    return out
 
 
 # ----------------------------------------------------------------------------------------------- conv3x3 / GEMM (implicit GEMM)

@@ -53,7 +53,8 @@ def _cat_channels(a, b):
             elif nb > na and nb % na == 0:
                 sb = sb.reshape(sb.shape[0], na, nb // na, sb.shape[2], 2).sum(2)
             if sa.shape[1] == sb.shape[1]:
-                tag_gn_stats(out, torch.cat([sa, sb], dim=2))
+                sa, sb = sa.contiguous(), sb.contiguous()
+                tag_gn_stats(out, ops.concat_gn_stats(sa, sb) if sa.dtype == sb.dtype == torch.float32 else torch.cat([sa, sb], dim=2))
         return out
     return th.cat([a, b], dim=1)
 

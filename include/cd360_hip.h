@@ -197,6 +197,16 @@ int cd360_nerf_mlp_aggregate(const void* cams, const void* xs, const void* ys, c
 int cd360_volrender(const void* feats, const void* sigma_raw, const void* rgb_raw, const void* dists, int d_ray_stride, void* rendered,
                     void* fg, void* alphas, void* weights, void* rgb, int b, int hw, int S, int C, int dtype, int flags, void* stream);
 
+/* cd360_nerf_mlp_aggregate in TWO passes (the default of the Python binding): pass 1 computes, once per (batch, view, sample), what does
+ * not depend on the channel slice -- the projection into the view, the bilinear corner pixel / clamps / mask / fractions (the same ordered
+ * fp32 chains: indices bit-exact), the view logit and the softmax statistics over the views -- into `ws`; pass 2 is the gather + 99-input
+ * MFMA slice + SiLU + weighted accumulate per 64-channel slice, reading a 32-byte record instead of redoing that work C / 64 times.
+ * ntab = table images in Y / lv (b * n without img_map); ws: cd360_nerf_ws_bytes(b, n, r, S) bytes, 16-byte aligned scratch. */
+int64_t cd360_nerf_ws_bytes(int b, int n, int r, int S);
+int cd360_nerf_mlp_aggregate_ws(const void* cams, const void* xs, const void* ys, const void* t, int t_ray_stride, const void* Y, const void* zP,
+                                const void* lv, const void* cview, const void* Wk, const void* img_map, void* g, void* logits, void* lse, int b,
+                                int n, int r, int S, int C, int ntab, void* ws, int64_t ws_bytes, void* stream);
+
 /* Backward of cd360_nerf_mlp_aggregate for the fine-tuning loop (torch autograd through FeatureNeRFEncoding.forward in the
  * reference; the trainable parameters here are plane_coefs, nviews and decoder, diffusion.py:139-144).  Inputs as the forward,
  * plus its outputs g and lse, and dg [b, hw*S, C] bf16.  Writes dz [b, n, hw*S, C] bf16 (= softmax_i dg SiLU'(z_i)) and the

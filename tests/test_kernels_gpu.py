@@ -233,6 +233,44 @@ def test_render_kernel_full_line_gathers_equal_register_gathers(C, r, n, S, b, v
         assert all(torch.equal(a, b_) for a, b_ in zip(o, ref))
 
 
+@pytest.mark.parametrize("geometry", [3, 4])
+@pytest.mark.parametrize("C,r,n,S,b", [(64, 8, 2, 4, 2), (640, 16, 5, 24, 1), (1280, 8, 7, 6, 2), (128, 7, 3, 3, 1), (64, 8, 1, 4, 1)])
+def test_render_two_pass_equals_one_pass(C, r, n, S, b, geometry, tune):
+    """The two-pass render (round 6: cd360_nerf_mlp_aggregate_ws = nerf_geom_kernel + nerf_fused_rec_kernel, the binding's default)
+    against the one-pass full-line kernel (cd360_tuning.nerf_kernel = 1): the view logits are the same fp32 chain (bit-identical), the
+    softmax statistics agree to fp32 rounding, and the aggregated features differ only through the softmax weights' rounding (exp2(lg - m)
+    / l with the final maximum instead of the online rescales): a last-bit flip of a bf16 output here and there.  Eight repeated launches
+    of the two-pass form are bit-identical (no atomics, no ordering freedom); (.., n = 1, ..) exercises the short record pipeline.
+    geometry = cd360_tuning.nerf_kernel: 3 = pass 2 on 64 channels per workgroup, 4 = on 32 (the same arithmetic per channel: the two are
+    bit-identical to each other)."""
+    from cd360 import nerf, ops
+    w = nerf_weights(C, seed=C + n)
+    cams = cams_for(b, n, seed=C).to(DEV)
+    xref = bf(W.tensor("xref", (b, n, r * r, C), seed=C)).to(DEV, torch.bfloat16)
+    fw = nerf.FusedNerfWeights(*(w[k].to(DEV) for k in ("plane_coefs.0.weight", "plane_coefs.0.bias", "plane_coefs.2.weight", "plane_coefs.2.bias",
+                                                        "nviews.weight", "nviews.bias", "decoder.weight")))
+    xs = nerf.patch_positions(r, DEV)
+    t, _ = nerf.depth_samples(S, 2.0, 0.0, DEV, r * r)
+    Y, lv = nerf.reference_tables(fw, xref)
+    g = torch.Generator().manual_seed(C)
+    zP = bf(torch.randn(b * n, r * r, C, generator=g)).to(DEV, torch.bfloat16)
+    cview = nerf.view_constants(fw, cams)
+    tune(nerf_kernel=1)
+    ref = ops.nerf_mlp_aggregate(cams, xs, xs, t, Y, zP, lv, cview, fw.Wk, want_logits=True)
+    tune(nerf_kernel=7 - geometry)
+    other = ops.nerf_mlp_aggregate(cams, xs, xs, t, Y, zP, lv, cview, fw.Wk, want_logits=True)
+    tune(nerf_kernel=geometry)
+    outs = [ops.nerf_mlp_aggregate(cams, xs, xs, t, Y, zP, lv, cview, fw.Wk, want_logits=True) for _ in range(8)]
+    assert all(torch.equal(a, b_) for a, b_ in zip(other, outs[0]))           # the two pass-2 geometries agree bit for bit
+    assert torch.equal(outs[0][1], ref[1])                                    # logits: bit-identical
+    assert torch.allclose(outs[0][2], ref[2], rtol=2e-6, atol=2e-6)          # (max ln 2, sum)
+    assert rel(outs[0][0], ref[0]) < 4e-3 and (outs[0][0] != ref[0]).float().mean() < 0.05  # a bf16 ulp, on few entries
+    nolog = ops.nerf_mlp_aggregate(cams, xs, xs, t, Y, zP, lv, cview, fw.Wk)
+    assert torch.equal(nolog[0], outs[0][0]) and nolog[1] is None
+    for o in outs[1:]:
+        assert all(torch.equal(a, b_) for a, b_ in zip(o, outs[0]))
+
+
 # ------------------------------------------------------------------------------------------------ volume rendering (A10)
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_volrender(dtype):
