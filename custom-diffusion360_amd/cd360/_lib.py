@@ -97,7 +97,7 @@ SIGNATURES = {
 
 TUNING_FIELDS = ("gemm_cfg", "gemm_group_m", "gemm_movers", "gemm_ksplit", "conv_cfg", "conv_dma", "conv_kgroup", "conv_wide", "conv_wmajor",
                  "conv_split", "attn_smallk", "attn_smallk_wgs", "attn_self", "attn_fast", "nerf_kernel", "qattn_cfg", "whatif", "gemm_small", "qattn_keys16",
-                 "qattn_split", "store_wt")
+                 "qattn_split", "store_wt", "conv_halo")
 
 
 class Tuning(ctypes.Structure):
@@ -110,7 +110,7 @@ TUNING_ENV = {
     "CD360_GEMM_CFG": "gemm_cfg", "CD360_GEMM_GROUP_M": "gemm_group_m", "CD360_GEMM_MOVERS": "gemm_movers", "CD360_GEMM_KSPLIT": "gemm_ksplit",
     "CD360_CONV_CFG": "conv_cfg", "CD360_CONV_DMA": "conv_dma", "CD360_CONV_KGROUP": "conv_kgroup", "CD360_CONV_WIDE": "conv_wide",
     "CD360_CONV_WMAJOR": "conv_wmajor", "CD360_CONV_SPLIT": "conv_split", "CD360_ATTN_SMALLK": "attn_smallk", "CD360_SMALLK_WGS": "attn_smallk_wgs",
-    "CD360_ATTN_SELF": "attn_self", "CD360_ATTN_FAST": "attn_fast", "CD360_NERF_KERNEL": "nerf_kernel", "CD360_QATTN_CFG": "qattn_cfg",
+    "CD360_ATTN_SELF": "attn_self", "CD360_ATTN_FAST": "attn_fast", "CD360_NERF_KERNEL": "nerf_kernel", "CD360_CONV_HALO": "conv_halo", "CD360_QATTN_CFG": "qattn_cfg",
     "CD360_GEMM_ABL": "whatif", "CD360_GEMM_SMALL": "gemm_small", "CD360_QATTN_KEYS16": "qattn_keys16", "CD360_QATTN_SPLIT": "qattn_split",
     "CD360_STORE_WT": "store_wt",
 }

@@ -120,13 +120,14 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   // once, through the LDS, in front of the epilogue: each group hands the other one half of its channel blocks and finishes the half it
   // keeps, so all eight waves run the epilogue on 64 x 32 as in the unsplit tiling.
   static_assert(KS == 1 || KS == 2, "k-step groups");
-  static_assert(KS == 1 || ((EPI == 0 || EPI == 5 || EPI == 6) && NCB % KS == 0), "split K: linear / convolution epilogues");
+  static_assert(KS == 1 || ((EPI == 0 || EPI == 5 || EPI == 6 || EPI == 11) && NCB % KS == 0), "split K: linear / convolution epilogues");
   constexpr int ECB = NCB / KS;                    // channel blocks a wave finishes in the epilogue
   constexpr int NWT = WM * WN;                     // waves of one k-step group (one output block each)
   constexpr int NWC = NWT * KS;                    // waves that multiply
   constexpr int NW = NWC + MV;                     // waves
   constexpr int NWD = MV ? MV : NW;                // waves that move data
-  static_assert(MV == 0 || (EPI >= 0 && EPI <= 10), "mover waves: every epilogue (in the attention epilogues they also fetch K / V)");
+  static_assert(MV == 0 || (EPI >= 0 && EPI <= 11), "mover waves: every epilogue (in the attention epilogues they also fetch K / V)");
+  static_assert(EPI != 11 || (MV > 0 && NBUF == 4), "halo convolution: mover waves issue the pieces, four channel buffers");
   constexpr int KPW = 4 / KS;                      // k-steps of a K-tile that one wave multiplies
   constexpr int BM = WM * NMB * 32, BN = WN * NCB * 32;
   // bytes of one buffer of each operand (64-deep K-tile, 128-byte rows), rounded UP to whole DMA pieces: a tile side that is not a
@@ -139,15 +140,26 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   // EPI 6 = linear epilogue + the per-slab channel statistics of EPI 5 (a Linear whose output feeds a GroupNorm: SpatialTransformer.proj_out)
   // 10 = the 6-group attention epilogue with both contractions on fp8 MFMA (K / V pre-packed by cd360_kv_pack_fp8)
   constexpr bool F8 = EPI == 10;
-  constexpr bool GEGLU = EPI == 1, ATTN = (EPI >= 2 && EPI <= 4) || (EPI >= 7 && EPI <= 10), CONV = EPI == 5, CSTATS = EPI == 5 || EPI == 6;
+  // EPI 11 = the convolution (EPI 5's epilogue) with the A operand read from a HALO image of the tile's input pixels (see `HALO` below)
+  constexpr bool HALO = EPI == 11;
+  constexpr bool GEGLU = EPI == 1, ATTN = (EPI >= 2 && EPI <= 4) || (EPI >= 7 && EPI <= 10), CONV = EPI == 5 || HALO, CSTATS = EPI == 5 || EPI == 6 || HALO;
   // LDS map: NBUF token buffers, then NBUF channel buffers.  The attention epilogues interleave them instead (buffer b = tokens, then
   // channels, at b * (XB + WB)) and rotate the ring so that the LAST K-tile sits in buffer 0: everything behind buffer 0 is then free
   // one tile before the loop ends, and the K / V rows of the tile's heads are fetched into it under the last K-tile's MFMAs.
   constexpr uint32_t BB = XB + WB;
   constexpr uint32_t XSTR = ATTN ? BB : XB, WSTR = ATTN ? BB : WB;  // byte distance between consecutive buffers of one operand
-  constexpr uint32_t XREG = 0, WREG = ATTN ? XB : NBUF * XB;
   constexpr int PR = 8 * NWD;                      // rows one DMA piece of all moving waves covers (8 per wave)
-  constexpr int XP = (BM + PR - 1) / PR, WP = (BN + PR - 1) / PR;  // pieces per wave per K-tile
+  // HALO (round 6): the nine taps of a 3 x 3 convolution read the SAME input pixels nine times -- as nine K-tiles of the implicit im2col
+  // matrix that is nine trips through the L2 -> LDS path, which is what the 128 x 128 tilings run out of.  Here the
+  // token operand of a 64-channel chunk is ONE image in the LDS: the tile's BM / W image rows plus one row above / below and one
+  // pixel left / right ((BM / W + 2) (W + 2) rows of 128 bytes, zeros outside the image), fetched once per chunk; the nine taps are nine
+  // row-shifted views of it (fragment row = pixel + dy (W + 2) + dx).  K runs chunk-major here (all nine taps of a chunk back to back --
+  // the weights stay in cd360_conv_k_order's order, K-tile (chunk, tap) is simply read from where that order puts it); two halo
+  // buffers alternate by chunk, the channel operand keeps its ring.  Per chunk the path carries 26-36 KB of pixels instead of 9 x 16.
+  constexpr int HPMAX = 9;                          // pieces (of PR rows) of one halo image, at most
+  constexpr uint32_t HB = HALO ? HPMAX * PR * 128 : 0;  // bytes of one halo buffer
+  constexpr uint32_t XREG = 0, WREG = HALO ? 2 * HB : (ATTN ? XB : NBUF * XB);
+  constexpr int XP = HALO ? 2 : (BM + PR - 1) / PR, WP = (BN + PR - 1) / PR;  // pieces per wave per K-tile (HALO: up to two halo pieces ride with a K-tile)
   constexpr int NP = XP + WP, NMMA = NCB * NMB;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   // (LDS-DMA destinations of the attention epilogues are formed in address space 3 from here: a generic pointer that reaches the cast
@@ -196,8 +208,8 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   // Convolution: bit `tap` of xmask[i] = the pixel of this lane's row of piece i has an in-image neighbour under that tap (rows past M:
   // none).  The shifted pixel is the same row offset plus a wave-uniform tap offset; a padding neighbour reads from an offset past the
   // end of the buffer descriptor, i.e. zeros.
-  uint32_t xmask[CONV ? XP : 1];
-  if constexpr (CONV) {
+  uint32_t xmask[(CONV && !HALO) ? XP : 1];
+  if constexpr (CONV && !HALO) {
     const int hw = p.cv_H * p.cv_W;
 #pragma unroll
     for (int i = 0; i < XP; ++i) {
@@ -229,17 +241,65 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
       }
     }
   };
+  // HALO: geometry of the tile's halo image and the chunk-major walk of the K-tiles.  Issue side (tiles are issued in order): is_hc / is_ht =
+  // chunk / tap of the K-tile about to be issued, is_wcol = byte column of its weights in cd360_conv_k_order's layout.
+  const int hW2 = HALO ? p.cv_W + 2 : 1;                                  // row pitch of the halo image in pixels
+  const int hHR = HALO ? (BM / (HALO ? p.cv_W : 1) + 2) * hW2 : 0;         // its rows
+  const int hNC = HALO ? (int)(p.lda >> 6) : 0;                            // 64-channel chunks
+  int h_img0 = 0;                                                          // (image index * H + first image row of the tile - 1) -- row of halo row 0
+  if constexpr (HALO) {
+    const int hw = p.cv_H * p.cv_W;
+    h_img0 = (int)(m0 / hw) * p.cv_H + (int)(m0 % hw) / p.cv_W - 1;
+  }
+  const int h_ylo = HALO ? (int)(m0 / (p.cv_H * p.cv_W)) * p.cv_H : 0;     // first / one-past-last image row index (image included) that exists
+  const int h_yhi = h_ylo + (HALO ? p.cv_H : 0);
+  const uint32_t h_inv = HALO ? (uint32_t)((1u << 20) / (uint32_t)hW2 + 1u) : 0u;  // row / hW2 = (row * h_inv) >> 20 for row < 1024 (checked by the launcher)
+  int is_hc = 0, is_ht = 0, is_hg = 0, is_hj = 0;
+  uint32_t is_wcol = 0;
+  auto halo_next = [&]() {  // wave-uniform
+    is_hc = is_hg * p.cv_kg + is_hj;
+    is_ht = cv_tap;
+    is_wcol = (uint32_t)((((is_hg * 9 + cv_tap) * p.cv_kg + is_hj) * 64) * 2);
+    if (++cv_tap == 9) {
+      cv_tap = 0;
+      if (++is_hj == p.cv_kg) {
+        is_hj = 0;
+        ++is_hg;
+      }
+    }
+  };
+  // halo piece h (PR rows from row h PR) of chunk c into halo buffer c & 1: this lane's row = h PR + srow, its pixel = (h_img0 + row / hW2,
+  // row % hW2 - 1); a pixel outside the image (or a row past the image's end) is fetched from past the end of the descriptor: zeros
+  auto halo_piece = [&](int c, int h) {
+    const int row = h * PR + srow;
+    const int hy = (int)(((uint32_t)row * h_inv) >> 20), hx = row - hy * hW2 - 1;
+    const int yy = h_img0 + hy;
+    uint32_t o = (uint32_t)(((long)yy * p.cv_W + hx) * p.lda * 2 + c * 128 + schunk * 16);
+    if (row >= hHR || yy < h_ylo || yy >= h_yhi || hx < 0 || hx >= p.cv_W) o = 0x80000000u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, LDS_AS3(dma_base + (c & 1) * HB + h * (PR * 128)), 16, o, 0, 0, 0);
+  };
+  const int hPM = HALO ? (hHR + PR - 1) / PR : 0;                          // pieces of a halo image
   // DMA piece i (0 .. NP-1) of K-tile kt into the buffers at byte offsets bx / bw (0 | one buffer).  The wave-uniform part of the
   // source offset is added with an opaque v_add (otherwise the compiler keeps NP strength-reduced per-piece offsets live in VGPRs).
   auto piece = [&](int kt, int i, uint32_t bx, uint32_t bw) {
     uint32_t o;
+    if constexpr (HALO) {
+      if (i < XP) {
+        // up to two pieces of the NEXT chunk's halo ride with the K-tiles of taps NBUF .. 8 of this chunk: issued after the barrier that
+        // ended the chunk before (whose buffer they overwrite), landed -- they are older than this chunk's last channel pieces -- before
+        // the first K-tile of the next chunk is waited for
+        const int h = 2 * (is_ht - NBUF) + i;
+        if (is_ht >= NBUF && h < hPM && is_hc + 1 < hNC) halo_piece(is_hc + 1, h);
+        return;
+      }
+    }
     if (i < XP) {
       const uint32_t su = (CONV ? is_tapoff : (uint32_t)(kt * 128)) + (uint32_t)i * xstep;
       asm volatile("v_add_u32 %0, %1, %2" : "=v"(o) : "s"(su), "v"(xoff0));
       if constexpr (CONV) o = ((xmask[i < XP ? i : 0] >> is_tap) & 1u) ? o : 0x80000000u;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc, LDS_AS3(dma_base + XREG + bx + i * (PR * 128)), 16, o, 0, 0, 0);
     } else {
-      const uint32_t su = (uint32_t)(kt * 128) + (uint32_t)(i - XP) * wstep;
+      const uint32_t su = (HALO ? is_wcol : (uint32_t)(kt * 128)) + (uint32_t)(i - XP) * wstep;
       asm volatile("v_add_u32 %0, %1, %2" : "=v"(o) : "s"(su), "v"(woff0));
       __builtin_amdgcn_raw_ptr_buffer_load_lds(wrsrc, LDS_AS3(dma_base + WREG + bw + (i - XP) * (PR * 128)), 16, o, 0, 0, 0);
     }
@@ -254,12 +314,43 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
     xo[i] = XREG + (uint32_t)((wr * NMB * 32 + l31) * 128 + (((2 * ks + hh) ^ ((l31 >> 1) & 7)) << 4));
     wo[i] = WREG + (uint32_t)((wc * NCB * 32 + cp) * 128 + (((2 * ks + hh) ^ ((cp >> 1) & 7)) << 4));
   }
+  // HALO: the token fragments of K-tile (chunk, tap) are rows pixel + dy (W + 2) + dx of halo buffer chunk & 1: per-lane byte offsets
+  // xh[k-step][block], recomputed for every K-tile (the 16-byte XOR swizzle follows the ROW, which moves with the tap)
+  uint32_t xh[HALO ? KPW : 1][HALO ? NMB : 1];
+  int hb_[HALO ? NMB : 1];  // halo row of the lane's pixel of block mb under tap (0, 0)
+  if constexpr (HALO) {
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) {
+      const int px = wr * (NMB * 32) + mb * 32 + l31;
+      hb_[mb] = (px / p.cv_W) * hW2 + px % p.cv_W;
+    }
+  }
+  int c_tap = 0, c_par = 0;  // compute side: tap and chunk parity of the K-tile whose fragments are read next
+  auto halo_offsets = [&]() {
+    if constexpr (HALO) {
+      const int shift = (c_tap / 3) * hW2 + c_tap % 3;  // wave-uniform
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb) {
+        const int row = hb_[mb] + shift;
+        const uint32_t base = (uint32_t)(c_par * HB) + (uint32_t)row * 128u, swz = (uint32_t)(row >> 1) & 7u;
+#pragma unroll
+        for (int i = 0; i < KPW; ++i) xh[i][mb] = base + ((((uint32_t)(2 * (kg * KPW + i) + hh)) ^ swz) << 4);
+      }
+      if (++c_tap == 9) {
+        c_tap = 0;
+        c_par ^= 1;
+      }
+    }
+  };
   bf16x8 fx[2][NMB], fw[2][NCB];
   auto read_ks = [&](int set, int ks) {
 #pragma unroll
     for (int nb = 0; nb < NCB; ++nb) fw[set][nb] = *reinterpret_cast<const bf16x8*>(lds + wo[ks] + nb * 4096);
 #pragma unroll
-    for (int mb = 0; mb < NMB; ++mb) fx[set][mb] = *reinterpret_cast<const bf16x8*>(lds + xo[ks] + mb * 4096);
+    for (int mb = 0; mb < NMB; ++mb) {
+      if constexpr (HALO) fx[set][mb] = *reinterpret_cast<const bf16x8*>(lds + xh[ks][mb]);
+      else fx[set][mb] = *reinterpret_cast<const bf16x8*>(lds + xo[ks] + mb * 4096);
+    }
   };
 
   f32x16 acc[NCB][NMB];
@@ -371,17 +462,24 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   // counted wait: everything but the `later` most recently issued tiles has landed (s_waitcnt takes an immediate)
   auto wait_tiles_in_flight = [&](int later) {
     if (abl & 8) return;
+    // (HALO: a K-tile carries WP channel pieces and 0 .. 2 halo pieces; counting the guaranteed WP per younger tile waits for at most two
+    // pieces more than necessary and never for fewer)
+    constexpr int NPG = HALO ? WP : NP;
     if (later <= 0) WAIT_VM0();
-    else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NP) : "memory");
-    else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NP) : "memory");
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NP) : "memory");
+    else if (later == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPG) : "memory");
+    else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPG) : "memory");
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NPG) : "memory");
   };
   static_assert(NBUF >= 2 && NBUF <= 4 && (NBUF - 1) * NP <= 63, "counted waits: up to 3 tiles, 6-bit vmcnt");
   if (!MV || mover) {
+    if constexpr (HALO) {  // the first chunk's halo image: older than every channel piece, so the first counted wait covers it
+      for (int h = 0; h < hPM; ++h) halo_piece(0, h);
+    }
 #pragma unroll
     for (int b = 0; b < NBUF; ++b)
       if (b < nk) {
-        if constexpr (CONV) conv_next();
+        if constexpr (HALO) halo_next();
+        else if constexpr (CONV) conv_next();
 #pragma unroll
         for (int i = 0; i < NP; ++i) piece(b, i, ((b + rot) % NBUF) * XSTR, ((b + rot) % NBUF) * WSTR);
       }
@@ -394,6 +492,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
     wait_tiles_in_flight((nk < NBUF ? nk : NBUF) - 1);
   }
   BARRIER();
+  halo_offsets();
   read_ks(0, 0);
   if constexpr (ATTN) {
     const float inv = p.ln_stats ? 1.f / (float)p.ln_dim : 0.f;
@@ -488,13 +587,16 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
           xo[ks] += ax;
           wo[ks] += aw;
         }
+        halo_offsets();  // (every read of tile t has been issued: the offsets move on to tile t + 1)
         read_ks(0, 0);
         FENCE();
       }
       {  // last k-step: its MFMAs with the DMA pieces of tile t+NBUF (into the buffer just released) spread between them.  The MFMAs
          // are unconditional code: accumulators defined in two branch arms make the register allocator copy and spill them.
         const bool more = MOVE && t + NBUF < nk && !(abl & 4);
-        if constexpr (CONV) {
+        if constexpr (HALO) {
+          if (more) halo_next();
+        } else if constexpr (CONV) {
           if (more) conv_next();
         }
 #pragma unroll
@@ -1118,7 +1220,9 @@ int launch_mv(const GemmParams& p0, hipStream_t stream) {
   constexpr int ATTN_KV_END = (BM + BN) * 128 + WN * (EPI == 10 ? 96 * 64 + 64 * 128 : 2 * NK16 * 16 * 128);  // (EPI 10: the packed fp8 image)
   constexpr int ATTN_BYTES = ATTN ? ATTN_KV_END + ((BN * 4 <= 1024 && ATTN_KV_END + 2048 <= 160 * 1024) ? 2048 : 0) : 0;  // + bias / wsum slices (BW_LDS)
   constexpr int PRL = 8 * (MV ? MV : WM * WN * KS);  // rows per DMA piece: the ring's buffers are whole pieces (see XB / WB in the kernel)
-  constexpr int RING_BYTES = NBUF * (((BM + PRL - 1) / PRL) * PRL + ((BN + PRL - 1) / PRL) * PRL) * 128, STAGE_BYTES0 = ATTN ? 0 : BM * BN * 2 + (KS == 2 ? BM * BN * 4 : 0);
+  constexpr int RING_BYTES = EPI == 11 ? 2 * 9 * PRL * 128 + NBUF * (((BN + PRL - 1) / PRL) * PRL) * 128  // two halo buffers + the channel ring
+                                       : NBUF * (((BM + PRL - 1) / PRL) * PRL + ((BN + PRL - 1) / PRL) * PRL) * 128,
+                STAGE_BYTES0 = ATTN ? 0 : BM * BN * 2 + (KS == 2 ? BM * BN * 4 : 0);
   constexpr int STAGE_BYTES = STAGE_BYTES0 > ATTN_BYTES ? STAGE_BYTES0 : ATTN_BYTES;
 #ifdef CD360_GEMM_STAMP
   constexpr int BASE_BYTES = RING_BYTES > STAGE_BYTES ? RING_BYTES : STAGE_BYTES;
@@ -1173,6 +1277,9 @@ int launch_mv(const GemmParams& p0, hipStream_t stream) {
 template <int WM, int WN, int NCB, int NMB, int NBUF, int KS, int EPI>
 int launch_ks(const GemmParams& p, hipStream_t stream) {
   constexpr bool CAN = NCB * NMB <= 6 && WM * WN * KS + 4 <= 16;
+  if constexpr (EPI == 11) {  // the halo convolution exists with mover waves only
+    return launch_mv<WM, WN, NCB, NMB, NBUF, KS, 4, EPI>(p, stream);
+  } else {
   if constexpr (CAN) {
     // measured (hipGraph-timed, interleaved): the four- and three-buffer arrangements -5 ... -10 % (C -> C 18.7 -> 17.8 us, FF2 50.1 -> 47.0,
     // 3 x 3 convolutions at 32^2 / 64^2 108 -> 98 / 176 -> 161), 256 x 192 -2.6 %, the two-buffer 128 x 128 with two workgroups per CU +-0
@@ -1181,6 +1288,7 @@ int launch_ks(const GemmParams& p, hipStream_t stream) {
     if (mv >= 0 ? mv == 4 : DEFAULT_ON) return launch_mv<WM, WN, NCB, NMB, NBUF, KS, 4, EPI>(p, stream);
   }
   return launch_mv<WM, WN, NCB, NMB, NBUF, KS, 0, EPI>(p, stream);
+  }
 }
 
 template <int WM, int WN, int NCB, int NMB, int NBUF, int EPI>
@@ -1590,6 +1698,17 @@ int pick_conv_cfg(long M, int Cout) {
   }
   return best;
 }
+// The halo form of the 3 x 3 convolution (gemm_mfma_kernel EPI 11: 128 x 128 tiles of whole image rows, the tile's input pixels fetched once
+// per 64-channel chunk): image rows that divide the 128-pixel tile, images that are whole tiles, a halo image of at most nine 32-row
+// pieces -- W = 8 ... 64, i.e. the 32^2 and 64^2 levels of the SDXL UNet.  cd360_tuning.conv_halo: 0 never, 1 wherever it fits, -1 = the
+// measured default (launches whose tiling is 128 x 128: the 32^2 level).
+bool conv_halo_ok(int N, int H, int W, int Cin, int Cout, int cfg) {
+  const int mode = cd360_tune().conv_halo;
+  if (mode == 0) return false;
+  if (W < 8 || 128 % W || ((long)H * W) % 128 || (128 / W + 2) * (W + 2) > 9 * 32 || (128 / W + 2) * (W + 2) >= 1024) return false;
+  if (Cin < 64 || 9 * Cin < 64 * 4) return false;
+  return mode == 1 || cfg == 4;  // (measured, tools/probe/conv_halo_ab.py: 32^2 level -3 ... -7 %; the 64^2 level's 256 x 128 tiling beats 128 x 128 halo tiles by 15 %)
+}
 bool conv_dma_ok(int N, int H, int W, int Cin, int Cout, int taps, int stride) {
   if (cd360_tune().conv_dma == 0) return false;
   if (taps != 9 || stride != 1 || Cin % 64 || Cout % 16 || N <= 0 || H <= 0 || W <= 0) return false;
@@ -1629,6 +1748,7 @@ extern "C" int cd360_conv3x3_dma_bf16(const void* x, const void* w_packed, const
   p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f; p.a_dup = p.a_dup_from = 0; p.a_kv8 = nullptr; p.a_kvs = nullptr; p.a_heads = 0;
   p.cv_H = H; p.cv_W = W; p.cv_kg = cd360_conv_k_order(Cin, 9); p.cv_up = 0;
   p.emb = (const uint16_t*)emb; p.emb_stride = emb ? emb_stride : 0; p.cstats = (float*)tile_stats;
+  if (conv_halo_ok(N, H, W, Cin, Cout, cfg)) return launch_128x4<11>(p, (hipStream_t)stream);
   switch (cfg) {
     case 1: return launch_epi<4, 2, 5, 2, 2, 5>(p, (hipStream_t)stream);
     case 2: return launch_epi<4, 2, 2, 2, 3, 5>(p, (hipStream_t)stream);

@@ -52,29 +52,43 @@ __global__ __launch_bounds__(256) void gn_partial_kernel(const uint16_t* __restr
   }
 }
 
-// grid (G, N): one workgroup reduces the nslab x cpg x (sum, sumsq) partials of one group (fixed tree order: deterministic)
+// grid (G, N): one workgroup reduces the nslab x cpg x (sum, sumsq) partials of one group -- every thread a fixed stride of them with
+// four independent loads in flight, an xor tree inside each wave, the four wave sums through the LDS in a fixed order: deterministic, ONE
+// workgroup barrier (the eight-barrier LDS tree of rounds 1-5 was most of this kernel's 6 us: 46 launches per denoise step).
 __global__ __launch_bounds__(256) void gn_finalize_kernel(const float* __restrict__ partial, float* __restrict__ stat, int P, int C, int G,
                                                           float eps, int nslab) {
-  __shared__ float red[2 * 256];
-  const int g = blockIdx.x, n = blockIdx.y, cpg = C / G, tid = threadIdx.x;
-  float s = 0.f, ss = 0.f;
-  for (int i = tid; i < nslab * cpg; i += 256) {
-    const int sl = i / cpg, c = g * cpg + (i - sl * cpg);
-    const float* src = partial + (((long)n * nslab + sl) * C + c) * 2;
-    s += src[0];
-    ss += src[1];
+  __shared__ float red[8];
+  const int g = blockIdx.x, n = blockIdx.y, cpg = C / G, tid = threadIdx.x, lane = tid & 63, items = nslab * cpg;
+  const f32x2* src = reinterpret_cast<const f32x2*>(partial) + (long)n * nslab * C + g * cpg;
+  float s[4] = {0.f, 0.f, 0.f, 0.f}, ss[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i0 = tid; i0 < items; i0 += 1024) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int i = i0 + 256 * u;
+      if (i < items) {
+        const int sl = i / cpg;
+        const f32x2 v = src[(long)sl * C + (i - sl * cpg)];
+        s[u] += v[0];
+        ss[u] += v[1];
+      }
+    }
   }
-  red[2 * tid] = s;
-  red[2 * tid + 1] = ss;
+  float a = (s[0] + s[1]) + (s[2] + s[3]), b = (ss[0] + ss[1]) + (ss[2] + ss[3]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    a += __shfl_xor(a, o);
+    b += __shfl_xor(b, o);
+  }
+  if (lane == 0) {
+    red[2 * (tid >> 6)] = a;
+    red[2 * (tid >> 6) + 1] = b;
+  }
   __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (tid < off) { red[2 * tid] += red[2 * (tid + off)]; red[2 * tid + 1] += red[2 * (tid + off) + 1]; }
-    __syncthreads();
-  }
   if (tid == 0) {
+    const float sum = (red[0] + red[2]) + (red[4] + red[6]), sq = (red[1] + red[3]) + (red[5] + red[7]);
     const float cnt = (float)cpg * (float)P;
-    const float mean = red[0] / cnt;
-    const float var = fmaxf(red[1] / cnt - mean * mean, 0.f);
+    const float mean = sum / cnt;
+    const float var = fmaxf(sq / cnt - mean * mean, 0.f);
     stat[((long)n * G + g) * 2] = mean;
     stat[((long)n * G + g) * 2 + 1] = 1.f / sqrtf(var + eps);
   }

@@ -443,6 +443,43 @@ def test_conv3x3_on_the_dma_gemm_core_all_tilings(cfg, N, H, W, Cin, Cout, tune)
     assert rel(got, ops.conv_igemm(*args)) < 4e-3  # same sums in another order, both rounded to bf16
 
 
+@pytest.mark.parametrize("N,H,W,Cin,Cout", [(3, 32, 32, 320, 640), (2, 64, 64, 128, 128), (1, 16, 16, 64, 48), (3, 16, 8, 64, 320), (2, 32, 32, 1280, 256),
+                                            (1, 64, 64, 640, 80), (2, 8, 16, 192, 128)])
+def test_conv3x3_halo_form_equals_the_tap_shifted_form(N, H, W, Cin, Cout, tune):
+    """The halo form of the 3 x 3 convolution (gemm8p.hip EPI 11, round 6: the tile's input pixels fetched ONCE per 64-channel chunk into a
+    (rows + 2) x (W + 2) image in the LDS, the nine taps read as row-shifted views of it, K walked chunk-major over weights that stay in
+    cd360_conv_k_order's layout) against torch's fp32 conv2d and against the tap-shifted form (EPI 5, nine DMA passes): bias + per-image
+    addend + residual, the GroupNorm slab statistics, image borders (every tile touches the left / right border; (1, 16, 16, ...) and
+    (2, 8, 16, ...) have tiles that are a whole image or more than one image row band), K-split (Cin >= 384) and un-split arrangements,
+    ragged channel tiles (48 / 80 / 320 of 128)."""
+    from cd360 import ops
+    g = torch.Generator().manual_seed(N * 100 + H + Cin + Cout)
+    x = bf(torch.randn(N, Cin, H, W, generator=g))
+    w = bf(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
+    bias = torch.randn(Cout, generator=g)
+    emb = bf(torch.randn(N, Cout, generator=g))
+    res = bf(torch.randn(N, Cout, H, W, generator=g))
+    want = torch.nn.functional.conv2d(x, w, bias, padding=1) + emb[:, :, None, None] + res
+    xt = x.permute(0, 2, 3, 1).reshape(N, H * W, Cin).contiguous().to(DEV, torch.bfloat16)
+    wp = ops.pack_conv_weight(w).to(DEV)
+    rt = res.permute(0, 2, 3, 1).reshape(N, H * W, Cout).contiguous().to(DEV, torch.bfloat16)
+    args = (xt, wp, bias.to(DEV), N, H, W, 9, emb.to(DEV, torch.bfloat16), rt)
+    tune(conv_halo=0, conv_cfg=4)
+    shifted = ops.conv_igemm(*args)
+    tune(conv_halo=1, conv_cfg=4)
+    outs = [ops.conv_igemm(*args, want_stats=True) for _ in range(6)]
+    got, stats = outs[0]
+    assert rel(got.reshape(N, H, W, Cout).permute(0, 3, 1, 2), want) < 8e-3
+    assert rel(got, shifted) < 4e-3  # the same products summed chunk-major instead of group-major, both rounded to bf16
+    assert not torch.equal(got, shifted) or Cin == 64  # (it IS another kernel: one chunk has one summation order)
+    slabs = stats.shape[1]
+    ref = got.float().reshape(N, slabs, H * W // slabs, Cout)
+    assert rel(stats[..., 0], ref.sum(2)) < 1e-5 and rel(stats[..., 1], (ref * ref).sum(2)) < 1e-5
+    for o, st in outs[1:]:
+        assert torch.equal(o, got) and torch.equal(st, stats)  # no ordering freedom: repeated launches agree bit for bit
+    assert torch.equal(ops.conv_igemm(xt, wp, None, N, H, W, 9), ops.conv_igemm(xt, wp, torch.zeros(Cout, device=DEV), N, H, W, 9))
+
+
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(3, 32, 32, 1280, 1280), (3, 64, 64, 640, 640), (2, 8, 8, 64, 64), (1, 5, 7, 128, 320), (2, 16, 12, 192, 80)])
 def test_upsample_nearest2x_folded_into_the_convolution(N, H, W, Cin, Cout, tune):
     """Upsample.forward (openaimodel.py:114-181): nearest 2x + conv3x3 as ONE launch of four 2 x 2-tap phase convolutions of the source image

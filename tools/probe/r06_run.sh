@@ -1,3 +1,6 @@
-python -m pytest tests -m gpu -x -q 2>&1 | tail -5
-python bench.py --steps 20 --warmup 5 --no-train-step --no-cpu-baseline > gpurun_out/r06d_bench_20.json 2>/dev/null; python -c "
-import json; d=json.load(open('gpurun_out/r06d_bench_20.json')); c=d['config']; print(d['value'], d['ms_per_step'], c['steady_step_ms'], c['render_step_ms']); print({k:(v['frac'],v['avg_us']) for k,v in d['rooflines'].items() if 'avg_us' in v})"
+b() { python bench.py --steps 20 --warmup 5 --no-train-step --no-cpu-baseline --no-profile 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', d['value'], d['ms_per_step'], d['config']['steady_step_ms'], d['config']['render_step_ms'])"; }
+for i in 1 2 3; do
+b new
+CD360_LIB=$PWD/custom-diffusion360_amd/lib/libcd360_oldgn.so b oldgn
+done
+python -m pytest tests/test_kernels_gpu.py -x -q -k "gn or group" 2>&1 | tail -2
