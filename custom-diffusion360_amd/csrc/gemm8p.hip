@@ -30,6 +30,9 @@
 #include "cd360_prefetch.h"
 #include <stdlib.h>
 #include <type_traits>
+#ifndef CD360_GEMM_SCHED
+#define CD360_GEMM_SCHED 0  // probe builds (tools/probe/gemm_sched_ab.sh): 1 s_setprio around the MFMA runs, 2 static priority for waves NW/2 .., 4 reads interleaved with the MFMAs
+#endif
 
 namespace {
 
@@ -549,7 +552,12 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
 #pragma unroll
       for (int i = 0; i + 1 < KPW; ++i) {  // (the wave's last k-step, fragment set 1, runs below with the DMA issue)
         read_ks((i + 1) & 1, i + 1);
+#if !(CD360_GEMM_SCHED & 4)
         FENCE();
+#endif
+#if CD360_GEMM_SCHED & 1
+        if constexpr (MUL) __builtin_amdgcn_s_setprio(1);
+#endif
         if constexpr (SPREAD) {
 #pragma unroll
           for (int m = 0; m < NMMA; ++m) {
@@ -560,6 +568,19 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
         } else {
           mma_ks(i & 1);
         }
+#if CD360_GEMM_SCHED & 4
+        // (probe: the fragment reads of the next k-step interleaved one by one with this k-step's MFMAs instead of issued ahead of them)
+        if constexpr (MUL) {
+#pragma unroll
+          for (int m = 0; m < NMMA; ++m) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            if (m < NCB + NMB) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+        }
+#endif
+#if CD360_GEMM_SCHED & 1
+        if constexpr (MUL) __builtin_amdgcn_s_setprio(0);
+#endif
         FENCE();
       }
       if (t + 1 < nk) {
@@ -599,6 +620,9 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
         } else if constexpr (CONV) {
           if (more) conv_next();
         }
+#if CD360_GEMM_SCHED & 1
+        if constexpr (MUL) __builtin_amdgcn_s_setprio(1);
+#endif
 #pragma unroll
         for (int i = 0; i < NMMA; ++i) {
           if constexpr (MUL)
@@ -612,6 +636,9 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
             }
           }
         }
+#if CD360_GEMM_SCHED & 1
+        if constexpr (MUL) __builtin_amdgcn_s_setprio(0);
+#endif
       }
       if constexpr (ATTN && MOVE) {
         // the barrier of this iteration released every buffer but the last tile's (buffer 0): K / V of the tile's heads travel under
@@ -1042,6 +1069,9 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
       }  // rep
     }
   };
+#if CD360_GEMM_SCHED & 2
+  if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);  // (probe: static priority for the second-dispatched half of the workgroup)
+#endif
   if constexpr (MV > 0) {
     if (mover) k_loop(std::false_type{}, std::true_type{});
     else if (has_ch) k_loop(std::true_type{}, std::false_type{});
