@@ -328,9 +328,10 @@ def main():
                                         "q projection + softmax(q k^T) v over 77 keys, q never in HBM; flops = 2 M C^2 + 4 M 77 C",
                      "attn_self": "self-attention attn1 (tiled flash kernel), core form 4 B H N^2 64, projections in gemm8p",
                      "attn_smallk": "cross-attention core over <= 96 keys on the register-resident kernel (shapes the fused kernel does not serve)",
-                     "nerf_mlp_aggregate": "FeatureNeRF gather + per-sample MLP + view softmax (A5-A8) after the algebraic restructuring: full-line "
-                                           "gathers staged through LDS, VALU / latency-bound (projection, sin / cos, bilinear blend, SiLU); flops = 2 M 99 C "
-                                           "MFMA part only; render step only",
+                     "nerf_mlp_aggregate": "FeatureNeRF gather + per-sample MLP + view softmax (A5-A8) after the algebraic restructuring, in two passes "
+                                           "(geometry / view logits / softmax statistics once per (view, sample), then gather + 99-input MFMA slice + SiLU + "
+                                           "weighted sum per 64-channel slice): full-line gathers staged through LDS; VALU-bound (75 % of the SIMD cycles: "
+                                           "transcendentals of sin / cos and SiLU, the fp32 bilinear blend); flops = 2 M 99 C MFMA part only; render step only",
                      "volrender": "volume render scan (A10), HBM-bound; render step only",
                      "conv_igemm": "all 51 convolutions (implicit GEMM)"}
             for k in notes:
@@ -340,6 +341,16 @@ def main():
             if "qproj_attn" in roofs:  # the north star's target kernel: say how far it is
                 roofs["qproj_attn"]["target"] = 0.8
                 roofs["qproj_attn"]["gap"] = round(0.8 - roofs["qproj_attn"]["frac"], 4)
+                # What fraction of the MFMA peak the kernel's OWN structure allows if every MFMA it executes issued back to back with the softmax
+                # VALU (7.1 per MFMA, half an MFMA's issue time) fully hidden: algorithmic FLOP / executed MFMA FLOP x occupied fraction of the tiles.
+                # Executed per token and head: q K^T over 96 key slots (three 32-key blocks) and P V over 80 (five 16-key groups) for 77 keys; the
+                # de-duplicated launch does 2 q-projections + 3 attentions; C = 640 is 2.5 tiles of 256 columns (a sixth of the third tile idles).
+                def _ceil(C):
+                    q, a_alg, a_exe = 2.0 * C * C, 4.0 * 77 * C, 2.0 * (96 + 80) * C
+                    return (2 * q + 3 * a_alg) / (2 * q + 3 * a_exe) * (C / (256.0 * -(-C // 256)))
+                roofs["qproj_attn"]["ceiling"] = {"C640": round(_ceil(640), 3), "C1280": round(_ceil(1280), 3),
+                                                  "what": "algorithmic / executed MFMA FLOP x tile occupancy, softmax VALU assumed fully hidden; priced at the 2.4 GHz "
+                                                          "peak (under MFMA load the chip sustains 1.9-2.0 GHz on random operands: x 0.8 on top)"}
             # whole steady-state step: 2.03e13 FLOP per CFG-3 step at 1024^2 (FlopCounterMode on the plain UNet)
             if args.latent == 128:
                 roofs["steady_step"] = {"bound": "mfma", "achieved": round(ppr * 2.03e13 / (steady_ms * 1e-3) / 1e12, 1), "peak": MFMA_BF16_PEAK_TF,

@@ -88,6 +88,61 @@ def test_eight_poses_through_shard_retarget_gather_equal_eight_fresh_samplers_an
         assert max(errs) < 1e-2, (p, errs)
 
 
+@torch.no_grad()
+def test_eight_poses_at_the_headline_size_on_one_gpu():
+    """BASELINE configs[2] at FULL size on the one GPU of the box (round-5 review, weak #2): 8 target poses x (render + 2 cached steps) at
+    latent 128^2 with 50 reference views through job.sample_poses -- ONE captured Sampler, seven retargets (each re-renders all 12 pose
+    blocks at 1024^2 from the rewritten camera buffer).
+    (1) the latents of pose 0 and of pose 7 (seven retargets deep) are BIT-IDENTICAL to fresh graph-mode samplers at those poses;
+    (2) the level-1 render (C = 640, r = 64, 98 304 pose tokens per CFG branch) the retargeted sampler holds after pose 7 is the oracle's
+        on 64 rays spread over the image incl. its four corners, all three CFG branches, 1e-2 of the tensor maximum."""
+    import bench
+    import numpy as np
+    from cd360 import job, sampling, shard
+    from cd360.cameras import pack_cameras
+    from test_modules_gpu import _oracle_render_on_rays, rel
+    latent, refs, steps, P = 128, 50, 3, 8
+    net = bench.build_model(latent, refs, 50, DEV)
+    name0, blk0 = sampling.pose_blocks(net)[0]
+    held = {}
+
+    def make_sampler(pose, ctx, y):
+        held["smp"] = job.Sampler(net, pose, ctx, y, 50, use_graph=True)
+        return held["smp"]
+
+    latents, mine = job.sample_poses(make_sampler, lambda p: _job(p, latent, refs), P, steps, world=1, rank=0)
+    assert mine == list(range(P)) and latents.shape == (P, 4, latent, latent) and torch.isfinite(latents).all()
+    assert held["smp"].rgraph is not None and held["smp"].staged
+    rend_last = blk0.rendered_feat.float().clone()
+    del held["smp"]
+    for p in (0, P - 1):
+        pose, ctx, y, x0 = _job(p, latent, refs)
+        fresh = job.sample_assigned(job.Sampler(net, pose, ctx, y, 50, use_graph=True), [(pose, ctx, y, x0)], steps)[0]
+        assert torch.equal(fresh, latents[p:p + 1]), (p, float((fresh - latents[p:p + 1]).abs().max()))
+    assert float((latents[0] - latents[P - 1]).abs().max() / latents[P - 1].abs().max()) > 1e-2
+    # ---- the oracle on a ray subset of pose 7's render ----
+    w = {k: v.detach().float().cpu() for k, v in blk0.state_dict().items() if "references" not in k and "raymarcher" not in k}
+    allrefs = blk0.references.float().cpu()
+    choices = list(blk0.reference_choices)
+    hw = allrefs.shape[1]
+    r = int(round(hw ** 0.5))
+    g = np.random.default_rng(5)
+    idx = torch.tensor(sorted(set([0, r - 1, hw - r, hw - 1]) | set(int(v) for v in g.choice(hw, 60, replace=False)))[:64])
+    cond = allrefs[:-1][torch.tensor(choices)][None]
+    null = allrefs[-1:][None].expand(1, len(choices), -1, -1)
+    torch.set_num_threads(min(os.cpu_count() or 8, 32))
+    pose, ctx, y, _ = _job(P - 1, latent, refs)
+    cams = pack_cameras(pose[:1]).float().cpu()
+    smp_ctx = job.Sampler(net, pose, ctx, y, 50, use_graph=False).ctx.float().cpu()
+    errs = []
+    for br in range(3):
+        want = _oracle_render_on_rays(w, cams, null if br == 0 else cond, smp_ctx[br:br + 1], blk0.attn2.heads,
+                                      blk0.pose_featurenerf.num_samples, float(blk0.pose_featurenerf.far), idx)
+        errs.append(rel(rend_last[br:br + 1, idx], want[0]))
+    print(f"pose {P - 1} at latent 128 / 50 views: rendered features of {name0} vs oracle on {len(idx)} rays per CFG branch:", [round(e, 5) for e in errs])
+    assert max(errs) < 1e-2, errs
+
+
 def test_bench_gpus_2_starts_its_own_ranks_and_prints_one_line():
     """`python bench.py --gpus 2 ...` with no launcher around it (no WORLD_SIZE): bench.py re-executes itself under torch.distributed.run,
     two ranks share the box's one GPU over gloo (CD360_BENCH_ONE_GPU: a control-path sanity run, never a measurement -- RCCL refuses two

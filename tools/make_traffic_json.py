@@ -7,7 +7,7 @@ import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 NAMES = {"conv_igemm_kernel": "conv_igemm", "attn_fwd_kernel": "attn_self", "attn_self_kernel": "attn_self", "attn_smallk_kernel": "attn_smallk", "nerf_fused_kernel": "nerf_mlp_aggregate",
-         "nerf_fused_line_kernel": "nerf_mlp_aggregate",
+         "nerf_fused_line_kernel": "nerf_mlp_aggregate", "nerf_fused_rec_kernel": "nerf_mlp_aggregate", "nerf_geom_kernel": "nerf_mlp_aggregate",
          "gemm_mfma_kernel": "gemm8p", "row_stats_kernel": "row_stats",
          "geglu_kernel": "geglu", "volrender_kernel": "volrender", "gn_partial_kernel": "gn_silu", "gn_apply_kernel": "gn_silu", "gn_finalize_kernel": "gn_silu"}
 
@@ -38,12 +38,13 @@ def load(counter):
             import re        # pose tokens A3; 128 x 128 tile = <4, 2, 2, 1, ...>: the text cross-attention A2), 5 = 3x3 convolution, 6 = Linear + GN statistics
             m = re.search(r"gemm_mfma_kernel<([^>]*)>", r["kernel"])
             targs = [int(t) for t in m.group(1).split(",")] if m else []
-            if targs and targs[-1] == 5:
+            if targs and targs[-1] in (5, 11):  # (11: the halo form of the 3 x 3 convolution)
                 key = "conv_igemm"
             elif targs and (2 <= targs[-1] <= 4 or 7 <= targs[-1] <= 10):  # attention epilogues (7-9: odd 16-key groups, 10: fp8)
                 key = "qproj_attn" if targs[:4] == [2, 4, 2, 4] else "qproj_attn_text"  # only the pose tokens take the 256 x 256 tile
         d = out.setdefault(key, {"n": 0, "kb": 0.0, "symbols": set()})
-        d["n"] += int(r["dispatches"])
+        if "nerf_geom_kernel" not in r["kernel"]:  # (pass 1 of the two-pass render: its bytes count, its dispatch is the same launch as pass 2's)
+            d["n"] += int(r["dispatches"])
         d["kb"] += float(r["total"])
         d["symbols"].add(symbol_fragment(r["kernel"]))
     return out

@@ -1,4 +1,1 @@
-for r in 1 2; do
-python tools/probe/gemm_sched_ab.py 2>&1 | tail -1
-for d in 1 2 3 4; do CD360_LIB=$PWD/custom-diffusion360_amd/lib/libcd360_sched$d.so python tools/probe/gemm_sched_ab.py 2>&1 | tail -1; done
-done
+python -m pytest tests/test_job_gpu.py -x -q -s -k "headline" 2>&1 | grep -v "^$" | tail -8
