@@ -7,7 +7,8 @@
 //   z_i = bilinear(Y_i) + zP_i(k) + Wk . F(q_i)        a_i = softmax_i(bilinear(lv_i) + cview_i)        g = sum_i a_i silu(z_i)
 // Backward, given dg:
 //   dz_i      = a_i dg silu'(z_i)                                     -> written out [b, n, hw*S, C] bf16
-//   dlogit_i  = a_i <dg, silu(z_i) - g>   (over ALL channels)         -> fp32 atomics into dlogit [b, n, hw*S] (one add per 64-channel chunk)
+//   dlogit_i  = a_i <dg, silu(z_i) - g>   (over ALL channels)         -> fp32 atomics into dlogit [b, n, hw*S] (one add per 64-channel chunk);
+//               the deterministic form (dlogit_parts) takes g = sum_j a_j silu(z_j) from its own fp32 terms instead of the saved bf16 g
 //   dY        += w_corner dz_i   at the four gathered texels         -> fp32 atomics into dY [tables, hw, C]
 // and the generated inputs F(q_i) (the 112 sin / cos / xyz columns, bf16, the forward's k order) are written once [b, n, hw*S, 112].
 // The remaining reductions are plain library work on those two tensors (host side, grad.NerfAggregateFn):
@@ -197,8 +198,10 @@ __global__ __launch_bounds__(256) void nerf_bwd_kernel(NerfBwdParams p) {
             }
             const float sg0 = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z0));
             const float sg1 = __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.4426950408889634f * z1));
-            dot = fmaf(dgv[mb][r0], z0 * sg0 - gv[mb][r0], dot);
-            dot = fmaf(dgv[mb][r0 + 1], z1 * sg1 - gv[mb][r0 + 1], dot);
+            // (deterministic form: <dg, silu(z)> alone -- the mean over the views is taken from these very terms afterwards, see
+            // nerf_dlogit_sum_kernel; the atomic form subtracts the SAVED, bf16-rounded g)
+            dot = fmaf(dgv[mb][r0], p.dlogit_parts ? z0 * sg0 : z0 * sg0 - gv[mb][r0], dot);
+            dot = fmaf(dgv[mb][r0 + 1], p.dlogit_parts ? z1 * sg1 : z1 * sg1 - gv[mb][r0 + 1], dot);
             dzv[r0] = a * dgv[mb][r0] * (sg0 * (1.f + z0 * (1.f - sg0)));
             dzv[r0 + 1] = a * dgv[mb][r0 + 1] * (sg1 * (1.f + z1 * (1.f - sg1)));
           }
@@ -226,19 +229,38 @@ __global__ __launch_bounds__(256) void nerf_bwd_kernel(NerfBwdParams p) {
       }
       dot += __shfl_xor(dot, 32);
       if (valid && hh == 0) {
-        if (p.dlogit_parts) p.dlogit_parts[((long)cc * p.b * p.n + img) * npts + pt] = a * dot;
-        else atomicAdd(p.dlogit + img * npts + pt, a * dot);
+        if (p.dlogit_parts) {
+          p.dlogit_parts[((long)cc * p.b * p.n + img) * npts + pt] = a * dot;
+          if (cc == 0) p.dlogit[img * npts + pt] = a;  // the softmax weight itself, for nerf_dlogit_sum_kernel (which overwrites it)
+        } else {
+          atomicAdd(p.dlogit + img * npts + pt, a * dot);
+        }
       }
     }
   }
 }
 
-// dlogit[i] = sum over the channel chunks, in chunk order, of parts[cc][i]: a fixed order of additions whatever order the chunks' workgroups ran in
-__global__ __launch_bounds__(256) void nerf_dlogit_sum_kernel(const float* __restrict__ parts, float* __restrict__ dlogit, long total, int ncc) {
-  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    float acc = parts[i];
-    for (int cc = 1; cc < ncc; ++cc) acc += parts[(long)cc * total + i];
-    dlogit[i] = acc;
+// dlogit_i = a_i (e_i - sum_j a_j e_j), e_i = <dg, silu(z_i)> over ALL channels.  parts[cc][b, i, pt] = a_i e_i restricted to channel chunk cc,
+// dlogit holds a_i on entry.  One thread per (batch, sample): E_i = the chunks' terms added in chunk order, their sum over the views is
+// the mean term -- so the view-logit gradients of a sample sum to zero to fp32 rounding, as the softmax demands.  (Rounds 1-5 used
+// a_i <dg, silu(z_i) - g> with the SAVED g: g is bf16, and its rounding, the same for every view of a sample, left each sample's gradients
+// with a common-mode error that no cancellation removes: 3e-2 ... 5e-2 of the nviews.weight gradient against the reference's autograd.)
+__global__ __launch_bounds__(256) void nerf_dlogit_sum_kernel(float* __restrict__ parts, float* __restrict__ dlogit, int b, int n, long npts, int ncc) {
+  const long total = (long)b * n * npts;
+  for (long j = (long)blockIdx.x * blockDim.x + threadIdx.x; j < (long)b * npts; j += (long)gridDim.x * blockDim.x) {
+    const long bi = j / npts, pt = j - bi * npts;
+    float ebar = 0.f;
+    for (int iv = 0; iv < n; ++iv) {
+      const long i = (bi * n + iv) * npts + pt;
+      float acc = parts[i];
+      for (int cc = 1; cc < ncc; ++cc) acc += parts[(long)cc * total + i];
+      parts[i] = acc;
+      ebar += acc;
+    }
+    for (int iv = 0; iv < n; ++iv) {
+      const long i = (bi * n + iv) * npts + pt;
+      dlogit[i] = parts[i] - dlogit[i] * ebar;
+    }
   }
 }
 
@@ -311,9 +333,9 @@ static int nerf_bwd_launch(const void* cams, const void* xs, const void* ys, con
   hipLaunchKernelGGL(nerf_bwd_kernel, dim3((unsigned)nwg), dim3(256), 0, (hipStream_t)stream, p);
   CD360_LAUNCH_CHECK();
   if (dlogit_parts) {
-    const long total = (long)b * n * npts, blocks = (total + 255) / 256;
+    const long blocks = ((long)b * npts + 255) / 256;
     hipLaunchKernelGGL(nerf_dlogit_sum_kernel, dim3((unsigned)(blocks > 4096 ? 4096 : blocks)), dim3(256), 0, (hipStream_t)stream,
-                       (const float*)dlogit_parts, (float*)dlogit, total, p.ncc);
+                       (float*)dlogit_parts, (float*)dlogit, b, n, npts, p.ncc);
     CD360_LAUNCH_CHECK();
   }
   if (!dlv) return CD360_OK;
