@@ -17,11 +17,6 @@ import torch
 from . import shard
 
 
-def routes_no_emb_merge() -> bool:
-    from cd360 import routes
-    return bool(routes.no_emb_merge)
-
-
 class Sampler:
     """Minimal Euler (DDIM-equivalent, EpsScaling) step with the 3-way image/text CFG of guiders.py:102-133.
     With `use_graph` the steady-state step (cached render) and the render step are each captured once into a hipGraph and
@@ -73,12 +68,14 @@ class Sampler:
 
     # ------------------------------------------------------------------------------------------------ staged steps
     def _stageable(self) -> bool:
+        """The staged step serves the UNet this package builds (4 -> C input convolution, 4-channel output, merged emb projections)."""
+        from cd360 import routes
         net = self.net
         try:
             conv = net.input_blocks[0][0]
             return (isinstance(conv, torch.nn.Conv2d) and conv.in_channels == 4 and conv.kernel_size == (3, 3) and conv.padding == (1, 1)
                     and conv.stride == (1, 1) and conv.out_channels % 8 == 0 and conv.weight.dtype == torch.bfloat16 and conv.weight.is_cuda
-                    and net.out[2].out_channels == 4 and hasattr(net, "forward_staged") and not routes_no_emb_merge())
+                    and net.out[2].out_channels == 4 and hasattr(net, "forward_staged") and not routes.no_emb_merge)
         except (AttributeError, IndexError, TypeError):
             return False
 

@@ -196,7 +196,34 @@ def patch_positions(r: int, device, jitter: Optional[torch.Tensor] = None) -> to
         lower, upper = _const(("bounds",) + key, lambda: tuple(t.to(device) for t in bounds()))
         return (lower + (upper - lower) * jitter)[:-1].contiguous()
     lower, upper = bounds()
-    return (lower + (upper - lower) * jitter)[:-1].to(device)
+    return _upload_small((lower + (upper - lower) * jitter)[:-1], device)
+
+
+_SYNC_UPLOAD = bool(__import__("os").environ.get("CD360_SYNC_UPLOAD"))  # A/B: the pageable, host-blocking copy of rounds 1-5
+_PIN_RINGS = {}  # (numel, dtype) -> [pinned [32, numel] buffer, 32 events, next slot]
+
+
+def _upload_small(t: torch.Tensor, device) -> torch.Tensor:
+    """A small host tensor to the device WITHOUT stalling the host: a pageable `.to(device)` is a synchronous copy, and inside an eagerly
+    launched step every one of them (24 per fine-tuning step: the stratified patch jitter of 12 pose blocks on the reference's CPU
+    generator) parked the Python thread until the GPU had caught up -- 7 ms of a 130 ms step (tools/probe/train_host_profile.py, round 6).
+    Rows of a pinned ring + non-blocking copies; a slot is reused only after the event behind its last copy has completed."""
+    if not torch.cuda.is_available() or torch.device(device).type != "cuda" or _SYNC_UPLOAD:
+        return t.to(device)
+    key = (t.numel(), t.dtype)
+    ring = _PIN_RINGS.get(key)
+    if ring is None:
+        ring = _PIN_RINGS[key] = [torch.empty(32, t.numel(), dtype=t.dtype).pin_memory(), [None] * 32, 0]
+    buf, events, i = ring
+    if events[i] is not None:
+        events[i].synchronize()
+    buf[i].copy_(t.reshape(-1))
+    out = buf[i].to(device, non_blocking=True).reshape(t.shape)
+    ev = torch.cuda.Event()
+    ev.record()
+    events[i] = ev
+    ring[2] = (i + 1) % 32
+    return out
 
 
 _depth_cache = {}

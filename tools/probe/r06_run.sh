@@ -1,1 +1,9 @@
-python -m pytest tests/test_backward_gpu.py tests/test_linear_gpu.py -q -s 2>&1 | grep -a "worst gradient\|passed\|failed" | cut -c1-400
+cat > /tmp/t.py <<'PY'
+import sys, os
+sys.path[:0] = [os.getcwd(), os.path.join(os.getcwd(), "custom-diffusion360_amd"), os.path.join(os.getcwd(), "tools")]
+import bench_train
+mine = bench_train.measure(steps=3, warmup=1, batch=4, views=4, latent=64, profile=False, library=False)
+lib = bench_train.measure(steps=3, warmup=1, batch=4, views=4, latent=64, profile=False, library=True)
+print(os.environ.get("CD360_SYNC_UPLOAD", "async"), "eager cd360_ms", mine["ms_per_step"], "library_ms", lib["ms_per_step"])
+PY
+for i in 1 2; do python /tmp/t.py 2>&1 | tail -1; CD360_SYNC_UPLOAD=1 python /tmp/t.py 2>&1 | tail -1; done

@@ -49,6 +49,8 @@ def main():
     st = pstats.Stats(pr)
     st.sort_stats("tottime").print_stats(28)
     st.sort_stats("cumulative").print_stats(40)
+    st.print_callers("method 'to' of")
+    st.print_callers("torch.empty")
 
 
 if __name__ == "__main__":
