@@ -504,3 +504,16 @@ def test_per_stream_tuning_table_semantics_without_a_gpu():
             _lib.clear_stream_tuning(h)
     assert _lib.get_stream_tuning(h1) == base and _lib.get_tuning() == base and not _lib._stream_overrides
     assert lib.cd360_gemm_tile_n(3072, 1280) == 128
+
+
+def test_host_glue_builds_and_binds_to_the_loaded_library():
+    """csrc_host/cd360_host.cpp (the C++ autograd node of the fine-tuning Linears) is host glue above the C ABI: it builds with g++ against
+    torch's headers (no device code), resolves its launches in the libcd360_hip.so cd360._lib has loaded, and exposes `linear`.  No compute
+    call here (no GPU)."""
+    import __graft_entry__ as G
+    G._build_host_glue()
+    from cd360 import _host
+    mod = _host.get()
+    assert mod is not None and callable(mod.linear) and callable(mod.init)
+    with pytest.raises(Exception):
+        mod.init("/nonexistent/libcd360_hip.so")  # never a second copy of the library, never a fallback

@@ -304,3 +304,34 @@ def test_fused_adamw_updates_are_seen_by_every_weight_cache():
             assert torch.equal(a, w_), f"burst {burst}: a cache survived the fused optimiser step"
         assert not torch.equal(now[0], prev[0]) and not torch.equal(now[1], prev[1])
         prev = now
+
+
+@pytest.mark.parametrize("trainable", [False, True])
+def test_cpp_autograd_node_of_linear_equals_the_python_node(trainable):
+    """cd360/_host.py (csrc_host/cd360_host.cpp): the fine-tuning Linear's autograd node as C++ host glue issues exactly the launches
+    grad.LinearFn issues from Python -- output, dX, dW, db and the residual's gradient bit-identical, frozen and trainable weights, 3-D
+    inputs, a strided weight view (pose_emb_layers' column halves)."""
+    from cd360 import _host, ops, routes
+    assert _host.get() is not None, "the host glue must be built on a GPU box (__graft_entry__.build)"
+    g = torch.Generator(device=DEV).manual_seed(11)
+    x0 = torch.randn(3, 80, 256, generator=g, device=DEV).to(torch.bfloat16)
+    wfull = (torch.randn(128, 512, generator=g, device=DEV) * 0.05).to(torch.bfloat16)
+    b0 = torch.randn(128, generator=g, device=DEV).to(torch.bfloat16)
+    r0 = torch.randn(3, 80, 128, generator=g, device=DEV).to(torch.bfloat16)
+    cot = torch.randn(3, 80, 128, generator=g, device=DEV).to(torch.bfloat16)
+
+    def run(glue):
+        x = x0.clone().requires_grad_(True)
+        wf = wfull.clone().requires_grad_(trainable)
+        w = wf[:, 256:]  # a column-half view: row stride 512
+        b = b0.clone().requires_grad_(trainable)
+        r = r0.clone().requires_grad_(True)
+        with routes.override(no_host_glue=not glue):
+            y = ops.linear(x, w, b, r)
+            y.backward(cot)
+        return [y.detach(), x.grad, r.grad] + ([wf.grad, b.grad] if trainable else [])
+
+    a, p = run(True), run(False)
+    assert len(a) == len(p)
+    for u, v in zip(a, p):
+        assert u is not None and v is not None and torch.equal(u, v)

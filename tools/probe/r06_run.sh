@@ -1,9 +1,13 @@
-cat > /tmp/t.py <<'PY'
+python - <<'PY'
 import sys, os
-sys.path[:0] = [os.getcwd(), os.path.join(os.getcwd(), "custom-diffusion360_amd"), os.path.join(os.getcwd(), "tools")]
-import bench_train
-mine = bench_train.measure(steps=3, warmup=1, batch=4, views=4, latent=64, profile=False, library=False)
-lib = bench_train.measure(steps=3, warmup=1, batch=4, views=4, latent=64, profile=False, library=True)
-print(os.environ.get("CD360_SYNC_UPLOAD", "async"), "eager cd360_ms", mine["ms_per_step"], "library_ms", lib["ms_per_step"])
+sys.path[:0] = [os.getcwd(), os.path.join(os.getcwd(), "custom-diffusion360_amd")]
+import torch
+from cd360 import _host, ops
+h = _host.get()
+print("host glue:", h is not None, "stream equal:", h.current_stream() == ops._stream())
+s = torch.cuda.Stream()
+with torch.cuda.stream(s):
+    print("side stream equal:", h.current_stream() == ops._stream())
 PY
-for i in 1 2; do python /tmp/t.py 2>&1 | tail -1; CD360_SYNC_UPLOAD=1 python /tmp/t.py 2>&1 | tail -1; done
+python -m pytest tests/test_linear_gpu.py tests/test_backward_gpu.py tests/test_capture_gpu.py -q 2>&1 | grep -a "passed\|failed"
+for i in 1 2; do python tools/probe/train_ab.py 2>&1 | tail -1; CD360_NO_HOST_GLUE=1 python tools/probe/train_ab.py 2>&1 | tail -1; done
