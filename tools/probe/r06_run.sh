@@ -1,4 +1,11 @@
-python -c "import __graft_entry__ as G; G.smoke()" 2>&1 | grep -v amdgpu | tail -4
-python -m pytest tests -m gpu -q -p no:cacheprovider > gpurun_out/r06f_pytest_gpu.log 2>&1; grep -a "passed\|failed" gpurun_out/r06f_pytest_gpu.log | tail -2
-python bench.py --steps 20 --warmup 5 > gpurun_out/r06f_bench_20.log 2>gpurun_out/r06f_bench_20.err; tail -1 gpurun_out/r06f_bench_20.log | python -c "
-import sys,json; d=json.loads(sys.stdin.read()); c=d['config']; print(d['value'], d['ms_per_step'], c['steady_step_ms'], c['render_step_ms'], d['roofline']['frac'], d['roofline'].get('traffic_source')); t=d['train_step']; print({k:t[k] for k in ('ms','library_graph_ms','cd360_ms','library_ms')}); print(d['cpu_baseline']['value'])"
+#!/bin/bash
+# scratch: run on the GPU box
+mkdir -p gpurun_out
+python -m pytest tests/test_kernels_gpu.py -q -x -k "skip_convolution or out_conv4 or halo" 2>&1 | tail -15 > gpurun_out/skip_tests.log
+python -m pytest tests/test_modules_gpu.py tests/test_f_rows_gpu.py -q -x 2>&1 | tail -8 >> gpurun_out/skip_tests.log
+for rep in 1 2; do
+  for v in 0 1; do
+    CD360_NO_SKIP_FUSE=$v python bench.py --steps 20 --warmup 3 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('no_skip_fuse=$v', d['value'], d['ms_per_step'], d.get('config',{}).get('steady_ms'))" >> gpurun_out/skip_ab.log
+  done
+done
+cat gpurun_out/skip_tests.log gpurun_out/skip_ab.log
