@@ -28,6 +28,7 @@
 #include "cd360_common.h"
 #include "cd360_tuning.h"
 #include "cd360_prefetch.h"
+#include "gemm4w_loop.inc"
 #include <stdlib.h>
 #include <type_traits>
 #ifndef CD360_GEMM_SCHED
@@ -152,6 +153,9 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   // EPI 11 = the convolution (EPI 5's epilogue) with the A operand read from a HALO image of the tile's input pixels (see `HALO` below)
   constexpr bool HALO = EPI == 11;
   constexpr bool GEGLU = EPI == 1, ATTN = (EPI >= 2 && EPI <= 4) || (EPI >= 7 && EPI <= 10), CONV = EPI == 5 || HALO, CSTATS = EPI == 5 || EPI == 6 || HALO;
+  // ASM4 (round 6): 256 x 256 as FOUR waves of 128 x 128, one per SIMD, on the generated instruction stream of gemm4w_loop.inc
+  // (tools/gen_gemm4w_loop.py): operands global -> registers -> LDS with one tile of slack per piece instead of LDS-DMA.
+  constexpr bool ASM4 = WM == 2 && WN == 2 && NCB == 4 && NMB == 4 && NBUF == 2 && KS == 1 && MV == 0 && (EPI == 0 || EPI == 1);
   // LDS map: NBUF token buffers, then NBUF channel buffers.  The attention epilogues interleave them instead (buffer b = tokens, then
   // channels, at b * (XB + WB)) and rotate the ring so that the LAST K-tile sits in buffer 0: everything behind buffer 0 is then free
   // one tile before the loop ends, and the K / V rows of the tile's heads are fetched into it under the last K-tile's MFMAs.
@@ -475,6 +479,34 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
     }
   };
 
+  // Linear / convolution epilogues (round 6): the tile's slices of bias and wsum travel by LDS-DMA too -- into 2 .. 4 KB behind the ring and
+  // the staging image, requested BEFORE the first operand piece (older than every piece: the counted waits still count pieces only) --
+  // and the epilogue reads them with ds_read_b128.  They were one dependent L2 round trip per 8-channel slice of the epilogue, in front
+  // of its arithmetic, on a CU with nothing else to run (tools/probe/gemm4w_ab.py ksweep: 24 us of a FF1 launch did not depend on K;
+  // the library's 14 are the 63 MB it writes).  The four-wave arrangement's ring is all of the LDS: it fetches them behind the loop.
+  constexpr uint32_t RINGK = ASM4 ? 5u * 32768u : (HALO ? 2 * HB + NBUF * WB : NBUF * (XB + WB));
+  constexpr uint32_t STAGEK = BM * BN * 2 + (KS == 2 ? BM * BN * 4 : 0);
+  constexpr uint32_t LBW = ASM4 ? STAGEK : (RINGK > STAGEK ? RINGK : STAGEK);
+  constexpr uint32_t LBW_SLICE = ((BN * 4 + 1023) / 1024) * 1024;
+  constexpr bool LIN_BW = !ATTN && LBW + 2 * LBW_SLICE <= 160 * 1024;
+  auto lin_bw_issue = [&]() {
+    if constexpr (LIN_BW) {
+#pragma unroll
+      for (int q = 0; q < (int)(LBW_SLICE / 1024); ++q) {
+        const int c = q * 256 + lane * 4;
+        const uint32_t off = (c < BN && n0 + c < p.N) ? (uint32_t)((n0 + c) * 4) : 0x80000000u;
+        if (p.bias && dwave == 0) {
+          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.bias, 0, p.N * 4, 0x00020000);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds3 + (LBW + q * 1024), 16, off, 0, 0, 0);
+        }
+        if (p.ln_stats && dwave == (NWD > 1 ? 1 : 0)) {
+          const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)p.wsum, 0, p.N * 4, 0x00020000);
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, lds3 + (LBW + LBW_SLICE + q * 1024), 16, off, 0, 0, 0);
+        }
+      }
+    }
+  };
+
   // attention epilogues: the rows' LayerNorm constants (q = acc * c1 + (c2 * wsum + bias), c1 = rstd, c2 = -rstd * mean) are requested
   // here, ahead of the first operand pieces (older than every piece: the counted waits below still count pieces only), so that their
   // L2 round trip is over long before the epilogue wants them
@@ -503,8 +535,37 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
     else if (later == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPG) : "memory");
     else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NPG) : "memory");
   };
+  // LayerNorm fold: the rows' mean / rstd from the producer's partial sums -- requested HERE, ahead of the K loop (round 6: they were a
+  // dependent L2 round trip at the head of the epilogue), two registers per 32-token block across the loop
+  float mu[ATTN ? 1 : NMB], rs[ATTN ? 1 : NMB];
+  if constexpr (!ATTN) {
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) { mu[mb] = 0.f; rs[mb] = 1.f; }
+    if (p.ln_stats && !mover) {
+      const float inv = 1.f / (float)p.ln_dim;
+#pragma unroll
+      for (int mb = 0; mb < NMB; ++mb) {
+        const long m = m0 + wr * (NMB * 32) + l31 + mb * 32;
+        float s_ = 0.f, ss = 0.f;
+        if (m < p.M) {
+          const f32x2* st = reinterpret_cast<const f32x2*>(p.ln_stats) + m * p.ln_parts;
+          for (int q = 0; q < p.ln_parts; ++q) {
+            const f32x2 v = st[q];
+            s_ += v[0];
+            ss += v[1];
+          }
+        }
+        const float mean = s_ * inv;
+        const float var = fmaxf(ss * inv - mean * mean, 0.f);
+        mu[mb] = mean;
+        rs[mb] = rsqrtf(var + p.ln_eps);
+      }
+    }
+  }
   static_assert(NBUF >= 2 && NBUF <= 4 && (NBUF - 1) * NP <= 63, "counted waits: up to 3 tiles, 6-bit vmcnt");
+  if constexpr (!ASM4) {
   if (!MV || mover) {
+    lin_bw_issue();
     if constexpr (HALO) {  // the first chunk's halo image: older than every channel piece, so the first counted wait covers it
       for (int h = 0; h < hPM; ++h) halo_piece(0, h);
     }
@@ -527,6 +588,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   BARRIER();
   halo_offsets();
   read_ks(0, 0);
+  }  // !ASM4
   if constexpr (ATTN) {
     const float inv = p.ln_stats ? 1.f / (float)p.ln_dim : 0.f;
 #pragma unroll
@@ -716,8 +778,11 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
     *reinterpret_cast<u32x4*>(stage + tr * RB + ((c ^ (tr & SWZ)) << 4)) = o;
   };
   auto store_tile = [&]() {
-  float mu[NMB], rs[NMB];
-  if (p.ln_stats) {
+  float mu_[NMB], rs_[NMB];
+  if constexpr (!ATTN) {
+#pragma unroll
+    for (int mb = 0; mb < NMB; ++mb) { mu_[mb] = mu[mb]; rs_[mb] = rs[mb]; }
+  } else if (p.ln_stats) {
     const float inv = 1.f / (float)p.ln_dim;
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb) {
@@ -733,8 +798,8 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
       }
       const float mean = s * inv;
       const float var = fmaxf(ss * inv - mean * mean, 0.f);
-      mu[mb] = mean;
-      rs[mb] = rsqrtf(var + p.ln_eps);
+      mu_[mb] = mean;
+      rs_[mb] = rsqrtf(var + p.ln_eps);
     }
   }
   if constexpr (GEGLU) {  // its own instantiation: the erf code next to 256 live accumulators costs the plain epilogue registers
@@ -750,12 +815,27 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
           const int no = ((n0 + wc * (NCB * 32)) >> 1) + q * 32 + 16 * hh + 8 * c8;
           if (nv >= p.N) continue;
           float bv[8], bg[8], sv[8], sg[8];
+          if constexpr (LIN_BW) {
+            const float* const bl = reinterpret_cast<const float*>(lds + LBW) + (nv - n0);
+            const float* const sl = reinterpret_cast<const float*>(lds + LBW + LBW_SLICE) + (nv - n0);
+            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+            const f32x4 b0 = p.bias ? *reinterpret_cast<const f32x4*>(bl) : z4, b1 = p.bias ? *reinterpret_cast<const f32x4*>(bl + 4) : z4;
+            const f32x4 g0 = p.bias ? *reinterpret_cast<const f32x4*>(bl + 32) : z4, g1 = p.bias ? *reinterpret_cast<const f32x4*>(bl + 36) : z4;
+            const f32x4 s0 = p.ln_stats ? *reinterpret_cast<const f32x4*>(sl) : z4, s1 = p.ln_stats ? *reinterpret_cast<const f32x4*>(sl + 4) : z4;
+            const f32x4 t0 = p.ln_stats ? *reinterpret_cast<const f32x4*>(sl + 32) : z4, t1 = p.ln_stats ? *reinterpret_cast<const f32x4*>(sl + 36) : z4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              bv[r] = b0[r]; bv[4 + r] = b1[r]; bg[r] = g0[r]; bg[4 + r] = g1[r];
+              sv[r] = s0[r]; sv[4 + r] = s1[r]; sg[r] = t0[r]; sg[4 + r] = t1[r];
+            }
+          } else {
 #pragma unroll
           for (int r = 0; r < 8; ++r) {
             bv[r] = p.bias ? p.bias[nv + r] : 0.f;
             bg[r] = p.bias ? p.bias[nv + 32 + r] : 0.f;
             sv[r] = p.ln_stats ? p.wsum[nv + r] : 0.f;
             sg[r] = p.ln_stats ? p.wsum[nv + 32 + r] : 0.f;
+          }
           }
 #pragma unroll
           for (int mb = 0; mb < NMB; ++mb) {
@@ -766,8 +846,8 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
             for (int r = 0; r < 8; ++r) {
               float xv = acc[2 * q][mb][8 * c8 + r], gv = acc[2 * q + 1][mb][8 * c8 + r];
               if (p.ln_stats) {
-                xv = rs[mb] * (xv - mu[mb] * sv[r]);
-                gv = rs[mb] * (gv - mu[mb] * sg[r]);
+                xv = rs_[mb] * (xv - mu_[mb] * sv[r]);
+                gv = rs_[mb] * (gv - mu_[mb] * sg[r]);
               }
               v[r] = (xv + bv[r]) * gelu_erf(gv + bg[r]);
             }
@@ -795,10 +875,23 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
       const int n = n0 + cbase + nb * 32 + 16 * hh + 8 * c8;
       if (n >= p.N) continue;  // N % 16 == 0
       float bv[8], sv[8];
+      if constexpr (LIN_BW) {
+        const float* const bl = reinterpret_cast<const float*>(lds + LBW) + (n - n0);
+        const float* const sl = reinterpret_cast<const float*>(lds + LBW + LBW_SLICE) + (n - n0);
+        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+        const f32x4 b0 = p.bias ? *reinterpret_cast<const f32x4*>(bl) : z4, b1 = p.bias ? *reinterpret_cast<const f32x4*>(bl + 4) : z4;
+        const f32x4 s0 = p.ln_stats ? *reinterpret_cast<const f32x4*>(sl) : z4, s1 = p.ln_stats ? *reinterpret_cast<const f32x4*>(sl + 4) : z4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          bv[r] = b0[r]; bv[4 + r] = b1[r];
+          sv[r] = s0[r]; sv[4 + r] = s1[r];
+        }
+      } else {
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
         bv[r] = p.bias ? p.bias[n + r] : 0.f;
         sv[r] = p.ln_stats ? p.wsum[n + r] : 0.f;
+      }
       }
 #pragma unroll
       for (int mb = 0; mb < NMB; ++mb) {
@@ -808,7 +901,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
 #pragma unroll
         for (int r = 0; r < 8; ++r) {
           float t = acc[nb][mb][8 * c8 + r];
-          if (p.ln_stats) t = rs[mb] * (t - mu[mb] * sv[r]);
+          if (p.ln_stats) t = rs_[mb] * (t - mu_[mb] * sv[r]);
           v[r] = t + bv[r];
         }
         if constexpr (CONV) {
@@ -1102,7 +1195,46 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
 #if CD360_GEMM_SCHED & 2
   if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);  // (probe: static priority for the second-dispatched half of the workgroup)
 #endif
-  if constexpr (MV > 0) {
+  if constexpr (ASM4) {
+    // descriptors as plain words (the asm takes them in SGPRs): base, base_hi (stride 0), bytes, flags -- the ranges of xrsrc / wrsrc
+    const uint64_t pa = (uint64_t)p.a, pw = (uint64_t)p.w;
+    u32x4 xd = {(uint32_t)pa, (uint32_t)(pa >> 32) & 0xffffu, (uint32_t)(((long)p.M - 1) * p.lda * 2 + (long)p.K * 2), 0x00020000u};
+    u32x4 wd = {(uint32_t)pw, (uint32_t)(pw >> 32) & 0xffffu, (uint32_t)(((long)p.N - 1) * p.ldw * 2 + (long)p.K * 2), 0x00020000u};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      xd[i] = __builtin_amdgcn_readfirstlane(xd[i]);
+      wd[i] = __builtin_amdgcn_readfirstlane(wd[i]);
+    }
+    const uint32_t s_lds = __builtin_amdgcn_readfirstlane((uint32_t)(dwave * 1024));
+    const uint32_t xo0 = xo[0] - XREG, wo0 = wo[0] - WREG;  // offsets inside a 32 KB ring slot
+    const uint32_t s_xstep = __builtin_amdgcn_readfirstlane(xstep), s_wstep = __builtin_amdgcn_readfirstlane(wstep);
+    const uint32_t s_nk = __builtin_amdgcn_readfirstlane((uint32_t)nk);
+#ifdef CD360_WHATIF
+#define CD360_G4_ASM(TXT)                                                                                                                     \
+    asm volatile(TXT : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]),     \
+                 "+a"(acc[1][3]), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]), "+a"(acc[3][0]), "+a"(acc[3][1]),         \
+                 "+a"(acc[3][2]), "+a"(acc[3][3])                                                                                                \
+                 : "v"(xoff0), "v"(woff0), "s"(s_lds), "v"(xo0), "v"(wo0), "s"(xd), "s"(wd), "s"(s_xstep), "s"(s_wstep), "s"(s_nk)                \
+                 : CD360_GEMM4W_CLOBBERS)
+    if (abl & 0x80000) CD360_G4_ASM(CD360_GEMM4W_LOOP_V128);
+    else if (abl & 0x40000) CD360_G4_ASM(CD360_GEMM4W_LOOP_V64);
+    else if (abl & 0x20000) CD360_G4_ASM(CD360_GEMM4W_LOOP_V32);
+    else if (abl & 0x10000) CD360_G4_ASM(CD360_GEMM4W_LOOP_V16);
+    else if (abl & 0x8000) CD360_G4_ASM(CD360_GEMM4W_LOOP_V8);
+    else if (abl & 0x4000) CD360_G4_ASM(CD360_GEMM4W_LOOP_V4);
+    else if (abl & 0x2000) CD360_G4_ASM(CD360_GEMM4W_LOOP_V3);
+    else if (abl & 0x1000) CD360_G4_ASM(CD360_GEMM4W_LOOP_V1);
+    else CD360_G4_ASM(CD360_GEMM4W_LOOP);
+#undef CD360_G4_ASM
+#else
+    asm volatile(CD360_GEMM4W_LOOP
+                 : "+a"(acc[0][0]), "+a"(acc[0][1]), "+a"(acc[0][2]), "+a"(acc[0][3]), "+a"(acc[1][0]), "+a"(acc[1][1]), "+a"(acc[1][2]),
+                   "+a"(acc[1][3]), "+a"(acc[2][0]), "+a"(acc[2][1]), "+a"(acc[2][2]), "+a"(acc[2][3]), "+a"(acc[3][0]), "+a"(acc[3][1]),
+                   "+a"(acc[3][2]), "+a"(acc[3][3])
+                 : "v"(xoff0), "v"(woff0), "s"(s_lds), "v"(xo0), "v"(wo0), "s"(xd), "s"(wd), "s"(s_xstep), "s"(s_wstep), "s"(s_nk)
+                 : CD360_GEMM4W_CLOBBERS);
+#endif
+  } else if constexpr (MV > 0) {
     if (mover) k_loop(std::false_type{}, std::true_type{});
     else if (has_ch) k_loop(std::true_type{}, std::false_type{});
     else k_loop(std::false_type{}, std::false_type{});
@@ -1112,6 +1244,11 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   }
   if constexpr (ATTN) WAIT_VM0();  // this wave's K / V pieces have landed (visible to the others behind the barrier)
   __syncthreads();  // every wave is past its last fragment read: the K-loop buffers become the output staging area
+  if constexpr (ASM4 && LIN_BW) {
+    lin_bw_issue();
+    WAIT_VM0();
+    __syncthreads();
+  }
 #ifdef CD360_GEMM_STAMP
   if (p.stamp) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(lds + NBUF * (XB + WB));
@@ -1280,10 +1417,15 @@ int launch_mv(const GemmParams& p0, hipStream_t stream) {
   constexpr int ATTN_KV_END = (BM + BN) * 128 + WN * (EPI == 10 ? 96 * 64 + 64 * 128 : 2 * NK16 * 16 * 128);  // (EPI 10: the packed fp8 image)
   constexpr int ATTN_BYTES = ATTN ? ATTN_KV_END + ((BN * 4 <= 1024 && ATTN_KV_END + 2048 <= 160 * 1024) ? 2048 : 0) : 0;  // + bias / wsum slices (BW_LDS)
   constexpr int PRL = 8 * (MV ? MV : WM * WN * KS);  // rows per DMA piece: the ring's buffers are whole pieces (see XB / WB in the kernel)
-  constexpr int RING_BYTES = EPI == 11 ? 2 * 9 * PRL * 128 + NBUF * (((BN + PRL - 1) / PRL) * PRL) * 128  // two halo buffers + the channel ring
+  constexpr bool ASM4 = WM == 2 && WN == 2 && NCB == 4 && NMB == 4 && NBUF == 2 && KS == 1 && MV == 0 && (EPI == 0 || EPI == 1);  // five 32 KB slots
+  constexpr int RING_BYTES = ASM4 ? 5 * 32768 : EPI == 11 ? 2 * 9 * PRL * 128 + NBUF * (((BN + PRL - 1) / PRL) * PRL) * 128  // two halo buffers + the channel ring
                                        : NBUF * (((BM + PRL - 1) / PRL) * PRL + ((BN + PRL - 1) / PRL) * PRL) * 128,
                 STAGE_BYTES0 = ATTN ? 0 : BM * BN * 2 + (KS == 2 ? BM * BN * 4 : 0);
-  constexpr int STAGE_BYTES = STAGE_BYTES0 > ATTN_BYTES ? STAGE_BYTES0 : ATTN_BYTES;
+  // linear / convolution epilogues: + the bias / wsum slices behind ring and staging image when they fit (LIN_BW in the kernel)
+  constexpr int LBW0 = ASM4 ? STAGE_BYTES0 : (RING_BYTES > STAGE_BYTES0 ? RING_BYTES : STAGE_BYTES0), LBW_SL = ((BN * 4 + 1023) / 1024) * 1024;
+  constexpr int LIN_BW_END = (!ATTN && LBW0 + 2 * LBW_SL <= 160 * 1024) ? LBW0 + 2 * LBW_SL : 0;
+  constexpr int STAGE_BYTES1 = STAGE_BYTES0 > ATTN_BYTES ? STAGE_BYTES0 : ATTN_BYTES;
+  constexpr int STAGE_BYTES = STAGE_BYTES1 > LIN_BW_END ? STAGE_BYTES1 : LIN_BW_END;
 #ifdef CD360_GEMM_STAMP
   constexpr int BASE_BYTES = RING_BYTES > STAGE_BYTES ? RING_BYTES : STAGE_BYTES;
   constexpr int STAMP_BYTES = BASE_BYTES + WM * WN * KS * 64 * 32 <= 160 * 1024 ? WM * WN * KS * 64 * 32 : 0;
@@ -1392,8 +1534,8 @@ int launch(const GemmParams& p, hipStream_t stream) {
 // 2 = 128 x 128, 8 waves of 64 x 32, 2 buffers; 3 = 256 x 256, 8 waves of 128 x 64, 2 buffers; 4 = as 2 with 4 buffers (3 tiles in
 // flight: long K loops of launches with one workgroup per CU); 5 = 256 x 128, 8 waves of 64 x 64, 3 buffers; 6 = 256 x 192, 8 waves of
 // 64 x 96, 2 buffers; 7 = 256 x 256, SIXTEEN waves of 64 x 64 (four per SIMD), 2 buffers; 8 = 64 x 128, 8 waves, 4 buffers (launch_64x4)
-constexpr int NCFG = 8;
-constexpr int CFG_BM[NCFG + 1] = {0, 128, 128, 256, 128, 256, 256, 256, 64}, CFG_BN[NCFG + 1] = {0, 128, 128, 256, 128, 128, 192, 256, 128};
+constexpr int NCFG = 9;  // 9 = 256 x 256 as FOUR waves of 128 x 128 (one per SIMD): A/B
+constexpr int CFG_BM[NCFG + 1] = {0, 128, 128, 256, 128, 256, 256, 256, 64, 256}, CFG_BN[NCFG + 1] = {0, 128, 128, 256, 128, 128, 192, 256, 128, 256};
 int pick_cfg(int64_t M, int N, bool geglu) {
   const int cfg = cd360_tune().gemm_cfg;  // tuning / A-B override
   if (cfg >= 1 && cfg <= NCFG && !(geglu && (cfg == 2 || cfg == 4 || cfg == 6 || cfg == 8))) return cfg;
@@ -1478,6 +1620,7 @@ extern "C" int cd360_gemm_bf16(const void* a, const void* w, void* out, int64_t 
     case 5: return launch<4, 2, 2, 2, 3>(p, (hipStream_t)stream);
     case 7: return launch<4, 4, 2, 2, 2>(p, (hipStream_t)stream);  // 256 x 256 as sixteen waves of 64 x 64 (four per SIMD): A/B only
     case 6: return geglu ? CD360_ERR_SHAPE : launch_epi<4, 2, 3, 2, 2, 0>(p, (hipStream_t)stream);
+    case 9: return launch<2, 2, 4, 4, 2>(p, (hipStream_t)stream);
     default: return launch<2, 4, 2, 4, 2>(p, (hipStream_t)stream);
   }
 }
