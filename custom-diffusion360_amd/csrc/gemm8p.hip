@@ -488,7 +488,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   constexpr uint32_t STAGEK = BM * BN * 2 + (KS == 2 ? BM * BN * 4 : 0);
   constexpr uint32_t LBW = ASM4 ? STAGEK : (RINGK > STAGEK ? RINGK : STAGEK);
   constexpr uint32_t LBW_SLICE = ((BN * 4 + 1023) / 1024) * 1024;
-  constexpr bool LIN_BW = !ATTN && LBW + 2 * LBW_SLICE <= 160 * 1024;
+  constexpr bool LIN_BW = !ATTN && LBW + (ASM4 ? 4096u : 2 * LBW_SLICE) <= 160 * 1024;
   auto lin_bw_issue = [&]() {
     if constexpr (LIN_BW) {
 #pragma unroll
@@ -816,8 +816,9 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
           if (nv >= p.N) continue;
           float bv[8], bg[8], sv[8], sg[8];
           if constexpr (LIN_BW) {
-            const float* const bl = reinterpret_cast<const float*>(lds + LBW) + (nv - n0);
-            const float* const sl = reinterpret_cast<const float*>(lds + LBW + LBW_SLICE) + (nv - n0);
+            const float* const bl = ASM4 ? reinterpret_cast<const float*>(lds + LBW + wave * 1024) + (nv - n0 - wc * (NCB * 32))
+                                         : reinterpret_cast<const float*>(lds + LBW) + (nv - n0);
+            const float* const sl = ASM4 ? bl + 128 : reinterpret_cast<const float*>(lds + LBW + LBW_SLICE) + (nv - n0);
             const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
             const f32x4 b0 = p.bias ? *reinterpret_cast<const f32x4*>(bl) : z4, b1 = p.bias ? *reinterpret_cast<const f32x4*>(bl + 4) : z4;
             const f32x4 g0 = p.bias ? *reinterpret_cast<const f32x4*>(bl + 32) : z4, g1 = p.bias ? *reinterpret_cast<const f32x4*>(bl + 36) : z4;
@@ -876,8 +877,9 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
       if (n >= p.N) continue;  // N % 16 == 0
       float bv[8], sv[8];
       if constexpr (LIN_BW) {
-        const float* const bl = reinterpret_cast<const float*>(lds + LBW) + (n - n0);
-        const float* const sl = reinterpret_cast<const float*>(lds + LBW + LBW_SLICE) + (n - n0);
+        const float* const bl = ASM4 ? reinterpret_cast<const float*>(lds + LBW + wave * 1024) + (n - n0 - wc * (NCB * 32))
+                                     : reinterpret_cast<const float*>(lds + LBW) + (n - n0);
+        const float* const sl = ASM4 ? bl + 128 : reinterpret_cast<const float*>(lds + LBW + LBW_SLICE) + (n - n0);
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
         const f32x4 b0 = p.bias ? *reinterpret_cast<const f32x4*>(bl) : z4, b1 = p.bias ? *reinterpret_cast<const f32x4*>(bl + 4) : z4;
         const f32x4 s0 = p.ln_stats ? *reinterpret_cast<const f32x4*>(sl) : z4, s1 = p.ln_stats ? *reinterpret_cast<const f32x4*>(sl + 4) : z4;
@@ -1195,6 +1197,16 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
 #if CD360_GEMM_SCHED & 2
   if (wave >= NW / 2) __builtin_amdgcn_s_setprio(1);  // (probe: static priority for the second-dispatched half of the workgroup)
 #endif
+  // ASM4: the ring is all of the LDS while the loop runs, so this wave's 128 channels of bias and wsum wait in four registers
+  // (lane l: channels l and 64 + l), requested here, and are parked in the LDS behind the loop
+  float bw4[ASM4 ? 4 : 1];
+  if constexpr (ASM4) {
+    const int c = n0 + wc * (NCB * 32) + lane;
+    bw4[0] = (p.bias && c < p.N) ? p.bias[c] : 0.f;
+    bw4[1] = (p.bias && c + 64 < p.N) ? p.bias[c + 64] : 0.f;
+    bw4[2] = (p.ln_stats && c < p.N) ? p.wsum[c] : 0.f;
+    bw4[3] = (p.ln_stats && c + 64 < p.N) ? p.wsum[c + 64] : 0.f;
+  }
   if constexpr (ASM4) {
     // descriptors as plain words (the asm takes them in SGPRs): base, base_hi (stride 0), bytes, flags -- the ranges of xrsrc / wrsrc
     const uint64_t pa = (uint64_t)p.a, pw = (uint64_t)p.w;
@@ -1244,10 +1256,12 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   }
   if constexpr (ATTN) WAIT_VM0();  // this wave's K / V pieces have landed (visible to the others behind the barrier)
   __syncthreads();  // every wave is past its last fragment read: the K-loop buffers become the output staging area
-  if constexpr (ASM4 && LIN_BW) {
-    lin_bw_issue();
-    WAIT_VM0();
-    __syncthreads();
+  if constexpr (ASM4) {  // (bw4: requested ahead of the loop, see there) -> this wave's kilobyte behind the staging image
+    float* const d = reinterpret_cast<float*>(lds + LBW + wave * 1024) + lane;
+    d[0] = bw4[0];
+    d[64] = bw4[1];
+    d[128] = bw4[2];
+    d[192] = bw4[3];
   }
 #ifdef CD360_GEMM_STAMP
   if (p.stamp) {
@@ -1312,12 +1326,28 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
 #pragma unroll
       for (int e = 0; e < 8; ++e) { cs[e] = 0.f; cq[e] = 0.f; }
     }
+    // The image is read back in batches of eight row groups -- eight ds_read_b128 in flight, then their stores: one read, one wait, one
+    // store per row group left the LDS latency in the open 16 .. 32 times per wave (round 6).  Rows / lanes without an output row read a
+    // clamped address of the wave's own image and store nothing.
+    constexpr int NIT = (NMB * 32 + RPI - 1) / RPI, RBATCH = 8;
 #pragma unroll
-    for (int it = 0; it < (NMB * 32 + RPI - 1) / RPI; ++it) {
+    for (int it0 = 0; it0 < NIT; it0 += RBATCH) {
+      u32x4 ob[RBATCH];
+#pragma unroll
+      for (int b = 0; b < RBATCH; ++b) {
+        if (it0 + b < NIT) {
+          const int rr = (it0 + b) * RPI + rl, rc = rr < NMB * 32 ? rr : NMB * 32 - 1;
+          ob[b] = *reinterpret_cast<const u32x4*>(stage + rc * RB + (((j < NCH ? j : 0) ^ (rc & SWZ)) << 4));
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < RBATCH; ++b) {
+      if (it0 + b >= NIT) continue;
+      const int it = it0 + b;
       const int r = it * RPI + rl;
       const long m = m0 + wr * (NMB * 32) + r;
       if (rl < RPI && r < NMB * 32 && m < p.M && ocol0 + j * 8 < nout && !(abl & 64)) {
-        const u32x4 o = *reinterpret_cast<const u32x4*>(stage + r * RB + ((j ^ (r & SWZ)) << 4));
+        const u32x4 o = ob[b];
         long orow_ = m;
         if constexpr (CONV) {
           if (p.cv_up) {  // source pixel (n, i, j) of phase (a, b) -> pixel (n, 2 i + a, 2 j + b) of the 2 H x 2 W output
@@ -1342,6 +1372,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
           }
         }
       }
+      }  // b
     }
     if constexpr (CSTATS) {
       if (p.cstats) {  // fold the RPI row groups (lanes j, j + NCH, ...) in a fixed order, lane j writes its 8 channels
@@ -1423,7 +1454,7 @@ int launch_mv(const GemmParams& p0, hipStream_t stream) {
                 STAGE_BYTES0 = ATTN ? 0 : BM * BN * 2 + (KS == 2 ? BM * BN * 4 : 0);
   // linear / convolution epilogues: + the bias / wsum slices behind ring and staging image when they fit (LIN_BW in the kernel)
   constexpr int LBW0 = ASM4 ? STAGE_BYTES0 : (RING_BYTES > STAGE_BYTES0 ? RING_BYTES : STAGE_BYTES0), LBW_SL = ((BN * 4 + 1023) / 1024) * 1024;
-  constexpr int LIN_BW_END = (!ATTN && LBW0 + 2 * LBW_SL <= 160 * 1024) ? LBW0 + 2 * LBW_SL : 0;
+  constexpr int LIN_BW_END = (!ATTN && LBW0 + (ASM4 ? 4096 : 2 * LBW_SL) <= 160 * 1024) ? LBW0 + (ASM4 ? 4096 : 2 * LBW_SL) : 0;
   constexpr int STAGE_BYTES1 = STAGE_BYTES0 > ATTN_BYTES ? STAGE_BYTES0 : ATTN_BYTES;
   constexpr int STAGE_BYTES = STAGE_BYTES1 > LIN_BW_END ? STAGE_BYTES1 : LIN_BW_END;
 #ifdef CD360_GEMM_STAMP
