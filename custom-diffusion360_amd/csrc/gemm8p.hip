@@ -105,6 +105,24 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.f + copysignf(e, x));
 }
 
+// the same on two values (v_pk_fma_f32 / v_pk_mul_f32 where the scalar form has fma / mul: identical roundings, half the instructions;
+// the two transcendentals stay scalar) -- the GEGLU epilogue is VALU time on a CU with nothing else to run
+__device__ __forceinline__ f32x2 gelu_erf2(f32x2 x) {
+  const f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+  const f32x2 z = ax * f32x2{0.70710678118654752f, 0.70710678118654752f};
+  const f32x2 d = __builtin_elementwise_fma(f32x2{0.3275911f, 0.3275911f}, z, f32x2{1.f, 1.f});
+  const f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+  f32x2 poly = __builtin_elementwise_fma(f32x2{1.061405429f, 1.061405429f}, t, f32x2{-1.453152027f, -1.453152027f});
+  poly = __builtin_elementwise_fma(poly, t, f32x2{1.421413741f, 1.421413741f});
+  poly = __builtin_elementwise_fma(poly, t, f32x2{-0.284496736f, -0.284496736f});
+  poly = __builtin_elementwise_fma(poly, t, f32x2{0.254829592f, 0.254829592f});
+  const f32x2 a = (-z) * z * f32x2{1.4426950408889634f, 1.4426950408889634f};
+  const f32x2 ex = {__builtin_amdgcn_exp2f(a[0]), __builtin_amdgcn_exp2f(a[1])};
+  const f32x2 e = f32x2{1.f, 1.f} - poly * t * ex;
+  const f32x2 se = {copysignf(e[0], x[0]), copysignf(e[1], x[1])};
+  return f32x2{0.5f, 0.5f} * x * (f32x2{1.f, 1.f} + se);
+}
+
 #define LDS_AS3(p) ((__attribute__((address_space(3))) void*)(p))
 #define WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
 #define WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
@@ -182,6 +200,17 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool mover = MV > 0 && wave >= NWC;
+#ifdef CD360_GEMM_STAMP  // ASM4 phase stamps (100 MHz counter): [workgroup][wave][8] at p.stamp, lane 0 of every wave
+#define G4STAMP(i)                                                                                                            \
+  do {                                                                                                                        \
+    if constexpr (ASM4) {                                                                                                     \
+      if (p.stamp && (tid & 63) == 0) p.stamp[((long)blockIdx.x * 4 + wave) * 8 + (i)] = (uint32_t)__builtin_amdgcn_s_memrealtime(); \
+    }                                                                                                                         \
+  } while (0)
+#else
+#define G4STAMP(i) do { } while (0)
+#endif
+  G4STAMP(0);
   const int dwave = MV ? (mover ? wave - NWC : 0) : wave;  // index among the moving waves
   const int kg = mover ? 0 : wave / NWT, wv = mover ? 0 : wave - kg * NWT;  // k-step group, wave inside it
   const int wr = wv / WN, wc = wv % WN;      // token / channel position of the wave in the tile
@@ -742,7 +771,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
       }
       FENCE();
 #ifdef CD360_GEMM_STAMP
-      if (p.stamp && t < 64 && wave < NWC) {  // stamps parked in the LDS behind the ring (a global store would count in vmcnt); lane 0 of each wave
+      if (!ASM4 && p.stamp && t < 64 && wave < NWC) {  // stamps parked in the LDS behind the ring (a global store would count in vmcnt); lane 0 of each wave
         const uint64_t stE = __builtin_amdgcn_s_memtime();
         if (lane == 0) {
           uint32_t* d = reinterpret_cast<uint32_t*>(lds + NBUF * (XB + WB)) + (wave * 64 + t) * 8;
@@ -777,6 +806,13 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
     const int tr = mb * 32 + l31;
     *reinterpret_cast<u32x4*>(stage + tr * RB + ((c ^ (tr & SWZ)) << 4)) = o;
   };
+  // The epilogue's residual pointer, its row pitch and the statistics pointer as values the compiler cannot re-read from the kernel
+  // arguments: with 256 accumulators live it re-loaded each of them in every one of the 32 (slice, block) steps of the four-wave
+  // arrangement's epilogue, an s_load + s_waitcnt each (4 of its 6.5 us, tools/probe/gemm4w_stamp.py).
+  const uint16_t* e_res = p.res;
+  long e_ldr = p.ldr;
+  float* e_so = p.stats_out;
+  asm volatile("" : "+s"(e_res), "+s"(e_ldr), "+s"(e_so));
   auto store_tile = [&]() {
   float mu_[NMB], rs_[NMB];
   if constexpr (!ATTN) {
@@ -842,19 +878,19 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
           for (int mb = 0; mb < NMB; ++mb) {
             const long m = m0 + mrow0 + mb * 32;
             if (m >= p.M) continue;
-            float v[8];
-#pragma unroll
-            for (int r = 0; r < 8; ++r) {
-              float xv = acc[2 * q][mb][8 * c8 + r], gv = acc[2 * q + 1][mb][8 * c8 + r];
-              if (p.ln_stats) {
-                xv = rs_[mb] * (xv - mu_[mb] * sv[r]);
-                gv = rs_[mb] * (gv - mu_[mb] * sg[r]);
-              }
-              v[r] = (xv + bv[r]) * gelu_erf(gv + bg[r]);
-            }
+            // LayerNorm fold + bias as two fused multiply-adds per value, two values per instruction: rstd (acc - mu wsum) + bias =
+            // acc rstd + (bias - rstd mu wsum); without a fold rstd = 1, mu = 0 and the same expression is acc + bias exactly
+            const f32x2 rs2 = {rs_[mb], rs_[mb]}, c22 = {-rs_[mb] * mu_[mb], -rs_[mb] * mu_[mb]};
             u32x4 o;
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
+            for (int e = 0; e < 4; ++e) {
+              const f32x2 xa = {acc[2 * q][mb][8 * c8 + 2 * e], acc[2 * q][mb][8 * c8 + 2 * e + 1]};
+              const f32x2 ga = {acc[2 * q + 1][mb][8 * c8 + 2 * e], acc[2 * q + 1][mb][8 * c8 + 2 * e + 1]};
+              const f32x2 xv = __builtin_elementwise_fma(xa, rs2, __builtin_elementwise_fma(c22, f32x2{sv[2 * e], sv[2 * e + 1]}, f32x2{bv[2 * e], bv[2 * e + 1]}));
+              const f32x2 gv = __builtin_elementwise_fma(ga, rs2, __builtin_elementwise_fma(c22, f32x2{sg[2 * e], sg[2 * e + 1]}, f32x2{bg[2 * e], bg[2 * e + 1]}));
+              const f32x2 v2 = xv * gelu_erf2(gv);
+              o[e] = pack_bf16x2(v2[0], v2[1]);
+            }
             stage_put(mb, q * 4 + 2 * hh + c8, o);
           }
         }
@@ -900,11 +936,15 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
         const long m = m0 + mrow0 + mb * 32;
         if (m >= p.M) continue;
         float v[8];
+        {  // (the fold as in the GEGLU epilogue above: two packed fused multiply-adds per pair of values)
+          const f32x2 rs2 = {rs_[mb], rs_[mb]}, c22 = {-rs_[mb] * mu_[mb], -rs_[mb] * mu_[mb]};
 #pragma unroll
-        for (int r = 0; r < 8; ++r) {
-          float t = acc[nb][mb][8 * c8 + r];
-          if (p.ln_stats) t = rs_[mb] * (t - mu_[mb] * sv[r]);
-          v[r] = t + bv[r];
+          for (int e = 0; e < 4; ++e) {
+            const f32x2 a2 = {acc[nb][mb][8 * c8 + 2 * e], acc[nb][mb][8 * c8 + 2 * e + 1]};
+            const f32x2 t2 = __builtin_elementwise_fma(a2, rs2, __builtin_elementwise_fma(c22, f32x2{sv[2 * e], sv[2 * e + 1]}, f32x2{bv[2 * e], bv[2 * e + 1]}));
+            v[2 * e] = t2[0];
+            v[2 * e + 1] = t2[1];
+          }
         }
         if constexpr (CONV) {
           if (p.emb) {
@@ -916,8 +956,8 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
             }
           }
         }
-        if (p.res) {
-          const u32x4 e0 = *reinterpret_cast<const u32x4*>(p.res + m * p.ldr + n);
+        if (e_res) {
+          const u32x4 e0 = *reinterpret_cast<const u32x4*>(e_res + m * e_ldr + n);
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             v[2 * e] += bf16lo_to_f32(e0[e]);
@@ -928,7 +968,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
 #pragma unroll
         for (int e = 0; e < 4; ++e) o[e] = pack_bf16x2(v[2 * e], v[2 * e + 1]);
         stage_put(mb, nb * 4 + 2 * hh + c8, o);
-        if (!CONV && p.stats_out) {  // statistics of the values as stored (bf16-rounded): what the consumer's LayerNorm fold sees
+        if (!CONV && e_so) {  // statistics of the values as stored (bf16-rounded): what the consumer's LayerNorm fold sees
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const float a0 = bf16lo_to_f32(o[e]), a1 = bf16hi_to_f32(o[e]);
@@ -1207,6 +1247,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
     bw4[2] = (p.ln_stats && c < p.N) ? p.wsum[c] : 0.f;
     bw4[3] = (p.ln_stats && c + 64 < p.N) ? p.wsum[c + 64] : 0.f;
   }
+  G4STAMP(1);
   if constexpr (ASM4) {
     // descriptors as plain words (the asm takes them in SGPRs): base, base_hi (stride 0), bytes, flags -- the ranges of xrsrc / wrsrc
     const uint64_t pa = (uint64_t)p.a, pw = (uint64_t)p.w;
@@ -1254,8 +1295,10 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
     if (has_ch) k_loop(std::true_type{}, std::true_type{});
     else k_loop(std::false_type{}, std::true_type{});
   }
+  G4STAMP(2);
   if constexpr (ATTN) WAIT_VM0();  // this wave's K / V pieces have landed (visible to the others behind the barrier)
   __syncthreads();  // every wave is past its last fragment read: the K-loop buffers become the output staging area
+  G4STAMP(3);
   if constexpr (ASM4) {  // (bw4: requested ahead of the loop, see there) -> this wave's kilobyte behind the staging image
     float* const d = reinterpret_cast<float*>(lds + LBW + wave * 1024) + lane;
     d[0] = bw4[0];
@@ -1264,7 +1307,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
     d[192] = bw4[3];
   }
 #ifdef CD360_GEMM_STAMP
-  if (p.stamp) {
+  if (!ASM4 && p.stamp) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(lds + NBUF * (XB + WB));
     for (int i = tid; i < NWC * 64 * 8; i += 64 * NW) p.stamp[(long)blockIdx.x * (NWC * 64 * 8) + i] = src[i];
     __syncthreads();
@@ -1313,6 +1356,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   }
   if (has_ch) {
     store_tile();
+    G4STAMP(4);
     // (wave-private image: the compiler's lgkmcnt wait orders the ds_writes before the ds_reads, no barrier)
     const int ocol0 = GEGLU ? (n0 >> 1) + wc * OCH : n0 + cbase;
     const int nout = GEGLU ? (p.N >> 1) : p.N;
@@ -1405,6 +1449,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
     }
   }
 
+  G4STAMP(5);
   if (!CONV && p.stats_out) {  // kernel-uniform: per-row sums over this N tile = both lane halves, all channel blocks, the WN waves of the row
     float* red = reinterpret_cast<float*>(lds);  // [wc][BM][2]; the K-loop buffers are idle once every wave is past its last read
     __syncthreads();
@@ -1487,7 +1532,7 @@ int launch_mv(const GemmParams& p0, hipStream_t stream) {
 #endif
 #ifdef CD360_GEMM_STAMP
   p.stamp = nullptr;
-  if (STAMP_BYTES && !(tune.reserved[0] == -1 && tune.reserved[1] == -1))  // probe build: device pointer of the stamp buffer in reserved[0..1]
+  if ((STAMP_BYTES || ASM4) && !(tune.reserved[0] == -1 && tune.reserved[1] == -1))  // probe build: device pointer of the stamp buffer in reserved[0..1]
     p.stamp = reinterpret_cast<uint32_t*>(((uint64_t)(uint32_t)tune.reserved[1] << 32) | (uint64_t)(uint32_t)tune.reserved[0]);
 #endif
   const long nwg = (long)p.tiles_m * p.tiles_n * ((EPI == 5 && p.cv_up) ? 4 : 1);
