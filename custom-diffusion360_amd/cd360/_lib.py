@@ -99,7 +99,7 @@ SIGNATURES = {
 
 TUNING_FIELDS = ("gemm_cfg", "gemm_group_m", "gemm_movers", "gemm_ksplit", "conv_cfg", "conv_dma", "conv_kgroup", "conv_wide", "conv_wmajor",
                  "conv_split", "attn_smallk", "attn_smallk_wgs", "attn_self", "attn_fast", "nerf_kernel", "qattn_cfg", "whatif", "gemm_small", "qattn_keys16",
-                 "qattn_split", "store_wt", "conv_halo")
+                 "qattn_split", "store_wt", "conv_halo", "gemm_asm4")
 
 
 class Tuning(ctypes.Structure):
@@ -114,7 +114,7 @@ TUNING_ENV = {
     "CD360_CONV_WMAJOR": "conv_wmajor", "CD360_CONV_SPLIT": "conv_split", "CD360_ATTN_SMALLK": "attn_smallk", "CD360_SMALLK_WGS": "attn_smallk_wgs",
     "CD360_ATTN_SELF": "attn_self", "CD360_ATTN_FAST": "attn_fast", "CD360_NERF_KERNEL": "nerf_kernel", "CD360_CONV_HALO": "conv_halo", "CD360_QATTN_CFG": "qattn_cfg",
     "CD360_GEMM_ABL": "whatif", "CD360_GEMM_SMALL": "gemm_small", "CD360_QATTN_KEYS16": "qattn_keys16", "CD360_QATTN_SPLIT": "qattn_split",
-    "CD360_STORE_WT": "store_wt",
+    "CD360_STORE_WT": "store_wt", "CD360_GEMM_ASM4": "gemm_asm4",
 }
 
 _lib = None

@@ -31,6 +31,7 @@ typedef struct cd360_tuning {
   int32_t qattn_split;      // 1: second launch for the last 128 columns of a width that is 128 short of a multiple of 256 (A/B: slower)
   int32_t store_wt;         // 0 | 1: output tiles of the GEMM family leave by plain stores / by write-through (sc1) stores (gemm8p.hip: store_tile)
   int32_t conv_halo;        // 0 | 1: the halo form of the 3 x 3 convolution never / wherever it fits (-1: the launches it was measured to help)
+  int32_t gemm_asm4;        // 0 | 1: the four-wave 256 x 256 arrangement on the generated instruction stream (gemm4w_loop.inc) never / for every 256 x 256 launch (-1: where measured: FF1 + GEGLU with K >= 1024)
   int32_t reserved[2];
 } cd360_tuning;
 

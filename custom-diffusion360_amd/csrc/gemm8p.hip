@@ -878,16 +878,17 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
           for (int mb = 0; mb < NMB; ++mb) {
             const long m = m0 + mrow0 + mb * 32;
             if (m >= p.M) continue;
-            // LayerNorm fold + bias as two fused multiply-adds per value, two values per instruction: rstd (acc - mu wsum) + bias =
-            // acc rstd + (bias - rstd mu wsum); without a fold rstd = 1, mu = 0 and the same expression is acc + bias exactly
-            const f32x2 rs2 = {rs_[mb], rs_[mb]}, c22 = {-rs_[mb] * mu_[mb], -rs_[mb] * mu_[mb]};
+            // LayerNorm fold + bias on pairs of values (v_pk_mul_f32 / v_pk_add_f32), in the operation order this epilogue has always had
+            // -- rstd (acc - mu wsum) + bias, every product and sum rounded -- and without a select: no fold means rstd = 1, mu = 0,
+            // wsum = 0, for which the same expression is acc + bias exactly
+            const f32x2 rs2 = {rs_[mb], rs_[mb]}, mu2 = {mu_[mb], mu_[mb]};
             u32x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               const f32x2 xa = {acc[2 * q][mb][8 * c8 + 2 * e], acc[2 * q][mb][8 * c8 + 2 * e + 1]};
               const f32x2 ga = {acc[2 * q + 1][mb][8 * c8 + 2 * e], acc[2 * q + 1][mb][8 * c8 + 2 * e + 1]};
-              const f32x2 xv = __builtin_elementwise_fma(xa, rs2, __builtin_elementwise_fma(c22, f32x2{sv[2 * e], sv[2 * e + 1]}, f32x2{bv[2 * e], bv[2 * e + 1]}));
-              const f32x2 gv = __builtin_elementwise_fma(ga, rs2, __builtin_elementwise_fma(c22, f32x2{sg[2 * e], sg[2 * e + 1]}, f32x2{bg[2 * e], bg[2 * e + 1]}));
+              const f32x2 xv = rs2 * (xa - mu2 * f32x2{sv[2 * e], sv[2 * e + 1]}) + f32x2{bv[2 * e], bv[2 * e + 1]};
+              const f32x2 gv = rs2 * (ga - mu2 * f32x2{sg[2 * e], sg[2 * e + 1]}) + f32x2{bg[2 * e], bg[2 * e + 1]};
               const f32x2 v2 = xv * gelu_erf2(gv);
               o[e] = pack_bf16x2(v2[0], v2[1]);
             }
@@ -936,12 +937,12 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
         const long m = m0 + mrow0 + mb * 32;
         if (m >= p.M) continue;
         float v[8];
-        {  // (the fold as in the GEGLU epilogue above: two packed fused multiply-adds per pair of values)
-          const f32x2 rs2 = {rs_[mb], rs_[mb]}, c22 = {-rs_[mb] * mu_[mb], -rs_[mb] * mu_[mb]};
+        {  // (the fold as in the GEGLU epilogue above: packed, in the order it has always had, no select)
+          const f32x2 rs2 = {rs_[mb], rs_[mb]}, mu2 = {mu_[mb], mu_[mb]};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             const f32x2 a2 = {acc[nb][mb][8 * c8 + 2 * e], acc[nb][mb][8 * c8 + 2 * e + 1]};
-            const f32x2 t2 = __builtin_elementwise_fma(a2, rs2, __builtin_elementwise_fma(c22, f32x2{sv[2 * e], sv[2 * e + 1]}, f32x2{bv[2 * e], bv[2 * e + 1]}));
+            const f32x2 t2 = rs2 * (a2 - mu2 * f32x2{sv[2 * e], sv[2 * e + 1]}) + f32x2{bv[2 * e], bv[2 * e + 1]};
             v[2 * e] = t2[0];
             v[2 * e + 1] = t2[1];
           }
@@ -1688,6 +1689,15 @@ extern "C" int cd360_gemm_bf16(const void* a, const void* w, void* out, int64_t 
   // (same 128-column statistics partials; tools/bench_gemm.py mid_m "narrow": 4096 x 1280 x 5120 64.7 -> 58.5 us, 12288 x 640 x 2560 44.8 -> 40.9,
   // K = 1280 22.1 -> 21.2, K = 640 equal).  Decided here, not in pick_cfg: the tile width the host sizes buffers from does not change.
   if (cfg == 2 && K >= 1280 && cd360_tune().gemm_cfg < 1 && cd360_tune().gemm_small != 0 && ((M + 127) / 128) * ((N + 127) / 128) <= 512) cfg = 5;
+  // 256 x 256 tiles as four waves of 128 x 128 on the generated instruction stream (gemm4w_loop.inc).  Measured against the sixteen- /
+  // eight-wave arrangements on one box, interleaved (tools/probe/gemm4w_ab.py, us): plain 8192^3 771 / 875, 4096^3 106 / 116; FF1 + GEGLU
+  // 3072 x 10240 x 1280 84.0 / 86.0 as a chain of itself -- but inside the captured denoise step (cold weights, a neighbour's tail)
+  // the sixty FF1 launches come out 0.2 % SLOWER on it (32.2 against 32.3 steps/s, three alternations on one box).  So by default it
+  // serves long plain K loops only; cd360_tuning.gemm_asm4 = 1 puts every 256 x 256 launch on it, 0 none.
+  if ((cfg == 7 || cfg == 3) && cd360_tune().gemm_cfg < 1) {
+    const int a4 = cd360_tune().gemm_asm4;
+    if (a4 > 0 || (a4 < 0 && !geglu && K >= 4096 && M >= 2048)) cfg = 9;
+  }
   switch (cfg) {
     case 1: return launch<2, 2, 2, 2, 2>(p, (hipStream_t)stream);
     case 2: return geglu ? CD360_ERR_SHAPE : launch_epi<2, 4, 1, 2, 2, 0>(p, (hipStream_t)stream);

@@ -60,6 +60,7 @@ typedef struct cd360_tuning {
   int32_t qattn_split;      /* 1: second launch for the last 128 columns of a 256 k + 128 wide projection (A/B only: measured slower) */
   int32_t store_wt;         /* 0 | 1: GEMM-family output tiles by plain / write-through (sc1) stores; -1 = the measured default */
   int32_t conv_halo;        /* 0 | 1: halo form of the 3x3 convolution (input pixels of a tile fetched once per 64-channel chunk) never / wherever it fits */
+  int32_t gemm_asm4;        /* 0 | 1: 256 x 256 tiles as four waves of 128 x 128 on a generated instruction stream never / always; -1 = where measured */
   int32_t reserved[2];
 } cd360_tuning;
 int cd360_set_tuning(const cd360_tuning* t);   /* the process-wide DEFAULT (NULL restores the built-in defaults) */

@@ -1,12 +1,5 @@
 #!/bin/bash
 mkdir -p gpurun_out
-python -m pytest tests/test_gemm_gpu.py tests/test_linear_gpu.py -x -q 2>&1 | tail -2 > gpurun_out/lbw_tests.txt
-python -m pytest tests/test_kernels_gpu.py -x -q -k "conv or gemm or geglu" 2>&1 | tail -2 >> gpurun_out/lbw_tests.txt
-cat gpurun_out/lbw_tests.txt
-timeout 600 python tools/probe/gemm4w_stamp.py > gpurun_out/gemm4w_stamp.txt 2>&1
-tail -7 gpurun_out/gemm4w_stamp.txt | cut -c1-220
-timeout 600 python tools/probe/gemm4w_ab.py ksweep > gpurun_out/gemm4w_ksweep.txt 2>&1
-tail -6 gpurun_out/gemm4w_ksweep.txt
 rm -f gpurun_out/lbw_bench.txt
 for rep in 1 2; do
   for lib in libcd360_old.so libcd360_lbw.so libcd360_hip.so; do
