@@ -813,19 +813,24 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   long e_ldr = p.ldr;
   float* e_so = p.stats_out;
   asm volatile("" : "+s"(e_res), "+s"(e_ldr), "+s"(e_so));
+  const uint16_t* e_emb = p.emb;  // (the convolution tilings with ten slices per wave re-read these four per slice as well)
+  const float* e_bias = p.bias;
+  const float* e_ln = p.ln_stats;
+  int e_M = p.M, e_N = p.N;
+  asm volatile("" : "+s"(e_emb), "+s"(e_bias), "+s"(e_ln), "+s"(e_M), "+s"(e_N));
   auto store_tile = [&]() {
   float mu_[NMB], rs_[NMB];
   if constexpr (!ATTN) {
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb) { mu_[mb] = mu[mb]; rs_[mb] = rs[mb]; }
-  } else if (p.ln_stats) {
+  } else if (e_ln) {
     const float inv = 1.f / (float)p.ln_dim;
 #pragma unroll
     for (int mb = 0; mb < NMB; ++mb) {
       const long m = m0 + mrow0 + mb * 32;
       float s = 0.f, ss = 0.f;
-      if (m < p.M) {
-        const f32x2* st = reinterpret_cast<const f32x2*>(p.ln_stats) + m * p.ln_parts;
+      if (m < e_M) {
+        const f32x2* st = reinterpret_cast<const f32x2*>(e_ln) + m * p.ln_parts;
         for (int q = 0; q < p.ln_parts; ++q) {
           const f32x2 v = st[q];
           s += v[0];
@@ -849,17 +854,17 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
           FENCE();
           const int nv = n0 + wc * (NCB * 32) + q * 64 + 16 * hh + 8 * c8;  // packed row of the value block; gate block = + 32
           const int no = ((n0 + wc * (NCB * 32)) >> 1) + q * 32 + 16 * hh + 8 * c8;
-          if (nv >= p.N) continue;
+          if (nv >= e_N) continue;
           float bv[8], bg[8], sv[8], sg[8];
           if constexpr (LIN_BW) {
             const float* const bl = ASM4 ? reinterpret_cast<const float*>(lds + LBW + wave * 1024) + (nv - n0 - wc * (NCB * 32))
                                          : reinterpret_cast<const float*>(lds + LBW) + (nv - n0);
             const float* const sl = ASM4 ? bl + 128 : reinterpret_cast<const float*>(lds + LBW + LBW_SLICE) + (nv - n0);
             const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-            const f32x4 b0 = p.bias ? *reinterpret_cast<const f32x4*>(bl) : z4, b1 = p.bias ? *reinterpret_cast<const f32x4*>(bl + 4) : z4;
-            const f32x4 g0 = p.bias ? *reinterpret_cast<const f32x4*>(bl + 32) : z4, g1 = p.bias ? *reinterpret_cast<const f32x4*>(bl + 36) : z4;
-            const f32x4 s0 = p.ln_stats ? *reinterpret_cast<const f32x4*>(sl) : z4, s1 = p.ln_stats ? *reinterpret_cast<const f32x4*>(sl + 4) : z4;
-            const f32x4 t0 = p.ln_stats ? *reinterpret_cast<const f32x4*>(sl + 32) : z4, t1 = p.ln_stats ? *reinterpret_cast<const f32x4*>(sl + 36) : z4;
+            const f32x4 b0 = e_bias ? *reinterpret_cast<const f32x4*>(bl) : z4, b1 = e_bias ? *reinterpret_cast<const f32x4*>(bl + 4) : z4;
+            const f32x4 g0 = e_bias ? *reinterpret_cast<const f32x4*>(bl + 32) : z4, g1 = e_bias ? *reinterpret_cast<const f32x4*>(bl + 36) : z4;
+            const f32x4 s0 = e_ln ? *reinterpret_cast<const f32x4*>(sl) : z4, s1 = e_ln ? *reinterpret_cast<const f32x4*>(sl + 4) : z4;
+            const f32x4 t0 = e_ln ? *reinterpret_cast<const f32x4*>(sl + 32) : z4, t1 = e_ln ? *reinterpret_cast<const f32x4*>(sl + 36) : z4;
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
               bv[r] = b0[r]; bv[4 + r] = b1[r]; bg[r] = g0[r]; bg[4 + r] = g1[r];
@@ -868,16 +873,16 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
           } else {
 #pragma unroll
           for (int r = 0; r < 8; ++r) {
-            bv[r] = p.bias ? p.bias[nv + r] : 0.f;
-            bg[r] = p.bias ? p.bias[nv + 32 + r] : 0.f;
-            sv[r] = p.ln_stats ? p.wsum[nv + r] : 0.f;
-            sg[r] = p.ln_stats ? p.wsum[nv + 32 + r] : 0.f;
+            bv[r] = e_bias ? e_bias[nv + r] : 0.f;
+            bg[r] = e_bias ? e_bias[nv + 32 + r] : 0.f;
+            sv[r] = e_ln ? p.wsum[nv + r] : 0.f;
+            sg[r] = e_ln ? p.wsum[nv + 32 + r] : 0.f;
           }
           }
 #pragma unroll
           for (int mb = 0; mb < NMB; ++mb) {
             const long m = m0 + mrow0 + mb * 32;
-            if (m >= p.M) continue;
+            if (m >= e_M) continue;
             // LayerNorm fold + bias on pairs of values (v_pk_mul_f32 / v_pk_add_f32), in the operation order this epilogue has always had
             // -- rstd (acc - mu wsum) + bias, every product and sum rounded -- and without a select: no fold means rstd = 1, mu = 0,
             // wsum = 0, for which the same expression is acc + bias exactly
@@ -911,15 +916,15 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
     for (int c8 = 0; c8 < 2; ++c8) {
       FENCE();  // bound the scheduling region: hoisting every block's loads next to 256 live accumulators spills
       const int n = n0 + cbase + nb * 32 + 16 * hh + 8 * c8;
-      if (n >= p.N) continue;  // N % 16 == 0
+      if (n >= e_N) continue;  // N % 16 == 0
       float bv[8], sv[8];
       if constexpr (LIN_BW) {
         const float* const bl = ASM4 ? reinterpret_cast<const float*>(lds + LBW + wave * 1024) + (n - n0 - wc * (NCB * 32))
                                      : reinterpret_cast<const float*>(lds + LBW) + (n - n0);
         const float* const sl = ASM4 ? bl + 128 : reinterpret_cast<const float*>(lds + LBW + LBW_SLICE) + (n - n0);
         const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-        const f32x4 b0 = p.bias ? *reinterpret_cast<const f32x4*>(bl) : z4, b1 = p.bias ? *reinterpret_cast<const f32x4*>(bl + 4) : z4;
-        const f32x4 s0 = p.ln_stats ? *reinterpret_cast<const f32x4*>(sl) : z4, s1 = p.ln_stats ? *reinterpret_cast<const f32x4*>(sl + 4) : z4;
+        const f32x4 b0 = e_bias ? *reinterpret_cast<const f32x4*>(bl) : z4, b1 = e_bias ? *reinterpret_cast<const f32x4*>(bl + 4) : z4;
+        const f32x4 s0 = e_ln ? *reinterpret_cast<const f32x4*>(sl) : z4, s1 = e_ln ? *reinterpret_cast<const f32x4*>(sl + 4) : z4;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           bv[r] = b0[r]; bv[4 + r] = b1[r];
@@ -928,14 +933,14 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
       } else {
 #pragma unroll
       for (int r = 0; r < 8; ++r) {
-        bv[r] = p.bias ? p.bias[n + r] : 0.f;
-        sv[r] = p.ln_stats ? p.wsum[n + r] : 0.f;
+        bv[r] = e_bias ? e_bias[n + r] : 0.f;
+        sv[r] = e_ln ? p.wsum[n + r] : 0.f;
       }
       }
 #pragma unroll
       for (int mb = 0; mb < NMB; ++mb) {
         const long m = m0 + mrow0 + mb * 32;
-        if (m >= p.M) continue;
+        if (m >= e_M) continue;
         float v[8];
         {  // (the fold as in the GEGLU epilogue above: packed, in the order it has always had, no select)
           const f32x2 rs2 = {rs_[mb], rs_[mb]}, mu2 = {mu_[mb], mu_[mb]};
@@ -948,8 +953,8 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
           }
         }
         if constexpr (CONV) {
-          if (p.emb) {
-            const u32x4 e0 = *reinterpret_cast<const u32x4*>(p.emb + embrow[mb] + n);
+          if (e_emb) {
+            const u32x4 e0 = *reinterpret_cast<const u32x4*>(e_emb + embrow[mb] + n);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
               v[2 * e] += bf16lo_to_f32(e0[e]);

@@ -1,5 +1,7 @@
 #!/bin/bash
 mkdir -p gpurun_out
+python -m pytest tests/test_gemm_gpu.py tests/test_kernels_gpu.py -x -q 2>&1 | tail -2 > gpurun_out/lbw_tests.txt
+cat gpurun_out/lbw_tests.txt
 rm -f gpurun_out/lbw_bench.txt
 for rep in 1 2; do
   for lib in libcd360_old.so libcd360_lbw.so libcd360_hip.so; do
