@@ -203,8 +203,8 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
 #ifdef CD360_GEMM_STAMP  // ASM4 phase stamps (100 MHz counter): [workgroup][wave][8] at p.stamp, lane 0 of every wave
 #define G4STAMP(i)                                                                                                            \
   do {                                                                                                                        \
-    if constexpr (ASM4) {                                                                                                     \
-      if (p.stamp && (tid & 63) == 0) p.stamp[((long)blockIdx.x * 4 + wave) * 8 + (i)] = (uint32_t)__builtin_amdgcn_s_memrealtime(); \
+    if constexpr (ASM4 || (WM == 4 && WN == 4)) {                                                                             \
+      if (p.stamp && (tid & 63) == 0) p.stamp[((long)blockIdx.x * NW + wave) * 8 + (i)] = (uint32_t)__builtin_amdgcn_s_memrealtime(); \
     }                                                                                                                         \
   } while (0)
 #else
@@ -771,7 +771,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
       }
       FENCE();
 #ifdef CD360_GEMM_STAMP
-      if (!ASM4 && p.stamp && t < 64 && wave < NWC) {  // stamps parked in the LDS behind the ring (a global store would count in vmcnt); lane 0 of each wave
+      if (!ASM4 && !(WM == 4 && WN == 4) && p.stamp && t < 64 && wave < NWC) {  // stamps parked in the LDS behind the ring (a global store would count in vmcnt); lane 0 of each wave
         const uint64_t stE = __builtin_amdgcn_s_memtime();
         if (lane == 0) {
           uint32_t* d = reinterpret_cast<uint32_t*>(lds + NBUF * (XB + WB)) + (wave * 64 + t) * 8;
@@ -1313,7 +1313,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
     d[192] = bw4[3];
   }
 #ifdef CD360_GEMM_STAMP
-  if (!ASM4 && p.stamp) {
+  if (!ASM4 && !(WM == 4 && WN == 4) && p.stamp) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(lds + NBUF * (XB + WB));
     for (int i = tid; i < NWC * 64 * 8; i += 64 * NW) p.stamp[(long)blockIdx.x * (NWC * 64 * 8) + i] = src[i];
     __syncthreads();
@@ -1538,7 +1538,7 @@ int launch_mv(const GemmParams& p0, hipStream_t stream) {
 #endif
 #ifdef CD360_GEMM_STAMP
   p.stamp = nullptr;
-  if ((STAMP_BYTES || ASM4) && !(tune.reserved[0] == -1 && tune.reserved[1] == -1))  // probe build: device pointer of the stamp buffer in reserved[0..1]
+  if ((STAMP_BYTES || ASM4 || (WM == 4 && WN == 4)) && !(tune.reserved[0] == -1 && tune.reserved[1] == -1))  // probe build: device pointer of the stamp buffer in reserved[0..1]
     p.stamp = reinterpret_cast<uint32_t*>(((uint64_t)(uint32_t)tune.reserved[1] << 32) | (uint64_t)(uint32_t)tune.reserved[0]);
 #endif
   const long nwg = (long)p.tiles_m * p.tiles_n * ((EPI == 5 && p.cv_up) ? 4 : 1);

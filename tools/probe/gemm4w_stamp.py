@@ -10,17 +10,19 @@ _lib.LIB_PATH = os.path.join(ROOT, "custom-diffusion360_amd", "lib", "libcd360_s
 from cd360 import ops
 dev = "cuda"
 g = torch.Generator(device="cpu").manual_seed(0)
+CFG = int(os.environ.get("STAMP_CFG", "9"))
+NWV = 4 if CFG == 9 else 16
 for (M, N, K, geglu) in ((3072, 10240, 64, False), (3072, 10240, 1280, False), (3072, 10240, 1280, True), (3072, 3840, 1280, False)):
     a = torch.randn(M, K, generator=g).to(dev).to(torch.bfloat16)
     w = (torch.randn(N, K, generator=g) * K ** -0.5).to(dev).to(torch.bfloat16)
     bias = torch.randn(N, generator=g).to(dev)
-    _lib.set_tuning(gemm_cfg=9)
+    _lib.set_tuning(gemm_cfg=CFG)
     kw = dict(bias=bias, geglu=geglu)
     for _ in range(3):
         ops.gemm(a, w, **kw)
     torch.cuda.synchronize()
     nwg = ((M + 255) // 256) * ((N + 255) // 256)
-    buf = torch.zeros(nwg * 4 * 8, dtype=torch.int32, device=dev)
+    buf = torch.zeros(nwg * NWV * 8, dtype=torch.int32, device=dev)
     t = _lib.Tuning()
     _lib.load().cd360_get_tuning(ctypes.byref(t))
     ptr = buf.data_ptr()
@@ -30,7 +32,7 @@ for (M, N, K, geglu) in ((3072, 10240, 64, False), (3072, 10240, 1280, False), (
     torch.cuda.synchronize()
     t.reserved[0] = t.reserved[1] = -1
     _lib.load().cd360_set_tuning(ctypes.byref(t))
-    st = (buf.cpu().numpy().astype("int64") & 0xFFFFFFFF).reshape(nwg, 4, 8)
+    st = (buf.cpu().numpy().astype("int64") & 0xFFFFFFFF).reshape(nwg, NWV, 8)
     t0 = st[:, :, 0].min()
     rel = (st - t0) / 100.0  # us
     first = rel[:, 0, 0] < (rel[:, 0, 0].min() + 3.0)  # workgroups of the first round
