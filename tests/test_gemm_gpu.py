@@ -43,6 +43,61 @@ def test_gemm_mover_waves_change_no_bit(tune):
     assert bench_gemm.movers(time=False)
 
 
+@pytest.mark.parametrize("M,N,K,geglu,ln,res", [(256, 256, 64, False, False, False), (256, 256, 128, False, False, True), (300, 272, 192, False, True, True),
+                                                  (512, 768, 320, True, True, False), (1024, 512, 1280, True, False, False), (3072, 10240, 1280, True, True, False),
+                                                  (2000, 1280, 640, False, True, True), (4096, 4096, 4096, False, False, False), (640, 2560, 448, False, False, False)])
+def test_four_wave_generated_loop_changes_no_bit(tune, M, N, K, geglu, ln, res):
+    """gemm_cfg = 9 -- 256 x 256 tiles as four waves of 128 x 128 on the generated instruction stream of csrc/gemm4w_loop.inc (operands over a
+    five-slot LDS ring, tools/gen_gemm4w_loop.py) -- against the eight-wave arrangement of the same tile (gemm_cfg = 3): the same products
+    summed in the same order, so the outputs are bit-identical (the row statistics to fp32 rounding); one to 64 K-tiles (every residue of the ring's five-tile
+    period, loops that leave after the first trip), ragged M and N, every epilogue it serves (bias, LayerNorm fold, residual, GEGLU, row
+    statistics); repeated launches equal; and against fp32 torch."""
+    from bench_gemm import rnd
+    from cd360 import ops
+    a = rnd(M, K, seed=41).to(torch.bfloat16)
+    w = rnd(N, K, seed=42, scale=K ** -0.5)
+    b = rnd(N, seed=43)
+    r = rnd(M, N, seed=44).to(torch.bfloat16) if res else None
+    if ln:
+        a = (a.float() * (0.5 + rnd(M, 1, seed=45).abs()) + 0.7 * rnd(M, 1, seed=46)).to(torch.bfloat16)
+        gamma, beta = 1 + 0.2 * rnd(K, seed=47), 0.1 * rnd(K, seed=48)
+        wk, wsum, cb = ops.pack_ln_linear(w, b, gamma, beta)
+        want = torch.nn.functional.linear(torch.nn.functional.layer_norm(a.float(), (K,), gamma, beta, 1e-5), w, b)
+        kw = dict(bias=cb, ln=(ops.row_stats(a), wsum, 1e-5))
+    else:
+        wk = w.to(torch.bfloat16)
+        want = torch.nn.functional.linear(a.float(), wk.float(), b)
+        kw = dict(bias=b)
+    if geglu:
+        perm = ops.geglu_row_order(N // 2, a.device)
+        wk = wk[perm].contiguous()
+        kw = {k: ((v[0], v[1][perm].contiguous(), v[2]) if k == "ln" else v[perm].contiguous()) for k, v in kw.items()}
+        kw["geglu"] = True
+        want = want[:, :N // 2] * torch.nn.functional.gelu(want[:, N // 2:])
+    else:
+        kw["want_stats"] = True
+        if res:
+            kw["res"] = r
+            want = want + r.float()
+
+    def run(cfg):
+        tune(gemm_cfg=cfg)
+        o = ops.gemm(a, wk, **kw)
+        torch.cuda.synchronize()
+        return o if isinstance(o, tuple) else (o,)
+    ref = run(3)
+    outs = [run(9) for _ in range(3)]
+    def same(o, q):  # outputs bit for bit; the row statistics are sums over 2 instead of 4 waves' partials: equal to fp32 rounding
+        return torch.equal(o[0], q[0]) and all(((x - y).abs().max() <= 1e-5 * y.abs().max()).item() for x, y in zip(o[1:], q[1:]))
+    for o in outs:
+        assert same(o, ref) and all(torch.equal(x, y) for x, y in zip(o, outs[0]))
+    assert ((outs[0][0].float() - want).abs().max() / want.abs().max()).item() < 8e-3
+    tune(gemm_cfg=-1, gemm_asm4=1)  # the switch the dispatch reads: every launch that chose a 256 x 256 tiling moves onto the generated loop
+    o = ops.gemm(a, wk, **kw)
+    if ops._lib.load().cd360_gemm_tile_n(M, N) == 256:
+        assert same(o if isinstance(o, tuple) else (o,), ref)
+
+
 @pytest.mark.parametrize("ksplit", [0, 1])
 def test_gemm_cstats_in_both_wave_arrangements(tune, ksplit):
     from bench_gemm import rnd

@@ -517,3 +517,26 @@ def test_host_glue_builds_and_binds_to_the_loaded_library():
     assert mod is not None and callable(mod.linear) and callable(mod.init)
     with pytest.raises(Exception):
         mod.init("/nonexistent/libcd360_hip.so")  # never a second copy of the library, never a fallback
+
+
+def test_generated_gemm_loop_is_what_its_generator_writes():
+    """csrc/gemm4w_loop.inc (the instruction stream of the four-wave 256 x 256 GEMM arrangement) is generated text: the committed file must be
+    exactly what tools/gen_gemm4w_loop.py renders, and the stream must hold what its schedule promises -- per K-tile 64 MFMAs, 32 fragment
+    reads and 16 LDS-DMA pieces, five tiles per trip of the ring."""
+    import importlib.util
+    import re
+    spec = importlib.util.spec_from_file_location("gen_gemm4w_loop", os.path.join(ROOT, "tools", "gen_gemm4w_loop.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    with open(os.path.join(ROOT, "custom-diffusion360_amd", "csrc", "gemm4w_loop.inc")) as f:
+        assert f.read() == gen.render()
+    body = gen.body(0)
+    loop = body[body.index("1:"):body.index("9:")]
+    assert sum(1 for x in loop if x.startswith("v_mfma_f32_32x32x16_bf16")) == 5 * 64
+    assert sum(1 for x in loop if x.startswith("ds_read_b128")) == 5 * 32
+    assert sum(1 for x in loop if re.match(r"buffer_load_dwordx4 .* lds$", x)) == 5 * 16
+    assert sum(1 for x in loop if x == "s_barrier") == 5
+    for u in range(5):  # every ring slot is written by exactly the tiles that own it: operand tile n lives in slot n % 5
+        t = gen.tile(u, 0)
+        slots = sorted({int(m.group(1), 16) // gen.SLOT for x in t for m in [re.match(r"s_add_u32 m0, %18, (0x[0-9a-f]+)", x)] if m})
+        assert slots == sorted({(2 * u + 3) % 5, (2 * u + 4) % 5, (2 * u) % 5})

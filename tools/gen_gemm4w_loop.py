@@ -160,17 +160,22 @@ def emit(name, lines):
     return f"#define {name} \\\n" + " \\\n".join(f'  "{ln}\\n"' for ln in lines) + "\n"
 
 
-def main():
+def render() -> str:
     txt = "// GENERATED by tools/gen_gemm4w_loop.py -- do not edit; see that file for the schedule and the operand list.\n"
     txt += emit("CD360_GEMM4W_LOOP", body(0))
-    txt += "#ifdef CD360_WHATIF  // probe builds: 1 = no operand traffic, 3 = no fragment reads either, 4 = no barrier\n"
+    txt += ("#ifdef CD360_WHATIF  // probe builds: 1 = no operand traffic, 3 = no fragment reads either, 4 = no barrier, 8 = nobody waits for a piece,\n"
+            "                     // 16 / 32 = without the relaxed / the tight operand's pieces, 64 = every piece out of range, 128 = pieces with no lane active\n")
     for v in (1, 3, 4, 8, 16, 32, 64, 128):
         txt += emit(f"CD360_GEMM4W_LOOP_V{v}", body(v))
     txt += "#endif\n"
     clob = ['"memory"', '"scc"'] + [f'"s{s}"' for s in CLOBBER_S] + [f'"v{v}"' for v in CLOBBER_V]
     txt += "#define CD360_GEMM4W_CLOBBERS " + ", ".join(clob) + "\n"
+    return txt
+
+
+def main():
     with open(OUT, "w") as f:
-        f.write(txt)
+        f.write(render())
     print(OUT, len(body(0)), "instructions", file=sys.stderr)
 
 
