@@ -54,7 +54,6 @@ SIGNATURES = {
     "cd360_cfg_euler_step_f32": (c_int, [_P, _P, _P, _P, c_float, c_float, _P, c_int64, _P]),
     "cd360_unet_stage_in": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P]),
     "cd360_cfg_euler_step_cl": (c_int, [_P, _P, _P, _P, c_float, c_float, c_int, c_int64, c_int, _P]),
-    "cd360_conv3x3_skip_bf16": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),
     "cd360_out_conv4_bf16": (c_int, [_P, _P, _P, _P, c_int, c_int, c_int, c_int, _P]),
     "cd360_conv_k_order": (c_int, [c_int, c_int]),
     "cd360_conv_igemm_bf16": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, c_int, c_int, c_int, c_int, c_int, c_int, c_int, _P, _P]),

@@ -1201,37 +1201,3 @@ def out_conv4(x: torch.Tensor, w36: torch.Tensor, bias: torch.Tensor, N: int, H:
     with _timed("conv_igemm", 2.0 * N * H * W * 9 * cin * 4, 2.0 * (N * H * W * (cin + 4) + 36 * cin)):
         check(_lib.load().cd360_out_conv4_bf16(_ptr(x), _ptr(w36), _ptr(bias), _ptr(out), N, H, W, cin, _stream()), "cd360_out_conv4_bf16")
     return out
-
-
-def conv3x3_skip(x: torch.Tensor, x2: torch.Tensor, w_cat: torch.Tensor, bias: Optional[torch.Tensor], N: int, H: int, W: int,
-                 emb: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None, want_stats: bool = False):
-    """conv3x3(x, pad 1) + conv1x1(x2) + bias [+ emb[n]] [+ res] in one launch (cd360_conv3x3_skip_bf16): the ResBlock output convolution with
-    its 1 x 1 skip_connection as extra K-tiles.  x [N, H W, Cin], x2 [N, H W, Cin2] bf16; w_cat [Cout, 9 Cin + Cin2] = [pack_conv_weight(3 x 3)
-    | 1 x 1 weight].  Returns out (or (out, tile_stats)), or None when the shape is outside the LDS-DMA kernel's envelope (the caller then
-    issues the two convolutions separately).  Forward only."""
-    _need_gpu(x, x2, w_cat, bias, emb, res)
-    cin, cin2, cout = x.shape[-1], x2.shape[-1], w_cat.shape[0]
-    assert x.dtype == x2.dtype == w_cat.dtype == torch.bfloat16 and x.is_contiguous() and x2.is_contiguous() and w_cat.is_contiguous()
-    assert x.numel() == N * H * W * cin and x2.numel() == N * H * W * cin2 and w_cat.shape[1] == 9 * cin + cin2
-    assert bias is None or (bias.dtype == torch.float32 and bias.is_contiguous() and bias.numel() == cout)
-    assert emb is None or (emb.dtype == torch.bfloat16 and emb.shape == (N, cout) and emb.stride(1) == 1)
-    assert res is None or (res.dtype == torch.bfloat16 and res.is_contiguous() and res.numel() == N * H * W * cout)
-    lib = _lib.load()
-    _lib.query_stream(_stream())
-    if cin2 % 64 or lib.cd360_conv_dma_slab_rows(N, H, W, cin, cout, 9, 1) <= 0:
-        return None
-    stats = None
-    if want_stats:
-        rows = lib.cd360_conv_stats_rows(N, H, W, cin, cout, 9, 1)
-        if rows <= 0 or (H * W) % rows:
-            return None
-        stats = torch.empty(N, (H * W) // rows, cout, 2, dtype=torch.float32, device=x.device)
-    out = torch.empty(N, H * W, cout, dtype=torch.bfloat16, device=x.device)
-    m = N * H * W
-    with _timed("conv_igemm", 2.0 * m * (9 * cin + cin2) * cout, 2.0 * (m * (cin + cin2) + m * cout + (9 * cin + cin2) * cout)):
-        rc = lib.cd360_conv3x3_skip_bf16(_ptr(x), _ptr(x2), _ptr(w_cat), _ptr(bias), _ptr(emb), 0 if emb is None else emb.stride(0), _ptr(res), _ptr(out),
-                                         N, H, W, cin, cin2, cout, _ptr(stats), _stream())
-    if rc == -2:  # CD360_ERR_SHAPE
-        return None
-    check(rc, "cd360_conv3x3_skip_bf16")
-    return (out, stats) if want_stats else out

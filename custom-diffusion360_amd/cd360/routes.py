@@ -28,7 +28,6 @@ _ENV = {
     "no_train_fusions": "CD360_NO_TRAIN_FUSIONS",      # fine-tuning: derived FeatureNeRF weights, render loss terms and residual hand-offs op by op in torch
     "strict_sample_py": "CD360_STRICT_SAMPLE_PY",      # sample.py's rebound forwards are left in place and run themselves (the strict module route)
     "no_stage": "CD360_NO_STAGE",                      # the sampling job's captured steps with the denoiser / embedding scalar math as torch launches (round 5)
-    "no_skip_fuse": "CD360_NO_SKIP_FUSE",              # ResBlock: the 1 x 1 skip_connection convolution as its own launch instead of extra K-tiles of the output convolution
     "no_out_conv4": "CD360_NO_OUT_CONV4",              # the 320 -> 4 output convolution on the GEMM core with Cout padded to 16 (round 5) instead of cd360_out_conv4_bf16
     "no_host_glue": "CD360_NO_HOST_GLUE",              # fine-tuning Linears through the Python autograd node (grad.LinearFn) instead of the C++ one
     "fp8_attn": "CD360_FP8_ATTN",                      # BASELINE configs[4]: attention contractions of the fused cross-attention on fp8 MFMA

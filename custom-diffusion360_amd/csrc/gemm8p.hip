@@ -77,12 +77,6 @@ struct GemmParams {
               // four output phases (a, b) = (row, column parity), phase slowest in the tile order; phase (a, b) is a 2 x 2-tap convolution
               // of the SOURCE image (taps dy = (t >> 1) + a - 1, dx = (t & 1) + b - 1; K = 4 Cin; weights w + phase * N * ldw, the 3 x 3
               // taps that read the same source pixel summed at pack time) whose row (n, i, j) is output pixel (n, 2 i + a, 2 j + b)
-  // EPI 5 with a SECOND K segment (round 6): the ResBlock's 1 x 1 skip_connection convolution (openaimodel.py:335-343,376: `skip_connection(x) + h`)
-  // as extra K-tiles of the output convolution -- K-tiles >= cv_nk1 read the centre pixel of `a2` ([M, lda2] channels-last, the block's input)
-  // against the weight columns appended behind the 9 Cin of the 3 x 3 kernel; one launch and no [M, Cout] skip tensor instead of two launches
-  const uint16_t* a2;
-  long lda2;
-  int cv_nk1;           // K-tiles of the 3 x 3 segment (= K / 64 when a2 is null)
   const uint16_t* emb;  // [images, Cout] bf16 per-image addend (row stride emb_stride elements) or null
   long emb_stride;
   float* cstats;        // [M / (NMB 32), Cout, 2] fp32: per slab of NMB * 32 pixels and channel, (sum, sumsq) of the stored outputs, or null
@@ -243,11 +237,6 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
       __builtin_amdgcn_make_buffer_rsrc((void*)(p.w + (long)up_phase * p.N * p.ldw), 0, (int)(((long)p.N - 1) * p.ldw * 2 + (long)p.K * 2), 0x00020000);
   const int srow = dwave * 8 + (lane >> 3);
   const int schunk = (lane & 7) ^ ((srow >> 1) & 7);
-  // second K segment of a convolution (p.a2): its own descriptor / row pitch
-  const bool seg2_any = CONV && !HALO && p.a2 != nullptr;
-  const __amdgpu_buffer_rsrc_t xrsrc2 = __builtin_amdgcn_make_buffer_rsrc((void*)(seg2_any ? p.a2 : p.a), 0, seg2_any ? (int)((long)p.M * p.lda2 * 2) : 0, 0x00020000);
-  const uint32_t xoff0_2 = seg2_any ? (uint32_t)((m0 + srow) * p.lda2 * 2 + schunk * 16) : 0u;
-  const uint32_t xstep2 = seg2_any ? (uint32_t)(8 * NWD * p.lda2 * 2) : 0u;
   const uint32_t xoff0 = (uint32_t)((m0 + srow) * p.lda * 2 + schunk * 16);
   const uint32_t woff0 = (uint32_t)(((long)n0 + srow) * p.ldw * 2 + schunk * 16);
   const uint32_t xstep = (uint32_t)(PR * p.lda * 2), wstep = (uint32_t)(PR * p.ldw * 2);
@@ -276,17 +265,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   int cv_j = 0, cv_tap = 0, cv_cg = 0;  // K-tile about to be issued (tiles are issued in order)
   int is_tap = 0;
   uint32_t is_tapoff = 0;
-  int cv_t = 0;          // index of the K-tile about to be issued
-  bool is_seg2 = false;  // ... which belongs to the second K segment (p.a2: centre pixel, its own row pitch)
   auto conv_next = [&]() {  // wave-uniform: byte offset of the next K-tile's (tap shift, channel chunk) relative to the output pixel's row
-    if (seg2_any && cv_t >= p.cv_nk1) {
-      is_seg2 = true;
-      is_tap = 4;  // the centre tap: every in-range row is in the image
-      is_tapoff = (uint32_t)((cv_t - p.cv_nk1) * 128);
-      ++cv_t;
-      return;
-    }
-    ++cv_t;
     is_tap = cv_tap;
     const int dy = p.cv_up ? (cv_tap >> 1) + up_a : cv_tap / 3, dx = p.cv_up ? (cv_tap & 1) + up_b : cv_tap - 3 * (cv_tap / 3);
     is_tapoff = (uint32_t)((((dy - 1) * p.cv_W + (dx - 1)) * (int)p.lda + (cv_cg * p.cv_kg + cv_j) * 64) * 2);
@@ -351,15 +330,6 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
       }
     }
     if (i < XP) {
-      if constexpr (CONV && !HALO) {
-        if (is_seg2) {  // (wave-uniform) second K segment: rows of p.a2, no shift
-          const uint32_t su2 = is_tapoff + (uint32_t)i * xstep2;
-          asm volatile("v_add_u32 %0, %1, %2" : "=v"(o) : "s"(su2), "v"(xoff0_2));
-          o = ((xmask[i < XP ? i : 0] >> 4) & 1u) ? o : 0x80000000u;
-          __builtin_amdgcn_raw_ptr_buffer_load_lds(xrsrc2, LDS_AS3(dma_base + XREG + bx + i * (PR * 128)), 16, o, 0, 0, 0);
-          return;
-        }
-      }
       const uint32_t su = (CONV ? is_tapoff : (uint32_t)(kt * 128)) + (uint32_t)i * xstep;
       asm volatile("v_add_u32 %0, %1, %2" : "=v"(o) : "s"(su), "v"(xoff0));
       if constexpr (CONV) o = ((xmask[i < XP ? i : 0] >> is_tap) & 1u) ? o : 0x80000000u;
@@ -1688,7 +1658,7 @@ extern "C" int cd360_gemm_bf16(const void* a, const void* w, void* out, int64_t 
   p.M = (int)M; p.N = N; p.K = K; p.ln_parts = ln_parts; p.ln_dim = ln_dim; p.ln_eps = ln_eps; p.geglu = geglu ? 1 : 0;
   p.tiles_m = p.tiles_n = p.group_m = 0;
   p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f; p.a_dup = p.a_dup_from = 0; p.a_kv8 = nullptr; p.a_kvs = nullptr; p.a_heads = 0;
-  p.cv_H = p.cv_W = p.cv_kg = p.cv_up = 0; p.a2 = nullptr; p.lda2 = 0; p.cv_nk1 = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = nullptr;
+  p.cv_H = p.cv_W = p.cv_kg = p.cv_up = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = nullptr;
   int cfg = pick_cfg(M, N, geglu);
   // narrow outputs of 257 .. 512 tiles with a long K loop: 256 x 128 tiles with three buffers instead of two 128 x 128 workgroups per CU
   // (same 128-column statistics partials; tools/bench_gemm.py mid_m "narrow": 4096 x 1280 x 5120 64.7 -> 58.5 us, 12288 x 640 x 2560 44.8 -> 40.9,
@@ -1736,7 +1706,7 @@ extern "C" int cd360_gemm_cstats_bf16(const void* a, const void* w, void* out, i
   p.M = (int)M; p.N = N; p.K = K; p.ln_parts = 0; p.ln_dim = 0; p.ln_eps = 0.f; p.geglu = 0;
   p.tiles_m = p.tiles_n = p.group_m = 0;
   p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f; p.a_dup = p.a_dup_from = 0; p.a_kv8 = nullptr; p.a_kvs = nullptr; p.a_heads = 0;
-  p.cv_H = p.cv_W = p.cv_kg = p.cv_up = 0; p.a2 = nullptr; p.lda2 = 0; p.cv_nk1 = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = (float*)cstats;
+  p.cv_H = p.cv_W = p.cv_kg = p.cv_up = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = (float*)cstats;
   if (cfg == 8) return launch_64x4<6>(p, (hipStream_t)stream);
   return cfg == 2 ? launch_epi<2, 4, 1, 2, 2, 6>(p, (hipStream_t)stream) : launch_128x4<6>(p, (hipStream_t)stream);
 }
@@ -1814,7 +1784,7 @@ extern "C" int cd360_qproj_attn_dedup_bf16(const void* a, const void* w, void* o
   p.ak = (const uint16_t*)k; p.av = (const uint16_t*)v; p.ak_sb = k_sb; p.ak_sn = k_sn; p.av_sb = v_sb; p.av_sn = v_sn;
   p.a_nq = Nq; p.a_nk = Nk; p.a_scale_log2e = scale * 1.4426950408889634f;
   p.a_dup = dup; p.a_dup_from = (int)(M / Nq) - dup; p.a_kv8 = nullptr; p.a_kvs = nullptr; p.a_heads = N / 64;
-  p.cv_H = p.cv_W = p.cv_kg = p.cv_up = 0; p.a2 = nullptr; p.lda2 = 0; p.cv_nk1 = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = nullptr;
+  p.cv_H = p.cv_W = p.cv_kg = p.cv_up = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = nullptr;
   const bool keys16 = cd360_tune().qattn_keys16 != 0;
   // A width that is 128 short of a multiple of 256 (SDXL's 640 = 2.5 tiles) leaves half of the last 256-column tile's waves without
   // channels while the workgroup still holds its CU.  Sending the last 128 columns (two heads) to the 256 x 128 tile in a second launch
@@ -1946,7 +1916,7 @@ extern "C" int cd360_qproj_attn_fp8_bf16(const void* a, const void* w, void* out
   p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0;
   p.a_nq = Nq; p.a_nk = Nk; p.a_scale_log2e = scale * 1.4426950408889634f;
   p.a_dup = dup; p.a_dup_from = (int)(M / Nq) - dup; p.a_kv8 = (const unsigned char*)kv8; p.a_kvs = (const float*)scales; p.a_heads = N / 64;
-  p.cv_H = p.cv_W = p.cv_kg = p.cv_up = 0; p.a2 = nullptr; p.lda2 = 0; p.cv_nk1 = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = nullptr;
+  p.cv_H = p.cv_W = p.cv_kg = p.cv_up = 0; p.emb = nullptr; p.emb_stride = 0; p.cstats = nullptr;
   return qattn_launch(p, qcfg, Nk, true, (hipStream_t)stream);
 }
 
@@ -2023,29 +1993,9 @@ extern "C" int cd360_conv_dma_slab_rows(int N, int H, int W, int Cin, int Cout, 
 
 // Same contract as cd360_conv_igemm_bf16 for taps = 9, stride = 1; tile_stats fp32 [N H W / cd360_conv_dma_slab_rows(...), Cout, 2].
 // CD360_ERR_SHAPE when the shape is outside the envelope (the caller then uses the register-staged kernel).
-static int conv3x3_dma_launch(const void* x, const void* w_packed, const void* bias, const void* emb, int64_t emb_stride, const void* res, void* out,
-                              int N, int H, int W, int Cin, int Cout, void* tile_stats, const void* x2, int Cin2, void* stream);
-
 extern "C" int cd360_conv3x3_dma_bf16(const void* x, const void* w_packed, const void* bias, const void* emb, int64_t emb_stride, const void* res,
                                       void* out, int N, int H, int W, int Cin, int Cout, void* tile_stats, void* stream) {
   CD360_TUNE_SCOPE(stream);
-  return conv3x3_dma_launch(x, w_packed, bias, emb, emb_stride, res, out, N, H, W, Cin, Cout, tile_stats, nullptr, 0, stream);
-}
-
-// conv3x3(x, pad 1) + conv1x1(x2) + bias [+ emb per image] [+ res] in ONE launch: ResBlock's `skip_connection(x) + out_layers(h)`
-// (openaimodel.py:335-343,376) with the 1 x 1 skip convolution as Cin2 / 64 extra K-tiles of the output convolution.  x [N H W, Cin],
-// x2 [N H W, Cin2] channels-last bf16; w_cat [Cout, 9 Cin + Cin2] bf16 = [the 3 x 3 weight in cd360_conv_k_order's order | the 1 x 1 weight];
-// bias = the sum of the two biases; tile_stats as cd360_conv3x3_dma_bf16.  Cin2 % 64 == 0.  CD360_ERR_SHAPE outside the DMA envelope.
-extern "C" int cd360_conv3x3_skip_bf16(const void* x, const void* x2, const void* w_cat, const void* bias, const void* emb, int64_t emb_stride,
-                                       const void* res, void* out, int N, int H, int W, int Cin, int Cin2, int Cout, void* tile_stats, void* stream) {
-  CD360_TUNE_SCOPE(stream);
-  if (!x2 || Cin2 <= 0 || Cin2 % 64 || (uintptr_t)x2 % 16) return CD360_ERR_ARG;
-  if ((long)N * H * W * Cin2 * 2 >= (1L << 31) || ((long)Cout + 320) * (9L * Cin + Cin2) * 2 >= (1L << 32)) return CD360_ERR_SHAPE;
-  return conv3x3_dma_launch(x, w_cat, bias, emb, emb_stride, res, out, N, H, W, Cin, Cout, tile_stats, x2, Cin2, stream);
-}
-
-static int conv3x3_dma_launch(const void* x, const void* w_packed, const void* bias, const void* emb, int64_t emb_stride, const void* res, void* out,
-                              int N, int H, int W, int Cin, int Cout, void* tile_stats, const void* x2, int Cin2, void* stream) {
   if (!x || !w_packed || !out) return CD360_ERR_ARG;
   if (!conv_dma_ok(N, H, W, Cin, Cout, 9, 1)) return CD360_ERR_SHAPE;
   if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)out | (uintptr_t)emb | (uintptr_t)res | (uintptr_t)tile_stats) % 16) return CD360_ERR_ARG;
@@ -2056,14 +2006,13 @@ static int conv3x3_dma_launch(const void* x, const void* w_packed, const void* b
   GemmParams p;
   p.a = (const uint16_t*)x; p.w = (const uint16_t*)w_packed; p.out = (uint16_t*)out; p.bias = (const float*)bias; p.res = (const uint16_t*)res;
   p.ln_stats = nullptr; p.wsum = nullptr; p.stats_out = nullptr;
-  p.lda = Cin; p.ldw = 9L * Cin + Cin2; p.ldo = Cout; p.ldr = res ? Cout : 0;
-  p.M = (int)M; p.N = Cout; p.K = 9 * Cin + Cin2; p.ln_parts = 0; p.ln_dim = 0; p.ln_eps = 0.f; p.geglu = 0;
+  p.lda = Cin; p.ldw = 9L * Cin; p.ldo = Cout; p.ldr = res ? Cout : 0;
+  p.M = (int)M; p.N = Cout; p.K = 9 * Cin; p.ln_parts = 0; p.ln_dim = 0; p.ln_eps = 0.f; p.geglu = 0;
   p.tiles_m = p.tiles_n = p.group_m = 0;
   p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f; p.a_dup = p.a_dup_from = 0; p.a_kv8 = nullptr; p.a_kvs = nullptr; p.a_heads = 0;
   p.cv_H = H; p.cv_W = W; p.cv_kg = cd360_conv_k_order(Cin, 9); p.cv_up = 0;
-  p.a2 = (const uint16_t*)x2; p.lda2 = Cin2; p.cv_nk1 = 9 * Cin / 64;
   p.emb = (const uint16_t*)emb; p.emb_stride = emb ? emb_stride : 0; p.cstats = (float*)tile_stats;
-  if (!x2 && conv_halo_ok(N, H, W, Cin, Cout, cfg)) return launch_128x4<11>(p, (hipStream_t)stream);  // (the halo form has no second segment)
+  if (conv_halo_ok(N, H, W, Cin, Cout, cfg)) return launch_128x4<11>(p, (hipStream_t)stream);
   switch (cfg) {
     case 1: return launch_epi<4, 2, 5, 2, 2, 5>(p, (hipStream_t)stream);
     case 2: return launch_epi<4, 2, 2, 2, 3, 5>(p, (hipStream_t)stream);
@@ -2096,7 +2045,6 @@ extern "C" int cd360_conv_up2x_bf16(const void* x, const void* w_phases, const v
   p.tiles_m = p.tiles_n = p.group_m = 0;
   p.ak = p.av = nullptr; p.ak_sb = p.ak_sn = p.av_sb = p.av_sn = 0; p.a_nq = p.a_nk = 0; p.a_scale_log2e = 0.f; p.a_dup = p.a_dup_from = 0; p.a_kv8 = nullptr; p.a_kvs = nullptr; p.a_heads = 0;
   p.cv_H = H; p.cv_W = W; p.cv_kg = cd360_conv_k_order(Cin, 9); p.cv_up = 1;
-  p.a2 = nullptr; p.lda2 = 0; p.cv_nk1 = 4 * Cin / 64;
   p.emb = nullptr; p.emb_stride = 0; p.cstats = nullptr;
   switch (pick_conv_cfg(4 * M, Cout)) {  // the four phases share the launch: tile count of the full-resolution output
     case 1: return launch_epi<4, 2, 5, 2, 2, 5>(p, (hipStream_t)stream);

@@ -26,7 +26,6 @@ from ...modules.diffusionmodules.util import (
     conv_image,
     conv_nd,
     conv_tokens,
-    packed_conv,
     group_norm_tokens,
     linear,
     normalization,
@@ -192,39 +191,9 @@ class ResBlock(TimestepBlock):
         if isinstance(self.skip_connection, nn.Identity):
             skip = xt
         else:
-            fused = self._out_conv_with_skip(t2, xt, N, H, W)
-            if fused is not None:  # the 1 x 1 skip convolution rode along as extra K-tiles of the output convolution: one launch, no skip tensor
-                return tag_gn_stats(tokens_to_image(fused[0], H, W), fused[1])
             skip = conv_tokens(self.skip_connection, xt, N, H, W)
         out, out_stats = conv_tokens(self.out_layers[3], t2, N, H, W, res=skip if skip.dtype == t2.dtype else skip.to(t2.dtype), want_stats=True)
         return tag_gn_stats(tokens_to_image(out, H, W), out_stats)  # the next module's GroupNorm (if any) reuses them
-
-    def _out_conv_with_skip(self, t2, xt, N, H, W):
-        """`skip_connection(x) + out_layers(h)` (openaimodel.py:376) with a 1 x 1 skip_connection as ONE launch (ops.conv3x3_skip), when both
-        convolutions are frozen bf16 and inside the kernel's envelope; None otherwise.  -> (tokens, GroupNorm slab statistics | None)."""
-        conv, skipc = self.out_layers[3], self.skip_connection
-        if (routes.no_skip_fuse or torch.is_grad_enabled() or not isinstance(skipc, nn.Conv2d) or skipc.kernel_size != (1, 1) or skipc.stride != (1, 1)
-                or not (t2.is_cuda and t2.dtype == torch.bfloat16 and xt.dtype == torch.bfloat16) or conv.kernel_size != (3, 3) or conv.stride != (1, 1)
-                or conv.in_channels % 64 or skipc.in_channels % 64 or conv.out_channels % 16 or skipc.groups != 1):
-            return None
-        pk = packed_conv(conv)
-        if pk is None or pk[0].shape != (conv.out_channels, 9 * conv.in_channels):
-            return None
-        ws, bs = skipc.weight, skipc.bias
-        key = (pk[0].data_ptr(), conv.weight._version, ws.data_ptr(), ws._version, None if bs is None else bs._version, None if conv.bias is None else conv.bias._version)
-        if getattr(self, "_skip_pack", None) is None or self._skip_pack[0] != key:
-            w_cat = torch.cat([pk[0], ws.detach().reshape(conv.out_channels, -1).to(torch.bfloat16)], 1).contiguous()
-            bias = torch.zeros(conv.out_channels, dtype=torch.float32, device=w_cat.device)
-            if pk[1] is not None:
-                bias = bias + pk[1]
-            if bs is not None:
-                bias = bias + bs.detach().float()
-            self._skip_pack = (key, w_cat, bias.contiguous())
-        stats_ok = (H * W) % 128 == 0 and not routes.no_gn_stats
-        r = ops.conv3x3_skip(t2.contiguous(), xt.contiguous(), self._skip_pack[1], self._skip_pack[2], N, H, W, want_stats=stats_ok)
-        if r is None:
-            return None
-        return r if stats_ok else (r, None)
 
 
 class UNetModel(nn.Module):

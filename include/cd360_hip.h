@@ -333,14 +333,6 @@ int cd360_unet_stage_in(const void* x, const void* step_tab, const void* step, c
 int cd360_cfg_euler_step_cl(void* x, const void* eps, const void* step_tab, const void* step, float scale, float scale_im, int bs, int64_t HW,
                             int ld, void* stream);
 
-/* ResBlock's `skip_connection(x) + out_layers(h)` (openaimodel.py:335-343,376) with a 1 x 1 skip_connection convolution, as ONE launch:
- * conv3x3(x, pad 1) + conv1x1(x2) + bias [+ emb[n]] [+ res].  The 1 x 1 convolution rides as Cin2 / 64 extra K-tiles of the 3 x 3 one
- * (centre pixel of x2, no [M, Cout] skip tensor in between).  x [N H W, Cin], x2 [N H W, Cin2] bf16 channels-last; w_cat [Cout, 9 Cin + Cin2]
- * bf16 = [3 x 3 weight in cd360_conv_k_order's order | 1 x 1 weight]; bias fp32 [Cout] = both biases summed; tile_stats as
- * cd360_conv_igemm_bf16 (slab rows: cd360_conv_stats_rows(N, H, W, Cin, Cout, 9, 1)).  CD360_ERR_SHAPE outside the LDS-DMA kernel's envelope. */
-int cd360_conv3x3_skip_bf16(const void* x, const void* x2, const void* w_cat, const void* bias, const void* emb, int64_t emb_stride, const void* res,
-                            void* out, int N, int H, int W, int Cin, int Cin2, int Cout, void* tile_stats, void* stream);
-
 /* The UNet's output convolution (openaimodel.py:967-973: Conv2d(model_channels -> 4, 3 x 3, padding 1) behind GroupNorm + SiLU) as a small
  * MFMA kernel of its own: x [images, H W, Cin] bf16 channels-last, w36 [64, Cin] bf16 with row tap * 4 + co = weight[co, :, ky, kx] (tap = 3 ky +
  * kx; rows 36 .. 63 zero), bias fp32 [4] -> out [images, H W, 4] bf16 (the rows cd360_cfg_euler_step_cl reads).  W in {32, 64, 128}, H even,

@@ -480,43 +480,6 @@ def test_conv3x3_halo_form_equals_the_tap_shifted_form(N, H, W, Cin, Cout, tune)
     assert torch.equal(ops.conv_igemm(xt, wp, None, N, H, W, 9), ops.conv_igemm(xt, wp, torch.zeros(Cout, device=DEV), N, H, W, 9))
 
 
-@pytest.mark.parametrize("N,H,W,Cin,Cin2,Cout", [(3, 32, 32, 640, 1280, 640), (2, 64, 64, 320, 640, 320), (3, 32, 32, 1280, 2560, 1280), (1, 16, 16, 64, 64, 48),
-                                                 (2, 32, 32, 640, 320, 640), (2, 8, 16, 192, 960, 128), (3, 64, 64, 320, 960, 320)])
-def test_conv3x3_with_the_1x1_skip_convolution_as_extra_k_tiles(N, H, W, Cin, Cin2, Cout, tune):
-    """ResBlock.forward's last line (openaimodel.py:376: skip_connection(x) + out_layers(h)) with a 1 x 1 skip_connection as ONE launch
-    (cd360_conv3x3_skip_bf16: the 1 x 1 convolution's Cin2 / 64 K-tiles follow the nine taps' in the same accumulators) against torch's fp32
-    conv2d + conv2d on the same bf16 values and against the two-launch HIP route (1 x 1 convolution, then the 3 x 3 with it as residual):
-    both biases, a per-image addend, a residual, the GroupNorm slab statistics; K-split and un-split arrangements, ragged channel tiles."""
-    from cd360 import ops
-    g = torch.Generator().manual_seed(N * 100 + H + Cin + Cin2 + Cout)
-    x = bf(torch.randn(N, Cin, H, W, generator=g))
-    x2 = bf(torch.randn(N, Cin2, H, W, generator=g))
-    w = bf(torch.randn(Cout, Cin, 3, 3, generator=g) / (Cin * 9) ** 0.5)
-    w2 = bf(torch.randn(Cout, Cin2, 1, 1, generator=g) / Cin2 ** 0.5)
-    bias = torch.randn(Cout, generator=g)
-    emb = bf(torch.randn(N, Cout, generator=g))
-    res = bf(torch.randn(N, Cout, H, W, generator=g))
-    want = torch.nn.functional.conv2d(x, w, bias, padding=1) + torch.nn.functional.conv2d(x2, w2) + emb[:, :, None, None] + res
-    cl = lambda t: t.permute(0, 2, 3, 1).reshape(N, H * W, t.shape[1]).contiguous().to(DEV, torch.bfloat16)
-    xt, x2t, rt = cl(x), cl(x2), cl(res)
-    wp = ops.pack_conv_weight(w).to(DEV)
-    w_cat = torch.cat([wp, w2.reshape(Cout, Cin2).to(DEV, torch.bfloat16)], 1).contiguous()
-    outs = [ops.conv3x3_skip(xt, x2t, w_cat, bias.to(DEV), N, H, W, emb.to(DEV, torch.bfloat16), rt, want_stats=True) for _ in range(4)]
-    assert outs[0] is not None
-    got, stats = outs[0]
-    assert rel(got.reshape(N, H, W, Cout).permute(0, 3, 1, 2), want) < 8e-3
-    skip = ops.conv_igemm(x2t, w2.reshape(Cout, Cin2).to(DEV, torch.bfloat16).contiguous(), None, N, H, W, 1)
-    two = ops.conv_igemm(xt, wp, bias.to(DEV), N, H, W, 9, emb.to(DEV, torch.bfloat16), (skip.float() + rt.float()).to(torch.bfloat16))
-    assert rel(got, two) < 8e-3  # (the two-launch route rounds the 1 x 1 result to bf16 in between)
-    slabs = stats.shape[1]
-    ref = got.float().reshape(N, slabs, H * W // slabs, Cout)
-    assert rel(stats[..., 0], ref.sum(2)) < 1e-5 and rel(stats[..., 1], (ref * ref).sum(2)) < 1e-5
-    for o, st in outs[1:]:
-        assert torch.equal(o, got) and torch.equal(st, stats)
-    plain = ops.conv3x3_skip(xt, x2t, w_cat, None, N, H, W)
-    assert rel(plain.reshape(N, H, W, Cout).permute(0, 3, 1, 2), want - bias[None, :, None, None] - emb[:, :, None, None] - res) < 8e-3
-
-
 @pytest.mark.parametrize("N,H,W,Cin,Cout", [(3, 32, 32, 1280, 1280), (3, 64, 64, 640, 640), (2, 8, 8, 64, 64), (1, 5, 7, 128, 320), (2, 16, 12, 192, 80)])
 def test_upsample_nearest2x_folded_into_the_convolution(N, H, W, Cin, Cout, tune):
     """Upsample.forward (openaimodel.py:114-181): nearest 2x + conv3x3 as ONE launch of four 2 x 2-tap phase convolutions of the source image
