@@ -540,3 +540,25 @@ def test_generated_gemm_loop_is_what_its_generator_writes():
         t = gen.tile(u, 0)
         slots = sorted({int(m.group(1), 16) // gen.SLOT for x in t for m in [re.match(r"s_add_u32 m0, %18, (0x[0-9a-f]+)", x)] if m})
         assert slots == sorted({(2 * u + 3) % 5, (2 * u + 4) % 5, (2 * u) % 5})
+
+
+def test_no_kernel_keeps_a_stack_object_in_scratch_memory():
+    """build() records hipcc's per-kernel resource remarks next to every object (lib/obj/*.resources.json).  A kernel whose scratch size is
+    not explained by register spills holds a STACK OBJECT in memory -- e.g. loop counters captured by a lambda that the optimiser failed to
+    promote: one scratch load + store + s_waitcnt vmcnt(0) per iteration, invisible to every parity test (round 6: every tap-shifted
+    convolution ran at half speed behind such a counter).  None may; and VGPR spills stay confined to the kernels listed below."""
+    import glob
+    import json
+    files = sorted(glob.glob(os.path.join(ROOT, "custom-diffusion360_amd", "lib", "obj", "*.resources.json")))
+    if not files:
+        pytest.skip("no resource records: the library was not built by __graft_entry__.build() in this tree")
+    known_spills = ("ILi6ELi2ELi5ELi1ELi2ELi1ELi4ELi5E", "ILi4ELi2ELi2ELi2ELi2ELi1ELi4ELi4E", "ILi4ELi2ELi2ELi2ELi2ELi1ELi4ELi7E",  # gemm_movers = 4 forced on tilings that do not take movers by default
+                    "nerf_fused_rec_kernelILi2E")  # one 8-byte value at the 256-register cap, stored before and reloaded behind the view loop
+    seen = 0
+    for f in files:
+        for name, r in json.load(open(f)).items():
+            seen += 1
+            spills = r.get("vgpr_spill", 0) + r.get("sgpr_spill", 0)
+            assert r.get("scratch", 0) == 0 or spills > 0, f"{os.path.basename(f)}: {name} keeps {r['scratch']} bytes per lane in scratch without a register spill: a stack object in memory"
+            assert r.get("vgpr_spill", 0) == 0 or any(k in name for k in known_spills), f"{os.path.basename(f)}: {name} spills {r['vgpr_spill']} VGPRs"
+    assert seen > 100
