@@ -25,6 +25,6 @@ except Exception as e: print('$f: no line', e)"; done
 # round 6 additions: SQ counters of the two-pass render's pass 2, the A/B switches of the round on this box
 bash tools/gpu_pmc_kernel.sh ${TAG}_nerf nerf_fused "python tools/bench_kernels.py nerf1" "-" > /dev/null 2>&1
 b() { python bench.py --steps 20 --warmup 5 --no-train-step --no-cpu-baseline --no-profile 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$1', d['value'], d['ms_per_step'], d['config']['steady_step_ms'], d['config']['render_step_ms'])"; }
-for i in 1 2; do b default; CD360_NO_STAGE=1 b no_stage; CD360_CONV_HALO=0 b no_halo; CD360_NERF_KERNEL=1 b nerf_one_pass; CD360_NO_OUT_CONV4=1 b no_out_conv4; CD360_GEMM_ASM4=1 b asm4_everywhere; CD360_LIB=$GRAFT_REPO_ROOT/custom-diffusion360_amd/lib/libcd360_old.so b epilogues_before; done > gpurun_out/ab_$TAG.txt 2>&1
+for i in 1 2; do b default; CD360_NO_STAGE=1 b no_stage; CD360_CONV_HALO=0 b no_halo; CD360_NERF_KERNEL=1 b nerf_one_pass; CD360_NO_OUT_CONV4=1 b no_out_conv4; CD360_GEMM_ASM4=1 b asm4_everywhere; [ -f $GRAFT_REPO_ROOT/custom-diffusion360_amd/lib/libcd360_old.so ] && CD360_LIB=$GRAFT_REPO_ROOT/custom-diffusion360_amd/lib/libcd360_old.so b epilogues_before; done > gpurun_out/ab_$TAG.txt 2>&1
 cat gpurun_out/ab_$TAG.txt
 python tools/probe/conv_halo_ab.py 2>&1 | grep "^conv" > gpurun_out/conv_halo_ab_$TAG.txt

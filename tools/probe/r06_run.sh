@@ -1,9 +1,7 @@
 #!/bin/bash
+# scratch: run on the GPU box
 mkdir -p gpurun_out
-echo "# same box, alternating: libcd360_pre.so = this tree with csrc/gemm8p.hip of commit 9c5e82d (before the epilogue work of round 6's second half); columns: steps/s, ms per step over 20 steps, steady step ms, render step ms" > gpurun_out/epilogue_ab.txt
-for rep in 1 2 3; do
-  for lib in libcd360_pre.so libcd360_hip.so; do
-  CD360_LIB=$PWD/custom-diffusion360_amd/lib/$lib python bench.py --steps 20 --warmup 5 --no-train-step --no-cpu-baseline --no-profile 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$lib', d['value'], d['ms_per_step'], d['config'].get('steady_step_ms'), d['config'].get('render_step_ms'))" >> gpurun_out/epilogue_ab.txt
-  done
-done
-cat gpurun_out/epilogue_ab.txt
+python -c "import __graft_entry__ as g; g.build(); g.smoke(); print('smoke ok')" 2>&1 | tail -2
+python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > gpurun_out/final_bench.json
+python -c "
+import json; d=json.load(open('gpurun_out/final_bench.json')); print(d['value'], d['ms_per_step'], d['roofline']); print(d['cpu_baseline']['value'], d['train_step']['ms'])"
