@@ -81,7 +81,7 @@ struct GemmParams {
   long emb_stride;
   float* cstats;        // [M / (NMB 32), Cout, 2] fp32: per slab of NMB * 32 pixels and channel, (sum, sumsq) of the stored outputs, or null
 #ifdef CD360_GEMM_STAMP
-  uint32_t* stamp;      // probe build (tools/probe/gemm_stamp.py): [workgroup][wave][K-tile][4] s_memtime stamps, or null
+  uint32_t* stamp;      // probe builds (tools/probe/gemm_stamp.sh MODE): 1 = [workgroup][wave][K-tile][8] s_memtime stamps of the K loop, 2 = [workgroup][wave][8] phase stamps; or null
 #endif
 };
 
@@ -194,10 +194,10 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
   const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, hh = lane >> 5;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool mover = MV > 0 && wave >= NWC;
-#ifdef CD360_GEMM_STAMP  // ASM4 phase stamps (100 MHz counter): [workgroup][wave][8] at p.stamp, lane 0 of every wave
+#if defined(CD360_GEMM_STAMP) && CD360_GEMM_STAMP == 2  // phase stamps of a launch (100 MHz counter): [workgroup][wave][8] at p.stamp, lane 0 of every wave (tools/probe/gemm4w_stamp.py)
 #define G4STAMP(i)                                                                                                            \
   do {                                                                                                                        \
-    if constexpr (ASM4 || (WM == 4 && WN == 4)) {                                                                             \
+    if constexpr (!ATTN) {                                                                                                    \
       if (p.stamp && (tid & 63) == 0) p.stamp[((long)blockIdx.x * NW + wave) * 8 + (i)] = (uint32_t)__builtin_amdgcn_s_memrealtime(); \
     }                                                                                                                         \
   } while (0)
@@ -741,7 +741,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
       }
       FENCE();
 #ifdef CD360_GEMM_STAMP
-      if (!ASM4 && !(WM == 4 && WN == 4) && p.stamp && t < 64 && wave < NWC) {  // stamps parked in the LDS behind the ring (a global store would count in vmcnt); lane 0 of each wave
+      if (CD360_GEMM_STAMP == 1 && p.stamp && t < 64 && wave < NWC) {  // stamps parked in the LDS behind the ring (a global store would count in vmcnt); lane 0 of each wave
         const uint64_t stE = __builtin_amdgcn_s_memtime();
         if (lane == 0) {
           uint32_t* d = reinterpret_cast<uint32_t*>(lds + NBUF * (XB + WB)) + (wave * 64 + t) * 8;
@@ -1283,7 +1283,7 @@ __global__ __launch_bounds__(64 * (WM * WN * KS + MV)) void gemm_mfma_kernel(Gem
     d[192] = bw4[3];
   }
 #ifdef CD360_GEMM_STAMP
-  if (!ASM4 && !(WM == 4 && WN == 4) && p.stamp) {
+  if (CD360_GEMM_STAMP == 1 && p.stamp) {
     const uint32_t* src = reinterpret_cast<const uint32_t*>(lds + NBUF * (XB + WB));
     for (int i = tid; i < NWC * 64 * 8; i += 64 * NW) p.stamp[(long)blockIdx.x * (NWC * 64 * 8) + i] = src[i];
     __syncthreads();
@@ -1508,7 +1508,7 @@ int launch_mv(const GemmParams& p0, hipStream_t stream) {
 #endif
 #ifdef CD360_GEMM_STAMP
   p.stamp = nullptr;
-  if ((STAMP_BYTES || ASM4 || (WM == 4 && WN == 4)) && !(tune.reserved[0] == -1 && tune.reserved[1] == -1))  // probe build: device pointer of the stamp buffer in reserved[0..1]
+  if ((STAMP_BYTES || CD360_GEMM_STAMP == 2) && !(tune.reserved[0] == -1 && tune.reserved[1] == -1))  // probe build: device pointer of the stamp buffer in reserved[0..1]
     p.stamp = reinterpret_cast<uint32_t*>(((uint64_t)(uint32_t)tune.reserved[1] << 32) | (uint64_t)(uint32_t)tune.reserved[0]);
 #endif
   const long nwg = (long)p.tiles_m * p.tiles_n * ((EPI == 5 && p.cv_up) ? 4 : 1);

@@ -1,5 +1,5 @@
 """Where a K-tile of the GEMM core spends its cycles: s_memtime stamps taken by every wave at four points of every K-tile
-(A loop top, B k-steps 0..2 issued, D past the rendezvous, E last k-step issued) in the probe build (tools/probe/gemm_stamp.sh).
+(A loop top, B k-steps 0..2 issued, D past the rendezvous, E last k-step issued) in the probe build (tools/probe/gemm_stamp.sh 1).
     python tools/probe/gemm_stamp.py [M N K]          (default 3072 1280 1280; env CD360_GEMM_* select the tiling as usual)"""
 import os
 import sys
