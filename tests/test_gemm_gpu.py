@@ -98,6 +98,33 @@ def test_four_wave_generated_loop_changes_no_bit(tune, M, N, K, geglu, ln, res):
         assert same(o if isinstance(o, tuple) else (o,), ref)
 
 
+@pytest.mark.parametrize("M,N,K,cfg,geglu", [(3072, 1280, 1280, -1, False), (3072, 3840, 1280, -1, False), (3072, 10240, 1280, -1, True), (1024, 512, 256, 9, False),
+                                               (1024, 1280, 1280, -1, False), (256, 320, 128, -1, False)])
+def test_bias_and_wsum_need_only_the_abi_alignment(tune, M, N, K, cfg, geglu):
+    """The epilogue fetches the tile's slices of bias and wsum by LDS-DMA (16 bytes per lane, round 6).  The C ABI promises 8-byte alignment
+    for both (cd360_hip.h): a slice at element offset 2 of a larger fp32 tensor must give the result of an aligned copy, bit for bit, on
+    every tiling family (128 x 128 with movers, 256 x 192, sixteen-wave GEGLU, the generated four-wave loop, 64 x 128, a ragged 320-wide one)."""
+    from bench_gemm import rnd
+    from cd360 import ops
+    a = rnd(M, K, seed=51).to(torch.bfloat16)
+    w = rnd(N, K, seed=52, scale=K ** -0.5)
+    gamma, beta = 1 + 0.2 * rnd(K, seed=53), 0.1 * rnd(K, seed=54)
+    wp, wsum, cb = ops.pack_ln_linear(w, rnd(N, seed=55), gamma, beta)
+    kw = {}
+    if geglu:
+        perm = ops.geglu_row_order(N // 2, a.device)
+        wp, wsum, cb = wp[perm].contiguous(), wsum[perm].contiguous(), cb[perm].contiguous()
+        kw["geglu"] = True
+    bigw, bigc = torch.zeros(N + 8, device=a.device), torch.zeros(N + 8, device=a.device)
+    bigw[2:2 + N], bigc[2:2 + N] = wsum, cb
+    assert bigw[2:].data_ptr() % 16 == 8 and bigc[2:].data_ptr() % 16 == 8
+    tune(gemm_cfg=cfg)
+    st = ops.row_stats(a)
+    want = ops.gemm(a, wp, bias=cb, ln=(st, wsum, 1e-5), **kw)
+    got = ops.gemm(a, wp, bias=bigc[2:2 + N], ln=(st, bigw[2:2 + N], 1e-5), **kw)
+    assert torch.equal(want, got)
+
+
 @pytest.mark.parametrize("ksplit", [0, 1])
 def test_gemm_cstats_in_both_wave_arrangements(tune, ksplit):
     from bench_gemm import rnd
