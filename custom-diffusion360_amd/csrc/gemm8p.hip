@@ -1998,7 +1998,7 @@ extern "C" int cd360_conv3x3_dma_bf16(const void* x, const void* w_packed, const
   CD360_TUNE_SCOPE(stream);
   if (!x || !w_packed || !out) return CD360_ERR_ARG;
   if (!conv_dma_ok(N, H, W, Cin, Cout, 9, 1)) return CD360_ERR_SHAPE;
-  if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)out | (uintptr_t)emb | (uintptr_t)res | (uintptr_t)tile_stats) % 16) return CD360_ERR_ARG;
+  if (((uintptr_t)x | (uintptr_t)w_packed | (uintptr_t)out | (uintptr_t)emb | (uintptr_t)res | (uintptr_t)tile_stats) % 16 || (uintptr_t)bias % 8) return CD360_ERR_ARG;
   if (emb && (emb_stride < Cout || emb_stride % 8)) return CD360_ERR_SHAPE;
   const long M = (long)N * H * W;
   const int cfg = pick_conv_cfg(M, Cout);

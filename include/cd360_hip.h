@@ -345,7 +345,8 @@ int cd360_out_conv4_bf16(const void* x, const void* w36, const void* bias, void*
  * (the 1x1 skip_connection conv, :337).  x [N*H*W, Cin]; w_packed [Cout, taps*Cin] in the kernel's K order:
  * with G = cd360_conv_k_order(Cin, taps) 64-channel chunks per group, k = ((cg*taps + ky*3+kx)*G + j)*64 + ci%64 where
  * ci/64 = cg*G + j (group outer, tap middle, chunk inner; G = Cin/64 is plain tap-major k = tap*Cin + ci); taps = 1: the plain [Cout, Cin] matrix;
- * bias fp32 [Cout] | NULL; emb bf16 [N, Cout] | NULL (per-image addend); res bf16 [N*H*W, Cout] | NULL; out bf16 [N*H*W, Cout].
+ * bias fp32 [Cout] | NULL (8-byte aligned: the LDS-DMA kernels fetch its slices 16 bytes per lane); emb bf16 [N, Cout] | NULL (per-image addend);
+ * res bf16 [N*H*W, Cout] | NULL; out bf16 [N*H*W, Cout].
  * Cin % 64 == 0, Cout % 16 == 0, 16-byte aligned pointers. */
 int cd360_conv_k_order(int Cin, int taps);
 int cd360_conv_igemm_bf16(const void* x, const void* w_packed, const void* bias, const void* emb, int64_t emb_stride, const void* res,
